@@ -1,0 +1,269 @@
+#!/usr/bin/env python
+"""bench.py — Mcells/s of the hydraulic-erosion step (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one full erosion step of the hot path over the resident grid
+(SURVEY.md §3.1): re-seed the particle streams, fluvial + debris Monte-Carlo
+transport (N = H*W/8 particles, maxage 256), then the fused per-cell phase
+(normalise x2, mass transfer, creep, layer update, merge, flux re-zero).
+Workload at N=1: BASELINE.json configs[3], the 8192^2 coupled hydraulic +
+thermal step on synthetic OpenSimplex2-FBm terrain (soil.noise, generated on
+the device), inputs resident in HBM before the timed region.  N>1: weak
+scaling, one 8192-row slab per GPU (global grid (N*8192) x 8192) with deep-halo
+exchange over RCCL (soillib_amd/parallel.py).
+
+Prints ONE JSON line (rank 0).  `value` is whole-job throughput of the FULL
+step; the per-phase split, the roofline of the HBM-bound fused cell kernel
+(112 algorithmic bytes per cell) and the CPU baseline (the
+oracle, oracle/liboracle.so, on the host cores) ride along in the same line.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+CELL_BYTES = 112               # fused floor, SURVEY.md §8d / DESIGN.md §Roofline
+
+
+def script_param(soil):
+    """example/erosion_gpu.py:75-100 mapped onto the live param_t names."""
+    p = soil.param_t()
+    p.timeStep = 1000.0
+    p.maxage = 256
+    p.lrate = 1.0
+    p.gravity = 9.81
+    p.uplift = 0.01
+    p.rainfall = 1.0
+    p.evapRate = 0.0005
+    p.viscosityWater = 0.000001
+    p.bedShearWater = 12.5
+    p.suspensionRateFluvial = 0.0008
+    p.depositionRateFluvial = 0.00001
+    p.fluvialExponent = 0.01
+    p.exitSlope = 0.025
+    p.critSlopeBedrock = 0.57
+    p.landslideRateDebris = 0.0025
+    p.suspensionRateDebris = 0.00025
+    p.depositionRateDebris = 0.0001
+    p.yieldStress = 2E6
+    p.densityDebris = 2500.0
+    p.viscosityDebris = 0.004
+    p.bedShearDebris = 60 / 2500.0
+    return p
+
+
+class Events:
+    """HIP events on the launch stream (the C ABI's null stream by default)."""
+
+    def __init__(self, abi, n):
+        self.abi, self.lib = abi, abi.lib()
+        self.ev = []
+        for _ in range(n):
+            e = C.c_void_p()
+            abi.check(self.lib.soil_event_create(C.byref(e)))
+            self.ev.append(e)
+
+    def record(self, i):
+        self.abi.check(self.lib.soil_event_record(self.ev[i], self.abi.stream()))
+
+    def ms(self, i, j):
+        out = C.c_float()
+        self.abi.check(self.lib.soil_event_elapsed_ms(self.ev[i], self.ev[j], C.byref(out)))
+        return out.value
+
+
+def cpu_baseline(size, seconds_hint=20.0):
+    """Times the oracle (oracle/liboracle.so, the CPU restatement of the same
+    kernels) on the host cores on a bounded sample of the same workload."""
+    import numpy as np
+    from oracle import pyoracle as o
+    H = W = size
+    N = H * W // 8
+    cores = os.cpu_count() or 1
+    p = o.default_param()
+    sp = script_param(__import__("soillib_amd.soil", fromlist=["soil"]))
+    for name, _ in p._fields_:
+        if name not in ("force", "_pad"):
+            setattr(p, name, getattr(sp._c, name))
+    scale = (20.0 / H, 20.0 / W, 4.0)
+    layers = np.zeros((H, W, 2), np.float32)
+    layers[..., 0] = o.noise(H, W, seed=3.0, ext=(float(H), float(W)))
+    rain = np.ones((H, W), np.float32)
+    z1 = lambda: np.zeros((H, W), np.float32)
+    z2 = lambda: np.zeros((H, W, 2), np.float32)
+
+    def one_step(state, step, threads):
+        rng = o.rng_seed(N, 0, step * N)
+        wf, mf, vf, df, dvf = z1(), z1(), z2(), z1(), z2()
+        s1 = o.particles_fluvial(wf, mf, vf, None, rng, state["layers"], rain, state["wh"],
+                                 state["v"], None, scale, p, threads=threads)
+        s2 = o.particles_debris(df, dvf, None, rng, state["layers"], state["dv"], None, scale, p,
+                                threads=threads)
+        r = o.erode_cells(state["layers"], z1(), rain, wf, mf, vf, df, dvf, scale, p)
+        return dict(layers=r["layers_next"], wh=r["waterHeight"], v=r["velocity"],
+                    dv=r["debrisVelocity"]), s1 + s2
+
+    state = dict(layers=layers, wh=z1(), v=z2(), dv=z2())
+    t0 = time.perf_counter()
+    state, steps1 = one_step(state, 0, 1)
+    t_single = time.perf_counter() - t0
+    reps = max(1, min(8, int(seconds_hint / max(t_single / max(cores / 2, 1), 1e-3)) // 2))
+    t0 = time.perf_counter()
+    psteps = 0
+    for i in range(reps):
+        state, s = one_step(state, 1 + i, cores)
+        psteps += s
+    t_multi = (time.perf_counter() - t0) / reps
+    return {
+        "value": H * W / t_multi / 1e6, "unit": "Mcells/s", "cores": cores, "kind": "port",
+        "sample": "%dx%d grid, N=%d particles, maxage 256, full step; 1 step on 1 thread "
+                  "(%.2f Mcells/s) + %d steps with OpenMP on %d threads (particle loop); cell "
+                  "phase single-threaded" % (H, W, N, H * W / t_single / 1e6, reps, cores),
+        "value_1thread": H * W / t_single / 1e6,
+        "mparticle_steps_per_s": psteps / reps / t_multi / 1e6,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--size", type=int, default=8192, help="rows per GPU and columns")
+    ap.add_argument("--particles-div", type=int, default=8, help="N = cells / this")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-size", type=int, default=1024)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+        args.gpus = world
+
+    from soillib_amd import _abi, silt, soil
+    from soillib_amd.erosion import ErosionModel
+    lib = _abi.lib()
+    _abi.check(lib.soil_set_device(local_rank))
+
+    S = args.size
+    param = script_param(soil)
+    if world > 1:
+        from soillib_amd import parallel
+        runner = parallel.SlabRunner(rows_per_rank=S, W=S, param=param,
+                                     particles_div=args.particles_div, seed=0)
+        H_global, W = runner.H, S
+    else:
+        H_global, W = S, S
+        scale = (20.0 / H_global, 20.0 / W, 4.0)
+        model = ErosionModel(H_global, W, scale, param, H_global * W // args.particles_div, seed=0)
+        npar = soil.noise_t()
+        npar.seed = 3.0
+        npar.ext = [H_global, W]
+        bed = soil.noise(silt.shape(H_global, W), npar, host=silt.gpu)
+        # layers[..., 0] = bedrock noise, layers[..., 1] = 0 sediment
+        _interleave(lib, _abi, model.layers, bed)
+        silt.set(model.rainfall, 1.0)
+        silt.set(model.uplift, 0.0)
+
+        class _Single:
+            def step(self_inner, ev=None):
+                model.seed_step()
+                if ev: ev.record(0)
+                model.particles_fluvial()
+                if ev: ev.record(1)
+                model.particles_debris()
+                if ev: ev.record(2)
+                model.cells_fused()
+                if ev: ev.record(3)
+                model.swap_layers()
+                model.step_index += 1
+
+            def sync(self_inner):
+                _abi.check(lib.soil_device_synchronize())
+
+            def barrier(self_inner):
+                pass
+        runner = _Single()
+
+    ev = Events(_abi, 4)
+    for _ in range(args.warmup):
+        runner.step()
+    runner.barrier()
+    runner.sync()
+    phase = [0.0, 0.0, 0.0]
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        runner.step(ev)
+        # events are read back after the step's work is queued; elapsed_ms
+        # synchronises on the last event, so this also paces the host
+        phase[0] += ev.ms(0, 1)
+        phase[1] += ev.ms(1, 2)
+        phase[2] += ev.ms(2, 3)
+    runner.sync()
+    runner.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        elapsed = runner.max_over_ranks(elapsed)
+
+    if rank != 0:
+        return
+    K = args.steps
+    cells = H_global * W
+    ms_step = elapsed / K * 1e3
+    cells_rank = S * W
+    t_cells = phase[2] / K * 1e-3
+    achieved = CELL_BYTES * cells_rank / t_cells / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic_fused_cells.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    out = {
+        "metric": "Mcells/s on 8192^2 hydraulic-erosion step",
+        "value": cells / (elapsed / K) / 1e6,
+        "unit": "Mcells/s",
+        "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": ms_step,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {
+            "workload": "%dx%d coupled hydraulic+thermal erosion step (fluvial+debris particle "
+                        "transport, N=cells/%d, maxage 256, + fused cell phase), OpenSimplex2-FBm "
+                        "heightmap, example/erosion_gpu.py parameters" % (H_global, W,
+                                                                          args.particles_div),
+            "grid": [H_global, W], "particles": cells // args.particles_div, "maxage": 256,
+            "parallelism": "row-slabs x%d" % world if world > 1 else "single GPU",
+        },
+        "phases_ms": {"particles_fluvial": phase[0] / K, "particles_debris": phase[1] / K,
+                      "cells_fused": phase[2] / K},
+        "cell_phase_mcells_per_s": cells_rank / t_cells / 1e6 * world,
+        "roofline": {"bound": "hbm", "kernel": "k_erode_cells_fused", "achieved": achieved,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": traffic,
+                     "algorithmic_bytes_per_launch": CELL_BYTES * cells_rank,
+                     "avg_launch_ms": t_cells * 1e3},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.cpu_size)
+    print(json.dumps(out))
+
+
+def _interleave(lib, _abi, layers, bed):
+    """layers[..., 0] = bed, layers[..., 1] = 0, on the device (no host round trip)."""
+    _abi.check(lib.soil_layers_from_planes(layers.c_ptr, bed.c_ptr, None, bed.elem(),
+                                           _abi.stream()))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,381 @@
+/*
+ * soil_hip.h — C ABI of the MI355X-native grid-erosion hot path.
+ *
+ * Every entry point below replaces one free function of the reference's
+ * `namespace soil` operator API (the functions the nanobind module
+ * python/source/model.cpp binds).  The reference file:line each one stands in
+ * for is cited next to the declaration.  Paths are relative to the reference
+ * repository root:
+ *
+ *   erosion.hpp / erosion.cu / erosion_map.cu = source/soillib/model/path/...
+ *   graph.hpp / graph.cu                      = source/soillib/model/graph/...
+ *   grad.hpp / grad.cu                        = source/soillib/model/grad/...
+ *   filter.hpp / filter.cu                    = source/soillib/model/filter/...
+ *   path.hpp / path.cu / sample.hpp           = source/soillib/model/path/...
+ *   normal.hpp / noise.hpp                    = source/soillib/op/...
+ *   model.cpp                                 = python/source/model.cpp
+ *
+ * Conventions
+ *  - Plain pointers and sizes only.  All tensor pointers are DEVICE pointers
+ *    (HBM) to dense row-major fp32 / int32 arrays unless the name ends in
+ *    `_host`.  A grid has shape (H, W): axis 0 (x, H rows) is the slow axis,
+ *    axis 1 (y, W columns) is contiguous; a trailing channel axis is fastest
+ *    ((H,W,2) "vec2" planes are float pairs, (H,W,3) "vec3" planes triples).
+ *  - `scale` = {sx, sy, sz}: cell size along axis 0 / axis 1 and metres per
+ *    height unit (erosion.cu:50-51).  2-component scales are {sx, sy}.
+ *  - `stream` is a hipStream_t passed as void*; NULL = the null stream.  All
+ *    functions are asynchronous on that stream unless stated otherwise.
+ *  - Return value: 0 (SOIL_OK) or a negative soil_status; the message of the
+ *    last failure on the calling thread is available from soil_last_error().
+ *  - No entry point has a CPU fallback.  Without a usable HIP device every
+ *    compute call returns SOIL_ERR_NO_DEVICE.
+ */
+#ifndef SOIL_HIP_H
+#define SOIL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SOIL_HIP_ABI_VERSION 1
+
+/* ------------------------------------------------------------------ status */
+
+typedef enum soil_status {
+  SOIL_OK = 0,
+  SOIL_ERR_INVALID_ARGUMENT = -1, /* std::invalid_argument in the reference (graph.cu:88) */
+  SOIL_ERR_NO_DEVICE = -2,        /* no HIP device / runtime failure at init            */
+  SOIL_ERR_HIP = -3,              /* a HIP runtime call failed (message has the detail) */
+  SOIL_ERR_OUT_OF_MEMORY = -4
+} soil_status;
+
+/* graph.hpp:11-14  enum edge_t { D4 = 0, D8 = 1 } */
+typedef enum soil_edge { SOIL_D4 = 0, SOIL_D8 = 1 } soil_edge;
+
+/* ------------------------------------------------------------------- types */
+
+/* erosion.hpp:17-58  soil::param_t — same fields, same order, same defaults
+ * (see soil_param_default).  112 bytes, passed by const pointer, copied into
+ * kernel arguments. */
+typedef struct soil_param {
+  uint64_t maxage;              /* erosion.hpp:20 */
+  float lrate;                  /* :21 (read by no kernel) */
+  float timeStep;               /* :22 */
+  float exitSlope;              /* :25 */
+  float uplift;                 /* :26 */
+  float rainfall;               /* :27 */
+  float gravity;                /* :28 */
+  float evapRate;               /* :29 */
+  float frictionFactor;         /* :32 */
+  float fluvialExponent;        /* :33 */
+  float suspensionRateFluvial;  /* :35 */
+  float depositionRateFluvial;  /* :36 */
+  float suspensionRateDebris;   /* :38 */
+  float depositionRateDebris;   /* :39 */
+  float landslideRateDebris;    /* :40 */
+  float critSlopeBedrock;       /* :43 */
+  float critSlopeSediment;      /* :44 */
+  float yieldStress;            /* :45 */
+  float viscosityWater;         /* :47 */
+  float bedShearWater;          /* :48 */
+  float densityWater;           /* :49 */
+  float viscosityDebris;        /* :51 */
+  float bedShearDebris;         /* :52 */
+  float densityDebris;          /* :53 */
+  float force[2];               /* :56 */
+  float _pad;
+} soil_param;
+
+/* One element of a `silt::rng` tensor (erosion.hpp:6 uses curandState).
+ * The reference's generator is cuRAND XORWOW, closed source and not
+ * reproducible off NVIDIA hardware; this ABI fixes a counter-based generator
+ * instead: Philox4x32-10 with key = seed, counter =
+ * {offset, subsequence}, subsequence = element index — i.e. the same
+ * (seed, subsequence = n, offset) addressing as curand_init(seed, n, offset)
+ * at graph.cu:100.  One draw advances `offset` by one. */
+typedef struct soil_rng {
+  uint64_t seed;
+  uint64_t offset;
+} soil_rng;
+
+/* A row slab of a global (H, W) grid held by one GPU.  Every tensor handed to
+ * a *_slab entry point covers local rows [0, rows) == global rows
+ * [x0, x0+rows); the kernel writes only local rows [r0, r1) and evaluates
+ * boundary conditions (exitSlope, clamp-to-self) against the GLOBAL border.
+ * Single-GPU calls use {H, W, 0, H, 0, H}. */
+typedef struct soil_domain {
+  int64_t H, W;   /* global grid shape                              */
+  int64_t x0;     /* global row index of local row 0                */
+  int64_t rows;   /* local rows held by every buffer (owned+ghost)  */
+  int64_t r0, r1; /* local row range this call computes / owns      */
+} soil_domain;
+
+/* ---------------------------------------------------------------- runtime */
+
+int soil_abi_version(void);
+const char* soil_last_error(void);
+/* Number of visible HIP devices (0 if none); never fails. */
+int soil_device_count(void);
+int soil_set_device(int device);
+/* Writes the gcnArchName of the current device ("gfx950...") into buf. */
+int soil_device_name(char* buf, size_t len);
+void soil_param_default(soil_param* p);
+
+/* silt tensor storage (un-vendored silt: tensor_t(shape, GPU) allocations,
+ * .cpu()/.gpu() copies — call sites graph.cu:80, example/dem_multiflow.py:25). */
+int soil_malloc(void** ptr, size_t bytes);
+int soil_free(void* ptr);
+int soil_memcpy_h2d(void* dst, const void* src_host, size_t bytes, void* stream);
+int soil_memcpy_d2h(void* dst_host, const void* src, size_t bytes, void* stream);
+int soil_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream);
+int soil_stream_synchronize(void* stream);
+int soil_device_synchronize(void);
+
+/* HIP-event timing on the stream kernels are launched on (bench.py). */
+int soil_event_create(void** event);
+int soil_event_destroy(void* event);
+int soil_event_record(void* event, void* stream);
+int soil_event_elapsed_ms(void* start, void* stop, float* ms); /* synchronises on stop */
+
+/* silt element-wise ops used by the scripts (silt.set/add/multiply/seed:
+ * example/erosion_gpu.py:19, example/dem_process.py:46-47,81; graph.cu:552-553). */
+int soil_set_f32(float* t, float value, int64_t n, void* stream);
+int soil_set_i32(int32_t* t, int32_t value, int64_t n, void* stream);
+int soil_add_f32(float* t, const float* other, int64_t n, void* stream);       /* t += other */
+int soil_multiply_f32(float* t, float value, int64_t n, void* stream);         /* t *= value */
+int soil_rng_seed(soil_rng* rng, int64_t n, uint64_t seed, uint64_t offset, void* stream);
+
+/* Evaluates the library's numerical primitives on device arrays so that tests
+ * can compare them with the oracle bit for bit:
+ *   op 0: out[i] = expf_(a[i])        stand-in for __expf
+ *   op 1: out[i] = log2f_(a[i])
+ *   op 2: out[i] = powf_(a[i], b[i])  stand-in for __powf
+ *   op 3: out[i] = uniform in (0,1] of stream (seed = bits of a[i],
+ *                  subsequence = i, offset = bits of b[i])  — Philox4x32-10
+ *   op 4: out[i] = a[i] * b[i] (plain product; exposes denormal flushing) */
+int soil_selftest_math(float* out, const float* a, const float* b, int64_t n, int op,
+                       void* stream);
+
+/* --------------------------------------------------- erosion: particle ops */
+
+/* soil::transport_fluvial — erosion.hpp:69-84, erosion.cu:189-239
+ * (= __transport_fluvial :29-141 + __normalize_fluvial :143-187), bound at
+ * model.cpp:237-268.  Argument names follow erosion.cu:189-204.
+ *   layers (H,W,2)  rainfall (H,W)  waterHeight (H,W) out  waterFlux (H,W) inout
+ *   mass (H,W) out  massFlux (H,W) inout  velocity (H,W,2) inout
+ *   velocityFlux (H,W,2) inout  albedoFlux (H,W,3) inout  albedoSource (H,W,3)
+ *   rng [N] inout.
+ * The flux planes are only ever added to (atomics) and must be zeroed by the
+ * caller.  `albedo_bedrock` is accepted and unused, as in the reference.
+ * albedoFlux/albedoSource may both be NULL: the colour channels are then
+ * skipped (physics planes are unaffected). */
+int soil_transport_fluvial(const float* layers, const float* rainfall, float* waterHeight,
+                           float* waterFlux, float* mass, float* massFlux, float* velocity,
+                           float* velocityFlux, const float* albedo_bedrock, float* albedoFlux,
+                           const float* albedoSource, soil_rng* rng, int64_t N, int64_t H,
+                           int64_t W, const float scale[3], const soil_param* param,
+                           void* stream);
+
+/* soil::transport_debris — erosion.hpp:86-98, erosion.cu:395-436
+ * (= __transport_debris :245-351 + __normalize_debris :353-393), model.cpp:270-295. */
+int soil_transport_debris(const float* layers, float* velocity, float* velocityFlux, float* mass,
+                          float* massFlux, const float* albedo_bedrock, float* albedoFlux,
+                          const float* albedoSource, soil_rng* rng, int64_t N, int64_t H,
+                          int64_t W, const float scale[3], const soil_param* param,
+                          void* stream);
+
+/* ------------------------------------------------------- erosion: cell ops */
+
+/* soil::mass_transfer — erosion.hpp:104-119, erosion.cu:576-611 (__transfer
+ * :453-574), model.cpp:297-328.  delta (H,W,2) inout, layers (H,W,2),
+ * uplift/waterHeight/mass/debris (H,W), velocityFluvial/momentumDebris
+ * (H,W,2); waterHeight and momentumDebris are accepted and unread, as in the
+ * reference.  The four albedo planes (H,W,3) may all be NULL (colour mixing
+ * skipped). */
+int soil_mass_transfer(float* delta, const float* layers, const float* uplift,
+                       const float* waterHeight, const float* mass, const float* velocityFluvial,
+                       const float* debris, const float* momentumDebris,
+                       const float* albedo_bedrock, const float* albedoFluxFluvial,
+                       const float* albedoFluxDebris, float* albedo_surface, int64_t H, int64_t W,
+                       const float scale[3], const soil_param* param, void* stream);
+
+/* soil::mass_creep — erosion.hpp:121-126, erosion.cu:712-727 (__mass_creep
+ * :633-710), model.cpp:330-341. */
+int soil_mass_creep(float* delta, const float* layers, int64_t H, int64_t W,
+                    const float scale[3], const soil_param* param, void* stream);
+
+/* soil::layer_merge — erosion.hpp:130-133, erosion.cu:747-757 (__layer_merge
+ * :733-745), model.cpp:343-351.  n = H*W cells. */
+int soil_layer_merge(float* height, const float* layers, int64_t n, void* stream);
+
+/* Interleave / split the (n,2) layer plane and its two (n) component planes:
+ * the legacy map_t kept `height` (bedrock) and `sediment` apart
+ * (model.cpp:67-97, commented out) while the live kernels take `layers`
+ * (layer_t = vec2, erosion.hpp:60).  `sediment` == NULL reads as zeros in
+ * from_planes and is skipped in to_planes. */
+int soil_layers_from_planes(float* layers, const float* bedrock, const float* sediment, int64_t n,
+                            void* stream);
+int soil_layers_to_planes(float* bedrock, float* sediment, const float* layers, int64_t n,
+                          void* stream);
+
+/* soil::albedo_stratum / albedo_layer / albedo_discharge — erosion.hpp:139-166,
+ * erosion.cu:828-854 / :877-898 / :900-919, model.cpp:353-407. */
+int soil_albedo_stratum(float* albedoBedrock, const float* uplift, const float* layers,
+                        int64_t n, const float scale[3], const soil_param* param,
+                        const float colorA[3], const float colorB[3], float age, float freq,
+                        void* stream);
+int soil_albedo_layer(float* albedo, const float* albedoBedrock, const float* albedoSediment,
+                      const float* layers, int64_t n, float scaleSediment,
+                      const float shiftSediment[3], void* stream);
+int soil_albedo_discharge(float* albedo, const float* discharge, int64_t n,
+                          const float colorDischarge[3], float extinction, float scale,
+                          void* stream);
+
+/* ---------------------------------------------- erosion: fused step (slab) */
+
+/* The planes of one erosion model, for the fused step.  All device pointers.
+ * `layers`/`layers_next` are the double buffer of the (rows,W,2) layer plane:
+ * the step reads `layers`, writes `layers_next`; the caller swaps them. */
+typedef struct soil_erosion_planes {
+  const float* layers;      /* (rows,W,2) in   bedrock, sediment                         */
+  float* layers_next;       /* (rows,W,2) out  layers + delta                            */
+  float* height;            /* (rows,W)   out  layer_merge of layers_next (may be NULL)  */
+  const float* uplift;      /* (rows,W)   in                                             */
+  const float* rainfall;    /* (rows,W)   in   waterSource                               */
+  float* waterHeight;       /* (rows,W)   out  "discharge"                               */
+  float* waterFlux;         /* (rows,W)   in → re-zeroed  "discharge_track"              */
+  float* mass;              /* (rows,W)   out  fluvial suspended mass                    */
+  float* massFlux;          /* (rows,W)   in → re-zeroed                                 */
+  float* velocity;          /* (rows,W,2) out  fluvial "momentum"                        */
+  float* velocityFlux;      /* (rows,W,2) in → re-zeroed                                 */
+  float* debris;            /* (rows,W)   out  debris mass                               */
+  float* debrisFlux;        /* (rows,W)   in → re-zeroed                                 */
+  float* debrisVelocity;    /* (rows,W,2) out                                            */
+  float* debrisVelocityFlux;/* (rows,W,2) in → re-zeroed                                 */
+} soil_erosion_planes;
+
+/* Fused cell phase of one erosion step: for every owned cell, in one pass,
+ *   __normalize_fluvial (erosion.cu:143-187) + __normalize_debris (:353-393)
+ *   + [delta = 0] + __transfer (:453-574) + __mass_creep (:633-710)
+ *   + layers_next = layers + delta (silt.add, example/dem_process.py:47)
+ *   + __layer_merge (:733-745) + re-zero of the five flux planes,
+ * bit-identical to running those reference steps one after another (same
+ * operation order per cell).  Physics planes only (no albedo).  This is the
+ * HBM-roofline kernel: 112 algorithmic bytes per cell. */
+int soil_erode_cells_fused(const soil_erosion_planes* planes, const soil_domain* dom,
+                           const float scale[3], const soil_param* param, void* stream);
+
+/* Particle halves of transport_fluvial / transport_debris alone (no
+ * normalise), on a slab: __transport_fluvial erosion.cu:29-141,
+ * __transport_debris :245-351.  Thread n draws its spawn position in the
+ * GLOBAL (dom->H, dom->W) grid from rng[n]; only particles whose spawn row
+ * lies in global rows [x0+r0, x0+r1) are traced, the rest only advance their
+ * rng state, so N ranks that each own one slab trace every particle exactly
+ * once.  A trajectory that leaves local rows [0, rows) through an interior
+ * (non-global) slab edge is a caller error (size the ghost zone with
+ * soil_ghost_rows). */
+int soil_particles_fluvial_slab(float* waterFlux, float* massFlux, float* velocityFlux,
+                                float* albedoFlux, soil_rng* rng, int64_t N,
+                                const float* layers, const float* rainfall,
+                                const float* waterHeight, const float* velocity,
+                                const float* albedoSource, const soil_domain* dom,
+                                const float scale[3], const soil_param* param, void* stream);
+int soil_particles_debris_slab(float* massFlux, float* velocityFlux, float* albedoFlux,
+                               soil_rng* rng, int64_t N, const float* layers,
+                               const float* velocity, const float* albedoSource,
+                               const soil_domain* dom, const float scale[3],
+                               const soil_param* param, void* stream);
+/* Ghost rows a slab needs on each interior side so that no trajectory can
+ * leave it: ceil(sqrt(2) * maxage) + 2 (one __stepsize step moves a particle
+ * by at most sqrt(2) cells, erosion_map.cu:61-76). */
+int64_t soil_ghost_rows(const soil_param* param);
+
+/* ------------------------------------------------------------- flow graphs */
+
+/* soil::direction — graph.hpp:49, graph.cu:246-264 (__direction :201-243), model.cpp:157-159. */
+int soil_direction(int32_t* direction, const float* height, int64_t H, int64_t W, int edge,
+                   void* stream);
+/* soil::steepest — graph.hpp:52, graph.cu:73-91 (__steepest :27-70), model.cpp:169-171. */
+int soil_steepest(int32_t* graph, const float* height, int64_t H, int64_t W, int edge,
+                  void* stream);
+/* soil::random_weighted — graph.hpp:54, graph.cu:175-195 (__seed :97-101,
+ * __random_weighted :103-173), model.cpp:173-175.  Stateless: cell n draws
+ * its one uniform from (seed, subsequence n, offset). */
+int soil_random_weighted(int32_t* graph, const float* height, int64_t H, int64_t W, int edge,
+                         uint64_t seed, uint64_t offset, float T, void* stream);
+/* soil::slope — graph.hpp:63, graph.cu:297-311 (__slope :270-295), model.cpp:161-163. */
+int soil_slope(float* slope, const float* tensor, const int32_t* flow, int64_t H, int64_t W,
+               const float scale[2], void* stream);
+/* soil::accumulate / accumulate_decay — graph.hpp:57-60, graph.cu:578-593
+ * (__accumulate :526-576: __donor :321-348, __count :350-380, my_decay
+ * :382-420, __rake_compress :429-522), model.cpp:181-187.  `decay` == NULL
+ * selects accumulate (scalar decay 1).  Scratch comes from a cached
+ * per-device workspace, not from per-call allocations.  Synchronises the
+ * stream before returning, like the reference (graph.cu:564). */
+int soil_accumulate(float* out, const int32_t* graph, const float* source, const float* decay,
+                    int64_t H, int64_t W, int edge, void* stream);
+/* Frees the cached accumulate workspace of the current device. */
+int soil_workspace_release(void);
+
+/* ---------------------------------------------------------------- stencils */
+
+/* soil::gradient — grad.hpp:11, grad.cu:89-97 (__gradient :22-87), model.cpp:193-195.  out (H,W,2). */
+int soil_gradient(float* out, const float* in, int64_t H, int64_t W, const float scale[2],
+                  void* stream);
+/* soil::negslope — grad.hpp:17, grad.cu:133-141 (__negslope :101-131), model.cpp:201-203. */
+int soil_negslope(float* out, const float* in, int64_t H, int64_t W, const float scale[2],
+                  void* stream);
+/* soil::laplacian — grad.hpp:14, grad.cu:186-206 (__laplacian<D> :147-183), model.cpp:197-199.
+ * in/out (H,W,D), D in {1,2}. */
+int soil_laplacian(float* out, const float* in, int64_t H, int64_t W, int D,
+                   const float scale[2], void* stream);
+/* soil::gaussian_blur — filter.hpp:11, filter.cu:72-91 (__blur :59-70,
+ * __gaussian_blur :24-56), model.cpp:189-191.  tensor (H,W,C), C in {1,2}, is
+ * blurred IN PLACE (the reference returns its input handle, filter.cu:90);
+ * scratch (H,W,C) is the intermediate of the axis-0 pass. */
+int soil_gaussian_blur(float* tensor, float* scratch, int64_t H, int64_t W, int C, float sigma,
+                       void* stream);
+/* soil::op::normal — normal.hpp:19-39 (CPU loop in the reference; unbound in
+ * its module, used by example/tiff_normal.py:14).  out (H,W,3). */
+int soil_normal(float* out, const float* in, int64_t H, int64_t W, const float scale[3],
+                void* stream);
+/* Host twin of soil_normal for CPU tensors (the reference's only placement). */
+int soil_normal_host(float* out_host, const float* in_host, int64_t H, int64_t W,
+                     const float scale[3]);
+
+/* -------------------------------------------------------- path-integral MC */
+
+/* soil::solve_uniform — path.hpp:30-37, path.cu:180-219 (__solve_uniform<K>
+ * :52-139, __normalize<K> :142-170; bilinear gather sample.hpp:154-186),
+ * model.cpp:209-227.  flow (H,W,2), source/flux (H,W,K), K in {1,2}, decay
+ * (H,W), rng [N].  flux is zeroed, filled and normalised; synchronises. */
+int soil_solve_uniform(float* flux, const float* flow, const float* source, const float* decay,
+                       soil_rng* rng, int64_t N, int64_t H, int64_t W, int K,
+                       const float scale[2], uint64_t count, void* stream);
+
+/* ------------------------------------------------------------------- noise */
+
+/* soil::noise_param_t / soil::noise — noise.hpp:14-56, model.cpp:413-421:
+ * OpenSimplex2 FBm, 3-D sample at (x/ext0, y/ext1, seed). */
+typedef struct soil_noise_param {
+  float frequency;  /* noise.hpp:29, default 1    */
+  int32_t octaves;  /* :30, default 8             */
+  float gain;       /* :31, default 0.6           */
+  float lacunarity; /* :32, default 2             */
+  float seed;       /* :33, default 0 (z coord)   */
+  float ext[2];     /* :34, default {512, 512}    */
+} soil_noise_param;
+void soil_noise_param_default(soil_noise_param* p);
+/* Device generator (bench inputs at 8192^2+) and host twin (the reference's
+ * placement, noise.hpp:49-52); both produce identical bits. */
+int soil_noise(float* out, int64_t H, int64_t W, const soil_noise_param* p, void* stream);
+int soil_noise_host(float* out_host, int64_t H, int64_t W, const soil_noise_param* p);
+
+#ifdef __cplusplus
+} /* extern "C" */
+#endif
+
+#endif /* SOIL_HIP_H */

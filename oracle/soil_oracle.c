@@ -1,0 +1,1142 @@
+/*
+ * soil_oracle.c — CPU restatement of the reference's grid-erosion kernels.
+ * TEST INFRASTRUCTURE ONLY; see soil_oracle.h for the rules and for the
+ * "parity unpinned" statement.
+ *
+ * One function per reference __global__ kernel, statement order kept.  Paths:
+ *   erosion.cu / erosion_map.cu / path.cu / sample.hpp = source/soillib/model/path/
+ *   graph.hpp / graph.cu = source/soillib/model/graph/
+ *   grad.cu = source/soillib/model/grad/      filter.cu = source/soillib/model/filter/
+ *   normal.hpp = source/soillib/op/
+ *
+ * Build: gcc -O2 -ffp-contract=off -fopenmp (oracle/Makefile).  fp32 only; no
+ * fast-math; every expression is parenthesised the way C++ evaluates the
+ * reference's expression so that the HIP kernels can be compared bit for bit.
+ */
+#include "soil_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_SQRT2 1.41421354f /* CUDART_SQRT_TWO_F, erosion_map.cu:61 */
+
+/* ------------------------------------------------------------ parameters */
+
+void orc_param_default(orc_param* p) { /* erosion.hpp:20-56 */
+  memset(p, 0, sizeof(*p));
+  p->maxage = 512;
+  p->lrate = 1.0f;
+  p->timeStep = 250.0f;
+  p->exitSlope = 0.02f;
+  p->uplift = 0.001f;
+  p->rainfall = 1.0f;
+  p->gravity = 9.81f;
+  p->evapRate = 0.0002f;
+  p->frictionFactor = 0.06f;
+  p->fluvialExponent = 2.0f;
+  p->suspensionRateFluvial = 4.5E-8f;
+  p->depositionRateFluvial = 0.04f;
+  p->suspensionRateDebris = 0.001f;
+  p->depositionRateDebris = 0.01f;
+  p->landslideRateDebris = 0.003f;
+  p->critSlopeBedrock = 0.57f;
+  p->critSlopeSediment = 0.3f;
+  p->yieldStress = 0.001f;
+  p->viscosityWater = 1E-6f;
+  p->bedShearWater = 0.0075f;
+  p->densityWater = 1.0f;
+  p->viscosityDebris = 0.0f;
+  p->bedShearDebris = 0.99f;
+  p->densityDebris = 2.0f;
+  p->force[0] = 0.0f;
+  p->force[1] = 0.0f;
+}
+
+/* ------------------------------------------------------------- spec math */
+
+static float orc_bits2f(uint32_t u) {
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+static uint32_t orc_f2bits(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  return u;
+}
+/* 2^n for n in [-126, 127] */
+static float orc_pow2i(int n) { return orc_bits2f((uint32_t)(n + 127) << 23); }
+
+/* exp(r*...) core shared by expf / exp2f: p(r) ~ exp(r), |r| <= ln2/2 */
+static float orc_exp_poly(float r) {
+  float p = 1.9875691500E-4f;
+  p = p * r + 1.3981999507E-3f;
+  p = p * r + 8.3334519073E-3f;
+  p = p * r + 4.1665795894E-2f;
+  p = p * r + 1.6666665459E-1f;
+  p = p * r + 5.0000001201E-1f;
+  return (p * (r * r) + r) + 1.0f;
+}
+
+/* Software stand-in for CUDA's __expf (erosion.cu:134-136,345-346,872,
+ * graph.cu:139, filter.cu:48, path.cu:134).  Results below e^-87 flush to 0
+ * (the intrinsic is flush-to-zero as well). */
+float orc_expf(float x) {
+  if (x != x) return x;
+  if (x > 88.72283f) return INFINITY;
+  if (x < -87.0f) return 0.0f;
+  const float n = rintf(x * 1.44269504f);
+  float r = x - n * 0.693145752f;
+  r = r - n * 1.42860677e-6f;
+  const float y = orc_exp_poly(r);
+  const int ni = (int)n;
+  const int n1 = ni / 2;
+  const int n2 = ni - n1;
+  return (y * orc_pow2i(n1)) * orc_pow2i(n2);
+}
+
+/* log2 of a positive normal float; 0 and subnormals -> -inf, x<0 -> NaN. */
+float orc_log2f(float x) {
+  if (x != x) return x;
+  if (x < 0.0f) return NAN;
+  if (x < 1.17549435e-38f) return -INFINITY;
+  if (x == INFINITY) return INFINITY;
+  const uint32_t b = orc_f2bits(x);
+  int e = (int)((b >> 23) & 0xffu) - 127;
+  float m = orc_bits2f((b & 0x007fffffu) | 0x3f800000u);
+  if (m > ORC_SQRT2) {
+    m = m * 0.5f;
+    e = e + 1;
+  }
+  const float f = m - 1.0f;
+  const float z = f * f;
+  float p = 7.0376836292E-2f;
+  p = p * f - 1.1514610310E-1f;
+  p = p * f + 1.1676998740E-1f;
+  p = p * f - 1.2420140846E-1f;
+  p = p * f + 1.4249322787E-1f;
+  p = p * f - 1.6668057665E-1f;
+  p = p * f + 2.0000714765E-1f;
+  p = p * f - 2.4999993993E-1f;
+  p = p * f + 3.3333331174E-1f;
+  float y = (f * z) * p;
+  y = y - 0.5f * z;
+  const float ln_m = f + y;
+  return ln_m * 1.44269504f + (float)e;
+}
+
+/* Software stand-in for CUDA's __powf(x,y) = exp2f(y*__log2f(x))
+ * (erosion.cu:85,500; graph.cu:409-411). */
+float orc_powf(float x, float y) {
+  const float t = y * orc_log2f(x);
+  if (t != t) return t;
+  if (t > 128.0f) return INFINITY;
+  if (t < -126.0f) return 0.0f;
+  const float n = rintf(t);
+  const float r = (t - n) * 0.693147182f;
+  const float v = orc_exp_poly(r);
+  const int ni = (int)n;
+  const int n1 = ni / 2;
+  const int n2 = ni - n1;
+  return (v * orc_pow2i(n1)) * orc_pow2i(n2);
+}
+
+/* Philox4x32-10 (Salmon et al., SC'11), the stand-in for cuRAND XORWOW. */
+void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+  uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
+  uint32_t k0 = key[0], k1 = key[1];
+  for (int round = 0; round < 10; ++round) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c0 = n0;
+    c1 = n1;
+    c2 = n2;
+    c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0;
+  out[1] = c1;
+  out[2] = c2;
+  out[3] = c3;
+}
+
+/* counter = {offset, subsequence}, key = seed: the addressing of
+ * curand_init(seed, subsequence, offset) (graph.cu:100). */
+uint32_t orc_rng_next(orc_rng* s, uint64_t subsequence) {
+  const uint32_t ctr[4] = {(uint32_t)s->offset, (uint32_t)(s->offset >> 32), (uint32_t)subsequence,
+                           (uint32_t)(subsequence >> 32)};
+  const uint32_t key[2] = {(uint32_t)s->seed, (uint32_t)(s->seed >> 32)};
+  uint32_t out[4];
+  orc_philox4x32_10(ctr, key, out);
+  s->offset += 1;
+  return out[0];
+}
+
+/* (0, 1] like curand_uniform (graph.cu:150 relies on the closed upper end). */
+float orc_rng_uniform(orc_rng* s, uint64_t subsequence) {
+  const uint32_t r = orc_rng_next(s, subsequence);
+  return (float)((r >> 8) + 1u) * 5.9604644775390625e-08f; /* 2^-24 */
+}
+
+void orc_rng_seed(orc_rng* rng, int64_t n, uint64_t seed, uint64_t offset) {
+  for (int64_t i = 0; i < n; ++i) {
+    rng[i].seed = seed;
+    rng[i].offset = offset;
+  }
+}
+
+/* ---------------------------------------------------------- map helpers */
+
+static float orc_length2(float x, float y) { return sqrtf(x * x + y * y); } /* erosion_map.cu:49-53 */
+
+/* erosion_map.cu:56-78 (duplicate path.cu:27-49) */
+float orc_stepsize(float px, float py, float dx, float dy) {
+  const float tmax = ORC_SQRT2;
+  const float x_neg = floorf(px);
+  const float y_neg = floorf(py);
+  const float x_pos = 1.0f + x_neg;
+  const float y_pos = 1.0f + y_neg;
+  const float tx_neg = (x_neg - px) / dx;
+  const float tx_pos = (x_pos - px) / dx;
+  const float tx = fminf(fmaxf(tx_neg, tx_pos), tmax);
+  const float ty_neg = (y_neg - py) / dy;
+  const float ty_pos = (y_pos - py) / dy;
+  const float ty = fminf(fmaxf(ty_neg, ty_pos), tmax);
+  return 0.5f * (tx + ty);
+}
+
+/* layers of global cell (gx, y) in a slab-local buffer; erosion_map.cu:99-105 */
+static float orc_height(const float* layers, const orc_domain* d, int64_t gx, int64_t y) {
+  const int64_t i = (gx - d->x0) * d->W + y;
+  return layers[2 * i] + layers[2 * i + 1];
+}
+
+/* erosion_map.cu:107-159 */
+void orc_glocal(const float* layers, const orc_domain* d, const float scale[3], int64_t gx,
+                int64_t y, float exitSlope, float g[2]) {
+  const float h = orc_height(layers, d, gx, y);
+  const float hn0 = (gx - 1 < 0) ? NAN : orc_height(layers, d, gx - 1, y);     /* :122 */
+  const float hp0 = (gx + 1 >= d->H) ? NAN : orc_height(layers, d, gx + 1, y); /* :123 */
+  const float h0n = (y - 1 < 0) ? NAN : orc_height(layers, d, gx, y - 1);      /* :124 */
+  const float h0p = (y + 1 >= d->W) ? NAN : orc_height(layers, d, gx, y + 1);  /* :125 */
+
+  float gxn = (h - hn0) * scale[2] / scale[0]; /* :131-133 */
+  if (isnan(gxn)) gxn = exitSlope;
+  else gxn = fmaxf(gxn, 0.0f);
+  float gyn = (h - h0n) * scale[2] / scale[1]; /* :135-137 */
+  if (isnan(gyn)) gyn = exitSlope;
+  else gyn = fmaxf(gyn, 0.0f);
+  float gxp = (hp0 - h) * scale[2] / scale[0]; /* :139-141 */
+  if (isnan(gxp)) gxp = -exitSlope;
+  else gxp = fminf(gxp, 0.0f);
+  float gyp = (h0p - h) * scale[2] / scale[1]; /* :143-145 */
+  if (isnan(gyp)) gyp = -exitSlope;
+  else gyp = fminf(gyp, 0.0f);
+
+  float gx_ = 0.0f; /* :149-155 (device abs on floats == fabsf) */
+  if (fabsf(gxn) > fabsf(gx_)) gx_ = gxn;
+  if (fabsf(gxp) > fabsf(gx_)) gx_ = gxp;
+  float gy_ = 0.0f;
+  if (fabsf(gyn) > fabsf(gy_)) gy_ = gyn;
+  if (fabsf(gyp) > fabsf(gy_)) gy_ = gyp;
+  g[0] = gx_;
+  g[1] = gy_;
+}
+
+/* __oob, erosion_map.cu:29-40, against the GLOBAL shape */
+static int orc_oob(const orc_domain* d, float px, float py) {
+  if (px < 0) return 1;
+  if (py < 0) return 1;
+  if (px >= (float)d->H) return 1;
+  if (py >= (float)d->W) return 1;
+  return 0;
+}
+
+/* A slab may only trace particles while their 5-point stencil stays inside
+ * the rows it holds; the global border is handled by exitSlope instead. */
+static int orc_slab_escape(const orc_domain* d, int64_t gx) {
+  const int64_t lx = gx - d->x0;
+  const int64_t lo = (d->x0 == 0) ? 0 : 1;
+  const int64_t hi = (d->x0 + d->rows == d->H) ? d->rows - 1 : d->rows - 2;
+  return lx < lo || lx > hi;
+}
+
+static void orc_atomic_add(float* p, float v, int threads) {
+  if (threads > 1) {
+#pragma omp atomic
+    *p += v;
+  } else {
+    *p += v;
+  }
+}
+
+/* ------------------------------------------------ fluvial particles (A3) */
+
+/* __transport_fluvial, erosion.cu:29-141 */
+void orc_particles_fluvial(float* waterFlux, float* massFlux, float* velocityFlux,
+                           float* albedoFlux, orc_rng* rng, int64_t N, const float* layers,
+                           const float* waterSource, const float* waterHeight,
+                           const float* velocity, const float* albedoSource,
+                           const orc_domain* d, const float scale[3], const orc_param* param,
+                           int threads, int64_t* steps_out) {
+  const int64_t W = d->W;
+  const int64_t base = d->x0 * W; /* global flat index of local element 0 */
+  int64_t steps_total = 0;
+  const int nthreads = threads > 1 ? threads : 1;
+
+#pragma omp parallel for schedule(dynamic, 256) num_threads(nthreads) reduction(+ : steps_total)
+  for (int64_t n = 0; n < N; ++n) {
+    const float A = scale[0] * scale[1];                   /* :50 */
+    const float Lx = scale[0], Ly = scale[1];              /* :51 */
+    const float P = 1.0f / (A * (float)(d->H * d->W));     /* :53 */
+    const float Q = 1.0f / (P * (float)N);                 /* :54 */
+    const float eps = 1E-12f;                              /* :55 */
+    const float u1 = orc_rng_uniform(&rng[n], (uint64_t)n); /* :57 */
+    const float u2 = orc_rng_uniform(&rng[n], (uint64_t)n); /* :58 */
+    float px = 0.5f + u1 * (float)(d->H - 1);
+    float py = 0.5f + u2 * (float)(d->W - 1);
+    {
+      const int64_t sx = (int64_t)px - d->x0; /* spawn-row ownership (slab) */
+      if (sx < d->r0 || sx >= d->r1) continue;
+    }
+    int64_t ind = (int64_t)px * W + (int64_t)py; /* :60 (__flatten truncates, erosion_map.cu:42-47) */
+
+    const float rho_w = param->densityWater;               /* :63 */
+    const float tau = param->bedShearWater;                /* :65 */
+    const float nu = param->viscosityWater;                /* :66 */
+    const float g = param->gravity;                        /* :67 */
+    const float ks = param->suspensionRateFluvial / 64.0f; /* :68 */
+    const float kd = param->depositionRateFluvial * 1.33f; /* :69 */
+    const float fD = param->frictionFactor / 8.0f;         /* :70 */
+    const float alpha = param->fluvialExponent;            /* :71 */
+    const float R = param->rainfall;                       /* :72 */
+
+    const float velx = velocity[2 * (ind - base)], vely = velocity[2 * (ind - base) + 1]; /* :75 */
+    float grad[2];
+    orc_glocal(layers, d, scale, (int64_t)px, (int64_t)py, param->exitSlope, grad); /* :76 */
+    float spx = -(g * grad[0]) + nu * velx + param->force[0]; /* :77 */
+    float spy = -(g * grad[1]) + nu * vely + param->force[1];
+    {
+      const float den = sqrtf(orc_length2(Lx * spx, Ly * spy)); /* :78 */
+      spx = spx / den;
+      spy = spy / den;
+    }
+    if (orc_length2(spx, spy) < eps) continue; /* :79-80 */
+
+    const float v = orc_length2(velx, vely);                                /* :83 */
+    const float shear = 0.125f * fD * rho_w * v * v;                        /* :84 */
+    const float power = orc_powf(shear * orc_length2(grad[0], grad[1]), alpha); /* :85 */
+    const float source_m = Q * ks * power;                                  /* :88 */
+    const float source_w = Q * R * waterSource[ind - base];                 /* :89 */
+    const float source_vx = Q * (-(g * grad[0]) + nu * velx);               /* :90 */
+    const float source_vy = Q * (-(g * grad[1]) + nu * vely);
+    float source_a[3] = {0, 0, 0};
+    if (albedoSource) /* :91 */
+      for (int c = 0; c < 3; ++c) source_a[c] = source_m * albedoSource[3 * (ind - base) + c];
+
+    float att_w = 1.0f, att_m = 1.0f, att_v = 1.0f; /* :94-96 */
+    int64_t iter = 0;
+    while (!orc_oob(d, px, py) && (uint64_t)(++iter) < param->maxage) { /* :100 */
+      if (orc_slab_escape(d, (int64_t)px)) break;
+      ++steps_total;
+      const int64_t nind = (int64_t)px * W + (int64_t)py; /* :103 */
+      if (nind != ind) {                                  /* :104-113 */
+        ind = nind;
+        const int64_t l = ind - base;
+        orc_atomic_add(&waterFlux[l], att_w * source_w, threads);
+        orc_atomic_add(&massFlux[l], att_m * source_m, threads);
+        orc_atomic_add(&velocityFlux[2 * l], att_v * source_vx, threads);
+        orc_atomic_add(&velocityFlux[2 * l + 1], att_v * source_vy, threads);
+        if (albedoFlux)
+          for (int c = 0; c < 3; ++c)
+            orc_atomic_add(&albedoFlux[3 * l + c], att_m * source_a[c], threads);
+      }
+      const float v_norm = orc_length2(spx, spy);            /* :116 */
+      const float ux = spx / v_norm, uy = spy / v_norm;      /* :117 */
+      const float v_step = orc_stepsize(px, py, ux, uy);     /* :118 */
+      const float dL = v_step * orc_length2(Lx, Ly);         /* :119 */
+      const float ds = dL / v_norm;                          /* :120 */
+      if (v_norm < eps) break;                               /* :121-122 */
+
+      orc_glocal(layers, d, scale, (int64_t)px, (int64_t)py, param->exitSlope, grad); /* :125 */
+      const int64_t l = ind - base;
+      const float ax = -(g * grad[0]) + nu * velocity[2 * l] + param->force[0]; /* :126 */
+      const float ay = -(g * grad[1]) + nu * velocity[2 * l + 1] + param->force[1];
+      const float w0 = 1.0f / (1.0f + dL * (tau + nu)); /* :127 */
+      const float w1 = dL / (1.0f + dL * (tau + nu));
+      spx = w0 * spx + w1 * ax;
+      spy = w0 * spy + w1 * ay;
+
+      const float decay_m = kd;                                     /* :130 */
+      const float decay_w = param->evapRate;                        /* :131 */
+      const float decay_v = 0.125f * fD / (eps + waterHeight[l]);   /* :132 */
+      att_m = att_m * orc_expf(-ds * decay_m);                      /* :134 */
+      att_w = att_w * orc_expf(-ds * decay_w);                      /* :135 */
+      att_v = att_v * orc_expf(-dL * decay_v);                      /* :136 */
+      px += v_step * ux;                                            /* :137 */
+      py += v_step * uy;
+    }
+  }
+  if (steps_out) *steps_out = steps_total;
+}
+
+/* __normalize_fluvial, erosion.cu:143-187 */
+void orc_normalize_fluvial(const float* waterFlux, const float* massFlux,
+                           const float* velocityFlux, float* albedoFlux, const float* layers,
+                           const float* waterSource, float* waterHeight, float* mass,
+                           float* velocity, const float* albedoSource, const orc_domain* d,
+                           const float scale[3], const orc_param* param) {
+  const float A = scale[0] * scale[1];                                   /* :163 */
+  const float norm = fabsf(1.0f * scale[1]) + fabsf(0.0f * scale[0]);    /* :165-166 */
+  for (int64_t lx = d->r0; lx < d->r1; ++lx)
+    for (int64_t y = 0; y < d->W; ++y) {
+      const int64_t n = lx * d->W + y;
+      float grad[2];
+      orc_glocal(layers, d, scale, d->x0 + lx, y, param->exitSlope, grad); /* :168 */
+      const float m = massFlux[n];                                         /* :170 */
+      const float source_w = param->rainfall * waterSource[n];             /* :173 */
+      const float svx = -param->gravity * grad[0] + param->force[0];       /* :174 */
+      const float svy = -param->gravity * grad[1] + param->force[1];
+      const float source_m = 0.0f;                                         /* :175 */
+      waterHeight[n] = (A * source_w + waterFlux[n]) / norm;               /* :177 */
+      mass[n] = (A * source_m + m) / norm;                                 /* :178 */
+      velocity[2 * n] = (A * svx + velocityFlux[2 * n]) / norm;            /* :179 */
+      velocity[2 * n + 1] = (A * svy + velocityFlux[2 * n + 1]) / norm;
+      if (albedoFlux) { /* :181-185; 3-norm, SURVEY.md Appendix A4 */
+        const float a0 = albedoFlux[3 * n], a1 = albedoFlux[3 * n + 1], a2 = albedoFlux[3 * n + 2];
+        if (m > 0.0f && sqrtf(a0 * a0 + a1 * a1 + a2 * a2) > 0.0f) {
+          albedoFlux[3 * n] = a0 / m;
+          albedoFlux[3 * n + 1] = a1 / m;
+          albedoFlux[3 * n + 2] = a2 / m;
+        } else {
+          for (int c = 0; c < 3; ++c) albedoFlux[3 * n + c] = albedoSource[3 * n + c];
+        }
+      }
+    }
+}
+
+/* -------------------------------------------------- debris particles (A5) */
+
+/* __transport_debris, erosion.cu:245-351 */
+void orc_particles_debris(float* massFlux, float* velocityFlux, float* albedoFlux, orc_rng* rng,
+                          int64_t N, const float* layers, const float* velocity,
+                          const float* albedoSource, const orc_domain* d, const float scale[3],
+                          const orc_param* param, int threads, int64_t* steps_out) {
+  const int64_t W = d->W;
+  const int64_t base = d->x0 * W;
+  int64_t steps_total = 0;
+  const int nthreads = threads > 1 ? threads : 1;
+
+#pragma omp parallel for schedule(dynamic, 256) num_threads(nthreads) reduction(+ : steps_total)
+  for (int64_t n = 0; n < N; ++n) {
+    const float A = scale[0] * scale[1];               /* :263 */
+    const float Lx = scale[0], Ly = scale[1];          /* :264 */
+    const float P = 1.0f / (A * (float)(d->H * d->W)); /* :266 */
+    const float Q = 1.0f / (P * (float)N);             /* :267 */
+    const float eps = 1E-12f;                          /* :268 */
+    const float u1 = orc_rng_uniform(&rng[n], (uint64_t)n); /* :270 */
+    const float u2 = orc_rng_uniform(&rng[n], (uint64_t)n); /* :271 */
+    float px = 0.5f + u1 * (float)(d->H - 1);
+    float py = 0.5f + u2 * (float)(d->W - 1);
+    {
+      const int64_t sx = (int64_t)px - d->x0;
+      if (sx < d->r0 || sx >= d->r1) continue;
+    }
+    int64_t ind = (int64_t)px * W + (int64_t)py; /* :273 */
+
+    const float theta = param->critSlopeBedrock;   /* :276 */
+    const float nu = param->viscosityDebris;       /* :277 */
+    const float tau = param->bedShearDebris;       /* :278 */
+    const float g = param->gravity;                /* :279 */
+    const float kl = param->landslideRateDebris;   /* :280 */
+    const float kdd = param->depositionRateDebris; /* :281 */
+    const float kds = param->suspensionRateDebris; /* :282 */
+    const float tau_y = param->yieldStress;        /* :283 */
+
+    const float velx = velocity[2 * (ind - base)], vely = velocity[2 * (ind - base) + 1]; /* :286 */
+    float grad[2];
+    orc_glocal(layers, d, scale, (int64_t)px, (int64_t)py, param->exitSlope, grad); /* :287 */
+    float spx = -(g * grad[0]) + nu * velx; /* :288 */
+    float spy = -(g * grad[1]) + nu * vely;
+    {
+      const float den = sqrtf(orc_length2(Lx * spx, Ly * spy)); /* :289 */
+      spx = spx / den;
+      spy = spy / den;
+    }
+    if (orc_length2(spx, spy) < eps) continue; /* :290-291 */
+
+    const float excessSlope0 = orc_length2(grad[0], grad[1]) - theta; /* :294 */
+    const float suspend = fmaxf(0.0f, kl * excessSlope0);             /* :295 */
+    const float source_d = Q * suspend;                               /* :297 */
+    const float source_vx = Q * (-g * grad[0] + nu * velx);           /* :298 */
+    const float source_vy = Q * (-g * grad[1] + nu * vely);
+    float source_a[3] = {0, 0, 0};
+    if (albedoSource) /* :299 */
+      for (int c = 0; c < 3; ++c) source_a[c] = source_d * albedoSource[3 * (ind - base) + c];
+
+    float att_d = 1.0f, att_v = 1.0f; /* :301-302 */
+    int64_t iter = 0;
+    while (!orc_oob(d, px, py) && (uint64_t)(++iter) < param->maxage) { /* :306 */
+      if (orc_slab_escape(d, (int64_t)px)) break;
+      ++steps_total;
+      const int64_t nind = (int64_t)px * W + (int64_t)py; /* :309 */
+      if (nind != ind) {                                  /* :310-318 */
+        ind = nind;
+        const int64_t l = ind - base;
+        orc_atomic_add(&massFlux[l], att_d * source_d, threads);
+        orc_atomic_add(&velocityFlux[2 * l], att_v * source_vx, threads);
+        orc_atomic_add(&velocityFlux[2 * l + 1], att_v * source_vy, threads);
+        if (albedoFlux)
+          for (int c = 0; c < 3; ++c)
+            orc_atomic_add(&albedoFlux[3 * l + c], att_d * source_a[c], threads);
+      }
+      const float v_norm = orc_length2(spx, spy);        /* :321 */
+      const float ux = spx / v_norm, uy = spy / v_norm;  /* :322 */
+      const float v_step = orc_stepsize(px, py, ux, uy); /* :323 */
+      const float dL = v_step * orc_length2(Lx, Ly);     /* :324 */
+      const float ds = dL / v_norm;                      /* :325 */
+      if (v_norm < eps) break;                           /* :326-327 */
+
+      orc_glocal(layers, d, scale, (int64_t)px, (int64_t)py, param->exitSlope, grad); /* :330 */
+      const int64_t l = ind - base;
+      const float debrisHeight = eps + att_d * source_d;     /* :331 */
+      const float ax = -(g * grad[0]) + nu * velocity[2 * l]; /* :332 */
+      const float ay = -(g * grad[1]) + nu * velocity[2 * l + 1];
+      const float decay = nu + tau / debrisHeight; /* :333 */
+      const float w = 1.0f / (1.0f + dL * decay);  /* :334 */
+      spx = w * spx + w * dL * ax;                 /* :335 */
+      spy = w * spy + w * dL * ay;
+
+      const float excessSlope = orc_length2(grad[0], grad[1]) - theta;       /* :339 */
+      const float excessStress = g * (excessSlope - tau_y / debrisHeight);   /* :340 */
+      const float shearRate = (excessStress < 0.0f) ? kdd : kds;             /* :341 */
+      const float decay_d = ds * shearRate * excessStress / v_norm;          /* :342 */
+      const float decay_v = nu + tau / debrisHeight;                         /* :343 */
+      att_d = att_d * orc_expf(decay_d);                                     /* :345 */
+      att_v = att_v * orc_expf(-dL * decay_v);                               /* :346 */
+      px += v_step * ux;                                                     /* :347 */
+      py += v_step * uy;
+    }
+  }
+  if (steps_out) *steps_out = steps_total;
+}
+
+/* __normalize_debris, erosion.cu:353-393 */
+void orc_normalize_debris(const float* massFlux, const float* velocityFlux, float* albedoFlux,
+                          const float* layers, float* mass, float* velocity,
+                          const float* albedoSource, const orc_domain* d, const float scale[3],
+                          const orc_param* param) {
+  const float A = scale[0] * scale[1];                                /* :370 */
+  const float norm = fabsf(1.0f * scale[1]) + fabsf(0.0f * scale[0]); /* :372-373 */
+  for (int64_t lx = d->r0; lx < d->r1; ++lx)
+    for (int64_t y = 0; y < d->W; ++y) {
+      const int64_t n = lx * d->W + y;
+      float grad[2];
+      orc_glocal(layers, d, scale, d->x0 + lx, y, param->exitSlope, grad); /* :375 */
+      const float m = massFlux[n];                                         /* :377 */
+      const float svx = -param->gravity * grad[0];                         /* :380 */
+      const float svy = -param->gravity * grad[1];
+      const float source_d = 0.0f;                                         /* :381 */
+      mass[n] = (A * source_d + m) / norm;                                 /* :384 */
+      velocity[2 * n] = (A * svx + velocityFlux[2 * n]) / norm;            /* :385 */
+      velocity[2 * n + 1] = (A * svy + velocityFlux[2 * n + 1]) / norm;
+      if (albedoFlux) { /* :387-391 */
+        const float a0 = albedoFlux[3 * n], a1 = albedoFlux[3 * n + 1], a2 = albedoFlux[3 * n + 2];
+        if (m > 0.0f && sqrtf(a0 * a0 + a1 * a1 + a2 * a2) > 0.0f) {
+          albedoFlux[3 * n] = a0 / m;
+          albedoFlux[3 * n + 1] = a1 / m;
+          albedoFlux[3 * n + 2] = a2 / m;
+        } else {
+          for (int c = 0; c < 3; ++c) albedoFlux[3 * n + c] = albedoSource[3 * n + c];
+        }
+      }
+    }
+}
+
+/* ---------------------------------------------------- mass transfer (A6) */
+
+/* __transfer, erosion.cu:453-574 */
+void orc_mass_transfer(float* deltas, const float* layers, const float* upliftBase,
+                       const float* mass, const float* velocityFluvial, const float* debris,
+                       const float* albedo_bedrock, const float* albedoFluxFluvial,
+                       const float* albedoFluxDebris, float* albedo_surface,
+                       const orc_domain* d, const float scale[3], const orc_param* param) {
+  const float dt = param->timeStep;                        /* :476 */
+  const float ku = param->uplift;                          /* :477 */
+  const float kfs = param->suspensionRateFluvial / 64.0f;  /* :478 */
+  const float kfd = param->depositionRateFluvial * 1.33f;  /* :479 */
+  const float fD = param->frictionFactor / 8.0f;           /* :480 */
+  const float alpha = param->fluvialExponent;              /* :481 */
+  const float rho = param->densityWater;                   /* :482 */
+  const float g = param->gravity;                          /* :483 */
+  const float tau_y = param->yieldStress;                  /* :484 */
+  const float kds = param->suspensionRateDebris;           /* :485 */
+  const float kdd = param->depositionRateDebris;           /* :486 */
+  const float kL = param->landslideRateDebris;             /* :487 */
+  const float eps = 1E-12f;                                /* :488 */
+  const float L = orc_length2(scale[0], scale[1]);         /* :493 */
+
+  for (int64_t lx = d->r0; lx < d->r1; ++lx)
+    for (int64_t y = 0; y < d->W; ++y) {
+      const int64_t n = lx * d->W + y;
+      float grad[2];
+      orc_glocal(layers, d, scale, d->x0 + lx, y, param->exitSlope, grad); /* :492 */
+      const float slope = orc_length2(grad[0], grad[1]);                   /* :494 */
+
+      const float v = orc_length2(velocityFluvial[2 * n], velocityFluvial[2 * n + 1]); /* :497-498 */
+      const float shear = 0.125f * fD * rho * v * v;                                   /* :499 */
+      const float power = orc_powf(shear * slope, alpha);                              /* :500 */
+      const float suspend = kfs * power;                                               /* :502 */
+      const float massHeight = mass[n];                                                /* :504 */
+      const float deposit = kfd * massHeight;                                          /* :505 */
+      const float uplift = ku * upliftBase[n];                                         /* :506 */
+
+      const float debrisHeight = debris[n];                                            /* :509 */
+      const float excessSlope = slope - param->critSlopeBedrock;                       /* :510 */
+      const float shearLandslide = fmaxf(0.0f, kL * excessSlope);                      /* :511 */
+      const float shearYield = g * (debrisHeight * excessSlope - tau_y);               /* :512 */
+      const float suspendDebris = shearLandslide + kds * fmaxf(0.0f, shearYield);      /* :513 */
+      const float depositDebris = fminf(debrisHeight, fmaxf(0.0f, -kdd * shearYield)); /* :514 */
+
+      float transfer = dt * (deposit - suspend + depositDebris - suspendDebris); /* :526 */
+      transfer = fmaxf(transfer, -0.25f * L * slope);                            /* :527 */
+      transfer = fminf(transfer, 0.25f * L * 0.3f);                              /* :528 */
+
+      const float layer_y = layers[2 * n + 1]; /* :530 */
+      float dx_ = deltas[2 * n], dy_ = deltas[2 * n + 1]; /* :531 */
+      dx_ += dt * uplift / scale[2];                      /* :532 */
+      dy_ += fmaxf(0.0f, transfer / scale[2]);            /* :533 */
+      if (transfer < 0.0f) {                              /* :535-545 */
+        const float limited = fmaxf(-layer_y * scale[2], transfer);
+        dy_ += limited / scale[2];
+        transfer -= limited;
+        dx_ += transfer / scale[2];
+      }
+      deltas[2 * n] = dx_; /* :547 */
+      deltas[2 * n + 1] = dy_;
+
+      if (albedo_surface) { /* :553-572 */
+        const float totalHeight = massHeight + debrisHeight; /* :555 */
+        const float mixDepth = 1.0f;                         /* :556 */
+        if (layer_y == 0.0f) {                               /* :558-559 */
+          for (int c = 0; c < 3; ++c) albedo_surface[3 * n + c] = albedo_bedrock[3 * n + c];
+        } else if (totalHeight > 0.0f && transfer > eps) { /* :560 */
+          const float wMass = fminf(massHeight / totalHeight, 1.0f); /* :562 */
+          const float wSurf = fminf(mixDepth, layer_y * scale[2]);   /* :566 */
+          const float wTrsp = fmaxf(eps, transfer);                  /* :567 */
+          const float w = fminf(wTrsp / (wTrsp + wSurf), 1.0f);      /* :568 */
+          for (int c = 0; c < 3; ++c) {
+            const float colorTransport = fminf(
+                wMass * albedoFluxFluvial[3 * n + c] + (1.0f - wMass) * albedoFluxDebris[3 * n + c],
+                1.0f);                                                   /* :563 */
+            const float colorSurface = fminf(albedo_surface[3 * n + c], 1.0f); /* :564 */
+            albedo_surface[3 * n + c] = w * colorTransport + (1.0f - w) * colorSurface; /* :569-570 */
+          }
+        }
+      }
+    }
+}
+
+/* ------------------------------------------------------ mass creep (A7) */
+
+/* the lambda at erosion.cu:675-680 */
+static float orc_creep_T(float lbx, float lby, float ltx, float lty, float dx, float sz,
+                         float critSlope) {
+  const float hb = (lbx + lby) * sz;
+  const float ht = (ltx + lty) * sz;
+  const float tmax = 0.5f * ((ht - hb) - critSlope * dx);
+  return fmaxf(0.0f, fminf(lty * sz, tmax));
+}
+
+/* __mass_creep, erosion.cu:633-710 */
+void orc_mass_creep(float* delta, const float* layers, const orc_domain* d, const float scale[3],
+                    const orc_param* param) {
+  const float sz = scale[2];
+  const float critSlope = param->critSlopeSediment; /* :674 */
+  for (int64_t lx = d->r0; lx < d->r1; ++lx)
+    for (int64_t y = 0; y < d->W; ++y) {
+      const int64_t gx = d->x0 + lx;
+      const int64_t n = lx * d->W + y;
+      const float* l00 = &layers[2 * n]; /* :654 */
+      const float* ln0 = (gx - 1 < 0) ? l00 : &layers[2 * (n - d->W)];     /* :655 */
+      const float* lp0 = (gx + 1 >= d->H) ? l00 : &layers[2 * (n + d->W)]; /* :656 */
+      const float* l0n = (y - 1 < 0) ? l00 : &layers[2 * (n - 1)];         /* :657 */
+      const float* l0p = (y + 1 >= d->W) ? l00 : &layers[2 * (n + 1)];     /* :658 */
+      const float h00 = (l00[0] + l00[1]) * sz; /* :660-664 */
+      const float hn0 = (ln0[0] + ln0[1]) * sz;
+      const float hp0 = (lp0[0] + lp0[1]) * sz;
+      const float h0n = (l0n[0] + l0n[1]) * sz;
+      const float h0p = (l0p[0] + l0p[1]) * sz;
+
+      float t = 0.0f; /* :682 */
+      if (hp0 > h00) t += orc_creep_T(l00[0], l00[1], lp0[0], lp0[1], scale[0], sz, critSlope); /* :684-688 */
+      else t -= orc_creep_T(lp0[0], lp0[1], l00[0], l00[1], scale[0], sz, critSlope);
+      if (hn0 > h00) t += orc_creep_T(l00[0], l00[1], ln0[0], ln0[1], scale[0], sz, critSlope); /* :690-694 */
+      else t -= orc_creep_T(ln0[0], ln0[1], l00[0], l00[1], scale[0], sz, critSlope);
+      if (h0p > h00) t += orc_creep_T(l00[0], l00[1], l0p[0], l0p[1], scale[1], sz, critSlope); /* :696-700 */
+      else t -= orc_creep_T(l0p[0], l0p[1], l00[0], l00[1], scale[1], sz, critSlope);
+      if (h0n > h00) t += orc_creep_T(l00[0], l00[1], l0n[0], l0n[1], scale[1], sz, critSlope); /* :702-706 */
+      else t -= orc_creep_T(l0n[0], l0n[1], l00[0], l00[1], scale[1], sz, critSlope);
+
+      delta[2 * n + 1] += 0.25f * t / sz; /* :708 */
+    }
+}
+
+/* __layer_merge, erosion.cu:733-745 */
+void orc_layer_merge(float* height, const float* layers, int64_t n) {
+  for (int64_t i = 0; i < n; ++i) height[i] = layers[2 * i] + layers[2 * i + 1];
+}
+
+/* __albedo_stratum, erosion.cu:794-826 */
+void orc_albedo_stratum(float* albedoBedrock, const float* uplift, const float* layers, int64_t n,
+                        const float scale[3], const orc_param* param, const float colorA[3],
+                        const float colorB[3], float age, float freq) {
+  for (int64_t i = 0; i < n; ++i) {
+    const float shift = age * param->uplift * uplift[i];             /* :812 */
+    const float depth = fmaxf(shift - layers[2 * i] * scale[2], 0.0f); /* :814 */
+    const int index = (int)floorf(depth / freq);                     /* :819 */
+    const float* c = (index % 2 == 0) ? colorA : colorB;             /* :820-824 */
+    for (int k = 0; k < 3; ++k) albedoBedrock[3 * i + k] = c[k];
+  }
+}
+
+/* __albedo_layer, erosion.cu:759-791 */
+void orc_albedo_layer(float* albedo, const float* albedoBedrock, const float* albedoSediment,
+                      const float* layers, int64_t n, float scaleSediment,
+                      const float shiftSediment[3]) {
+  for (int64_t i = 0; i < n; ++i) {
+    const float blend = 1.0f / (1.0f + scaleSediment * layers[2 * i + 1]); /* :777 */
+    for (int k = 0; k < 3; ++k) {
+      const float colorSediment = fminf(albedoSediment[3 * i + k] + shiftSediment[k], 1.0f); /* :775 */
+      albedo[3 * i + k] = blend * albedoBedrock[3 * i + k] + (1.0f - blend) * colorSediment; /* :778 */
+    }
+  }
+}
+
+/* __albedo_discharge, erosion.cu:857-875 */
+void orc_albedo_discharge(float* albedo, const float* discharge, int64_t n,
+                          const float colorDischarge[3], float extinction, float scale) {
+  for (int64_t i = 0; i < n; ++i) {
+    const float value = fmaxf(0.0f, discharge[i]);                          /* :871 */
+    const float blend = scale * (1.0f - orc_expf(-extinction * value));     /* :872 */
+    for (int k = 0; k < 3; ++k)
+      albedo[3 * i + k] = blend * colorDischarge[k] + (1.0f - blend) * albedo[3 * i + k]; /* :873 */
+  }
+}
+
+/* ------------------------------------------------------------ graph (A8) */
+
+/* D4_t / D8_t neighbour tables, graph.hpp:21-46 */
+static const int ORC_SHIFT[8][2] = {{-1, 0}, {0, -1}, {0, 1}, {1, 0},
+                                    {-1, -1}, {-1, 1}, {1, -1}, {1, 1}};
+static int orc_K(int edge) { return edge == 0 ? 4 : 8; }
+
+/* __steepest (graph.cu:27-70) and __direction (:201-243) differ only in what they store */
+static void orc_steepest_impl(int32_t* out, const float* height, int64_t H, int64_t W, int edge,
+                              int store_k) {
+  const int K = orc_K(edge);
+  for (int64_t x = 0; x < H; ++x)
+    for (int64_t y = 0; y < W; ++y) {
+      const int64_t n = x * W + y;
+      const float hlocal = height[n]; /* :40 */
+      float smax = 0.0f;              /* :42 */
+      int32_t next = -1;              /* :43 */
+      for (int k = 0; k < K; ++k) {   /* :46 */
+        const int64_t nx = x + ORC_SHIFT[k][0], ny = y + ORC_SHIFT[k][1];
+        if (nx < 0 || ny < 0 || nx >= H || ny >= W) continue; /* :51-52 */
+        const int64_t nind = nx * W + ny;
+        const float len = orc_length2((float)ORC_SHIFT[k][0], (float)ORC_SHIFT[k][1]);
+        const float scur = (hlocal - height[nind]) / len; /* :56 */
+        if (scur > smax) {                                /* :57-60 */
+          smax = scur;
+          next = store_k ? (int32_t)k : (int32_t)nind;
+        }
+      }
+      out[n] = next; /* :68 */
+    }
+}
+void orc_steepest(int32_t* graph, const float* height, int64_t H, int64_t W, int edge) {
+  orc_steepest_impl(graph, height, H, W, edge, 0);
+}
+void orc_direction(int32_t* dir, const float* height, int64_t H, int64_t W, int edge) {
+  orc_steepest_impl(dir, height, H, W, edge, 1);
+}
+
+/* __seed (graph.cu:97-101) + __random_weighted (:103-173) */
+void orc_random_weighted(int32_t* graph, const float* height, int64_t H, int64_t W, int edge,
+                         uint64_t seed, uint64_t offset, float T) {
+  const int K = orc_K(edge);
+  for (int64_t x = 0; x < H; ++x)
+    for (int64_t y = 0; y < W; ++y) {
+      const int64_t n = x * W + y;
+      const float hlocal = height[n]; /* :118 */
+      float CDF[8];                   /* :126 */
+      float Z = 0.0f;                 /* :127 */
+      for (int k = 0; k < K; ++k) {   /* :129-143 */
+        const int64_t nx = x + ORC_SHIFT[k][0], ny = y + ORC_SHIFT[k][1];
+        if (nx < 0 || ny < 0 || nx >= H || ny >= W) continue;
+        const int64_t nind = nx * W + ny;
+        const float len = orc_length2((float)ORC_SHIFT[k][0], (float)ORC_SHIFT[k][1]);
+        const float dE = (hlocal - height[nind]) / len;             /* :138 */
+        const float P = (dE <= 0.0f) ? 0.0f : orc_expf(dE / T);     /* :139 */
+        CDF[k] = Z + P;                                             /* :140 */
+        Z += P;                                                     /* :141 */
+      }
+      int32_t next = -1;                                  /* :149 */
+      orc_rng st = {seed, offset};                        /* curand_init(seed, n, offset), :100 */
+      const float uniform = orc_rng_uniform(&st, (uint64_t)n); /* :150 */
+      for (int k = 0; k < K; ++k) {                       /* :151-165 */
+        const int64_t nx = x + ORC_SHIFT[k][0], ny = y + ORC_SHIFT[k][1];
+        if (nx < 0 || ny < 0 || nx >= H || ny >= W) continue;
+        if (uniform < (CDF[k] / Z)) { /* :160 (Z == 0 -> NaN -> false) */
+          next = (int32_t)(nx * W + ny);
+          break;
+        }
+      }
+      graph[n] = next; /* :171 */
+    }
+}
+
+/* __slope, graph.cu:270-295 */
+void orc_slope(float* slope, const float* tensor, const int32_t* flow, int64_t H, int64_t W,
+               const float scale[2]) {
+  for (int64_t n = 0; n < H * W; ++n) {
+    const int64_t next = flow[n];  /* :282 */
+    if (next < 0 || next == n) {   /* :283-286 */
+      slope[n] = 0.0f;
+      continue;
+    }
+    const float ix = (float)(n / W), iy = (float)(n % W);       /* :288 */
+    const float nx = (float)(next / W), ny = (float)(next % W); /* :289 */
+    const float ival = tensor[n];                               /* :291 */
+    const float nval = tensor[next];                            /* :292 */
+    slope[n] = (nval - ival) / orc_length2(scale[0] * (nx - ix), scale[1] * (ny - iy)); /* :293 */
+  }
+}
+
+typedef struct orc_acc { /* acc_t, graph.cu:422-427 */
+  int32_t* donor;
+  int32_t* count;
+  float* value;
+  float* decay;
+} orc_acc;
+
+/* __rake_compress, graph.cu:429-522: one synchronous round in -> out */
+static void orc_rake_compress(orc_acc out, const orc_acc in, int64_t elem, int K) {
+  for (int64_t n = 0; n < elem; ++n) {
+    float value = in.value[n]; /* :440 */
+    int count = in.count[n];   /* :441 */
+    int32_t donors[8];
+    float decays[8];
+    for (int k = 0; k < count; ++k) { /* :448-468 */
+      donors[k] = in.donor[K * n + k];
+      decays[k] = in.decay[K * n + k];
+    }
+    for (int k = 0; k < count; ++k) { /* :471 */
+      const int32_t donor = donors[k];
+      const float decay = decays[k];
+      const int dcount = in.count[donor]; /* :476 */
+      if (dcount == 0) {                  /* :479-487 */
+        value += decay * in.value[donor];
+        donors[k] = donors[count - 1];
+        decays[k] = decays[count - 1];
+        donors[count - 1] = -1;
+        decays[count - 1] = 0.0f;
+        count -= 1;
+        k -= 1;
+      } else if (dcount == 1) { /* :490-494 */
+        value += decay * in.value[donor];
+        donors[k] = in.donor[(int64_t)K * donor];
+        decays[k] = decay * in.decay[(int64_t)K * donor];
+      }
+    }
+    out.value[n] = value; /* :498 */
+    out.count[n] = count; /* :499 */
+    for (int k = 0; k < count; ++k) { /* :500-520 */
+      out.donor[K * n + k] = donors[k];
+      out.decay[K * n + k] = decays[k];
+    }
+  }
+}
+
+/* __accumulate, graph.cu:526-576 */
+int orc_accumulate(float* out, const int32_t* graph, const float* source, const float* decayIn,
+                   int64_t H, int64_t W, int edge) {
+  const int K = orc_K(edge);
+  const int64_t elem = H * W;
+  orc_acc A, B;
+  A.count = (int32_t*)malloc(sizeof(int32_t) * elem); /* :540-550 */
+  A.value = (float*)malloc(sizeof(float) * elem);
+  B.count = (int32_t*)malloc(sizeof(int32_t) * elem);
+  B.value = (float*)malloc(sizeof(float) * elem);
+  A.donor = (int32_t*)malloc(sizeof(int32_t) * elem * K);
+  A.decay = (float*)malloc(sizeof(float) * elem * K);
+  B.donor = (int32_t*)malloc(sizeof(int32_t) * elem * K);
+  B.decay = (float*)malloc(sizeof(float) * elem * K);
+  if (!A.count || !A.value || !B.count || !B.value || !A.donor || !A.decay || !B.donor ||
+      !B.decay) {
+    free(A.count); free(A.value); free(B.count); free(B.value);
+    free(A.donor); free(A.decay); free(B.donor); free(B.decay);
+    return -1;
+  }
+  /* cudaMalloc'd scratch is uninitialised in the reference; zero B so that runs are repeatable */
+  memset(B.count, 0, sizeof(int32_t) * elem);
+  memset(B.value, 0, sizeof(float) * elem);
+  memset(B.donor, 0, sizeof(int32_t) * elem * K);
+  memset(B.decay, 0, sizeof(float) * elem * K);
+  memset(A.decay, 0, sizeof(float) * elem * K);
+
+  for (int64_t i = 0; i < elem * K; ++i) A.donor[i] = -1; /* :552 */
+  memcpy(A.value, source, sizeof(float) * elem);           /* :553 */
+
+  /* __donor, :321-348 */
+  for (int64_t x = 0; x < H; ++x)
+    for (int64_t y = 0; y < W; ++y) {
+      const int64_t n = x * W + y;
+      const int64_t next = graph[n]; /* :333 */
+      for (int k = 0; k < K; ++k) {
+        const int64_t nx = x + ORC_SHIFT[k][0], ny = y + ORC_SHIFT[k][1];
+        if (nx < 0 || ny < 0 || nx >= H || ny >= W) continue; /* :340-341 */
+        const int64_t nind = nx * W + ny;
+        if (nind == next) A.donor[K * nind + k] = (int32_t)n; /* :344-345 */
+      }
+    }
+  /* __count, :350-380 */
+  for (int64_t n = 0; n < elem; ++n) {
+    int c = 0;
+    int32_t dn[8];
+    for (int k = 0; k < K; ++k) {
+      const int32_t dd = A.donor[K * n + k];
+      if (dd >= 0) dn[c++] = dd;
+    }
+    A.count[n] = c;
+    for (int k = 0; k < K; ++k) A.donor[K * n + k] = (k < c) ? dn[k] : -1;
+  }
+  /* my_decay, :382-420 (diagonal exponent by compacted slot index, Appendix B2) */
+  for (int64_t n = 0; n < elem; ++n)
+    for (int k = 0; k < K; ++k) {
+      const int32_t dd = A.donor[K * n + k];
+      if (dd < 0) break;
+      const float D = decayIn ? decayIn[dd] : 1.0f;
+      A.decay[K * n + k] = (k < 4) ? D : orc_powf(D, 1.414f);
+    }
+
+  const int64_t iter = (int64_t)ceilf(log2f((float)elem) / 2.0f); /* :559 */
+  for (int64_t i = 0; i <= iter; ++i) {                           /* :560-563 */
+    orc_rake_compress(B, A, elem, K);
+    orc_rake_compress(A, B, elem, K);
+  }
+  memcpy(out, A.value, sizeof(float) * elem); /* :566 */
+  free(A.count); free(A.value); free(B.count); free(B.value);
+  free(A.donor); free(A.decay); free(B.donor); free(B.decay);
+  return 0;
+}
+
+/* --------------------------------------------------------- stencils (A9) */
+
+/* __gradient, grad.cu:22-87 */
+void orc_gradient(float* out, const float* in, int64_t H, int64_t W, const float scale[2]) {
+  for (int64_t x = 0; x < H; ++x)
+    for (int64_t y = 0; y < W; ++y) {
+      const int64_t n = x * W + y;
+      const float h = in[n];
+      const float hn0 = (x - 1 < 0) ? NAN : in[n - W];  /* :35-38 */
+      const float hp0 = (x + 1 >= H) ? NAN : in[n + W];
+      const float h0n = (y - 1 < 0) ? NAN : in[n - 1];
+      const float h0p = (y + 1 >= W) ? NAN : in[n + 1];
+      const float gxn = (h - hn0) / scale[0]; /* :46 */
+      const float gyn = (h - h0n) / scale[1]; /* :50 */
+      const float gxp = (hp0 - h) / scale[0]; /* :54 */
+      const float gyp = (h0p - h) / scale[1]; /* :58 */
+      float gx = 0.5f * (hp0 - hn0) / scale[0]; /* :62 */
+      float gy = 0.5f * (h0p - h0n) / scale[1]; /* :63 */
+      if (isnan(gx)) gx = gxn; /* :65-67 */
+      if (isnan(gx)) gx = gxp;
+      if (isnan(gx)) gx = 0.0f;
+      if (isnan(gy)) gy = gyn; /* :69-71 */
+      if (isnan(gy)) gy = gyp;
+      if (isnan(gy)) gy = 0.0f;
+      out[2 * n] = gx; /* :84-85 */
+      out[2 * n + 1] = gy;
+    }
+}
+
+/* __negslope, grad.cu:101-131 */
+void orc_negslope(float* out, const float* in, int64_t H, int64_t W, const float scale[2]) {
+  for (int64_t x = 0; x < H; ++x)
+    for (int64_t y = 0; y < W; ++y) {
+      const int64_t n = x * W + y;
+      const float h = in[n];
+      float gx = 0.0f; /* :120-122 (glm::max(a,b) = (a<b)?b:a) */
+      if (x - 1 >= 0) { const float c = (h - in[n - W]) / scale[0]; gx = (gx < c) ? c : gx; }
+      if (x + 1 < H)  { const float c = (h - in[n + W]) / scale[0]; gx = (gx < c) ? c : gx; }
+      float gy = 0.0f; /* :124-126 */
+      if (y - 1 >= 0) { const float c = (h - in[n - 1]) / scale[1]; gy = (gy < c) ? c : gy; }
+      if (y + 1 < W)  { const float c = (h - in[n + 1]) / scale[1]; gy = (gy < c) ? c : gy; }
+      out[n] = orc_length2(gx, gy); /* :129 */
+    }
+}
+
+/* __laplacian<D>, grad.cu:147-183 */
+void orc_laplacian(float* out, const float* in, int64_t H, int64_t W, int D,
+                   const float scale[2]) {
+  const float hx = (1.0f / scale[0] / scale[0]); /* :175 */
+  const float hy = (1.0f / scale[1] / scale[1]); /* :176 */
+  for (int64_t x = 0; x < H; ++x)
+    for (int64_t y = 0; y < W; ++y)
+      for (int c = 0; c < D; ++c) {
+        const int64_t n = x * W + y;
+#define ORC_AT(dx, dy)                                                                  \
+  (((x + (dx)) < 0 || (x + (dx)) >= H || (y + (dy)) < 0 || (y + (dy)) >= W)             \
+       ? in[D * n + c]                                                                  \
+       : in[D * ((x + (dx)) * W + (y + (dy))) + c])
+        const float v00 = in[D * n + c]; /* :165-173 */
+        const float vn0 = ORC_AT(-1, 0), vp0 = ORC_AT(1, 0), v0n = ORC_AT(0, -1), v0p = ORC_AT(0, 1);
+        const float vnn = ORC_AT(-1, -1), vpp = ORC_AT(1, 1), vpn = ORC_AT(1, -1), vnp = ORC_AT(-1, 1);
+#undef ORC_AT
+        const float LH = (vn0 - v00) * hx + (vp0 - v00) * hx + (v0n - v00) * hy + (v0p - v00) * hy; /* :178 */
+        const float LD = 0.5f * (vnn - v00) * hx + 0.5f * (vpp - v00) * hx +
+                         0.5f * (vpn - v00) * hy + 0.5f * (vnp - v00) * hy; /* :179 */
+        out[D * n + c] = 0.5f * LH + 0.5f * LD; /* :181 */
+      }
+}
+
+/* __gaussian_blur / __blur, filter.cu:24-70; host wrapper :72-91 */
+static void orc_blur_pass(float* out, const float* in, int64_t H, int64_t W, int C, float sigma,
+                          int xdir) {
+  const int kwindow = 16; /* :34 */
+  for (int64_t x = 0; x < H; ++x)
+    for (int64_t y = 0; y < W; ++y)
+      for (int c = 0; c < C; ++c) {
+        float val = 0.0f; /* :35 */
+        for (int k = -kwindow; k <= kwindow; ++k) {
+          int64_t nx = x + (xdir ? k : 0), ny = y + (xdir ? 0 : k); /* :39 */
+          if (nx < 0) nx = 0;                                        /* :40-43 */
+          if (ny < 0) ny = 0;
+          if (nx > H - 1) nx = H - 1;
+          if (ny > W - 1) ny = W - 1;
+          const float Z = sqrtf(2.0f * 3.14159265f) * sigma;                          /* :47 */
+          const float kernel = orc_expf(-0.5f * ((float)k / sigma) * ((float)k / sigma)) / Z; /* :48 */
+          val += in[C * (nx * W + ny) + c] * kernel; /* :49-50 */
+        }
+        out[C * (x * W + y) + c] = val; /* :54 */
+      }
+}
+void orc_gaussian_blur(float* tensor, float* scratch, int64_t H, int64_t W, int C, float sigma) {
+  orc_blur_pass(scratch, tensor, H, W, C, sigma, 1); /* :81 / :86 */
+  orc_blur_pass(tensor, scratch, H, W, C, sigma, 0); /* :82 / :87 */
+}
+
+/* soil::op::normal, normal.hpp:19-39.  lerp5_t::grad lives in the un-vendored
+ * silt library; the definition used here is the documented build decision of
+ * 4th-order central difference when all five samples exist and
+ * are finite, else 2nd-order central, else one-sided, else 0; times
+ * scale.z / scale.{x,y}.  Parity for this op is unpinned. */
+static float orc_lerp5_axis(const float* in, int64_t n, int64_t stride, int64_t i, int64_t len) {
+  const int hm2 = (i - 2 >= 0), hm1 = (i - 1 >= 0), hp1 = (i + 1 < len), hp2 = (i + 2 < len);
+  const float f0 = in[n];
+  const float fm2 = hm2 ? in[n - 2 * stride] : NAN, fm1 = hm1 ? in[n - stride] : NAN;
+  const float fp1 = hp1 ? in[n + stride] : NAN, fp2 = hp2 ? in[n + 2 * stride] : NAN;
+  if (isfinite(fm2) && isfinite(fm1) && isfinite(fp1) && isfinite(fp2))
+    return ((fm2 - 8.0f * fm1) + (8.0f * fp1 - fp2)) / 12.0f;
+  if (isfinite(fm1) && isfinite(fp1)) return 0.5f * (fp1 - fm1);
+  if (isfinite(fp1) && isfinite(f0)) return fp1 - f0;
+  if (isfinite(fm1) && isfinite(f0)) return f0 - fm1;
+  return 0.0f;
+}
+void orc_normal(float* out, const float* in, int64_t H, int64_t W, const float scale[3]) {
+  for (int64_t x = 0; x < H; ++x)
+    for (int64_t y = 0; y < W; ++y) {
+      const int64_t n = x * W + y;
+      const float gx = orc_lerp5_axis(in, n, W, x, H) * scale[2] / scale[0]; /* :31-32 */
+      const float gy = orc_lerp5_axis(in, n, 1, y, W) * scale[2] / scale[1];
+      const float vx = -gx, vy = -gy, vz = 1.0f; /* :33 */
+      const float inv = 1.0f / sqrtf(vx * vx + vy * vy + vz * vz);
+      out[3 * n] = vx * inv;
+      out[3 * n + 1] = vy * inv;
+      out[3 * n + 2] = vz * inv;
+    }
+}
+
+/* ------------------------------------------------- solve_uniform (A10) */
+
+/* sample_t<vec2,2,1>::gather(view) + val(), sample.hpp:154-186, :92-94, :48-50 */
+static void orc_bilinear(const float* flow, int64_t H, int64_t W, float px, float py, float v[2]) {
+  const float rx = (float)H, ry = (float)W;
+  if (px < 0 || py < 0 || px > rx - 1 || py > ry - 1) { /* :167-170 */
+    v[0] = NAN;
+    v[1] = NAN;
+    return;
+  }
+  const int64_t ix = (int64_t)px, iy = (int64_t)py;   /* :156-159 */
+  float wx = px - floorf(px), wy = py - floorf(py);   /* :160 */
+  int64_t i00 = ix * W + iy, i01 = ix * W + (iy + 1); /* :162-165 */
+  int64_t i10 = (ix + 1) * W + iy, i11 = (ix + 1) * W + (iy + 1);
+  if (px + 1 > rx - 1) { wx = 0; i10 = 0; i11 = 0; } /* :172 */
+  if (py + 1 > ry - 1) { wy = 0; i01 = 0; i11 = 0; } /* :173 */
+  for (int c = 0; c < 2; ++c) {
+    const float h00 = flow[2 * i00 + c], h01 = flow[2 * i01 + c];
+    const float h10 = flow[2 * i10 + c], h11 = flow[2 * i11 + c];
+    const float l0 = (1.0f + -1.0f * wy) * h00 + (0.0f + 1.0f * wy) * h01; /* :48-50 with M :55-60 */
+    const float l1 = (1.0f + -1.0f * wy) * h10 + (0.0f + 1.0f * wy) * h11;
+    v[c] = (1.0f + -1.0f * wx) * l0 + (0.0f + 1.0f * wx) * l1; /* :92-94 */
+  }
+}
+
+/* __solve_uniform<K> (path.cu:52-139) + __normalize<K> (:142-170), host :180-219 */
+void orc_solve_uniform(float* flux, const float* flow, const float* source, const float* decay,
+                       orc_rng* rng, int64_t N, int64_t H, int64_t W, int K,
+                       const float scale[2], uint64_t count) {
+  const float epsilon = 1E-16f;         /* :199 */
+  const float maxstep = (float)(H + W); /* :200 */
+  memset(flux, 0, sizeof(float) * H * W * K); /* :196 */
+  orc_domain d = {H, W, 0, H, 0, H};
+  for (int64_t n = 0; n < N; ++n) {
+    float att = 1.0f;                                             /* :78 */
+    float px = orc_rng_uniform(&rng[n], (uint64_t)n) * (float)H;  /* :81 */
+    float py = orc_rng_uniform(&rng[n], (uint64_t)n) * (float)W;  /* :82 */
+    /* u == 1 puts the spawn on the far edge; the reference then indexes out
+     * of bounds at :90 (undefined behaviour) — such a sample is dropped here. */
+    if (orc_oob(&d, px, py)) continue;
+    int64_t ind = (int64_t)px * W + (int64_t)py;                  /* :84 */
+    const float L = orc_length2(scale[0], scale[1]);              /* :87 */
+    const float A = scale[0] * scale[1];                          /* :88 */
+    const float P = 1.0f / (A * (float)(H * W));                  /* :89 */
+    float S[2] = {0, 0};
+    for (int c = 0; c < K; ++c) S[c] = source[K * ind + c] / P;   /* :90 */
+    const float Slen = (K == 1) ? sqrtf(S[0] * S[0]) : orc_length2(S[0], S[1]);
+    if (Slen < epsilon) continue; /* :91-92 */
+    float v[2];
+    orc_bilinear(flow, H, W, px, py, v); /* :99-100 */
+    int step = 0;
+    while (!orc_oob(&d, px, py) && epsilon < fabsf(att) && (float)(++step) < maxstep) { /* :104 */
+      const int64_t nind = (int64_t)px * W + (int64_t)py; /* :107 */
+      if (nind != ind) {                                  /* :108-116 */
+        ind = nind;
+        for (int c = 0; c < K; ++c) flux[K * ind + c] += S[c] * att;
+      }
+      orc_bilinear(flow, H, W, px, py, v);         /* :119-120 */
+      const float v_len = orc_length2(v[0], v[1]); /* :123 */
+      if (v_len < epsilon) break;                  /* :124-125 */
+      const float ux = v[0] / v_len, uy = v[1] / v_len; /* :128 */
+      const float st = orc_stepsize(px, py, ux, uy);    /* :129 */
+      px += st * ux;                                    /* :130 */
+      py += st * uy;
+      const float dlambda = st * L / v_len;             /* :133 */
+      att *= orc_expf(-dlambda * decay[ind]);           /* :134 */
+    }
+  }
+  for (int64_t n = 0; n < H * W; ++n) { /* __normalize, :142-170 */
+    const float vx = flow[2 * n], vy = flow[2 * n + 1];          /* :160 */
+    const float A = scale[0] * scale[1];                         /* :161 */
+    const float norm = fabsf(vx * scale[1]) + fabsf(vy * scale[0]); /* :162 */
+    for (int c = 0; c < K; ++c)
+      flux[K * n + c] = (source[K * n + c] * A + flux[K * n + c] / (float)count) / norm; /* :168 */
+  }
+}

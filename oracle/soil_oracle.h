@@ -1,0 +1,144 @@
+/*
+ * soil_oracle.h — CPU restatement of the reference's grid-erosion kernels.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under soillib_amd/ (the product) may
+ * include, link or call this; only tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py do, and only as the checker.
+ *
+ * PARITY STATUS: **parity unpinned by the reference.**  erosiv/soillib ships
+ * no tests, golden vectors or fixtures for this path, all of its kernels are
+ * CUDA-only and depend on the un-vendored `silt` library, so neither the
+ * reference nor its own test data can be run here.  What pins
+ * this oracle instead: (1) every function follows the cited reference lines
+ * statement by statement, (2) analytic known-answer tests derived from the
+ * kernel semantics (tests/test_oracle_kat.py), (3) for soil.noise only, golden
+ * heightmaps produced by compiling the reference's vendored FastNoiseLite.h in
+ * place (oracle/_ref, tests/golden/noise_*.npy).
+ *
+ * Numerical contract shared with the HIP kernels: plain
+ * IEEE fp32, no contraction (-ffp-contract=off), division and sqrt correctly
+ * rounded, fmaxf/fminf NaN semantics; the reference's fast intrinsics
+ * __expf/__powf are replaced by the software functions orc_expf/orc_powf
+ * below (same formula on both sides so that results are bit-comparable); the
+ * reference's cuRAND XORWOW is replaced by Philox4x32-10.
+ */
+#ifndef SOIL_ORACLE_H
+#define SOIL_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Mirrors soil::param_t, erosion.hpp:17-58 (same layout as soil_param). */
+typedef struct orc_param {
+  uint64_t maxage;
+  float lrate, timeStep;
+  float exitSlope, uplift, rainfall, gravity, evapRate;
+  float frictionFactor, fluvialExponent;
+  float suspensionRateFluvial, depositionRateFluvial;
+  float suspensionRateDebris, depositionRateDebris, landslideRateDebris;
+  float critSlopeBedrock, critSlopeSediment, yieldStress;
+  float viscosityWater, bedShearWater, densityWater;
+  float viscosityDebris, bedShearDebris, densityDebris;
+  float force[2];
+  float _pad;
+} orc_param;
+
+typedef struct orc_rng { uint64_t seed, offset; } orc_rng;
+
+/* Row slab of a global grid; {H,W,0,H,0,H} is the whole grid. */
+typedef struct orc_domain { int64_t H, W, x0, rows, r0, r1; } orc_domain;
+
+void orc_param_default(orc_param* p);
+
+/* spec math */
+float orc_expf(float x);
+float orc_log2f(float x);
+float orc_powf(float x, float y);
+void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+uint32_t orc_rng_next(orc_rng* state, uint64_t subsequence);
+float orc_rng_uniform(orc_rng* state, uint64_t subsequence);
+void orc_rng_seed(orc_rng* rng, int64_t n, uint64_t seed, uint64_t offset);
+
+/* helpers exposed for known-answer tests */
+float orc_stepsize(float px, float py, float dx, float dy);
+void orc_glocal(const float* layers, const orc_domain* dom, const float scale[3], int64_t gx,
+                int64_t y, float exitSlope, float g[2]);
+
+/* erosion ops (threads > 1 parallelises the particle loop with OpenMP atomics) */
+void orc_particles_fluvial(float* waterFlux, float* massFlux, float* velocityFlux,
+                           float* albedoFlux, orc_rng* rng, int64_t N, const float* layers,
+                           const float* waterSource, const float* waterHeight,
+                           const float* velocity, const float* albedoSource,
+                           const orc_domain* dom, const float scale[3], const orc_param* param,
+                           int threads, int64_t* steps_out);
+void orc_normalize_fluvial(const float* waterFlux, const float* massFlux,
+                           const float* velocityFlux, float* albedoFlux, const float* layers,
+                           const float* waterSource, float* waterHeight, float* mass,
+                           float* velocity, const float* albedoSource, const orc_domain* dom,
+                           const float scale[3], const orc_param* param);
+void orc_particles_debris(float* massFlux, float* velocityFlux, float* albedoFlux, orc_rng* rng,
+                          int64_t N, const float* layers, const float* velocity,
+                          const float* albedoSource, const orc_domain* dom,
+                          const float scale[3], const orc_param* param, int threads,
+                          int64_t* steps_out);
+void orc_normalize_debris(const float* massFlux, const float* velocityFlux, float* albedoFlux,
+                          const float* layers, float* mass, float* velocity,
+                          const float* albedoSource, const orc_domain* dom,
+                          const float scale[3], const orc_param* param);
+void orc_mass_transfer(float* delta, const float* layers, const float* uplift, const float* mass,
+                       const float* velocityFluvial, const float* debris,
+                       const float* albedo_bedrock, const float* albedoFluxFluvial,
+                       const float* albedoFluxDebris, float* albedo_surface,
+                       const orc_domain* dom, const float scale[3], const orc_param* param);
+void orc_mass_creep(float* delta, const float* layers, const orc_domain* dom,
+                    const float scale[3], const orc_param* param);
+void orc_layer_merge(float* height, const float* layers, int64_t n);
+void orc_albedo_stratum(float* albedoBedrock, const float* uplift, const float* layers, int64_t n,
+                        const float scale[3], const orc_param* param, const float colorA[3],
+                        const float colorB[3], float age, float freq);
+void orc_albedo_layer(float* albedo, const float* albedoBedrock, const float* albedoSediment,
+                      const float* layers, int64_t n, float scaleSediment,
+                      const float shiftSediment[3]);
+void orc_albedo_discharge(float* albedo, const float* discharge, int64_t n,
+                          const float colorDischarge[3], float extinction, float scale);
+
+/* graph ops */
+void orc_steepest(int32_t* graph, const float* height, int64_t H, int64_t W, int edge);
+void orc_direction(int32_t* dir, const float* height, int64_t H, int64_t W, int edge);
+void orc_random_weighted(int32_t* graph, const float* height, int64_t H, int64_t W, int edge,
+                         uint64_t seed, uint64_t offset, float T);
+void orc_slope(float* slope, const float* tensor, const int32_t* flow, int64_t H, int64_t W,
+               const float scale[2]);
+/* decay == NULL: accumulate (scalar decay 1); returns 0 or -1 on allocation failure */
+int orc_accumulate(float* out, const int32_t* graph, const float* source, const float* decay,
+                   int64_t H, int64_t W, int edge);
+
+/* stencils */
+void orc_gradient(float* out, const float* in, int64_t H, int64_t W, const float scale[2]);
+void orc_negslope(float* out, const float* in, int64_t H, int64_t W, const float scale[2]);
+void orc_laplacian(float* out, const float* in, int64_t H, int64_t W, int D,
+                   const float scale[2]);
+void orc_gaussian_blur(float* tensor, float* scratch, int64_t H, int64_t W, int C, float sigma);
+void orc_normal(float* out, const float* in, int64_t H, int64_t W, const float scale[3]);
+
+/* path-integral solver */
+void orc_solve_uniform(float* flux, const float* flow, const float* source, const float* decay,
+                       orc_rng* rng, int64_t N, int64_t H, int64_t W, int K,
+                       const float scale[2], uint64_t count);
+
+/* noise (own restatement of OpenSimplex2 FBm; pinned by oracle/_ref fixtures) */
+typedef struct orc_noise_param {
+  float frequency;
+  int32_t octaves;
+  float gain, lacunarity, seed;
+  float ext[2];
+} orc_noise_param;
+void orc_noise(float* out, int64_t H, int64_t W, const orc_noise_param* p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

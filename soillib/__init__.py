@@ -1,0 +1,18 @@
+"""`import soillib as soil` — the reference's Python module name
+(python/soillib/__init__.py:1-3: `import silt; from .soillib import *; from .util import *`).
+
+Live API: soillib_amd.soil (mirror of python/source/model.cpp).  Legacy API used
+by example/erosion_gpu.py (map_t, data_t, erode, multiply, legacy param names,
+normal): soillib_amd.legacy.  Helpers (`soil.util`): soillib_amd.util.
+"""
+import silt  # noqa: F401
+
+from soillib_amd.soil import *  # noqa: F401,F403
+from soillib_amd.soil import (accumulate, accumulate_decay, albedo_discharge, albedo_layer,  # noqa: F401
+                              albedo_stratum, d4, d8, direction, edge, gaussian_blur, gradient,
+                              laplacian, layer_merge, mass_creep, mass_transfer, ms, negslope,
+                              noise, noise_t, normal, ns, random_weighted, s, slope,
+                              solve_uniform, steepest, timer, transport_debris, transport_fluvial,
+                              us)
+from soillib_amd.legacy import (clamp, data_t, erode, map_t, multiply, param_t)  # noqa: F401
+from soillib_amd import util  # noqa: F401

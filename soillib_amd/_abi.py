@@ -1,0 +1,173 @@
+"""ctypes binding of the C ABI in include/soil_hip.h (soillib_amd/lib/libsoil_hip.so).
+
+This is the only place Python touches the shared library.  There is no CPU
+fallback: if the library is missing it must be built (soillib_amd.build), and
+every compute entry point returns SOIL_ERR_NO_DEVICE without a HIP device,
+which `check` turns into a RuntimeError.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libsoil_hip.so")
+
+SOIL_OK = 0
+SOIL_ERR_INVALID_ARGUMENT = -1
+SOIL_ERR_NO_DEVICE = -2
+SOIL_ERR_HIP = -3
+SOIL_ERR_OUT_OF_MEMORY = -4
+
+D4, D8 = 0, 1
+
+_PARAM_FLOATS = (
+    "lrate", "timeStep", "exitSlope", "uplift", "rainfall", "gravity", "evapRate",
+    "frictionFactor", "fluvialExponent", "suspensionRateFluvial", "depositionRateFluvial",
+    "suspensionRateDebris", "depositionRateDebris", "landslideRateDebris",
+    "critSlopeBedrock", "critSlopeSediment", "yieldStress", "viscosityWater",
+    "bedShearWater", "densityWater", "viscosityDebris", "bedShearDebris", "densityDebris")
+
+
+class Param(C.Structure):
+    """soil_param == soil::param_t (erosion.hpp:17-58)."""
+    _fields_ = ([("maxage", C.c_uint64)] + [(n, C.c_float) for n in _PARAM_FLOATS] +
+                [("force", C.c_float * 2), ("_pad", C.c_float)])
+
+
+class Rng(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("offset", C.c_uint64)]
+
+
+class Domain(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in ("H", "W", "x0", "rows", "r0", "r1")]
+
+
+class NoiseParam(C.Structure):
+    _fields_ = [("frequency", C.c_float), ("octaves", C.c_int32), ("gain", C.c_float),
+                ("lacunarity", C.c_float), ("seed", C.c_float), ("ext", C.c_float * 2)]
+
+
+_PLANES = ("layers", "layers_next", "height", "uplift", "rainfall", "waterHeight", "waterFlux",
+           "mass", "massFlux", "velocity", "velocityFlux", "debris", "debrisFlux",
+           "debrisVelocity", "debrisVelocityFlux")
+
+
+class ErosionPlanes(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in _PLANES]
+
+
+vp, i64, u64, f32, cint = C.c_void_p, C.c_int64, C.c_uint64, C.c_float, C.c_int
+F3 = C.POINTER(C.c_float)
+
+# name -> (restype, argtypes); every symbol include/soil_hip.h declares
+SIGNATURES = {
+    "soil_abi_version": (cint, []),
+    "soil_last_error": (C.c_char_p, []),
+    "soil_device_count": (cint, []),
+    "soil_set_device": (cint, [cint]),
+    "soil_device_name": (cint, [C.c_char_p, C.c_size_t]),
+    "soil_param_default": (None, [C.POINTER(Param)]),
+    "soil_malloc": (cint, [C.POINTER(vp), C.c_size_t]),
+    "soil_free": (cint, [vp]),
+    "soil_memcpy_h2d": (cint, [vp, vp, C.c_size_t, vp]),
+    "soil_memcpy_d2h": (cint, [vp, vp, C.c_size_t, vp]),
+    "soil_memcpy_d2d": (cint, [vp, vp, C.c_size_t, vp]),
+    "soil_stream_synchronize": (cint, [vp]),
+    "soil_device_synchronize": (cint, []),
+    "soil_event_create": (cint, [C.POINTER(vp)]),
+    "soil_event_destroy": (cint, [vp]),
+    "soil_event_record": (cint, [vp, vp]),
+    "soil_event_elapsed_ms": (cint, [vp, vp, C.POINTER(f32)]),
+    "soil_set_f32": (cint, [vp, f32, i64, vp]),
+    "soil_set_i32": (cint, [vp, C.c_int32, i64, vp]),
+    "soil_add_f32": (cint, [vp, vp, i64, vp]),
+    "soil_multiply_f32": (cint, [vp, f32, i64, vp]),
+    "soil_rng_seed": (cint, [vp, i64, u64, u64, vp]),
+    "soil_selftest_math": (cint, [vp, vp, vp, i64, cint, vp]),
+    "soil_transport_fluvial": (cint, [vp] * 12 + [i64, i64, i64, F3, C.POINTER(Param), vp]),
+    "soil_transport_debris": (cint, [vp] * 9 + [i64, i64, i64, F3, C.POINTER(Param), vp]),
+    "soil_mass_transfer": (cint, [vp] * 12 + [i64, i64, F3, C.POINTER(Param), vp]),
+    "soil_mass_creep": (cint, [vp, vp, i64, i64, F3, C.POINTER(Param), vp]),
+    "soil_layer_merge": (cint, [vp, vp, i64, vp]),
+    "soil_layers_from_planes": (cint, [vp, vp, vp, i64, vp]),
+    "soil_layers_to_planes": (cint, [vp, vp, vp, i64, vp]),
+    "soil_albedo_stratum": (cint, [vp, vp, vp, i64, F3, C.POINTER(Param), F3, F3, f32, f32, vp]),
+    "soil_albedo_layer": (cint, [vp, vp, vp, vp, i64, f32, F3, vp]),
+    "soil_albedo_discharge": (cint, [vp, vp, i64, F3, f32, f32, vp]),
+    "soil_erode_cells_fused": (cint, [C.POINTER(ErosionPlanes), C.POINTER(Domain), F3,
+                                      C.POINTER(Param), vp]),
+    "soil_particles_fluvial_slab": (cint, [vp] * 5 + [i64] + [vp] * 5 +
+                                    [C.POINTER(Domain), F3, C.POINTER(Param), vp]),
+    "soil_particles_debris_slab": (cint, [vp] * 4 + [i64] + [vp] * 3 +
+                                   [C.POINTER(Domain), F3, C.POINTER(Param), vp]),
+    "soil_ghost_rows": (i64, [C.POINTER(Param)]),
+    "soil_direction": (cint, [vp, vp, i64, i64, cint, vp]),
+    "soil_steepest": (cint, [vp, vp, i64, i64, cint, vp]),
+    "soil_random_weighted": (cint, [vp, vp, i64, i64, cint, u64, u64, f32, vp]),
+    "soil_slope": (cint, [vp, vp, vp, i64, i64, F3, vp]),
+    "soil_accumulate": (cint, [vp, vp, vp, vp, i64, i64, cint, vp]),
+    "soil_workspace_release": (cint, []),
+    "soil_gradient": (cint, [vp, vp, i64, i64, F3, vp]),
+    "soil_negslope": (cint, [vp, vp, i64, i64, F3, vp]),
+    "soil_laplacian": (cint, [vp, vp, i64, i64, cint, F3, vp]),
+    "soil_gaussian_blur": (cint, [vp, vp, i64, i64, cint, f32, vp]),
+    "soil_normal": (cint, [vp, vp, i64, i64, F3, vp]),
+    "soil_normal_host": (cint, [vp, vp, i64, i64, F3]),
+    "soil_solve_uniform": (cint, [vp] * 5 + [i64, i64, i64, cint, F3, u64, vp]),
+    "soil_noise_param_default": (None, [C.POINTER(NoiseParam)]),
+    "soil_noise": (cint, [vp, i64, i64, C.POINTER(NoiseParam), vp]),
+    "soil_noise_host": (cint, [vp, i64, i64, C.POINTER(NoiseParam)]),
+}
+
+_lib = None
+
+
+def lib():
+    """Loads libsoil_hip.so (fails loudly if it has not been built)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libsoil_hip.so is missing (%s): build it with `python -m soillib_amd.build`; "
+                "there is no CPU fallback" % LIB_PATH)
+        _lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(_lib, name)
+            fn.restype = res
+            fn.argtypes = args
+    return _lib
+
+
+class SoilError(RuntimeError):
+    pass
+
+
+def check(rc):
+    if rc == SOIL_OK:
+        return
+    msg = lib().soil_last_error().decode("utf-8", "replace")
+    if rc == SOIL_ERR_INVALID_ARGUMENT:
+        raise ValueError(msg)  # std::invalid_argument in the reference
+    if rc == SOIL_ERR_OUT_OF_MEMORY:
+        raise MemoryError(msg)
+    raise SoilError("libsoil_hip error %d: %s" % (rc, msg))
+
+
+def vec(values, n):
+    values = [float(v) for v in values]
+    if len(values) != n:
+        raise ValueError("expected %d components, got %d" % (n, len(values)))
+    return (C.c_float * n)(*values)
+
+
+# current stream (hipStream_t as int); 0 = the null stream
+_stream = 0
+
+
+def set_stream(handle):
+    """Route subsequent launches to `handle` (e.g. torch.cuda.current_stream().cuda_stream)."""
+    global _stream
+    _stream = int(handle or 0)
+
+
+def stream():
+    return C.c_void_p(_stream)

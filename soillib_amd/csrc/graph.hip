@@ -1,0 +1,361 @@
+// graph.hip — flow-graph kernels: steepest / direction / random_weighted / slope
+// and rake-compress upstream accumulation (graph.hpp:49-63, graph.cu).
+//
+// Index arithmetic is 64-bit: K*n overflows int32 at 16384^2 with D8
+// (graph.cu:345 uses int).  Scratch for accumulate lives in a per-device
+// workspace that is grown on demand and reused, instead of the reference's
+// eight cudaMallocs per call (graph.cu:539-550).
+#include <mutex>
+#include <unordered_map>
+
+#include "common.hpp"
+
+namespace soil {
+
+constexpr int kGBlock = 256;
+
+// D4_t / D8_t neighbour tables, graph.hpp:21-46 (first four entries = D4)
+__device__ __constant__ int kShiftX[8] = {-1, 0, 0, 1, -1, -1, 1, 1};
+__device__ __constant__ int kShiftY[8] = {0, -1, 1, 0, -1, 1, -1, 1};
+
+__device__ __forceinline__ float shift_len(int k) {  // __length(shift), graph.cu:23-25
+  const float dx = static_cast<float>(kShiftX[k]), dy = static_cast<float>(kShiftY[k]);
+  return sqrtf(dx * dx + dy * dy);
+}
+
+// __steepest (graph.cu:27-70) / __direction (:201-243)
+template <int K, bool STORE_K>
+__global__ void __launch_bounds__(kGBlock)
+    k_steepest(int32_t* __restrict__ out, const float* __restrict__ height, int64_t H, int64_t W) {
+  const int64_t n = static_cast<int64_t>(blockIdx.x) * kGBlock + threadIdx.x;
+  if (n >= H * W) return;
+  const int64_t x = n / W, y = n % W;
+  const float hlocal = height[n];  // :40
+  float smax = 0.0f;               // :42
+  int32_t next = -1;               // :43
+#pragma unroll
+  for (int k = 0; k < K; ++k) {  // :46
+    const int64_t nx = x + kShiftX[k], ny = y + kShiftY[k];
+    if (nx < 0 || ny < 0 || nx >= H || ny >= W) continue;  // :51-52
+    const int64_t nind = nx * W + ny;
+    const float scur = (hlocal - height[nind]) / shift_len(k);  // :56
+    if (scur > smax) {                                          // :57-60
+      smax = scur;
+      next = STORE_K ? static_cast<int32_t>(k) : static_cast<int32_t>(nind);
+    }
+  }
+  out[n] = next;  // :68
+}
+
+// __seed (graph.cu:97-101) + __random_weighted (:103-173): the per-cell
+// generator state is never materialised — cell n reads its one uniform straight
+// from stream (seed, subsequence n) at position `offset`.
+template <int K>
+__global__ void __launch_bounds__(kGBlock)
+    k_random_weighted(int32_t* __restrict__ graph, const float* __restrict__ height, int64_t H,
+                      int64_t W, uint64_t seed, uint64_t offset, float T) {
+  const int64_t n = static_cast<int64_t>(blockIdx.x) * kGBlock + threadIdx.x;
+  if (n >= H * W) return;
+  const int64_t x = n / W, y = n % W;
+  const float hlocal = height[n];  // :118
+  float CDF[K];                    // :126
+  float Z = 0.0f;                  // :127
+#pragma unroll
+  for (int k = 0; k < K; ++k) {  // :129-143
+    CDF[k] = 0.0f;
+    const int64_t nx = x + kShiftX[k], ny = y + kShiftY[k];
+    if (nx < 0 || ny < 0 || nx >= H || ny >= W) continue;
+    const float dE = (hlocal - height[nx * W + ny]) / shift_len(k);  // :138
+    const float P = (dE <= 0.0f) ? 0.0f : expf_(dE / T);             // :139
+    CDF[k] = Z + P;                                                  // :140
+    Z += P;                                                          // :141
+  }
+  int32_t next = -1;                                                            // :149
+  const float uniform = rng_uniform_at(seed, static_cast<uint64_t>(n), offset);  // :100, :150
+  bool found = false;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {  // :151-165
+    const int64_t nx = x + kShiftX[k], ny = y + kShiftY[k];
+    if (nx < 0 || ny < 0 || nx >= H || ny >= W) continue;
+    if (!found && uniform < (CDF[k] / Z)) {  // :160 (Z == 0 -> NaN -> false)
+      next = static_cast<int32_t>(nx * W + ny);
+      found = true;
+    }
+  }
+  graph[n] = next;  // :171
+}
+
+// __slope, graph.cu:270-295
+__global__ void __launch_bounds__(kGBlock)
+    k_slope(float* __restrict__ slope, const float* __restrict__ tensor,
+            const int32_t* __restrict__ flow, int64_t H, int64_t W, Scale2 s) {
+  const int64_t n = static_cast<int64_t>(blockIdx.x) * kGBlock + threadIdx.x;
+  if (n >= H * W) return;
+  const int64_t next = flow[n];  // :282
+  if (next < 0 || next == n) {   // :283-286
+    slope[n] = 0.0f;
+    return;
+  }
+  const float ix = static_cast<float>(n / W), iy = static_cast<float>(n % W);        // :288
+  const float nx = static_cast<float>(next / W), ny = static_cast<float>(next % W);  // :289
+  const float ival = tensor[n];                                                      // :291
+  const float nval = tensor[next];                                                   // :292
+  const float dx = s.x * (nx - ix), dy = s.y * (ny - iy);
+  slope[n] = (nval - ival) / sqrtf(dx * dx + dy * dy);  // :293
+}
+
+// ---- accumulate --------------------------------------------------------------
+
+struct Acc {  // acc_t, graph.cu:422-427
+  int32_t* donor;
+  int32_t* count;
+  float* value;
+  float* decay;
+};
+
+// __donor, graph.cu:321-348: one writer per (receiver, k) slot, race-free
+template <int K>
+__global__ void __launch_bounds__(kGBlock)
+    k_donor(int32_t* __restrict__ donor, const int32_t* __restrict__ graph, int64_t H, int64_t W) {
+  const int64_t n = static_cast<int64_t>(blockIdx.x) * kGBlock + threadIdx.x;
+  if (n >= H * W) return;
+  const int64_t x = n / W, y = n % W;
+  const int64_t next = graph[n];  // :333
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const int64_t nx = x + kShiftX[k], ny = y + kShiftY[k];
+    if (nx < 0 || ny < 0 || nx >= H || ny >= W) continue;  // :340-341
+    const int64_t nind = nx * W + ny;
+    if (nind == next) donor[K * nind + k] = static_cast<int32_t>(n);  // :344-345
+  }
+}
+
+// __count (graph.cu:350-380) fused with my_decay (:382-420): compact the donor
+// slots, count them and assign the per-edge decay (diagonal exponent by
+// COMPACTED slot index k >= 4).
+template <int K, bool TENSOR_DECAY>
+__global__ void __launch_bounds__(kGBlock)
+    k_count_decay(int32_t* __restrict__ count, int32_t* __restrict__ donor,
+                  float* __restrict__ decay, const float* __restrict__ decayIn, int64_t elem) {
+  const int64_t n = static_cast<int64_t>(blockIdx.x) * kGBlock + threadIdx.x;
+  if (n >= elem) return;
+  int c = 0;
+  int32_t dn[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const int32_t dd = donor[K * n + k];
+    if (dd >= 0) dn[c++] = dd;
+  }
+  count[n] = c;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const bool live = k < c;
+    donor[K * n + k] = live ? dn[k] : -1;
+    if (live) {
+      const float D = TENSOR_DECAY ? decayIn[dn[k]] : 1.0f;
+      decay[K * n + k] = (k < 4) ? D : powf_(D, 1.414f);
+    }
+  }
+}
+
+// __rake_compress, graph.cu:429-522: one synchronous round, in -> out
+template <int K>
+__global__ void __launch_bounds__(kGBlock)
+    k_rake_compress(Acc out, const Acc in, int64_t elem) {
+  const int64_t n = static_cast<int64_t>(blockIdx.x) * kGBlock + threadIdx.x;
+  if (n >= elem) return;
+  float value = in.value[n];  // :440
+  int count = in.count[n];    // :441
+  int32_t donors[K];
+  float decays[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {  // :448-468
+    if (k < count) {
+      donors[k] = in.donor[K * n + k];
+      decays[k] = in.decay[K * n + k];
+    }
+  }
+  for (int k = 0; k < count; ++k) {  // :471
+    const int32_t donor = donors[k];
+    const float decay = decays[k];
+    const int dcount = in.count[donor];  // :476
+    if (dcount == 0) {                   // :479-487
+      value += decay * in.value[donor];
+      donors[k] = donors[count - 1];
+      decays[k] = decays[count - 1];
+      donors[count - 1] = -1;
+      decays[count - 1] = 0.0f;
+      count -= 1;
+      k -= 1;
+    } else if (dcount == 1) {  // :490-494
+      value += decay * in.value[donor];
+      donors[k] = in.donor[static_cast<int64_t>(K) * donor];
+      decays[k] = decay * in.decay[static_cast<int64_t>(K) * donor];
+    }
+  }
+  out.value[n] = value;  // :498
+  out.count[n] = count;  // :499
+#pragma unroll
+  for (int k = 0; k < K; ++k) {  // :500-520
+    if (k < count) {
+      out.donor[K * n + k] = donors[k];
+      out.decay[K * n + k] = decays[k];
+    }
+  }
+}
+
+// per-device scratch for accumulate
+struct Workspace {
+  void* base = nullptr;
+  size_t bytes = 0;
+};
+static std::mutex g_ws_mutex;
+static std::unordered_map<int, Workspace> g_ws;
+
+static int workspace_get(size_t bytes, void** out) {
+  int dev = 0;
+  SOIL_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(g_ws_mutex);
+  Workspace& w = g_ws[dev];
+  if (w.bytes < bytes) {
+    if (w.base) SOIL_HIP(hipFree(w.base));
+    w.base = nullptr;
+    w.bytes = 0;
+    SOIL_HIP(hipMalloc(&w.base, bytes));
+    w.bytes = bytes;
+  }
+  *out = w.base;
+  return SOIL_OK;
+}
+
+template <int K>
+static int accumulate_impl(float* out, const int32_t* graph, const float* source,
+                           const float* decayIn, int64_t H, int64_t W, hipStream_t st) {
+  const int64_t elem = H * W;
+  auto align = [](size_t b) { return (b + 255) & ~static_cast<size_t>(255); };
+  const size_t b1 = align(sizeof(float) * elem), bK = align(sizeof(float) * elem * K);
+  void* base = nullptr;
+  int rc = workspace_get(4 * b1 + 4 * bK, &base);
+  if (rc != SOIL_OK) return rc;
+  char* p = static_cast<char*>(base);
+  Acc A, B;
+  A.count = reinterpret_cast<int32_t*>(p); p += b1;
+  A.value = reinterpret_cast<float*>(p);   p += b1;
+  B.count = reinterpret_cast<int32_t*>(p); p += b1;
+  B.value = reinterpret_cast<float*>(p);   p += b1;
+  A.donor = reinterpret_cast<int32_t*>(p); p += bK;
+  A.decay = reinterpret_cast<float*>(p);   p += bK;
+  B.donor = reinterpret_cast<int32_t*>(p); p += bK;
+  B.decay = reinterpret_cast<float*>(p);
+
+  const unsigned nb = blocks_for(elem, kGBlock);
+  SOIL_HIP(hipMemsetAsync(A.donor, 0xff, sizeof(int32_t) * elem * K, st));  // silt::set(donor,-1) :552
+  SOIL_HIP(hipMemcpyAsync(A.value, source, sizeof(float) * elem, hipMemcpyDeviceToDevice, st));  // :553
+  k_donor<K><<<nb, kGBlock, 0, st>>>(A.donor, graph, H, W);  // :554
+  if (decayIn)
+    k_count_decay<K, true><<<nb, kGBlock, 0, st>>>(A.count, A.donor, A.decay, decayIn, elem);  // :555-556
+  else
+    k_count_decay<K, false><<<nb, kGBlock, 0, st>>>(A.count, A.donor, A.decay, nullptr, elem);
+  SOIL_LAUNCH_CHECK();
+
+  const int64_t iter =
+      static_cast<int64_t>(std::ceil(std::log2(static_cast<float>(elem)) / 2.0f));  // :559
+  for (int64_t i = 0; i <= iter; ++i) {                                             // :560-563
+    k_rake_compress<K><<<nb, kGBlock, 0, st>>>(B, A, elem);
+    k_rake_compress<K><<<nb, kGBlock, 0, st>>>(A, B, elem);
+  }
+  SOIL_LAUNCH_CHECK();
+  SOIL_HIP(hipMemcpyAsync(out, A.value, sizeof(float) * elem, hipMemcpyDeviceToDevice, st));
+  SOIL_HIP(hipStreamSynchronize(st));  // cudaDeviceSynchronize, graph.cu:564
+  return SOIL_OK;
+}
+
+}  // namespace soil
+
+using namespace soil;
+
+extern "C" {
+
+int soil_direction(int32_t* direction, const float* height, int64_t H, int64_t W, int edge,
+                   void* stream) {
+  SOIL_DEVICE();
+  SOIL_REQUIRE(direction && height, "direction: null tensor");
+  SOIL_REQUIRE(H > 0 && W > 0, "direction: empty grid");
+  const unsigned nb = blocks_for(H * W, kGBlock);
+  switch (edge) {
+    case SOIL_D4: k_steepest<4, true><<<nb, kGBlock, 0, as_stream(stream)>>>(direction, height, H, W); break;
+    case SOIL_D8: k_steepest<8, true><<<nb, kGBlock, 0, as_stream(stream)>>>(direction, height, H, W); break;
+    default: return fail(SOIL_ERR_INVALID_ARGUMENT, "invalid edge enumerator");  // graph.cu:262
+  }
+  SOIL_LAUNCH_CHECK();
+  return SOIL_OK;
+}
+
+int soil_steepest(int32_t* graph, const float* height, int64_t H, int64_t W, int edge,
+                  void* stream) {
+  SOIL_DEVICE();
+  SOIL_REQUIRE(graph && height, "steepest: null tensor");
+  SOIL_REQUIRE(H > 0 && W > 0 && H * W <= INT32_MAX, "steepest: grid must have 1..2^31-1 cells");
+  const unsigned nb = blocks_for(H * W, kGBlock);
+  switch (edge) {
+    case SOIL_D4: k_steepest<4, false><<<nb, kGBlock, 0, as_stream(stream)>>>(graph, height, H, W); break;
+    case SOIL_D8: k_steepest<8, false><<<nb, kGBlock, 0, as_stream(stream)>>>(graph, height, H, W); break;
+    default: return fail(SOIL_ERR_INVALID_ARGUMENT, "invalid edge enumerator");  // graph.cu:88
+  }
+  SOIL_LAUNCH_CHECK();
+  return SOIL_OK;
+}
+
+int soil_random_weighted(int32_t* graph, const float* height, int64_t H, int64_t W, int edge,
+                         uint64_t seed, uint64_t offset, float T, void* stream) {
+  SOIL_DEVICE();
+  SOIL_REQUIRE(graph && height, "random_weighted: null tensor");
+  SOIL_REQUIRE(H > 0 && W > 0 && H * W <= INT32_MAX,
+               "random_weighted: grid must have 1..2^31-1 cells");
+  const unsigned nb = blocks_for(H * W, kGBlock);
+  switch (edge) {
+    case SOIL_D4: k_random_weighted<4><<<nb, kGBlock, 0, as_stream(stream)>>>(graph, height, H, W, seed, offset, T); break;
+    case SOIL_D8: k_random_weighted<8><<<nb, kGBlock, 0, as_stream(stream)>>>(graph, height, H, W, seed, offset, T); break;
+    default: return fail(SOIL_ERR_INVALID_ARGUMENT, "invalid edge enumerator");  // graph.cu:192
+  }
+  SOIL_LAUNCH_CHECK();
+  return SOIL_OK;
+}
+
+int soil_slope(float* slope, const float* tensor, const int32_t* flow, int64_t H, int64_t W,
+               const float scale[2], void* stream) {
+  SOIL_DEVICE();
+  SOIL_REQUIRE(slope && tensor && flow && scale, "slope: null argument");
+  SOIL_REQUIRE(H > 0 && W > 0, "slope: empty grid");
+  k_slope<<<blocks_for(H * W, kGBlock), kGBlock, 0, as_stream(stream)>>>(
+      slope, tensor, flow, H, W, Scale2{scale[0], scale[1]});
+  SOIL_LAUNCH_CHECK();
+  return SOIL_OK;
+}
+
+int soil_accumulate(float* out, const int32_t* graph, const float* source, const float* decay,
+                    int64_t H, int64_t W, int edge, void* stream) {
+  SOIL_DEVICE();
+  SOIL_REQUIRE(out && graph && source, "accumulate: null tensor");
+  SOIL_REQUIRE(H > 0 && W > 0 && H * W <= INT32_MAX, "accumulate: grid must have 1..2^31-1 cells");
+  switch (edge) {
+    case SOIL_D4: return accumulate_impl<4>(out, graph, source, decay, H, W, as_stream(stream));
+    case SOIL_D8: return accumulate_impl<8>(out, graph, source, decay, H, W, as_stream(stream));
+    default: return fail(SOIL_ERR_INVALID_ARGUMENT, "invalid edge enumerator");  // graph.cu:573
+  }
+}
+
+int soil_workspace_release(void) {
+  SOIL_DEVICE();
+  int dev = 0;
+  SOIL_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(g_ws_mutex);
+  auto it = g_ws.find(dev);
+  if (it != g_ws.end()) {
+    if (it->second.base) SOIL_HIP(hipFree(it->second.base));
+    g_ws.erase(it);
+  }
+  return SOIL_OK;
+}
+
+}  // extern "C"

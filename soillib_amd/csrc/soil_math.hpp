@@ -1,0 +1,132 @@
+// soil_math.hpp — numerical contract of the hot path.
+//
+// The reference leans on two things no other platform can reproduce: CUDA's
+// fast intrinsics __expf/__powf (erosion.cu:85,134-136,345-346,500,872;
+// graph.cu:139,409-411; filter.cu:48; path.cu:134) and cuRAND XORWOW
+// (erosion.cu:57-58, graph.cu:97-101,150).  This header fixes portable
+// replacements, written for host and device alike so that host-side setup
+// (blur weights, CPU twins) and the kernels agree to the bit:
+//
+//   soil::expf_  — range-reduced degree-6 polynomial, <= 1 ulp, flush below e^-87
+//   soil::log2f_ — mantissa polynomial, positive normal inputs
+//   soil::powf_  — exp2(y * log2 x), the definition of __powf
+//   soil::Philox — Philox4x32-10, counter = {offset, subsequence}, key = seed
+//
+// Everything is plain IEEE fp32 evaluated in the written order; the library is
+// compiled with -ffp-contract=off so no product-sum is fused behind our back.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define SOIL_HD __host__ __device__ __forceinline__
+
+namespace soil {
+
+constexpr float kSqrt2 = 1.41421354f;  // CUDART_SQRT_TWO_F, erosion_map.cu:61
+constexpr float kFltMin = 1.17549435e-38f;
+
+SOIL_HD float bits2f(uint32_t u) { return __builtin_bit_cast(float, u); }
+SOIL_HD uint32_t f2bits(float f) { return __builtin_bit_cast(uint32_t, f); }
+SOIL_HD float pow2i(int n) { return bits2f(static_cast<uint32_t>(n + 127) << 23); }  // n in [-126,127]
+
+SOIL_HD float exp_poly(float r) {  // ~ exp(r) on |r| <= ln2/2
+  float p = 1.9875691500E-4f;
+  p = p * r + 1.3981999507E-3f;
+  p = p * r + 8.3334519073E-3f;
+  p = p * r + 4.1665795894E-2f;
+  p = p * r + 1.6666665459E-1f;
+  p = p * r + 5.0000001201E-1f;
+  return (p * (r * r) + r) + 1.0f;
+}
+
+SOIL_HD float expf_(float x) {
+  if (x != x) return x;
+  if (x > 88.72283f) return __builtin_inff();
+  if (x < -87.0f) return 0.0f;
+  const float n = __builtin_rintf(x * 1.44269504f);
+  float r = x - n * 0.693145752f;
+  r = r - n * 1.42860677e-6f;
+  const float y = exp_poly(r);
+  const int ni = static_cast<int>(n);
+  const int n1 = ni / 2;
+  const int n2 = ni - n1;
+  return (y * pow2i(n1)) * pow2i(n2);
+}
+
+SOIL_HD float log2f_(float x) {
+  if (x != x) return x;
+  if (x < 0.0f) return __builtin_nanf("");
+  if (x < kFltMin) return -__builtin_inff();
+  if (x == __builtin_inff()) return x;
+  const uint32_t b = f2bits(x);
+  int e = static_cast<int>((b >> 23) & 0xffu) - 127;
+  float m = bits2f((b & 0x007fffffu) | 0x3f800000u);
+  if (m > kSqrt2) {
+    m = m * 0.5f;
+    e = e + 1;
+  }
+  const float f = m - 1.0f;
+  const float z = f * f;
+  float p = 7.0376836292E-2f;
+  p = p * f - 1.1514610310E-1f;
+  p = p * f + 1.1676998740E-1f;
+  p = p * f - 1.2420140846E-1f;
+  p = p * f + 1.4249322787E-1f;
+  p = p * f - 1.6668057665E-1f;
+  p = p * f + 2.0000714765E-1f;
+  p = p * f - 2.4999993993E-1f;
+  p = p * f + 3.3333331174E-1f;
+  float y = (f * z) * p;
+  y = y - 0.5f * z;
+  const float ln_m = f + y;
+  return ln_m * 1.44269504f + static_cast<float>(e);
+}
+
+SOIL_HD float powf_(float x, float y) {
+  const float t = y * log2f_(x);
+  if (t != t) return t;
+  if (t > 128.0f) return __builtin_inff();
+  if (t < -126.0f) return 0.0f;
+  const float n = __builtin_rintf(t);
+  const float r = (t - n) * 0.693147182f;
+  const float v = exp_poly(r);
+  const int ni = static_cast<int>(n);
+  const int n1 = ni / 2;
+  const int n2 = ni - n1;
+  return (v * pow2i(n1)) * pow2i(n2);
+}
+
+// Philox4x32-10 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as
+// easy as 1, 2, 3", SC'11).  Only word 0 of the block is consumed per draw.
+SOIL_HD uint32_t philox4x32_10_w0(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                  uint32_t k1) {
+#pragma unroll
+  for (int round = 0; round < 10; ++round) {
+    const uint64_t p0 = static_cast<uint64_t>(0xD2511F53u) * c0;
+    const uint64_t p1 = static_cast<uint64_t>(0xCD9E8D57u) * c2;
+    const uint32_t n0 = static_cast<uint32_t>(p1 >> 32) ^ c1 ^ k0;
+    const uint32_t n1 = static_cast<uint32_t>(p1);
+    const uint32_t n2 = static_cast<uint32_t>(p0 >> 32) ^ c3 ^ k1;
+    const uint32_t n3 = static_cast<uint32_t>(p0);
+    c0 = n0;
+    c1 = n1;
+    c2 = n2;
+    c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  return c0;
+}
+
+// One draw in (0, 1] from stream (seed, subsequence) at position `offset` —
+// the addressing of curand_init(seed, subsequence, offset) + curand_uniform.
+SOIL_HD float rng_uniform_at(uint64_t seed, uint64_t subsequence, uint64_t offset) {
+  const uint32_t r = philox4x32_10_w0(
+      static_cast<uint32_t>(offset), static_cast<uint32_t>(offset >> 32),
+      static_cast<uint32_t>(subsequence), static_cast<uint32_t>(subsequence >> 32),
+      static_cast<uint32_t>(seed), static_cast<uint32_t>(seed >> 32));
+  return static_cast<float>((r >> 8) + 1u) * 5.9604644775390625e-08f;  // 2^-24
+}
+
+}  // namespace soil

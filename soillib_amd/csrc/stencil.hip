@@ -1,0 +1,242 @@
+// stencil.hip — gradient / negslope / laplacian (grad.cu), separable Gaussian
+// blur (filter.cu) and the surface-normal map (op/normal.hpp).
+#include "common.hpp"
+
+namespace soil {
+
+constexpr int kSBlock = 256;
+
+// __gradient, grad.cu:22-87
+__global__ void __launch_bounds__(kSBlock)
+    k_gradient(float2* __restrict__ out, const float* __restrict__ in, int64_t H, int64_t W,
+               Scale2 s) {
+  const int64_t n = static_cast<int64_t>(blockIdx.x) * kSBlock + threadIdx.x;
+  if (n >= H * W) return;
+  const int64_t x = n / W, y = n % W;
+  const float nan = __builtin_nanf("");
+  const float h = in[n];
+  const float hn0 = (x - 1 < 0) ? nan : in[n - W];  // :35-38
+  const float hp0 = (x + 1 >= H) ? nan : in[n + W];
+  const float h0n = (y - 1 < 0) ? nan : in[n - 1];
+  const float h0p = (y + 1 >= W) ? nan : in[n + 1];
+  const float gxn = (h - hn0) / s.x;    // :46
+  const float gyn = (h - h0n) / s.y;    // :50
+  const float gxp = (hp0 - h) / s.x;    // :54
+  const float gyp = (h0p - h) / s.y;    // :58
+  float gx = 0.5f * (hp0 - hn0) / s.x;  // :62
+  float gy = 0.5f * (h0p - h0n) / s.y;  // :63
+  if (gx != gx) gx = gxn;               // :65-67
+  if (gx != gx) gx = gxp;
+  if (gx != gx) gx = 0.0f;
+  if (gy != gy) gy = gyn;  // :69-71
+  if (gy != gy) gy = gyp;
+  if (gy != gy) gy = 0.0f;
+  out[n] = make_float2(gx, gy);  // :84-85
+}
+
+// __negslope, grad.cu:101-131
+__global__ void __launch_bounds__(kSBlock)
+    k_negslope(float* __restrict__ out, const float* __restrict__ in, int64_t H, int64_t W,
+               Scale2 s) {
+  const int64_t n = static_cast<int64_t>(blockIdx.x) * kSBlock + threadIdx.x;
+  if (n >= H * W) return;
+  const int64_t x = n / W, y = n % W;
+  const float h = in[n];
+  float gx = 0.0f;  // :120-122, glm::max(a, b) = (a < b) ? b : a
+  if (x - 1 >= 0) {
+    const float c = (h - in[n - W]) / s.x;
+    gx = (gx < c) ? c : gx;
+  }
+  if (x + 1 < H) {
+    const float c = (h - in[n + W]) / s.x;
+    gx = (gx < c) ? c : gx;
+  }
+  float gy = 0.0f;  // :124-126
+  if (y - 1 >= 0) {
+    const float c = (h - in[n - 1]) / s.y;
+    gy = (gy < c) ? c : gy;
+  }
+  if (y + 1 < W) {
+    const float c = (h - in[n + 1]) / s.y;
+    gy = (gy < c) ? c : gy;
+  }
+  out[n] = sqrtf(gx * gx + gy * gy);  // :129
+}
+
+// __laplacian<D>, grad.cu:147-183 — one thread per (cell, channel)
+template <int D>
+__global__ void __launch_bounds__(kSBlock)
+    k_laplacian(float* __restrict__ out, const float* __restrict__ in, int64_t H, int64_t W,
+                Scale2 s) {
+  const int64_t t = static_cast<int64_t>(blockIdx.x) * kSBlock + threadIdx.x;
+  if (t >= H * W * D) return;
+  const int64_t n = t / D;
+  const int c = static_cast<int>(t % D);
+  const int64_t x = n / W, y = n % W;
+  auto at = [&](int dx, int dy) -> float {  // clamp-to-self, :166-173
+    const int64_t nx = x + dx, ny = y + dy;
+    if (nx < 0 || nx >= H || ny < 0 || ny >= W) return in[D * n + c];
+    return in[D * (nx * W + ny) + c];
+  };
+  const float v00 = in[D * n + c];
+  const float vn0 = at(-1, 0), vp0 = at(1, 0), v0n = at(0, -1), v0p = at(0, 1);
+  const float vnn = at(-1, -1), vpp = at(1, 1), vpn = at(1, -1), vnp = at(-1, 1);
+  const float hx = (1.0f / s.x / s.x);  // :175
+  const float hy = (1.0f / s.y / s.y);  // :176
+  const float LH = (vn0 - v00) * hx + (vp0 - v00) * hx + (v0n - v00) * hy + (v0p - v00) * hy;  // :178
+  const float LD = 0.5f * (vnn - v00) * hx + 0.5f * (vpp - v00) * hx + 0.5f * (vpn - v00) * hy +
+                   0.5f * (vnp - v00) * hy;   // :179
+  out[D * n + c] = 0.5f * LH + 0.5f * LD;    // :181
+}
+
+// __gaussian_blur / __blur, filter.cu:24-70.  The 33 tap weights depend on
+// sigma only; the host evaluates them once with the same expression as
+// filter.cu:47-48 instead of once per tap per cell.
+struct BlurWeights {
+  float w[33];
+};
+
+template <bool XDIR>
+__global__ void __launch_bounds__(kSBlock)
+    k_blur(float* __restrict__ out, const float* __restrict__ in, int64_t H, int64_t W, int C,
+           BlurWeights bw) {
+  const int64_t t = static_cast<int64_t>(blockIdx.x) * kSBlock + threadIdx.x;
+  if (t >= H * W * C) return;
+  const int64_t n = t / C;
+  const int c = static_cast<int>(t % C);
+  const int64_t x = n / W, y = n % W;
+  float val = 0.0f;  // :35
+#pragma unroll
+  for (int k = -16; k <= 16; ++k) {  // :37
+    int64_t nx = x + (XDIR ? k : 0), ny = y + (XDIR ? 0 : k);  // :39
+    if (nx < 0) nx = 0;                                         // :40-43
+    if (ny < 0) ny = 0;
+    if (nx > H - 1) nx = H - 1;
+    if (ny > W - 1) ny = W - 1;
+    val += in[C * (nx * W + ny) + c] * bw.w[k + 16];  // :49-50
+  }
+  out[t] = val;  // :54
+}
+
+// lerp5 gradient along one axis: the build's definition of silt's lerp5_t::grad
+// (un-vendored): 4th-order central difference when all five
+// samples exist and are finite, else 2nd-order central, else one-sided, else 0.
+SOIL_HD float lerp5_axis(const float* in, int64_t n, int64_t stride, int64_t i, int64_t len) {
+  const float nan = __builtin_nanf("");
+  const float f0 = in[n];
+  const float fm2 = (i - 2 >= 0) ? in[n - 2 * stride] : nan;
+  const float fm1 = (i - 1 >= 0) ? in[n - stride] : nan;
+  const float fp1 = (i + 1 < len) ? in[n + stride] : nan;
+  const float fp2 = (i + 2 < len) ? in[n + 2 * stride] : nan;
+  auto fin = [](float v) { return (v - v) == 0.0f; };  // finite: not NaN, not +-inf
+  if (fin(fm2) && fin(fm1) && fin(fp1) && fin(fp2))
+    return ((fm2 - 8.0f * fm1) + (8.0f * fp1 - fp2)) / 12.0f;
+  if (fin(fm1) && fin(fp1)) return 0.5f * (fp1 - fm1);
+  if (fin(fp1) && fin(f0)) return fp1 - f0;
+  if (fin(fm1) && fin(f0)) return f0 - fm1;
+  return 0.0f;
+}
+
+// soil::op::normal, normal.hpp:29-35, for one cell
+SOIL_HD void normal_cell(float* out, const float* in, int64_t n, int64_t H, int64_t W, Scale3 s) {
+  const int64_t x = n / W, y = n % W;
+  const float gx = lerp5_axis(in, n, W, x, H) * s.z / s.x;  // :31-32
+  const float gy = lerp5_axis(in, n, 1, y, W) * s.z / s.y;
+  const float vx = -gx, vy = -gy, vz = 1.0f;  // :33
+  const float inv = 1.0f / sqrtf(vx * vx + vy * vy + vz * vz);
+  out[3 * n] = vx * inv;
+  out[3 * n + 1] = vy * inv;
+  out[3 * n + 2] = vz * inv;
+}
+
+__global__ void __launch_bounds__(kSBlock)
+    k_normal(float* __restrict__ out, const float* __restrict__ in, int64_t H, int64_t W,
+             Scale3 s) {
+  const int64_t n = static_cast<int64_t>(blockIdx.x) * kSBlock + threadIdx.x;
+  if (n >= H * W) return;
+  normal_cell(out, in, n, H, W, s);
+}
+
+}  // namespace soil
+
+using namespace soil;
+
+extern "C" {
+
+int soil_gradient(float* out, const float* in, int64_t H, int64_t W, const float scale[2],
+                  void* stream) {
+  SOIL_DEVICE();
+  SOIL_REQUIRE(out && in && scale, "gradient: null argument");
+  SOIL_REQUIRE(H > 0 && W > 0, "gradient: empty grid");
+  k_gradient<<<blocks_for(H * W, kSBlock), kSBlock, 0, as_stream(stream)>>>(
+      reinterpret_cast<float2*>(out), in, H, W, Scale2{scale[0], scale[1]});
+  SOIL_LAUNCH_CHECK();
+  return SOIL_OK;
+}
+
+int soil_negslope(float* out, const float* in, int64_t H, int64_t W, const float scale[2],
+                  void* stream) {
+  SOIL_DEVICE();
+  SOIL_REQUIRE(out && in && scale, "negslope: null argument");
+  SOIL_REQUIRE(H > 0 && W > 0, "negslope: empty grid");
+  k_negslope<<<blocks_for(H * W, kSBlock), kSBlock, 0, as_stream(stream)>>>(
+      out, in, H, W, Scale2{scale[0], scale[1]});
+  SOIL_LAUNCH_CHECK();
+  return SOIL_OK;
+}
+
+int soil_laplacian(float* out, const float* in, int64_t H, int64_t W, int D, const float scale[2],
+                   void* stream) {
+  SOIL_DEVICE();
+  SOIL_REQUIRE(out && in && scale, "laplacian: null argument");
+  SOIL_REQUIRE(H > 0 && W > 0, "laplacian: empty grid");
+  const Scale2 s{scale[0], scale[1]};
+  const unsigned nb = blocks_for(H * W * D, kSBlock);
+  if (D == 1)  // grad.cu:196-198
+    k_laplacian<1><<<nb, kSBlock, 0, as_stream(stream)>>>(out, in, H, W, s);
+  else if (D == 2)  // grad.cu:200-202
+    k_laplacian<2><<<nb, kSBlock, 0, as_stream(stream)>>>(out, in, H, W, s);
+  else
+    return fail(SOIL_ERR_INVALID_ARGUMENT, "laplacian: channel count must be 1 or 2");
+  SOIL_LAUNCH_CHECK();
+  return SOIL_OK;
+}
+
+int soil_gaussian_blur(float* tensor, float* scratch, int64_t H, int64_t W, int C, float sigma,
+                       void* stream) {
+  SOIL_DEVICE();
+  SOIL_REQUIRE(tensor && scratch, "gaussian_blur: null tensor");
+  SOIL_REQUIRE(H > 0 && W > 0, "gaussian_blur: empty grid");
+  SOIL_REQUIRE(C == 1 || C == 2, "gaussian_blur: channel count must be 1 or 2");
+  BlurWeights bw;
+  for (int k = -16; k <= 16; ++k) {
+    const float Z = sqrtf(2.0f * 3.14159265f) * sigma;                                // filter.cu:47
+    bw.w[k + 16] = expf_(-0.5f * (static_cast<float>(k) / sigma) * (static_cast<float>(k) / sigma)) / Z;  // :48
+  }
+  const unsigned nb = blocks_for(H * W * C, kSBlock);
+  k_blur<true><<<nb, kSBlock, 0, as_stream(stream)>>>(scratch, tensor, H, W, C, bw);   // :81 / :86
+  k_blur<false><<<nb, kSBlock, 0, as_stream(stream)>>>(tensor, scratch, H, W, C, bw);  // :82 / :87
+  SOIL_LAUNCH_CHECK();
+  return SOIL_OK;
+}
+
+int soil_normal(float* out, const float* in, int64_t H, int64_t W, const float scale[3],
+                void* stream) {
+  SOIL_DEVICE();
+  SOIL_REQUIRE(out && in && scale, "normal: null argument");
+  SOIL_REQUIRE(H > 0 && W > 0, "normal: empty grid");
+  k_normal<<<blocks_for(H * W, kSBlock), kSBlock, 0, as_stream(stream)>>>(
+      out, in, H, W, Scale3{scale[0], scale[1], scale[2]});
+  SOIL_LAUNCH_CHECK();
+  return SOIL_OK;
+}
+
+int soil_normal_host(float* out, const float* in, int64_t H, int64_t W, const float scale[3]) {
+  SOIL_REQUIRE(out && in && scale, "normal_host: null argument");
+  SOIL_REQUIRE(H > 0 && W > 0, "normal_host: empty grid");
+  const Scale3 s{scale[0], scale[1], scale[2]};
+  for (int64_t n = 0; n < H * W; ++n) normal_cell(out, in, n, H, W, s);  // normal.hpp:29-35
+  return SOIL_OK;
+}
+
+}  // extern "C"

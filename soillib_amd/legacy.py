@@ -1,0 +1,149 @@
+"""Legacy `soillib` names that example/erosion_gpu.py still calls.
+
+The reference snapshot no longer binds them (they sit in a comment block,
+python/source/model.cpp:62-143, and `soil::erode` has no definition), so their
+meaning is reconstructed from the script and from the commented code
+(SURVEY.md F3, §3.1, §8a):
+
+    soil.map_t(shape, scale)   .height (bedrock) .sediment .uplift .rainfall   (model.cpp:67-97)
+    soil.data_t(shape)         .discharge .momentum .mass .debris .debris_momentum (:103-140)
+    soil.param_t()             legacy attribute names mapped onto the live ones (§8a)
+    soil.erode(model, data, track, param, steps)                                (:142)
+    soil.multiply(tensor, scalar) / soil.clamp(tensor, lo, hi)
+
+`erode` runs soillib_amd.erosion.ErosionModel on the caller's tensors: `data.*`
+are the transported fields, `track.*` the flux accumulators.
+"""
+import ctypes as C
+
+from . import _abi, silt
+from . import soil as _live
+from .erosion import ErosionModel
+
+# legacy attribute -> live param_t field (live names erosion.hpp:20-56)
+_LEGACY_PARAM = {
+    "viscosity": "viscosityWater",
+    "bedShear": "bedShearWater",
+    "suspensionRate": "suspensionRateFluvial",
+    "depositionRate": "depositionRateFluvial",
+    "critSlope": "critSlopeBedrock",
+    "debrisCreepRate": "landslideRateDebris",
+    "debrisSuspensionRate": "suspensionRateDebris",
+    "debrisDepositionRate": "depositionRateDebris",
+    "debrisYieldStress": "yieldStress",
+    "debrisDensity": "densityDebris",
+    "debrisViscosity": "viscosityDebris",
+    "debrisBedShear": "bedShearDebris",
+}
+
+
+class param_t(_live.param_t):
+    """Live param_t that also answers to the legacy names of example/erosion_gpu.py:75-100.
+    `samples` (particle count, = rng.elem() in the live API) is kept on the object."""
+
+    def __init__(self):
+        super().__init__()
+        object.__setattr__(self, "samples", 8192)
+
+    def __setattr__(self, name, value):
+        if name == "samples":
+            object.__setattr__(self, "samples", int(value))
+        else:
+            super().__setattr__(_LEGACY_PARAM.get(name, name), value)
+
+    def __getattr__(self, name):
+        return super().__getattr__(_LEGACY_PARAM.get(name, name))
+
+
+class map_t:
+    """model.cpp:67-97: terrain planes + pixel scale."""
+
+    def __init__(self, shape, scale):
+        self.shape = shape if isinstance(shape, silt.shape) else silt.shape(*shape)
+        self.scale = [float(v) for v in scale]
+        self.height = None     # bedrock
+        self.sediment = None
+        self.uplift = None
+        self.rainfall = None
+        self._engine = None
+
+
+class data_t:
+    """model.cpp:103-140: transported quantities (or their flux accumulators)."""
+
+    def __init__(self, shape):
+        self.shape = shape if isinstance(shape, silt.shape) else silt.shape(*shape)
+        self.discharge = None
+        self.momentum = None
+        self.mass = None
+        self.debris = None
+        self.debris_momentum = None
+
+
+def _engine(model, data, track, param):
+    H, W = model.shape[0], model.shape[1]
+    eng = model._engine
+    if eng is None or eng.N != param.samples:
+        # planes the caller owns are aliased, not copied
+        names = {
+            "uplift": model.uplift, "rainfall": model.rainfall,
+            "waterHeight": data.discharge, "mass": data.mass, "velocity": data.momentum,
+            "debris": data.debris, "debrisVelocity": data.debris_momentum,
+            "waterFlux": track.discharge, "massFlux": track.mass, "velocityFlux": track.momentum,
+            "debrisFlux": track.debris, "debrisVelocityFlux": track.debris_momentum,
+        }
+        for key, t in names.items():
+            if t is None or t.host is not silt.gpu or t.type is not silt.float32:
+                raise ValueError("erode: %s must be a float32 silt.gpu tensor" % key)
+        eng = ErosionModel.__new__(ErosionModel)
+        eng.H, eng.W = H, W
+        eng.scale = list(model.scale)
+        eng.param = param
+        eng.N = int(param.samples)
+        eng.seed = 0
+        eng.dom = _abi.Domain(H, W, 0, H, 0, H)
+        eng.rows = H
+        eng.step_index = 0
+        eng.layers = silt.tensor(silt.float32, silt.shape(H, W, 2), silt.gpu)
+        eng.layers_next = silt.tensor(silt.float32, silt.shape(H, W, 2), silt.gpu)
+        eng.height = silt.tensor(silt.float32, silt.shape(H, W), silt.gpu)
+        for key, t in names.items():
+            setattr(eng, key, t)
+        eng.rng = silt.tensor(silt.rng, silt.shape(eng.N), silt.gpu)
+        model._engine = eng
+    eng.param = param
+    return eng
+
+
+def erode(model, data, track, param, steps=1):
+    """One or more erosion steps on the legacy containers."""
+    eng = _engine(model, data, track, param)
+    lib = _abi.lib()
+    n = eng.H * eng.W
+    if model.sediment is None:
+        model.sediment = silt.tensor(silt.float32, silt.shape(eng.H, eng.W), silt.gpu)
+        silt.set(model.sediment, 0.0)
+    _abi.check(lib.soil_layers_from_planes(eng.layers.c_ptr, model.height.c_ptr,
+                                           model.sediment.c_ptr, n, _abi.stream()))
+    for t in (track.discharge, track.mass, track.momentum, track.debris, track.debris_momentum):
+        silt.set(t, 0.0)  # silt.set(track.*, 0): the kernels only add to the flux planes
+    for _ in range(int(steps)):
+        eng.step()
+    _abi.check(lib.soil_layers_to_planes(model.height.c_ptr, model.sediment.c_ptr,
+                                         eng.layers.c_ptr, n, _abi.stream()))
+
+
+def multiply(tensor, value):
+    """soil.multiply(tensor, scalar) (example/erosion_gpu.py:14)."""
+    silt.multiply(tensor, value)
+    return tensor
+
+
+def clamp(tensor, lo, hi):
+    """soil.clamp (example/erosion_gpu_multiscale.py): host tensors only — the
+    multiscale driver is outside the hot path."""
+    import numpy as np
+    if tensor.host is not silt.cpu:
+        raise _abi.SoilError("clamp: only silt.cpu tensors are supported")
+    np.clip(tensor.numpy(), lo, hi, out=tensor.numpy())
+    return tensor

@@ -1,0 +1,488 @@
+"""GPU parity tests: every HIP entry point against the CPU oracle on the same
+seeded inputs, through the C ABI.
+
+Bars:
+  * index / direction maps, and every deterministic per-cell kernel: BIT-EXACT
+    (both sides evaluate the same fp32 expression trees with no contraction and
+    share the software exp/pow and the Philox generator);
+  * particle kernels: trajectories are bit-identical, only the ORDER of the fp32
+    atomic additions differs -> flux planes compared with rtol 2e-5 of the
+    per-cell accumulated magnitude (stated next to each check).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from util import (assert_bit_equal, copy_param, product_param, rng_to_gpu, script_param, terrain,
+                  to_gpu, to_np)
+
+pytestmark = pytest.mark.gpu
+
+D4, D8 = 0, 1
+SIZES = [(64, 64), (37, 53), (128, 96)]       # square, ragged (W % 4 != 0), wide
+
+
+def _selftest(hip, a, b, op):
+    from soillib_amd import _abi
+    ga, gb = to_gpu(a), to_gpu(b)
+    out = to_gpu(np.zeros_like(a))
+    _abi.check(hip.soil_selftest_math(out.c_ptr, ga.c_ptr, gb.c_ptr, a.size, op, None))
+    return to_np(out)
+
+
+# ----------------------------------------------------------- numerics
+
+def test_device_is_gfx950(hip):
+    buf = C.create_string_buffer(64)
+    assert hip.soil_device_name(buf, 64) == 0
+    assert buf.value.decode().startswith("gfx950"), buf.value
+
+
+def test_spec_math_bit_exact(hip, oracle):
+    r = np.random.default_rng(0)
+    x = np.concatenate([np.linspace(-100, 100, 40001), r.normal(0, 3, 20000),
+                        [0.0, -0.0, np.inf, -np.inf, np.nan, 88.7, 88.73, -87.0, -87.1]]
+                       ).astype(np.float32)
+    assert_bit_equal(_selftest(hip, x, x, 0), oracle.expf(x), "expf_")
+    xp = np.concatenate([np.exp(r.uniform(-80, 80, 30000)), [0.0, 1.0, 2.0, 1e-39, np.inf]]
+                        ).astype(np.float32)
+    assert_bit_equal(_selftest(hip, xp, xp, 1), oracle.log2f(xp), "log2f_")
+    a = np.concatenate([r.uniform(0, 50, 30000), [0.0, 0.0, 1.0, 1e-30]]).astype(np.float32)
+    b = np.concatenate([r.uniform(0.005, 3, 30000), [2.0, 0.0, 1.414, 0.01]]).astype(np.float32)
+    assert_bit_equal(_selftest(hip, a, b, 2), oracle.powf(a, b), "powf_")
+
+
+def test_denormals_are_not_flushed(hip):
+    a = np.array([1e-30, 3e-39, 1.5e-38], np.float32)
+    b = np.array([1e-10, 0.5, 0.25], np.float32)
+    assert_bit_equal(_selftest(hip, a, b, 4), a * b, "denormal product")
+
+
+def test_philox_uniform_bit_exact(hip, oracle):
+    n = 5000
+    seeds = np.full(n, 7, np.uint32).view(np.float32)
+    offs = np.arange(n, dtype=np.uint32).view(np.float32)
+    got = _selftest(hip, seeds, offs, 3)
+    want = np.empty(n, np.float32)
+    for i in range(n):
+        st = oracle.rng_seed(1, 7, i)
+        want[i] = oracle.rng_uniform(st, [i])[0]
+    assert_bit_equal(got, want, "uniform")
+    assert (got > 0).all() and (got <= 1).all()
+
+
+# ----------------------------------------------------------- cell ops
+
+def _cell_inputs(oracle, H, W, seed=0):
+    r = np.random.default_rng(seed)
+    layers = terrain(oracle, H, W, sediment=0.02, rng_seed=seed)
+    f1 = lambda s: (r.random((H, W)) * s).astype(np.float32)
+    f2 = lambda s: (r.standard_normal((H, W, 2)) * s).astype(np.float32)
+    return dict(layers=layers, uplift=f1(1.0), rainfall=f1(2.0), waterFlux=f1(3.0),
+                massFlux=f1(0.5), velocityFlux=f2(2.0), debrisFlux=f1(0.2),
+                debrisVelocityFlux=f2(1.0))
+
+
+@pytest.mark.parametrize("H,W", SIZES)
+@pytest.mark.parametrize("which", ["default", "script"])
+def test_mass_transfer_and_creep_bit_exact(hip, oracle, H, W, which):
+    from soillib_amd import soil
+    inp = _cell_inputs(oracle, H, W)
+    op = oracle.default_param()
+    if which == "script":
+        script_param(op)
+    pp = product_param(op)
+    scale = (20.0 / H, 20.0 / W, 4.0)
+    r = np.random.default_rng(3)
+    mass = (r.random((H, W)) * 5).astype(np.float32)
+    vel = (r.standard_normal((H, W, 2)) * 4).astype(np.float32)
+    debris = (r.random((H, W)) * 2).astype(np.float32)
+    delta0 = (r.standard_normal((H, W, 2)) * 0.01).astype(np.float32)
+
+    want = delta0.copy()
+    oracle.mass_transfer(want, inp["layers"], inp["uplift"], mass, vel, debris, None, None, None,
+                         None, scale, op)
+    oracle.mass_creep(want, inp["layers"], scale, op)
+
+    g_delta, g_layers = to_gpu(delta0), to_gpu(inp["layers"])
+    z1, z2 = to_gpu(np.zeros((H, W), np.float32)), to_gpu(np.zeros((H, W, 2), np.float32))
+    soil.mass_transfer(g_delta, g_layers, to_gpu(inp["uplift"]), z1, to_gpu(mass), to_gpu(vel),
+                       to_gpu(debris), z2, None, None, None, None, scale, pp)
+    soil.mass_creep(g_delta, g_layers, scale, pp)
+    assert_bit_equal(to_np(g_delta), want, "delta after mass_transfer+mass_creep")
+
+    g_h = to_gpu(np.zeros((H, W), np.float32))
+    soil.layer_merge(g_h, g_layers)
+    assert_bit_equal(to_np(g_h), oracle.layer_merge(inp["layers"]), "layer_merge")
+
+
+@pytest.mark.parametrize("H,W", [(48, 40)])
+def test_mass_transfer_albedo_bit_exact(hip, oracle, H, W):
+    from soillib_amd import soil
+    inp = _cell_inputs(oracle, H, W)
+    inp["layers"][::3, ::2, 1] = 0.0          # exercise the layer.y == 0 branch (erosion.cu:558)
+    op = script_param(oracle.default_param())
+    pp = product_param(op)
+    scale = (20.0 / H, 20.0 / W, 4.0)
+    r = np.random.default_rng(4)
+    c3 = lambda: r.random((H, W, 3)).astype(np.float32) * 1.3
+    mass, debris = inp["massFlux"] * 8, inp["debrisFlux"] * 30
+    vel = inp["velocityFlux"]
+    a_bed, a_fl, a_db, a_surf = c3(), c3(), c3(), c3()
+    want_d = np.zeros((H, W, 2), np.float32)
+    want_s = a_surf.copy()
+    oracle.mass_transfer(want_d, inp["layers"], inp["uplift"], mass, vel, debris, a_bed, a_fl,
+                         a_db, want_s, scale, op)
+    g_d, g_s = to_gpu(np.zeros((H, W, 2), np.float32)), to_gpu(a_surf)
+    z1, z2 = to_gpu(np.zeros((H, W), np.float32)), to_gpu(np.zeros((H, W, 2), np.float32))
+    soil.mass_transfer(g_d, to_gpu(inp["layers"]), to_gpu(inp["uplift"]), z1, to_gpu(mass),
+                       to_gpu(vel), to_gpu(debris), z2, to_gpu(a_bed), to_gpu(a_fl), to_gpu(a_db),
+                       g_s, scale, pp)
+    assert_bit_equal(to_np(g_d), want_d, "delta")
+    assert_bit_equal(to_np(g_s), want_s, "albedo_surface")
+    assert (want_s != a_surf).any()
+
+
+@pytest.mark.parametrize("H,W", SIZES + [(256, 256), (8, 4), (1, 8), (5, 1)])
+def test_fused_cells_bit_exact(hip, oracle, H, W):
+    """soil_erode_cells_fused == normalize x2, transfer, creep, add, merge in sequence."""
+    from soillib_amd import _abi
+    inp = _cell_inputs(oracle, H, W, seed=H * 1000 + W)
+    op = script_param(oracle.default_param())
+    pp = product_param(op)
+    scale = (20.0 / H, 20.0 / W, 4.0)
+    want = oracle.erode_cells(inp["layers"], inp["uplift"], inp["rainfall"], inp["waterFlux"],
+                              inp["massFlux"], inp["velocityFlux"], inp["debrisFlux"],
+                              inp["debrisVelocityFlux"], scale, op)
+    g = {k: to_gpu(v) for k, v in inp.items()}
+    out1 = lambda: to_gpu(np.full((H, W), np.nan, np.float32))
+    out2 = lambda: to_gpu(np.full((H, W, 2), np.nan, np.float32))
+    g.update(layers_next=out2(), height=out1(), waterHeight=out1(), mass=out1(), velocity=out2(),
+             debris=out1(), debrisVelocity=out2())
+    planes = _abi.ErosionPlanes()
+    for name in _abi._PLANES:
+        setattr(planes, name, g[name].ptr)
+    dom = _abi.Domain(H, W, 0, H, 0, H)
+    _abi.check(hip.soil_erode_cells_fused(C.byref(planes), C.byref(dom), _abi.vec(scale, 3),
+                                          pp._ref(), None))
+    for name in ("layers_next", "height", "waterHeight", "mass", "velocity", "debris",
+                 "debrisVelocity"):
+        assert_bit_equal(to_np(g[name]), want[name], "fused " + name)
+    for name in ("waterFlux", "massFlux", "velocityFlux", "debrisFlux", "debrisVelocityFlux"):
+        assert (to_np(g[name]) == 0).all(), name + " not re-zeroed"
+    assert_bit_equal(to_np(g["layers"]), inp["layers"], "input layers untouched")
+
+
+def test_fused_cells_on_slabs_equals_whole_grid(hip, oracle):
+    """Row slabs with one ghost row reproduce the single-domain result bit for bit."""
+    from soillib_amd import _abi
+    H, W = 96, 64
+    inp = _cell_inputs(oracle, H, W, seed=9)
+    op = script_param(oracle.default_param())
+    pp = product_param(op)
+    scale = (20.0 / H, 20.0 / W, 4.0)
+    want = oracle.erode_cells(inp["layers"], inp["uplift"], inp["rainfall"], inp["waterFlux"],
+                              inp["massFlux"], inp["velocityFlux"], inp["debrisFlux"],
+                              inp["debrisVelocityFlux"], scale, op)
+    got = {k: np.zeros_like(v) for k, v in want.items() if k != "delta"}
+    for (o0, o1) in [(0, 40), (40, 41), (41, 96)]:              # owned global rows
+        x0, x1 = max(0, o0 - 1), min(H, o1 + 1)
+        rows = x1 - x0
+        sl = slice(x0, x1)
+        g = {k: to_gpu(v[sl]) for k, v in inp.items()}
+        g.update(layers_next=to_gpu(np.zeros((rows, W, 2), np.float32)),
+                 **{k: to_gpu(np.zeros((rows, W), np.float32))
+                    for k in ("height", "waterHeight", "mass", "debris")},
+                 **{k: to_gpu(np.zeros((rows, W, 2), np.float32))
+                    for k in ("velocity", "debrisVelocity")})
+        planes = _abi.ErosionPlanes()
+        for name in _abi._PLANES:
+            setattr(planes, name, g[name].ptr)
+        dom = _abi.Domain(H, W, x0, rows, o0 - x0, o1 - x0)
+        _abi.check(hip.soil_erode_cells_fused(C.byref(planes), C.byref(dom), _abi.vec(scale, 3),
+                                              pp._ref(), None))
+        for name in got:
+            got[name][o0:o1] = to_np(g[name])[o0 - x0:o1 - x0]
+    for name in got:
+        assert_bit_equal(got[name], want[name], "slab " + name)
+    # a slab whose first computed row lacks its ghost row is rejected
+    bad = _abi.Domain(H, W, 10, 20, 0, 20)
+    assert hip.soil_erode_cells_fused(C.byref(planes), C.byref(bad), _abi.vec(scale, 3),
+                                      pp._ref(), None) == _abi.SOIL_ERR_INVALID_ARGUMENT
+
+
+def test_albedo_ops_bit_exact(hip, oracle):
+    from soillib_amd import soil
+    H, W = 40, 56
+    r = np.random.default_rng(11)
+    layers = terrain(oracle, H, W, sediment=0.3)
+    c3 = lambda: r.random((H, W, 3)).astype(np.float32)
+    op = oracle.default_param()
+    pp = product_param(op)
+    scale = (1.0, 1.0, 80.0)
+    uplift = r.random((H, W)).astype(np.float32)
+    want = np.zeros((H, W, 3), np.float32)
+    oracle.albedo_stratum(want, uplift, layers, scale, op, (0.9, 0.5, 0.1), (0.2, 0.3, 0.4), 5e4, 2.5)
+    got = to_gpu(np.zeros((H, W, 3), np.float32))
+    soil.albedo_stratum(got, to_gpu(uplift), to_gpu(layers), scale, pp, (0.9, 0.5, 0.1),
+                        (0.2, 0.3, 0.4), 5e4, 2.5)
+    assert_bit_equal(to_np(got), want, "albedo_stratum")
+    assert len(np.unique(want[..., 0])) == 2
+
+    bed, sed = c3(), c3()
+    want = np.zeros((H, W, 3), np.float32)
+    oracle.albedo_layer(want, bed, sed, layers, 12.0, (0.1, 0.2, 0.3))
+    got = to_gpu(np.zeros((H, W, 3), np.float32))
+    soil.albedo_layer(got, to_gpu(bed), to_gpu(sed), to_gpu(layers), 12.0, (0.1, 0.2, 0.3))
+    assert_bit_equal(to_np(got), want, "albedo_layer")
+
+    alb = c3()
+    dis = (r.standard_normal((H, W)) * 40).astype(np.float32)
+    want = alb.copy()
+    oracle.albedo_discharge(want, dis, (0.1, 0.3, 0.8), 0.05, 0.7)
+    got = to_gpu(alb)
+    soil.albedo_discharge(got, to_gpu(dis), (0.1, 0.3, 0.8), 0.05, 0.7)
+    assert_bit_equal(to_np(got), want, "albedo_discharge")
+
+
+# ------------------------------------------------------- particle ops
+
+def _flux_close(got, want, what):
+    """Same trajectories, different fp32 summation order: compare against the
+    magnitude accumulated in each cell."""
+    scale = np.abs(want).max() + 1e-30
+    np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-6 * scale, err_msg=what)
+    assert ((got != 0) == (want != 0)).all(), what + ": different set of visited cells"
+
+
+@pytest.mark.parametrize("H,W,N", [(64, 64, 4096), (96, 40, 3000)])
+@pytest.mark.parametrize("which", ["default", "script"])
+def test_transport_fluvial_parity(hip, oracle, H, W, N, which):
+    from soillib_amd import soil
+    op = oracle.default_param()
+    if which == "script":
+        script_param(op)
+    op.maxage = 128
+    pp = product_param(op)
+    scale = (20.0 / H, 20.0 / W, 4.0)
+    r = np.random.default_rng(21)
+    layers = terrain(oracle, H, W, sediment=0.01)
+    rain = (0.5 + r.random((H, W))).astype(np.float32)
+    wh0 = (r.random((H, W)) * 0.1).astype(np.float32)
+    vel0 = (r.standard_normal((H, W, 2)) * 2).astype(np.float32)
+    asrc = r.random((H, W, 3)).astype(np.float32)
+    z1, z2, z3 = (np.zeros((H, W), np.float32), np.zeros((H, W, 2), np.float32),
+                  np.zeros((H, W, 3), np.float32))
+
+    o = dict(wh=wh0.copy(), wf=z1.copy(), m=z1.copy(), mf=z1.copy(), v=vel0.copy(), vf=z2.copy(),
+             af=z3.copy())
+    orng = oracle.rng_seed(N, 5, 100)
+    steps = oracle.transport_fluvial(layers, rain, o["wh"], o["wf"], o["m"], o["mf"], o["v"],
+                                     o["vf"], o["af"], asrc, orng, scale, op)
+    assert steps > N            # the particles really move
+
+    g = dict(wh=to_gpu(wh0), wf=to_gpu(z1), m=to_gpu(z1), mf=to_gpu(z1), v=to_gpu(vel0),
+             vf=to_gpu(z2), af=to_gpu(z3))
+    grng = rng_to_gpu(oracle.rng_seed(N, 5, 100))
+    soil.transport_fluvial(to_gpu(layers), to_gpu(rain), g["wh"], g["wf"], g["m"], g["mf"], g["v"],
+                           g["vf"], None, g["af"], to_gpu(asrc), grng, scale, pp)
+    assert (to_np(grng)["offset"] == orng["offset"]).all()
+    for k in ("wf", "mf", "vf"):
+        _flux_close(to_np(g[k]), o[k], "fluvial flux " + k)
+    for k in ("wh", "m", "v"):
+        np.testing.assert_allclose(to_np(g[k]), o[k], rtol=3e-5,
+                                   atol=3e-6 * (np.abs(o[k]).max() + 1e-30), err_msg=k)
+    np.testing.assert_allclose(to_np(g["af"]), o["af"], rtol=1e-3, atol=1e-5)
+
+
+@pytest.mark.parametrize("H,W,N", [(64, 64, 4096), (40, 96, 3000)])
+def test_transport_debris_parity(hip, oracle, H, W, N):
+    from soillib_amd import soil
+    op = script_param(oracle.default_param())
+    op.maxage = 128
+    op.critSlopeBedrock = 0.05          # make landslides happen on the synthetic terrain
+    op.yieldStress = 0.001
+    pp = product_param(op)
+    scale = (20.0 / H, 20.0 / W, 4.0)
+    r = np.random.default_rng(22)
+    layers = terrain(oracle, H, W, sediment=0.01)
+    vel0 = (r.standard_normal((H, W, 2)) * 0.5).astype(np.float32)
+    z1, z2 = np.zeros((H, W), np.float32), np.zeros((H, W, 2), np.float32)
+    o = dict(v=vel0.copy(), vf=z2.copy(), m=z1.copy(), mf=z1.copy())
+    orng = oracle.rng_seed(N, 6, 0)
+    steps = oracle.transport_debris(layers, o["v"], o["vf"], o["m"], o["mf"], None, None, orng,
+                                    scale, op)
+    assert steps > N and o["mf"].max() > 0
+    g = dict(v=to_gpu(vel0), vf=to_gpu(z2), m=to_gpu(z1), mf=to_gpu(z1))
+    grng = rng_to_gpu(oracle.rng_seed(N, 6, 0))
+    soil.transport_debris(to_gpu(layers), g["v"], g["vf"], g["m"], g["mf"], None, None, None, grng,
+                          scale, pp)
+    for k in ("mf", "vf"):
+        _flux_close(to_np(g[k]), o[k], "debris flux " + k)
+    for k in ("m", "v"):
+        np.testing.assert_allclose(to_np(g[k]), o[k], rtol=3e-5,
+                                   atol=3e-6 * (np.abs(o[k]).max() + 1e-30), err_msg=k)
+
+
+def test_erosion_model_fused_equals_unfused_and_oracle(hip, oracle):
+    """Three whole steps: fused step == stand-alone-op step (bit-exact cell phase,
+    atomics aside) == oracle composition."""
+    from soillib_amd import silt
+    from soillib_amd.erosion import ErosionModel
+    H = W = 64
+    N = H * W // 8
+    op = script_param(oracle.default_param())
+    op.maxage = 64
+    pp = product_param(op)
+    scale = (20.0 / H, 20.0 / W, 4.0)
+    layers0 = terrain(oracle, H, W)
+
+    def make():
+        m = ErosionModel(H, W, scale, pp, N, seed=0)
+        m.set_layers(to_gpu(layers0))
+        silt.set(m.rainfall, 1.0)
+        return m
+    a, b = make(), make()
+
+    # oracle state
+    z1 = lambda: np.zeros((H, W), np.float32)
+    z2 = lambda: np.zeros((H, W, 2), np.float32)
+    st = dict(layers=layers0.copy(), wh=z1(), m=z1(), v=z2(), d=z1(), dv=z2())
+    rain, uplift = np.ones((H, W), np.float32), z1()
+    for step in range(3):
+        a.step()
+        b.step_unfused()
+        rng = oracle.rng_seed(N, 0, step * N)
+        wf, mf, vf, df, dvf = z1(), z1(), z2(), z1(), z2()
+        oracle.particles_fluvial(wf, mf, vf, None, rng, st["layers"], rain, st["wh"], st["v"],
+                                 None, scale, op)
+        oracle.particles_debris(df, dvf, None, rng, st["layers"], st["dv"], None, scale, op)
+        res = oracle.erode_cells(st["layers"], uplift, rain, wf, mf, vf, df, dvf, scale, op)
+        st = dict(layers=res["layers_next"], wh=res["waterHeight"], m=res["mass"],
+                  v=res["velocity"], d=res["debris"], dv=res["debrisVelocity"])
+        for name, key in (("layers", "layers"), ("waterHeight", "wh"), ("velocity", "v"),
+                          ("debrisVelocity", "dv"), ("mass", "m")):
+            ga, gb = to_np(getattr(a, name)), to_np(getattr(b, name))
+            tol = dict(rtol=1e-4, atol=1e-5 * (np.abs(st[key]).max() + 1e-30))
+            np.testing.assert_allclose(ga, gb, err_msg="fused vs unfused " + name, **tol)
+            np.testing.assert_allclose(ga, st[key], err_msg="fused vs oracle " + name, **tol)
+    assert np.abs(st["layers"] - layers0).max() > 0          # the terrain really eroded
+    assert_bit_equal(to_np(a.height), to_np(a.layers)[..., 0] + to_np(a.layers)[..., 1], "height")
+
+
+# ---------------------------------------------------------- graph ops
+
+@pytest.mark.parametrize("H,W", SIZES)
+@pytest.mark.parametrize("edge", [D4, D8])
+def test_flow_maps_bit_exact(hip, oracle, H, W, edge):
+    from soillib_amd import soil
+    h = terrain(oracle, H, W)[..., 0].copy()
+    h[3:6, 3:6] = h[4, 4]                       # a flat patch: no receiver there
+    gh = to_gpu(h)
+    assert_bit_equal(to_np(soil.steepest(gh, edge)), oracle.steepest(h, edge), "steepest")
+    assert_bit_equal(to_np(soil.direction(gh, edge)), oracle.direction(h, edge), "direction")
+    for off in (0, 7):
+        assert_bit_equal(to_np(soil.random_weighted(gh, edge, 3, off, 10.0)),
+                         oracle.random_weighted(h, edge, 3, off, 10.0), "random_weighted")
+    flow = oracle.steepest(h, edge)
+    assert_bit_equal(to_np(soil.slope(gh, to_gpu(flow), (0.3, 0.7))),
+                     oracle.slope(h, flow, (0.3, 0.7)), "slope")
+    with pytest.raises(ValueError):
+        soil.steepest(gh, 5)                    # invalid edge enumerator, graph.cu:88
+
+
+@pytest.mark.parametrize("H,W", SIZES)
+@pytest.mark.parametrize("edge", [D4, D8])
+def test_accumulate_bit_exact(hip, oracle, H, W, edge):
+    from soillib_amd import soil
+    h = terrain(oracle, H, W)[..., 0].copy()
+    r = np.random.default_rng(1)
+    src = (0.5 + r.random((H, W))).astype(np.float32)
+    for graph in (oracle.steepest(h, edge), oracle.random_weighted(h, edge, 0, 1, 10.0)):
+        want = oracle.accumulate(graph, src, edge)
+        got = to_np(soil.accumulate(to_gpu(graph), to_gpu(src), edge))
+        assert_bit_equal(got, want, "accumulate")
+        decay = (0.8 + 0.2 * r.random((H, W))).astype(np.float32)
+        want = oracle.accumulate(graph, src, edge, decay=decay)
+        got = to_np(soil.accumulate_decay(to_gpu(graph), to_gpu(src), to_gpu(decay), edge))
+        assert_bit_equal(got, want, "accumulate_decay")
+    ones = np.ones((H, W), np.float32)
+    g = oracle.steepest(h, edge)
+    acc = to_np(soil.accumulate(to_gpu(g), to_gpu(ones), edge))
+    assert acc[g < 0].sum() == H * W            # every cell reaches exactly one outlet
+
+
+# ----------------------------------------------------------- stencils
+
+@pytest.mark.parametrize("H,W", SIZES + [(1, 1), (2, 40)])
+def test_stencils_bit_exact(hip, oracle, H, W):
+    from soillib_amd import soil
+    h = terrain(oracle, H, W)[..., 0].copy()
+    gh = to_gpu(h)
+    sc = (0.4, 1.7)
+    assert_bit_equal(to_np(soil.gradient(gh, sc)), oracle.gradient(h, sc), "gradient")
+    assert_bit_equal(to_np(soil.negslope(gh, sc)), oracle.negslope(h, sc), "negslope")
+    r = np.random.default_rng(2)
+    for D in (1, 2):
+        t = r.standard_normal((H, W, D)).astype(np.float32)
+        assert_bit_equal(to_np(soil.laplacian(to_gpu(t), sc)), oracle.laplacian(t, sc),
+                         "laplacian D=%d" % D)
+        gt = to_gpu(t)
+        ret = soil.gaussian_blur(gt, 3.0)
+        assert ret is gt                        # returns its input handle, filter.cu:90
+        assert_bit_equal(to_np(gt), oracle.gaussian_blur(t, 3.0), "gaussian_blur C=%d" % D)
+    s3 = (0.4, 1.7, 3.0)
+    assert_bit_equal(to_np(soil.normal(gh, s3)), oracle.normal(h, s3), "normal (gpu)")
+
+
+def test_solve_uniform_parity(hip, oracle):
+    from soillib_amd import soil
+    H, W, N = 48, 40, 6000
+    h = terrain(oracle, H, W)[..., 0].copy()
+    sc = (0.05, 0.05)
+    flow = -oracle.gradient(h, sc)
+    r = np.random.default_rng(3)
+    decay = (r.random((H, W)) * 0.01).astype(np.float32)
+    for K in (1, 2):
+        src = (r.random((H, W, K)) * 1e-3).astype(np.float32)
+        want = oracle.solve_uniform(flow, src, decay, oracle.rng_seed(N, 1, 0), sc, N)
+        got = to_np(soil.solve_uniform(to_gpu(flow), to_gpu(src), to_gpu(decay),
+                                       rng_to_gpu(oracle.rng_seed(N, 1, 0)), sc, N))
+        ok = np.isfinite(want)
+        assert (np.isfinite(got) == ok).all()
+        np.testing.assert_allclose(got[ok], want[ok], rtol=5e-5,
+                                   atol=1e-6 * np.abs(want[ok]).max())
+
+
+def test_noise_device_and_host_bit_exact(hip, oracle):
+    from soillib_amd import silt, soil
+    for (H, W, seed) in [(64, 64, 3.0), (50, 70, -1.5)]:
+        p = soil.noise_t()
+        p.seed = seed
+        p.ext = [H, W]
+        want = oracle.noise(H, W, seed=seed, ext=(H, W))
+        assert_bit_equal(soil.noise(silt.shape(H, W), p).numpy(), want, "noise host")
+        assert_bit_equal(to_np(soil.noise(silt.shape(H, W), p, host=silt.gpu)), want, "noise gpu")
+
+
+def test_silt_gpu_ops(hip):
+    from soillib_amd import _abi, silt
+    a = np.arange(1003, dtype=np.float32)
+    t = to_gpu(a)
+    silt.multiply(t, 0.5)
+    silt.add(t, to_gpu(np.ones(1003, np.float32)))
+    np.testing.assert_array_equal(to_np(t), a * 0.5 + 1)
+    c = silt.clone(t)
+    silt.set(t, 3.0)
+    assert (to_np(t) == 3).all() and (to_np(c) == a * 0.5 + 1).all()
+    i = silt.tensor(silt.int32, silt.shape(7, 9), silt.gpu)
+    silt.set(i, -1)
+    assert (to_np(i) == -1).all()
+    rg = silt.tensor(silt.rng, silt.shape(100), silt.gpu)
+    silt.seed(rg, 42, 1000)
+    got = to_np(rg)
+    assert (got["seed"] == 42).all() and (got["offset"] == 1000).all()
+    with pytest.raises(_abi.SoilError, match="mismatch_host"):
+        from soillib_amd import soil
+        soil.steepest(silt.tensor.from_numpy(np.zeros((4, 4), np.float32)), 0)

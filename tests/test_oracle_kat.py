@@ -1,0 +1,366 @@
+"""Known-answer / property tests that pin the CPU oracle.
+
+The reference ships no tests, fixtures or golden vectors for this path
+(SURVEY.md §4, §8c), so the oracle is pinned by the analytic consequences of
+the cited kernel code instead, plus — for soil.noise — by the reference's own
+vendored generator compiled in place (tests/test_noise_golden.py).
+"""
+import math
+
+import numpy as np
+import pytest
+
+from util import terrain
+
+D4, D8 = 0, 1
+
+
+# ------------------------------------------------------------ spec math
+
+def test_philox_known_answers(oracle):
+    # Random123 kat_vectors for philox4x32-10
+    assert oracle.philox([0, 0, 0, 0], [0, 0]) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert oracle.philox([0xffffffff] * 4, [0xffffffff] * 2) == [
+        0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert oracle.philox([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344],
+                         [0xa4093822, 0x299f31d0]) == [
+        0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+def test_uniform_range_and_state(oracle):
+    rng = oracle.rng_seed(4096, 7, 11)
+    u = oracle.rng_uniform(rng, np.arange(4096))
+    assert (u > 0).all() and (u <= 1).all()          # (0, 1] like curand_uniform
+    assert (rng["offset"] == 12).all()                # one draw advances the offset by one
+    assert abs(u.mean() - 0.5) < 0.03
+    # addressing: (seed, subsequence, offset) — same triple, same number
+    rng2 = oracle.rng_seed(1, 7, 11)
+    assert oracle.rng_uniform(rng2, [5])[0] == u[5]
+
+
+def test_expf_within_one_ulp_of_libm(oracle):
+    xs = np.concatenate([np.linspace(-87, 88, 20001), np.linspace(-1, 1, 2001)]).astype(np.float32)
+    mine = oracle.expf(xs).astype(np.float64)
+    ref = np.exp(xs.astype(np.float64))
+    ulp = np.abs(mine - ref) / np.spacing(ref.astype(np.float32)).astype(np.float64)
+    assert ulp.max() < 1.0
+    assert oracle.expf(np.float32(0.0)) == 1.0
+    assert oracle.expf(np.float32(-90.0)) == 0.0      # flush below e^-87
+    assert np.isinf(oracle.expf(np.float32(89.0)))
+    assert np.isnan(oracle.expf(np.float32(np.nan)))
+
+
+def test_powf_is_exp2_y_log2_x(oracle):
+    r = np.random.default_rng(0)
+    x = r.uniform(1e-6, 50, 5000).astype(np.float32)
+    y = r.uniform(0.01, 3, 5000).astype(np.float32)
+    mine = oracle.powf(x, y).astype(np.float64)
+    ref = np.power(x.astype(np.float64), y.astype(np.float64))
+    assert (np.abs(mine - ref) / ref).max() < 5e-6    # the error budget of CUDA's __powf
+    assert oracle.powf(0.0, 2.0) == 0.0
+    assert oracle.powf(1.0, 1.414) == 1.0
+    assert np.isnan(oracle.powf(0.0, 0.0))            # exp2(0 * -inf), as the intrinsic
+
+
+# ------------------------------------------------------- map helpers
+
+def test_stepsize_bounds_and_ieee_edges(oracle):
+    r = np.random.default_rng(1)
+    for _ in range(2000):
+        px, py = r.uniform(0, 50, 2)
+        a = r.uniform(0, 2 * math.pi)
+        s = oracle.stepsize(px, py, math.cos(a), math.sin(a))
+        assert 0 < s <= 1.41421354 + 1e-6              # erosion_map.cu:61-76
+    # axis-aligned direction: division by zero must resolve to sqrt(2) via fmaxf/fminf
+    s = oracle.stepsize(3.25, 7.5, 1.0, 0.0)
+    assert s == pytest.approx(0.5 * (0.75 + 1.41421354))
+    # NaN direction (the solve_uniform OOB case): both axes clamp to sqrt(2)
+    assert oracle.stepsize(1.5, 1.5, float("nan"), float("nan")) == pytest.approx(1.41421354)
+
+
+def test_glocal_ramp_and_boundary(oracle):
+    H, W = 8, 9
+    layers = np.zeros((H, W, 2), np.float32)
+    layers[..., 0] = (2.0 * np.arange(H)[:, None] + 0.0 * np.arange(W)[None, :]).astype(np.float32)
+    scale = (0.5, 0.25, 4.0)
+    ex = 0.02
+    g = oracle.glocal(layers, 4, 4, scale, ex)
+    # uphill toward +x: only the downhill (negative-x) side survives: (h - h(x-1)) * sz / sx
+    assert g[0] == pytest.approx(2.0 * 4.0 / 0.5) and g[1] == 0.0
+    # x = 0: the missing -x neighbour contributes +exitSlope; the +x side is uphill (clamped to 0)
+    assert oracle.glocal(layers, 0, 4, scale, ex)[0] == pytest.approx(ex)
+    # last row: -x side downhill slope 16 beats the -exitSlope of the missing +x neighbour
+    assert oracle.glocal(layers, H - 1, 4, scale, ex)[0] == pytest.approx(16.0)
+    # y borders on a field flat in y: +exitSlope at y=0 wins first (strict >), so gy = +ex;
+    # at y = W-1 the n side is 0 and the p side is -ex
+    assert oracle.glocal(layers, 4, 0, scale, ex)[1] == pytest.approx(ex)
+    assert oracle.glocal(layers, 4, W - 1, scale, ex)[1] == pytest.approx(-ex)
+
+
+# ---------------------------------------------------------- cell ops
+
+def test_layer_merge_identity(oracle):
+    layers = terrain(oracle, 16, 24, sediment=0.1)
+    np.testing.assert_array_equal(oracle.layer_merge(layers), layers[..., 0] + layers[..., 1])
+
+
+def test_mass_creep_conserves_sediment(oracle):
+    H, W = 32, 40
+    layers = terrain(oracle, H, W, sediment=0.05)
+    p = oracle.default_param()
+    p.critSlopeSediment = 0.01
+    scale = (20.0 / H, 20.0 / W, 4.0)
+    delta = np.zeros((H, W, 2), np.float32)
+    oracle.mass_creep(delta, layers, scale, p)
+    assert (delta[..., 0] == 0).all()                  # only delta.y is touched (erosion.cu:708)
+    assert np.abs(delta[..., 1]).max() > 0
+    # symmetric exchange (erosion.cu:675-706): what one cell loses its neighbour gains
+    assert abs(delta[..., 1].astype(np.float64).sum()) < 1e-6 * np.abs(delta[..., 1]).sum() + 1e-9
+    # never takes more than the sediment that is there
+    assert (layers[..., 1] + delta[..., 1] >= -1e-7).all()
+
+
+def test_mass_creep_flat_is_zero(oracle):
+    layers = np.zeros((8, 8, 2), np.float32)
+    layers[..., 0] = 1.0
+    layers[..., 1] = 0.5
+    delta = np.zeros_like(layers)
+    oracle.mass_creep(delta, layers, (1, 1, 1), oracle.default_param())
+    assert (delta == 0).all()
+
+
+def test_mass_transfer_limits(oracle):
+    H, W = 24, 24
+    layers = terrain(oracle, H, W, sediment=0.02)
+    p = oracle.default_param()
+    scale = (20.0 / H, 20.0 / W, 4.0)
+    r = np.random.default_rng(5)
+    uplift = r.random((H, W)).astype(np.float32)
+    mass = (r.random((H, W)) * 10).astype(np.float32)
+    vel = (r.standard_normal((H, W, 2)) * 5).astype(np.float32)
+    debris = (r.random((H, W)) * 3).astype(np.float32)
+    delta = np.zeros((H, W, 2), np.float32)
+    oracle.mass_transfer(delta, layers, uplift, mass, vel, debris, None, None, None, None, scale, p)
+    L = math.hypot(scale[0], scale[1])
+    total = (delta[..., 0] + delta[..., 1]) * scale[2] - p.timeStep * p.uplift * uplift
+    assert (total <= 0.25 * L * 0.3 * (1 + 1e-5) + 1e-6).all()     # deposition limit, erosion.cu:528
+    slope = np.array([[np.hypot(*oracle.glocal(layers, x, y, scale, p.exitSlope))
+                       for y in range(W)] for x in range(H)])
+    assert (total >= -0.25 * L * slope * (1 + 1e-5) - 1e-6).all()  # suspension limit, :527
+    # sediment is consumed before bedrock (:535-545)
+    assert (layers[..., 1] + delta[..., 1] >= -1e-6).all()
+
+
+def test_normalize_fluvial_zero_flux(oracle):
+    """With no flux, fields reduce to their source terms (erosion.cu:173-179)."""
+    H, W = 12, 10
+    layers = np.zeros((H, W, 2), np.float32)
+    layers[..., 0] = np.arange(H, dtype=np.float32)[:, None] * 0.1
+    p = oracle.default_param()
+    scale = (2.0, 3.0, 1.0)
+    z1 = np.zeros((H, W), np.float32)
+    z2 = np.zeros((H, W, 2), np.float32)
+    rain = np.full((H, W), 0.5, np.float32)
+    wh, m, v = z1.copy(), z1.copy(), z2.copy()
+    oracle.normalize_fluvial(z1, z1, z2, None, layers, rain, wh, m, v, None, scale, p)
+    A = scale[0] * scale[1]
+    np.testing.assert_allclose(wh, A * p.rainfall * 0.5 / scale[1], rtol=1e-6)
+    assert (m == 0).all()
+    g = oracle.glocal(layers, 5, 5, scale, p.exitSlope)
+    np.testing.assert_allclose(v[5, 5], A * (-p.gravity * g) / scale[1], rtol=1e-6)
+
+
+# ------------------------------------------------------------- graph
+
+@pytest.mark.parametrize("edge", [D4, D8])
+def test_steepest_on_ramp_and_flat(oracle, edge):
+    H, W = 9, 7
+    ramp = (np.arange(H, dtype=np.float32)[:, None] + np.zeros((1, W), np.float32))
+    g = oracle.steepest(ramp, edge)
+    d = oracle.direction(ramp, edge)
+    assert (g[0] == -1).all() and (d[0] == -1).all()          # lowest row: no receiver -> -1
+    n = np.arange(H * W).reshape(H, W)
+    np.testing.assert_array_equal(g[1:], n[:-1])              # receiver = cell directly downhill
+    assert (d[1:] == 0).all()                                 # direction k=0 is (-1, 0), graph.hpp:24
+    flat = np.ones((H, W), np.float32)
+    assert (oracle.steepest(flat, edge) == -1).all()          # graph.cu:43,64-68
+    assert (oracle.random_weighted(flat, edge, 0, 0, 10.0) == -1).all()   # Z = 0, graph.cu:160
+
+
+def test_d8_prefers_steeper_diagonal(oracle):
+    h = np.zeros((3, 3), np.float32) + 10
+    h[1, 1] = 20
+    h[0, 0] = 0            # diagonal drop 20/sqrt(2) = 14.1 > axis drop 10
+    assert oracle.steepest(h, D8)[1, 1] == 0
+    assert oracle.direction(h, D8)[1, 1] == 4                 # (-1,-1) is k=4, graph.hpp:40
+    assert oracle.steepest(h, D4)[1, 1] == 1                  # first axis neighbour in table order
+
+
+def test_random_weighted_is_downhill_and_seeded(oracle):
+    h = terrain(oracle, 32, 32)[..., 0].copy()
+    a = oracle.random_weighted(h, D8, 0, 3, 10.0)
+    b = oracle.random_weighted(h, D8, 0, 3, 10.0)
+    c = oracle.random_weighted(h, D8, 0, 4, 10.0)
+    np.testing.assert_array_equal(a, b)
+    assert (a != c).any()
+    flat = h.ravel()
+    idx = np.nonzero(a.ravel() >= 0)[0]
+    assert (flat[a.ravel()[idx]] < flat[idx]).all()           # only downhill receivers, graph.cu:139
+
+
+@pytest.mark.parametrize("edge", [D4, D8])
+def test_accumulate_counts_upstream_cells(oracle, edge):
+    H, W = 12, 9
+    ramp = (np.arange(H, dtype=np.float32)[:, None] + np.zeros((1, W), np.float32))
+    g = oracle.steepest(ramp, edge)
+    acc = oracle.accumulate(g, np.ones((H, W), np.float32), edge)
+    # each column drains straight down: value = number of cells upstream incl. self
+    expect = (H - np.arange(H))[:, None] + np.zeros((1, W))
+    np.testing.assert_array_equal(acc, expect.astype(np.float32))
+
+
+def test_accumulate_total_at_outlets(oracle):
+    h = terrain(oracle, 40, 40)[..., 0].copy()
+    g = oracle.steepest(h, D8)
+    acc = oracle.accumulate(g, np.ones_like(h), D8)
+    outlets = g < 0
+    assert acc[outlets].sum() == h.size                       # every cell drains to exactly one outlet
+    # brute-force upstream count for comparison
+    order = np.argsort(-h.ravel(), kind="stable")
+    val = np.ones(h.size, np.float64)
+    gf = g.ravel()
+    for n in order:
+        if gf[n] >= 0:
+            val[gf[n]] += val[n]
+    np.testing.assert_array_equal(acc.ravel(), val.astype(np.float32))
+
+
+def test_accumulate_decay_chain(oracle):
+    H, W = 6, 1
+    ramp = np.arange(H, dtype=np.float32)[:, None].copy()
+    g = oracle.steepest(ramp, D4)
+    decay = np.full((H, W), 0.5, np.float32)
+    acc = oracle.accumulate(g, np.ones((H, W), np.float32), D4, decay=decay)
+    # value[n] = 1 + 0.5 * value[n+1]  (graph.cu:478-494 with per-edge decay)
+    expect = np.zeros(H)
+    for n in range(H - 1, -1, -1):
+        expect[n] = 1 + (0.5 * expect[n + 1] if n + 1 < H else 0)
+    np.testing.assert_allclose(acc[:, 0], expect, rtol=1e-6)
+
+
+def test_slope_along_graph(oracle):
+    H, W = 6, 6
+    ramp = (3.0 * np.arange(H, dtype=np.float32)[:, None] + np.zeros((1, W), np.float32))
+    g = oracle.steepest(ramp, D8)
+    s = oracle.slope(ramp, g, (2.0, 5.0))
+    assert (s[0] == 0).all()                                   # no receiver -> 0, graph.cu:283
+    np.testing.assert_allclose(s[1:], -3.0 / 2.0)
+
+
+# ----------------------------------------------------------- stencils
+
+def test_gradient_of_plane(oracle):
+    H, W = 10, 12
+    x, y = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    f = (1.5 * x - 0.75 * y).astype(np.float32)
+    g = oracle.gradient(f, (0.5, 0.25))
+    np.testing.assert_allclose(g[..., 0], 1.5 / 0.5)           # one-sided fallback at borders too
+    np.testing.assert_allclose(g[..., 1], -0.75 / 0.25)
+    assert (oracle.gradient(np.ones((1, 1), np.float32), (1, 1)) == 0).all()  # isolated cell -> 0
+
+
+def test_negslope_of_plane(oracle):
+    H, W = 8, 8
+    x, y = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    f = (2.0 * x + 1.0 * y).astype(np.float32)
+    s = oracle.negslope(f, (1.0, 1.0))
+    assert s[0, 0] == 0                                        # the pit has no downhill neighbour
+    assert s[4, 4] == pytest.approx(math.hypot(2.0, 1.0))
+
+
+def test_laplacian_of_quadratic(oracle):
+    H, W = 12, 12
+    x, y = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    f = (x * x + 2 * y * y).astype(np.float32)[..., None].copy()
+    lap = oracle.laplacian(f, (1.0, 1.0))
+    # LH = 2 + 4 = 6; LD = 0.5[(2+4)+(2+4)]... per grad.cu:178-181 the interior value is 0.5*6 + 0.5*6
+    assert lap[5, 5, 0] == pytest.approx(6.0)
+    const = np.full((6, 6, 2), 3.0, np.float32)
+    assert (oracle.laplacian(const, (1, 1)) == 0).all()
+
+
+def test_blur_of_constant_is_sum_of_weights(oracle):
+    sigma = 4.0
+    k = np.arange(-16, 17, dtype=np.float64)
+    wsum = (np.exp(-0.5 * (k / sigma) ** 2) / (math.sqrt(2 * 3.14159265) * sigma)).sum()
+    c = np.full((40, 40, 1), 2.0, np.float32)
+    out = oracle.gaussian_blur(c, sigma)
+    np.testing.assert_allclose(out, 2.0 * wsum * wsum, rtol=1e-5)   # un-normalised, filter.cu:47-50
+
+
+def test_normal_of_plane(oracle):
+    H, W = 9, 9
+    x, y = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    f = (0.5 * x + 0.25 * y).astype(np.float32)
+    n = oracle.normal(f, (1.0, 1.0, 2.0))
+    v = np.array([-1.0, -0.5, 1.0])
+    np.testing.assert_allclose(n[4, 4], v / np.linalg.norm(v), rtol=1e-6)
+    np.testing.assert_allclose(np.linalg.norm(n, axis=-1), 1.0, rtol=1e-6)
+
+
+# ----------------------------------------------------- particle kernels
+
+def _particle_inputs(oracle, H, W):
+    layers = terrain(oracle, H, W, sediment=0.01)
+    z1 = np.zeros((H, W), np.float32)
+    z2 = np.zeros((H, W, 2), np.float32)
+    return layers, z1, z2
+
+
+def test_fluvial_particles_deposit_only_downstream(oracle):
+    H = W = 48
+    layers, z1, z2 = _particle_inputs(oracle, H, W)
+    p = oracle.default_param()
+    p.maxage = 64
+    scale = (20.0 / H, 20.0 / W, 4.0)
+    N = 2000
+    rng = oracle.rng_seed(N, 0, 0)
+    wf, mf, vf = z1.copy(), z1.copy(), z2.copy()
+    rain = np.ones((H, W), np.float32)
+    steps = oracle.particles_fluvial(wf, mf, vf, None, rng, layers, rain, z1, z2, None, scale, p)
+    assert (rng["offset"] == 2).all()                # two draws per particle (erosion.cu:57-58)
+    assert 0 < steps <= N * (p.maxage - 1)           # ++iter < maxage (Appendix B7)
+    assert (wf >= 0).all() and wf.sum() > 0
+    assert (mf == 0).all()                           # zero velocity field -> shear 0 -> no suspension
+    # the same call again continues the stream: different spawn points, different flux
+    wf2 = z1.copy()
+    oracle.particles_fluvial(wf2, z1.copy(), z2.copy(), None, rng, layers, rain, z1, z2, None,
+                             scale, p)
+    assert (rng["offset"] == 4).all() and (wf2 != wf).any()
+
+
+def test_slab_particles_partition_exactly(oracle):
+    """Two slabs that each own half of the rows trace every particle exactly once."""
+    H = W = 40
+    layers, z1, z2 = _particle_inputs(oracle, H, W)
+    p = oracle.default_param()
+    p.maxage = 8                                     # short walks: ghost zone of 14 rows suffices
+    scale = (20.0 / H, 20.0 / W, 4.0)
+    N = 3000
+    rain = np.ones((H, W), np.float32)
+    full = z1.copy()
+    oracle.particles_fluvial(full, z1.copy(), z2.copy(), None, oracle.rng_seed(N, 1, 0), layers,
+                             rain, z1, z2, None, scale, p)
+    G = 14
+    parts = np.zeros((H, W), np.float64)
+    for (x0, rows, r0, r1) in [(0, 20 + G, 0, 20), (20 - G, 20 + G, G, 20 + G)]:
+        dom = oracle.domain(H, W, x0, rows, r0, r1)
+        sl = slice(x0, x0 + rows)
+        wf = np.zeros((rows, W), np.float32)
+        oracle.particles_fluvial(wf, np.zeros((rows, W), np.float32),
+                                 np.zeros((rows, W, 2), np.float32), None,
+                                 oracle.rng_seed(N, 1, 0), np.ascontiguousarray(layers[sl]),
+                                 np.ascontiguousarray(rain[sl]), np.zeros((rows, W), np.float32),
+                                 np.zeros((rows, W, 2), np.float32), None, scale, p, dom=dom)
+        parts[sl] += wf
+    np.testing.assert_allclose(parts, full, rtol=1e-5, atol=1e-9)
