@@ -140,6 +140,8 @@ def main():
     ap.add_argument("--particles-div", type=int, default=8, help="N = cells / this")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-size", type=int, default=1024)
+    ap.add_argument("--particle-mode", type=int, default=0,
+                    help="0 auto, 1 direct (reference launch shape), 2 staged — ablation")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -154,6 +156,7 @@ def main():
     from soillib_amd.erosion import ErosionModel
     lib = _abi.lib()
     _abi.check(lib.soil_set_device(local_rank))
+    _abi.check(lib.soil_set_particle_mode(args.particle_mode))
 
     S = args.size
     param = script_param(soil)

@@ -276,18 +276,29 @@ int soil_erode_cells_fused(const soil_erosion_planes* planes, const soil_domain*
  * rng state, so N ranks that each own one slab trace every particle exactly
  * once.  A trajectory that leaves local rows [0, rows) through an interior
  * (non-global) slab edge is a caller error (size the ghost zone with
- * soil_ghost_rows). */
+ * soil_ghost_rows).
+ * `remote0` (device float[8], may be NULL) collects what the reference's "NaN
+ * walkers"  deposit into GLOBAL cell (0,0) when
+ * that cell is not held by this slab: [0..3] = water, mass, velocity.x/.y flux
+ * (fluvial), [4..6] = mass, velocity.x/.y flux (debris).  The owner of global
+ * row 0 adds the all-reduced sums to its cell (0,0). */
 int soil_particles_fluvial_slab(float* waterFlux, float* massFlux, float* velocityFlux,
                                 float* albedoFlux, soil_rng* rng, int64_t N,
                                 const float* layers, const float* rainfall,
                                 const float* waterHeight, const float* velocity,
-                                const float* albedoSource, const soil_domain* dom,
-                                const float scale[3], const soil_param* param, void* stream);
+                                const float* albedoSource, float* remote0,
+                                const soil_domain* dom, const float scale[3],
+                                const soil_param* param, void* stream);
 int soil_particles_debris_slab(float* massFlux, float* velocityFlux, float* albedoFlux,
                                soil_rng* rng, int64_t N, const float* layers,
-                               const float* velocity, const float* albedoSource,
+                               const float* velocity, const float* albedoSource, float* remote0,
                                const soil_domain* dom, const float scale[3],
                                const soil_param* param, void* stream);
+/* Launch shape of the particle kernels: 0 = auto (staged for N >= 1024),
+ * 1 = direct (the reference's: thread n = particle n, 5-point stencil gathers),
+ * 2 = staged (packed field plane + tile-ordered particles).  Results are the
+ * same up to the order of the fp32 atomic additions; for ablation and tests. */
+int soil_set_particle_mode(int mode);
 /* Ghost rows a slab needs on each interior side so that no trajectory can
  * leave it: ceil(sqrt(2) * maxage) + 2 (one __stepsize step moves a particle
  * by at most sqrt(2) cells, erosion_map.cu:61-76). */
@@ -373,6 +384,9 @@ void soil_noise_param_default(soil_noise_param* p);
  * placement, noise.hpp:49-52); both produce identical bits. */
 int soil_noise(float* out, int64_t H, int64_t W, const soil_noise_param* p, void* stream);
 int soil_noise_host(float* out_host, int64_t H, int64_t W, const soil_noise_param* p);
+/* Rows [x0, x0+rows) of the same heightmap (the slab a rank owns). */
+int soil_noise_window(float* out, int64_t rows, int64_t W, int64_t x0, const soil_noise_param* p,
+                      void* stream);
 
 #ifdef __cplusplus
 } /* extern "C" */

@@ -162,7 +162,8 @@ def glocal(layers, x, y, scale, exitSlope, dom=None):
 # ---------------------------------------------------------------- erosion ops
 
 def particles_fluvial(waterFlux, massFlux, velocityFlux, albedoFlux, rng, layers, waterSource,
-                      waterHeight, velocity, albedoSource, scale, param, dom=None, threads=1):
+                      waterHeight, velocity, albedoSource, scale, param, dom=None, threads=1,
+                      remote0=None):
     H, W = (dom.H, dom.W) if dom else layers.shape[:2]
     dom = dom or domain(H, W)
     steps = C.c_int64(0)
@@ -170,7 +171,7 @@ def particles_fluvial(waterFlux, massFlux, velocityFlux, albedoFlux, rng, layers
         _f(_chk(waterFlux)), _f(_chk(massFlux)), _f(_chk(velocityFlux)), _f(_chk(albedoFlux)),
         C.c_void_p(rng.ctypes.data), C.c_int64(len(rng)), _f(_chk(layers)), _f(_chk(waterSource)),
         _f(_chk(waterHeight)), _f(_chk(velocity)), _f(_chk(albedoSource)), C.byref(dom),
-        _scale(scale, 3), C.byref(param), C.c_int(threads), C.byref(steps))
+        _scale(scale, 3), C.byref(param), C.c_int(threads), C.byref(steps), _f(_chk(remote0)))
     return steps.value
 
 
@@ -185,14 +186,14 @@ def normalize_fluvial(waterFlux, massFlux, velocityFlux, albedoFlux, layers, wat
 
 
 def particles_debris(massFlux, velocityFlux, albedoFlux, rng, layers, velocity, albedoSource,
-                     scale, param, dom=None, threads=1):
+                     scale, param, dom=None, threads=1, remote0=None):
     dom = dom or domain(*layers.shape[:2])
     steps = C.c_int64(0)
     lib().orc_particles_debris(
         _f(_chk(massFlux)), _f(_chk(velocityFlux)), _f(_chk(albedoFlux)),
         C.c_void_p(rng.ctypes.data), C.c_int64(len(rng)), _f(_chk(layers)), _f(_chk(velocity)),
         _f(_chk(albedoSource)), C.byref(dom), _scale(scale, 3), C.byref(param),
-        C.c_int(threads), C.byref(steps))
+        C.c_int(threads), C.byref(steps), _f(_chk(remote0)))
     return steps.value
 
 

@@ -193,6 +193,15 @@ void orc_rng_seed(orc_rng* rng, int64_t n, uint64_t seed, uint64_t offset) {
 
 /* ---------------------------------------------------------- map helpers */
 
+/* float -> cell coordinate as the reference's device code performs it: CUDA's
+ * cvt.rzi truncates toward zero and turns NaN into 0.  The NaN case is reached
+ * in practice: a particle spawned on a pit cell (grad = 0) with zero velocity
+ * gets speed = 0/sqrt(0) = NaN (erosion.cu:77-78), passes the `< eps` test
+ * (:79), is not "out of bounds" (__oob compares false) and therefore walks on
+ * with NaN position, depositing its NaN-attenuated sources into cell (0,0)
+ * until maxage.  Restated as is. */
+static int64_t orc_cell(float f) { return (f != f) ? 0 : (int64_t)f; }
+
 static float orc_length2(float x, float y) { return sqrtf(x * x + y * y); } /* erosion_map.cu:49-53 */
 
 /* erosion_map.cu:56-78 (duplicate path.cu:27-49) */
@@ -284,7 +293,7 @@ void orc_particles_fluvial(float* waterFlux, float* massFlux, float* velocityFlu
                            const float* waterSource, const float* waterHeight,
                            const float* velocity, const float* albedoSource,
                            const orc_domain* d, const float scale[3], const orc_param* param,
-                           int threads, int64_t* steps_out) {
+                           int threads, int64_t* steps_out, float* remote0) {
   const int64_t W = d->W;
   const int64_t base = d->x0 * W; /* global flat index of local element 0 */
   int64_t steps_total = 0;
@@ -302,10 +311,10 @@ void orc_particles_fluvial(float* waterFlux, float* massFlux, float* velocityFlu
     float px = 0.5f + u1 * (float)(d->H - 1);
     float py = 0.5f + u2 * (float)(d->W - 1);
     {
-      const int64_t sx = (int64_t)px - d->x0; /* spawn-row ownership (slab) */
+      const int64_t sx = orc_cell(px) - d->x0; /* spawn-row ownership (slab) */
       if (sx < d->r0 || sx >= d->r1) continue;
     }
-    int64_t ind = (int64_t)px * W + (int64_t)py; /* :60 (__flatten truncates, erosion_map.cu:42-47) */
+    int64_t ind = orc_cell(px) * W + orc_cell(py); /* :60 (__flatten truncates, erosion_map.cu:42-47) */
 
     const float rho_w = param->densityWater;               /* :63 */
     const float tau = param->bedShearWater;                /* :65 */
@@ -319,7 +328,7 @@ void orc_particles_fluvial(float* waterFlux, float* massFlux, float* velocityFlu
 
     const float velx = velocity[2 * (ind - base)], vely = velocity[2 * (ind - base) + 1]; /* :75 */
     float grad[2];
-    orc_glocal(layers, d, scale, (int64_t)px, (int64_t)py, param->exitSlope, grad); /* :76 */
+    orc_glocal(layers, d, scale, orc_cell(px), orc_cell(py), param->exitSlope, grad); /* :76 */
     float spx = -(g * grad[0]) + nu * velx + param->force[0]; /* :77 */
     float spy = -(g * grad[1]) + nu * vely + param->force[1];
     {
@@ -343,9 +352,19 @@ void orc_particles_fluvial(float* waterFlux, float* massFlux, float* velocityFlu
     float att_w = 1.0f, att_m = 1.0f, att_v = 1.0f; /* :94-96 */
     int64_t iter = 0;
     while (!orc_oob(d, px, py) && (uint64_t)(++iter) < param->maxage) { /* :100 */
-      if (orc_slab_escape(d, (int64_t)px)) break;
+      if (orc_slab_escape(d, orc_cell(px))) {
+        /* a NaN walker's one deposit belongs to global cell (0,0); a slab that
+         * does not hold it parks the deposit in remote0[0..3] for the owner */
+        if (px != px && remote0 && ind != 0) {
+          orc_atomic_add(&remote0[0], att_w * source_w, threads);
+          orc_atomic_add(&remote0[1], att_m * source_m, threads);
+          orc_atomic_add(&remote0[2], att_v * source_vx, threads);
+          orc_atomic_add(&remote0[3], att_v * source_vy, threads);
+        }
+        break;
+      }
       ++steps_total;
-      const int64_t nind = (int64_t)px * W + (int64_t)py; /* :103 */
+      const int64_t nind = orc_cell(px) * W + orc_cell(py); /* :103 */
       if (nind != ind) {                                  /* :104-113 */
         ind = nind;
         const int64_t l = ind - base;
@@ -364,7 +383,7 @@ void orc_particles_fluvial(float* waterFlux, float* massFlux, float* velocityFlu
       const float ds = dL / v_norm;                          /* :120 */
       if (v_norm < eps) break;                               /* :121-122 */
 
-      orc_glocal(layers, d, scale, (int64_t)px, (int64_t)py, param->exitSlope, grad); /* :125 */
+      orc_glocal(layers, d, scale, orc_cell(px), orc_cell(py), param->exitSlope, grad); /* :125 */
       const int64_t l = ind - base;
       const float ax = -(g * grad[0]) + nu * velocity[2 * l] + param->force[0]; /* :126 */
       const float ay = -(g * grad[1]) + nu * velocity[2 * l + 1] + param->force[1];
@@ -427,7 +446,8 @@ void orc_normalize_fluvial(const float* waterFlux, const float* massFlux,
 void orc_particles_debris(float* massFlux, float* velocityFlux, float* albedoFlux, orc_rng* rng,
                           int64_t N, const float* layers, const float* velocity,
                           const float* albedoSource, const orc_domain* d, const float scale[3],
-                          const orc_param* param, int threads, int64_t* steps_out) {
+                          const orc_param* param, int threads, int64_t* steps_out,
+                          float* remote0) {
   const int64_t W = d->W;
   const int64_t base = d->x0 * W;
   int64_t steps_total = 0;
@@ -445,10 +465,10 @@ void orc_particles_debris(float* massFlux, float* velocityFlux, float* albedoFlu
     float px = 0.5f + u1 * (float)(d->H - 1);
     float py = 0.5f + u2 * (float)(d->W - 1);
     {
-      const int64_t sx = (int64_t)px - d->x0;
+      const int64_t sx = orc_cell(px) - d->x0;
       if (sx < d->r0 || sx >= d->r1) continue;
     }
-    int64_t ind = (int64_t)px * W + (int64_t)py; /* :273 */
+    int64_t ind = orc_cell(px) * W + orc_cell(py); /* :273 */
 
     const float theta = param->critSlopeBedrock;   /* :276 */
     const float nu = param->viscosityDebris;       /* :277 */
@@ -461,7 +481,7 @@ void orc_particles_debris(float* massFlux, float* velocityFlux, float* albedoFlu
 
     const float velx = velocity[2 * (ind - base)], vely = velocity[2 * (ind - base) + 1]; /* :286 */
     float grad[2];
-    orc_glocal(layers, d, scale, (int64_t)px, (int64_t)py, param->exitSlope, grad); /* :287 */
+    orc_glocal(layers, d, scale, orc_cell(px), orc_cell(py), param->exitSlope, grad); /* :287 */
     float spx = -(g * grad[0]) + nu * velx; /* :288 */
     float spy = -(g * grad[1]) + nu * vely;
     {
@@ -483,9 +503,16 @@ void orc_particles_debris(float* massFlux, float* velocityFlux, float* albedoFlu
     float att_d = 1.0f, att_v = 1.0f; /* :301-302 */
     int64_t iter = 0;
     while (!orc_oob(d, px, py) && (uint64_t)(++iter) < param->maxage) { /* :306 */
-      if (orc_slab_escape(d, (int64_t)px)) break;
+      if (orc_slab_escape(d, orc_cell(px))) {
+        if (px != px && remote0 && ind != 0) { /* NaN walker, see orc_particles_fluvial */
+          orc_atomic_add(&remote0[4], att_d * source_d, threads);
+          orc_atomic_add(&remote0[5], att_v * source_vx, threads);
+          orc_atomic_add(&remote0[6], att_v * source_vy, threads);
+        }
+        break;
+      }
       ++steps_total;
-      const int64_t nind = (int64_t)px * W + (int64_t)py; /* :309 */
+      const int64_t nind = orc_cell(px) * W + orc_cell(py); /* :309 */
       if (nind != ind) {                                  /* :310-318 */
         ind = nind;
         const int64_t l = ind - base;
@@ -503,7 +530,7 @@ void orc_particles_debris(float* massFlux, float* velocityFlux, float* albedoFlu
       const float ds = dL / v_norm;                      /* :325 */
       if (v_norm < eps) break;                           /* :326-327 */
 
-      orc_glocal(layers, d, scale, (int64_t)px, (int64_t)py, param->exitSlope, grad); /* :330 */
+      orc_glocal(layers, d, scale, orc_cell(px), orc_cell(py), param->exitSlope, grad); /* :330 */
       const int64_t l = ind - base;
       const float debrisHeight = eps + att_d * source_d;     /* :331 */
       const float ax = -(g * grad[0]) + nu * velocity[2 * l]; /* :332 */
@@ -1074,7 +1101,7 @@ static void orc_bilinear(const float* flow, int64_t H, int64_t W, float px, floa
     v[1] = NAN;
     return;
   }
-  const int64_t ix = (int64_t)px, iy = (int64_t)py;   /* :156-159 */
+  const int64_t ix = orc_cell(px), iy = orc_cell(py);   /* :156-159 */
   float wx = px - floorf(px), wy = py - floorf(py);   /* :160 */
   int64_t i00 = ix * W + iy, i01 = ix * W + (iy + 1); /* :162-165 */
   int64_t i10 = (ix + 1) * W + iy, i11 = (ix + 1) * W + (iy + 1);
@@ -1104,7 +1131,7 @@ void orc_solve_uniform(float* flux, const float* flow, const float* source, cons
     /* u == 1 puts the spawn on the far edge; the reference then indexes out
      * of bounds at :90 (undefined behaviour) — such a sample is dropped here. */
     if (orc_oob(&d, px, py)) continue;
-    int64_t ind = (int64_t)px * W + (int64_t)py;                  /* :84 */
+    int64_t ind = orc_cell(px) * W + orc_cell(py);                  /* :84 */
     const float L = orc_length2(scale[0], scale[1]);              /* :87 */
     const float A = scale[0] * scale[1];                          /* :88 */
     const float P = 1.0f / (A * (float)(H * W));                  /* :89 */
@@ -1116,7 +1143,7 @@ void orc_solve_uniform(float* flux, const float* flow, const float* source, cons
     orc_bilinear(flow, H, W, px, py, v); /* :99-100 */
     int step = 0;
     while (!orc_oob(&d, px, py) && epsilon < fabsf(att) && (float)(++step) < maxstep) { /* :104 */
-      const int64_t nind = (int64_t)px * W + (int64_t)py; /* :107 */
+      const int64_t nind = orc_cell(px) * W + orc_cell(py); /* :107 */
       if (nind != ind) {                                  /* :108-116 */
         ind = nind;
         for (int c = 0; c < K; ++c) flux[K * ind + c] += S[c] * att;

@@ -73,7 +73,7 @@ void orc_particles_fluvial(float* waterFlux, float* massFlux, float* velocityFlu
                            const float* waterSource, const float* waterHeight,
                            const float* velocity, const float* albedoSource,
                            const orc_domain* dom, const float scale[3], const orc_param* param,
-                           int threads, int64_t* steps_out);
+                           int threads, int64_t* steps_out, float* remote0);
 void orc_normalize_fluvial(const float* waterFlux, const float* massFlux,
                            const float* velocityFlux, float* albedoFlux, const float* layers,
                            const float* waterSource, float* waterHeight, float* mass,
@@ -83,7 +83,7 @@ void orc_particles_debris(float* massFlux, float* velocityFlux, float* albedoFlu
                           int64_t N, const float* layers, const float* velocity,
                           const float* albedoSource, const orc_domain* dom,
                           const float scale[3], const orc_param* param, int threads,
-                          int64_t* steps_out);
+                          int64_t* steps_out, float* remote0);
 void orc_normalize_debris(const float* massFlux, const float* velocityFlux, float* albedoFlux,
                           const float* layers, float* mass, float* velocity,
                           const float* albedoSource, const orc_domain* dom,

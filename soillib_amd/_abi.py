@@ -95,10 +95,11 @@ SIGNATURES = {
     "soil_albedo_discharge": (cint, [vp, vp, i64, F3, f32, f32, vp]),
     "soil_erode_cells_fused": (cint, [C.POINTER(ErosionPlanes), C.POINTER(Domain), F3,
                                       C.POINTER(Param), vp]),
-    "soil_particles_fluvial_slab": (cint, [vp] * 5 + [i64] + [vp] * 5 +
+    "soil_particles_fluvial_slab": (cint, [vp] * 5 + [i64] + [vp] * 6 +
                                     [C.POINTER(Domain), F3, C.POINTER(Param), vp]),
-    "soil_particles_debris_slab": (cint, [vp] * 4 + [i64] + [vp] * 3 +
+    "soil_particles_debris_slab": (cint, [vp] * 4 + [i64] + [vp] * 4 +
                                    [C.POINTER(Domain), F3, C.POINTER(Param), vp]),
+    "soil_set_particle_mode": (cint, [cint]),
     "soil_ghost_rows": (i64, [C.POINTER(Param)]),
     "soil_direction": (cint, [vp, vp, i64, i64, cint, vp]),
     "soil_steepest": (cint, [vp, vp, i64, i64, cint, vp]),
@@ -116,6 +117,7 @@ SIGNATURES = {
     "soil_noise_param_default": (None, [C.POINTER(NoiseParam)]),
     "soil_noise": (cint, [vp, i64, i64, C.POINTER(NoiseParam), vp]),
     "soil_noise_host": (cint, [vp, i64, i64, C.POINTER(NoiseParam)]),
+    "soil_noise_window": (cint, [vp, i64, i64, i64, C.POINTER(NoiseParam), vp]),
 }
 
 _lib = None

@@ -40,6 +40,13 @@ int require_device();
 // Reports launch-configuration errors of the kernel launched just before.
 #define SOIL_LAUNCH_CHECK() SOIL_HIP(hipGetLastError())
 
+// Per-device scratch, grown on demand and reused across calls (the reference
+// cudaMallocs its scratch on every call, graph.cu:539-550, 182-183).  Slot 0:
+// accumulate; slot 1: particle staging.  Calls that share a slot must be
+// stream-ordered with respect to each other.
+int workspace_get(int slot, size_t bytes, void** out);
+int workspace_release_all();
+
 inline hipStream_t as_stream(void* s) { return static_cast<hipStream_t>(s); }
 inline unsigned blocks_for(int64_t n, int threads) {
   return static_cast<unsigned>((n + threads - 1) / threads);
@@ -65,6 +72,15 @@ struct Scale2 {
 using Param = soil_param;
 
 // ---- device helpers shared by the erosion kernels --------------------------
+
+// float -> cell coordinate with the semantics of the reference's device code
+// (CUDA cvt.rzi: truncate toward zero, NaN -> 0).  The NaN case is live: a
+// particle spawned on a pit cell with zero velocity has speed 0/sqrt(0) = NaN
+// (erosion.cu:77-79), is never "out of bounds", and keeps depositing into cell
+// (0,0) until maxage — restated as is.
+__device__ __forceinline__ int64_t cell_of(float f) {
+  return (f != f) ? 0 : static_cast<int64_t>(f);
+}
 
 __device__ __forceinline__ float length2(float x, float y) {  // erosion_map.cu:49-53
   return sqrtf(x * x + y * y);

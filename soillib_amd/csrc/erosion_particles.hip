@@ -2,13 +2,29 @@
 //   __transport_fluvial erosion.cu:29-141, __transport_debris :245-351, and the
 //   host wrappers soil::transport_fluvial :189-239 / soil::transport_debris :395-436.
 //
-// One lane integrates one streamline.  The flux planes are accumulated with
+// One lane integrates one streamline; the flux planes are accumulated with
 // hardware fp32 atomics (global_atomic_add_f32; built with -munsafe-fp-atomics).
+//
+// The reference launches thread n on particle n and lets every step gather a
+// 5-point float2 stencil at a random place: on MI355X that is one HBM sector
+// per gather (measured, profiles/r01_first).  Two MI355X-side changes, neither
+// of which alters a single trajectory or deposit:
+//   * STAGED GATHERS — a streaming pre-pass evaluates __glocal once per cell and
+//     packs {grad.x, grad.y, vel.x, vel.y} into one float4 plane, so a step
+//     costs one 16-byte gather (+4 bytes of waterHeight for fluvial) instead of
+//     seven scattered loads;
+//   * SPATIAL ORDER — particles are bucketed by the 16x16-cell tile of their
+//     spawn point (count / scan / scatter) and traced in tile order, and the
+//     work-groups of one XCD walk a contiguous band of tiles, so the lanes of a
+//     wave and the waves of an XCD share cache lines for most of their walk.
+// The reference's launch shape (thread n = particle n, direct stencil gathers)
+// is kept as `direct` mode for ablation (soil_set_particle_mode).
 #include "cell_math.hpp"
 
 namespace soil {
 
 constexpr int kPBlock = 256;
+constexpr int kTile = 16;  // spawn-order bucket edge, in cells
 
 int launch_normalize_fluvial(const float* waterFlux, const float* massFlux,
                              const float* velocityFlux, float* albedoFlux, const float* layers,
@@ -20,6 +36,8 @@ int launch_normalize_debris(const float* massFlux, const float* velocityFlux, fl
                             const float* albedoSource, const Dom& d, Scale3 s, const Param& p,
                             hipStream_t st);
 
+static int g_particle_mode = 0;  // 0 auto, 1 direct, 2 staged
+
 __device__ __forceinline__ bool oob(const Dom& d, float px, float py) {  // erosion_map.cu:29-40
   if (px < 0) return true;
   if (py < 0) return true;
@@ -28,45 +46,83 @@ __device__ __forceinline__ bool oob(const Dom& d, float px, float py) {  // eros
   return false;
 }
 
-// A slab traces a particle only while the cell's 5-point stencil lies inside
-// the rows it holds (see soil_hip.h, soil_particles_*_slab).
+// local rows whose 5-point stencil lies inside the rows this slab holds
+__device__ __host__ __forceinline__ int64_t stencil_lo(const Dom& d) { return (d.x0 == 0) ? 0 : 1; }
+__device__ __host__ __forceinline__ int64_t stencil_hi(const Dom& d) {  // inclusive
+  return (d.x0 + d.rows == d.H) ? d.rows - 1 : d.rows - 2;
+}
+// A slab traces a particle only while its cell's stencil is available
+// (soil_hip.h, soil_particles_*_slab).
 __device__ __forceinline__ bool slab_escape(const Dom& d, int64_t gx) {
   const int64_t lx = gx - d.x0;
-  const int64_t lo = (d.x0 == 0) ? 0 : 1;
-  const int64_t hi = (d.x0 + d.rows == d.H) ? d.rows - 1 : d.rows - 2;
-  return lx < lo || lx > hi;
+  return lx < stencil_lo(d) || lx > stencil_hi(d);
 }
 
-__global__ void __launch_bounds__(kPBlock)
-    k_particles_fluvial(float* __restrict__ waterFlux, float* __restrict__ massFlux,
-                        float* __restrict__ velocityFlux, float* __restrict__ albedoFlux,
-                        soil_rng* __restrict__ rng, int64_t N, const float2* __restrict__ layers,
-                        const float* __restrict__ waterSource,
-                        const float* __restrict__ waterHeight, const float2* __restrict__ velocity,
-                        const float* __restrict__ albedoSource, Dom d, Scale3 s, Param param) {
-  const int64_t n = static_cast<int64_t>(blockIdx.x) * kPBlock + threadIdx.x;
-  if (n >= N) return;
+// ---- where a step gets grad(cell) and velocity(cell) from -------------------
 
-  const float A = s.x * s.y;                                       // :50
-  const float Lx = s.x, Ly = s.y;                                  // :51
-  const float P = 1.0f / (A * static_cast<float>(d.H * d.W));      // :53
-  const float Q = 1.0f / (P * static_cast<float>(N));              // :54
-  const float eps = 1E-12f;                                        // :55
+struct DirectFields {  // the reference's access pattern
+  const float2* __restrict__ layers;
+  const float2* __restrict__ velocity;
+  Dom d;
+  Scale3 s;
+  float exitSlope;
+  __device__ __forceinline__ void at(int64_t cx, int64_t cy, int64_t l, float2& grad,
+                                     float2& vel) const {
+    grad = glocal(layers, d, s, cx, cy, exitSlope);
+    vel = velocity[l];
+  }
+};
 
+struct PackedFields {  // one 16-byte gather per step
+  const float4* __restrict__ p4;
+  __device__ __forceinline__ void at(int64_t, int64_t, int64_t l, float2& grad,
+                                     float2& vel) const {
+    const float4 v = p4[l];
+    grad = make_float2(v.x, v.y);
+    vel = make_float2(v.z, v.w);
+  }
+};
+
+// first two draws of particle n: spawn position (erosion.cu:56-59 / :269-272)
+__device__ __forceinline__ float2 spawn_position(soil_rng* __restrict__ rng, int64_t n,
+                                                 const Dom& d) {
   soil_rng st = rng[n];
-  const float u1 = rng_uniform_at(st.seed, static_cast<uint64_t>(n), st.offset);      // :57
-  const float u2 = rng_uniform_at(st.seed, static_cast<uint64_t>(n), st.offset + 1);  // :58
+  const float u1 = rng_uniform_at(st.seed, static_cast<uint64_t>(n), st.offset);
+  const float u2 = rng_uniform_at(st.seed, static_cast<uint64_t>(n), st.offset + 1);
   st.offset += 2;
   rng[n] = st;  // the state persists in the tensor, like curandState
-  float px = 0.5f + u1 * static_cast<float>(d.H - 1);
-  float py = 0.5f + u2 * static_cast<float>(d.W - 1);
-  {
-    const int64_t sx = static_cast<int64_t>(px) - d.x0;  // spawn-row ownership
-    if (sx < d.r0 || sx >= d.r1) return;
-  }
+  return make_float2(0.5f + u1 * static_cast<float>(d.H - 1),
+                     0.5f + u2 * static_cast<float>(d.W - 1));
+}
+__device__ __forceinline__ bool owns_spawn(const Dom& d, float px) {
+  const int64_t sx = cell_of(px) - d.x0;
+  return sx >= d.r0 && sx < d.r1;
+}
+
+struct FluvialPlanes {
+  float* __restrict__ waterFlux;
+  float* __restrict__ massFlux;
+  float* __restrict__ velocityFlux;
+  float* __restrict__ albedoFlux;
+  const float* __restrict__ waterSource;
+  const float* __restrict__ waterHeight;
+  const float* __restrict__ albedoSource;
+  float* __restrict__ remote0;
+};
+
+// __transport_fluvial, erosion.cu:49-139, from the spawn position on
+template <class Fields>
+__device__ __forceinline__ void trace_fluvial(const Fields& F, const FluvialPlanes& P, float px,
+                                              float py, int64_t N, const Dom& d, Scale3 s,
+                                              const Param& param) {
+  const float A = s.x * s.y;                                   // :50
+  const float Lx = s.x, Ly = s.y;                              // :51
+  const float Pr = 1.0f / (A * static_cast<float>(d.H * d.W)); // :53
+  const float Q = 1.0f / (Pr * static_cast<float>(N));         // :54
+  const float eps = 1E-12f;                                    // :55
   const int64_t W = d.W;
   const int64_t base = d.x0 * W;
-  int64_t ind = static_cast<int64_t>(px) * W + static_cast<int64_t>(py);  // :60
+  int64_t ind = cell_of(px) * W + cell_of(py);  // :60
 
   const float rho_w = param.densityWater;                 // :63
   const float tau = param.bedShearWater;                  // :65
@@ -78,9 +134,8 @@ __global__ void __launch_bounds__(kPBlock)
   const float alpha = param.fluvialExponent;              // :71
   const float R = param.rainfall;                         // :72
 
-  const float2 vel = velocity[ind - base];  // :75
-  float2 grad = glocal(layers, d, s, static_cast<int64_t>(px), static_cast<int64_t>(py),
-                       param.exitSlope);  // :76
+  float2 vel, grad;
+  F.at(cell_of(px), cell_of(py), ind - base, grad, vel);    // :75-76
   float spx = -(g * grad.x) + nu * vel.x + param.force[0];  // :77
   float spy = -(g * grad.y) + nu * vel.y + param.force[1];
   {
@@ -90,44 +145,54 @@ __global__ void __launch_bounds__(kPBlock)
   }
   if (length2(spx, spy) < eps) return;  // :79-80
 
-  const float v = length2(vel.x, vel.y);                                // :83
-  const float shear = 0.125f * fD * rho_w * v * v;                      // :84
-  const float power = powf_(shear * length2(grad.x, grad.y), alpha);    // :85
-  const float source_m = Q * ks * power;                                // :88
-  const float source_w = Q * R * waterSource[ind - base];               // :89
-  const float source_vx = Q * (-(g * grad.x) + nu * vel.x);             // :90
+  const float v = length2(vel.x, vel.y);                              // :83
+  const float shear = 0.125f * fD * rho_w * v * v;                    // :84
+  const float power = powf_(shear * length2(grad.x, grad.y), alpha);  // :85
+  const float source_m = Q * ks * power;                              // :88
+  const float source_w = Q * R * P.waterSource[ind - base];           // :89
+  const float source_vx = Q * (-(g * grad.x) + nu * vel.x);           // :90
   const float source_vy = Q * (-(g * grad.y) + nu * vel.y);
   float source_a[3] = {0.0f, 0.0f, 0.0f};
-  if (albedoSource)  // :91
-    for (int c = 0; c < 3; ++c) source_a[c] = source_m * albedoSource[3 * (ind - base) + c];
+  if (P.albedoSource)  // :91
+    for (int c = 0; c < 3; ++c) source_a[c] = source_m * P.albedoSource[3 * (ind - base) + c];
 
   float att_w = 1.0f, att_m = 1.0f, att_v = 1.0f;  // :94-96
   const float lenL = length2(Lx, Ly);
   uint64_t iter = 0;
   while (!oob(d, px, py) && ++iter < param.maxage) {  // :100
-    const int64_t cx = static_cast<int64_t>(px), cy = static_cast<int64_t>(py);
-    if (slab_escape(d, cx)) break;
+    const int64_t cx = cell_of(px), cy = cell_of(py);
+    if (slab_escape(d, cx)) {
+      // a NaN walker's single deposit belongs to global cell (0,0); when that
+      // cell lives on another rank it is parked in `remote0` for its owner
+      if (px != px && P.remote0 && ind != 0) {
+        atomicAdd(&P.remote0[0], att_w * source_w);
+        atomicAdd(&P.remote0[1], att_m * source_m);
+        atomicAdd(&P.remote0[2], att_v * source_vx);
+        atomicAdd(&P.remote0[3], att_v * source_vy);
+      }
+      break;
+    }
     const int64_t nind = cx * W + cy;  // :103
     if (nind != ind) {                 // :104-113
       ind = nind;
       const int64_t l = ind - base;
-      atomicAdd(&waterFlux[l], att_w * source_w);
-      atomicAdd(&massFlux[l], att_m * source_m);
-      atomicAdd(&velocityFlux[2 * l], att_v * source_vx);
-      atomicAdd(&velocityFlux[2 * l + 1], att_v * source_vy);
-      if (albedoFlux)
-        for (int c = 0; c < 3; ++c) atomicAdd(&albedoFlux[3 * l + c], att_m * source_a[c]);
+      atomicAdd(&P.waterFlux[l], att_w * source_w);
+      atomicAdd(&P.massFlux[l], att_m * source_m);
+      atomicAdd(&P.velocityFlux[2 * l], att_v * source_vx);
+      atomicAdd(&P.velocityFlux[2 * l + 1], att_v * source_vy);
+      if (P.albedoFlux)
+        for (int c = 0; c < 3; ++c) atomicAdd(&P.albedoFlux[3 * l + c], att_m * source_a[c]);
     }
-    const float v_norm = length2(spx, spy);             // :116
-    const float ux = spx / v_norm, uy = spy / v_norm;   // :117
-    const float v_step = stepsize(px, py, ux, uy);      // :118
-    const float dL = v_step * lenL;                     // :119
-    const float ds = dL / v_norm;                       // :120
-    if (v_norm < eps) break;                            // :121-122
+    const float v_norm = length2(spx, spy);            // :116
+    const float ux = spx / v_norm, uy = spy / v_norm;  // :117
+    const float v_step = stepsize(px, py, ux, uy);     // :118
+    const float dL = v_step * lenL;                    // :119
+    const float ds = dL / v_norm;                      // :120
+    if (v_norm < eps) break;                           // :121-122
 
-    grad = glocal(layers, d, s, cx, cy, param.exitSlope);  // :125
     const int64_t l = ind - base;
-    const float2 vc = velocity[l];
+    float2 vc;
+    F.at(cx, cy, l, grad, vc);                                    // :125
     const float ax = -(g * grad.x) + nu * vc.x + param.force[0];  // :126
     const float ay = -(g * grad.y) + nu * vc.y + param.force[1];
     const float w0 = 1.0f / (1.0f + dL * (tau + nu));  // :127
@@ -135,45 +200,38 @@ __global__ void __launch_bounds__(kPBlock)
     spx = w0 * spx + w1 * ax;
     spy = w0 * spy + w1 * ay;
 
-    const float decay_m = kd;                                    // :130
-    const float decay_w = param.evapRate;                        // :131
-    const float decay_v = 0.125f * fD / (eps + waterHeight[l]);  // :132
-    att_m = att_m * expf_(-ds * decay_m);                        // :134
-    att_w = att_w * expf_(-ds * decay_w);                        // :135
-    att_v = att_v * expf_(-dL * decay_v);                        // :136
-    px += v_step * ux;                                           // :137
+    const float decay_m = kd;                                      // :130
+    const float decay_w = param.evapRate;                          // :131
+    const float decay_v = 0.125f * fD / (eps + P.waterHeight[l]);  // :132
+    att_m = att_m * expf_(-ds * decay_m);                          // :134
+    att_w = att_w * expf_(-ds * decay_w);                          // :135
+    att_v = att_v * expf_(-dL * decay_v);                          // :136
+    px += v_step * ux;                                             // :137
     py += v_step * uy;
   }
 }
 
-__global__ void __launch_bounds__(kPBlock)
-    k_particles_debris(float* __restrict__ massFlux, float* __restrict__ velocityFlux,
-                       float* __restrict__ albedoFlux, soil_rng* __restrict__ rng, int64_t N,
-                       const float2* __restrict__ layers, const float2* __restrict__ velocity,
-                       const float* __restrict__ albedoSource, Dom d, Scale3 s, Param param) {
-  const int64_t n = static_cast<int64_t>(blockIdx.x) * kPBlock + threadIdx.x;
-  if (n >= N) return;
+struct DebrisPlanes {
+  float* __restrict__ massFlux;
+  float* __restrict__ velocityFlux;
+  float* __restrict__ albedoFlux;
+  const float* __restrict__ albedoSource;
+  float* __restrict__ remote0;
+};
 
-  const float A = s.x * s.y;                                   // :263
-  const float Lx = s.x, Ly = s.y;                              // :264
-  const float P = 1.0f / (A * static_cast<float>(d.H * d.W));  // :266
-  const float Q = 1.0f / (P * static_cast<float>(N));          // :267
-  const float eps = 1E-12f;                                    // :268
-
-  soil_rng st = rng[n];
-  const float u1 = rng_uniform_at(st.seed, static_cast<uint64_t>(n), st.offset);      // :270
-  const float u2 = rng_uniform_at(st.seed, static_cast<uint64_t>(n), st.offset + 1);  // :271
-  st.offset += 2;
-  rng[n] = st;
-  float px = 0.5f + u1 * static_cast<float>(d.H - 1);
-  float py = 0.5f + u2 * static_cast<float>(d.W - 1);
-  {
-    const int64_t sx = static_cast<int64_t>(px) - d.x0;
-    if (sx < d.r0 || sx >= d.r1) return;
-  }
+// __transport_debris, erosion.cu:262-349, from the spawn position on
+template <class Fields>
+__device__ __forceinline__ void trace_debris(const Fields& F, const DebrisPlanes& P, float px,
+                                             float py, int64_t N, const Dom& d, Scale3 s,
+                                             const Param& param) {
+  const float A = s.x * s.y;                                    // :263
+  const float Lx = s.x, Ly = s.y;                               // :264
+  const float Pr = 1.0f / (A * static_cast<float>(d.H * d.W));  // :266
+  const float Q = 1.0f / (Pr * static_cast<float>(N));          // :267
+  const float eps = 1E-12f;                                     // :268
   const int64_t W = d.W;
   const int64_t base = d.x0 * W;
-  int64_t ind = static_cast<int64_t>(px) * W + static_cast<int64_t>(py);  // :273
+  int64_t ind = cell_of(px) * W + cell_of(py);  // :273
 
   const float theta = param.critSlopeBedrock;    // :276
   const float nu = param.viscosityDebris;        // :277
@@ -184,10 +242,9 @@ __global__ void __launch_bounds__(kPBlock)
   const float kds = param.suspensionRateDebris;  // :282
   const float tau_y = param.yieldStress;         // :283
 
-  const float2 vel = velocity[ind - base];  // :286
-  float2 grad = glocal(layers, d, s, static_cast<int64_t>(px), static_cast<int64_t>(py),
-                       param.exitSlope);  // :287
-  float spx = -(g * grad.x) + nu * vel.x;  // :288
+  float2 vel, grad;
+  F.at(cell_of(px), cell_of(py), ind - base, grad, vel);  // :286-287
+  float spx = -(g * grad.x) + nu * vel.x;                 // :288
   float spy = -(g * grad.y) + nu * vel.y;
   {
     const float den = sqrtf(length2(Lx * spx, Ly * spy));  // :289
@@ -202,24 +259,31 @@ __global__ void __launch_bounds__(kPBlock)
   const float source_vx = Q * (-g * grad.x + nu * vel.x);      // :298
   const float source_vy = Q * (-g * grad.y + nu * vel.y);
   float source_a[3] = {0.0f, 0.0f, 0.0f};
-  if (albedoSource)  // :299
-    for (int c = 0; c < 3; ++c) source_a[c] = source_d * albedoSource[3 * (ind - base) + c];
+  if (P.albedoSource)  // :299
+    for (int c = 0; c < 3; ++c) source_a[c] = source_d * P.albedoSource[3 * (ind - base) + c];
 
   float att_d = 1.0f, att_v = 1.0f;  // :301-302
   const float lenL = length2(Lx, Ly);
   uint64_t iter = 0;
   while (!oob(d, px, py) && ++iter < param.maxage) {  // :306
-    const int64_t cx = static_cast<int64_t>(px), cy = static_cast<int64_t>(py);
-    if (slab_escape(d, cx)) break;
+    const int64_t cx = cell_of(px), cy = cell_of(py);
+    if (slab_escape(d, cx)) {
+      if (px != px && P.remote0 && ind != 0) {  // NaN walker: see trace_fluvial
+        atomicAdd(&P.remote0[4], att_d * source_d);
+        atomicAdd(&P.remote0[5], att_v * source_vx);
+        atomicAdd(&P.remote0[6], att_v * source_vy);
+      }
+      break;
+    }
     const int64_t nind = cx * W + cy;  // :309
     if (nind != ind) {                 // :310-318
       ind = nind;
       const int64_t l = ind - base;
-      atomicAdd(&massFlux[l], att_d * source_d);
-      atomicAdd(&velocityFlux[2 * l], att_v * source_vx);
-      atomicAdd(&velocityFlux[2 * l + 1], att_v * source_vy);
-      if (albedoFlux)
-        for (int c = 0; c < 3; ++c) atomicAdd(&albedoFlux[3 * l + c], att_d * source_a[c]);
+      atomicAdd(&P.massFlux[l], att_d * source_d);
+      atomicAdd(&P.velocityFlux[2 * l], att_v * source_vx);
+      atomicAdd(&P.velocityFlux[2 * l + 1], att_v * source_vy);
+      if (P.albedoFlux)
+        for (int c = 0; c < 3; ++c) atomicAdd(&P.albedoFlux[3 * l + c], att_d * source_a[c]);
     }
     const float v_norm = length2(spx, spy);            // :321
     const float ux = spx / v_norm, uy = spy / v_norm;  // :322
@@ -228,9 +292,9 @@ __global__ void __launch_bounds__(kPBlock)
     const float ds = dL / v_norm;                      // :325
     if (v_norm < eps) break;                           // :326-327
 
-    grad = glocal(layers, d, s, cx, cy, param.exitSlope);  // :330
     const int64_t l = ind - base;
-    const float2 vc = velocity[l];
+    float2 vc;
+    F.at(cx, cy, l, grad, vc);                          // :330
     const float debrisHeight = eps + att_d * source_d;  // :331
     const float ax = -(g * grad.x) + nu * vc.x;         // :332
     const float ay = -(g * grad.y) + nu * vc.y;
@@ -251,31 +315,225 @@ __global__ void __launch_bounds__(kPBlock)
   }
 }
 
+// ---- direct mode: thread n = particle n ---------------------------------------
+
+__global__ void __launch_bounds__(kPBlock)
+    k_fluvial_direct(FluvialPlanes P, soil_rng* __restrict__ rng, int64_t N, DirectFields F,
+                     Param param) {
+  const int64_t n = static_cast<int64_t>(blockIdx.x) * kPBlock + threadIdx.x;
+  if (n >= N) return;
+  const float2 pos = spawn_position(rng, n, F.d);
+  if (!owns_spawn(F.d, pos.x)) return;
+  trace_fluvial(F, P, pos.x, pos.y, N, F.d, F.s, param);
+}
+
+__global__ void __launch_bounds__(kPBlock)
+    k_debris_direct(DebrisPlanes P, soil_rng* __restrict__ rng, int64_t N, DirectFields F,
+                    Param param) {
+  const int64_t n = static_cast<int64_t>(blockIdx.x) * kPBlock + threadIdx.x;
+  if (n >= N) return;
+  const float2 pos = spawn_position(rng, n, F.d);
+  if (!owns_spawn(F.d, pos.x)) return;
+  trace_debris(F, P, pos.x, pos.y, N, F.d, F.s, param);
+}
+
+// ---- staged mode ------------------------------------------------------------------
+
+// pre-pass: p4[cell] = {__glocal(cell), velocity[cell]} for every row with a full stencil
+__global__ void __launch_bounds__(kPBlock)
+    k_pack_fields(float4* __restrict__ p4, const float2* __restrict__ layers,
+                  const float2* __restrict__ velocity, Dom d, Scale3 s, float exitSlope,
+                  int64_t row_lo, int64_t cells) {
+  const int64_t t = static_cast<int64_t>(blockIdx.x) * kPBlock + threadIdx.x;
+  if (t >= cells) return;
+  const int64_t lx = row_lo + t / d.W, y = t % d.W;
+  const int64_t l = lx * d.W + y;
+  const float2 g = glocal(layers, d, s, d.x0 + lx, y, exitSlope);
+  const float2 v = velocity[l];
+  p4[l] = make_float4(g.x, g.y, v.x, v.y);
+}
+
+__device__ __forceinline__ int64_t tile_of(const Dom& d, float px, float py, int64_t tiles_w) {
+  const int64_t lx = cell_of(px) - d.x0, cy = cell_of(py);
+  return (lx / kTile) * tiles_w + cy / kTile;
+}
+
+// pass 1: draw the spawn points (advancing every particle's stream) and count per tile
+__global__ void __launch_bounds__(kPBlock)
+    k_spawn_count(float2* __restrict__ spawn, uint32_t* __restrict__ count,
+                  soil_rng* __restrict__ rng, int64_t N, Dom d, int64_t tiles_w) {
+  const int64_t n = static_cast<int64_t>(blockIdx.x) * kPBlock + threadIdx.x;
+  if (n >= N) return;
+  const float2 pos = spawn_position(rng, n, d);
+  spawn[n] = pos;
+  if (owns_spawn(d, pos.x)) atomicAdd(&count[tile_of(d, pos.x, pos.y, tiles_w)], 1u);
+}
+
+// pass 2: exclusive scan of the tile counts (one work-group; tiles <= a few 1e5)
+__global__ void __launch_bounds__(1024)
+    k_tile_scan(uint32_t* __restrict__ start, const uint32_t* __restrict__ count, int64_t tiles) {
+  __shared__ uint32_t part[1024];
+  const int tid = threadIdx.x;
+  const int64_t chunk = (tiles + 1023) / 1024;
+  const int64_t b = tid * chunk, e = (b + chunk < tiles) ? b + chunk : tiles;
+  uint32_t sum = 0;
+  for (int64_t i = b; i < e; ++i) sum += count[i];
+  part[tid] = sum;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
+    const uint32_t v = (tid >= off) ? part[tid - off] : 0u;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  uint32_t run = part[tid] - sum;
+  for (int64_t i = b; i < e; ++i) {
+    start[i] = run;
+    run += count[i];
+  }
+  if (tid == 1023) start[tiles] = part[1023];  // total number of owned particles
+}
+
+// pass 3: drop every owned spawn point into its tile's range
+__global__ void __launch_bounds__(kPBlock)
+    k_spawn_scatter(float2* __restrict__ sorted, uint32_t* __restrict__ fill,
+                    const uint32_t* __restrict__ start, const float2* __restrict__ spawn,
+                    int64_t N, Dom d, int64_t tiles_w) {
+  const int64_t n = static_cast<int64_t>(blockIdx.x) * kPBlock + threadIdx.x;
+  if (n >= N) return;
+  const float2 pos = spawn[n];
+  if (!owns_spawn(d, pos.x)) return;
+  const int64_t tile = tile_of(d, pos.x, pos.y, tiles_w);
+  sorted[start[tile] + atomicAdd(&fill[tile], 1u)] = pos;
+}
+
+// work-group -> slot in the sorted order: block b runs on XCD b % 8; give every
+// XCD one contiguous eighth of the tile sequence
+__device__ __forceinline__ int64_t sorted_slot(const uint32_t* __restrict__ total_ptr) {
+  const int64_t total = *total_ptr;
+  const int64_t nb = (total + kPBlock - 1) / kPBlock;
+  const int64_t per = (nb + 7) / 8;
+  const int64_t b = blockIdx.x;
+  const int64_t slot = b / 8;
+  if (slot >= per) return -1;
+  const int64_t blk = (b % 8) * per + slot;
+  const int64_t t = blk * kPBlock + threadIdx.x;
+  return (blk < nb && t < total) ? t : -1;
+}
+
+__global__ void __launch_bounds__(kPBlock)
+    k_fluvial_sorted(FluvialPlanes P, const float2* __restrict__ sorted,
+                     const uint32_t* __restrict__ total, int64_t N, PackedFields F, Dom d,
+                     Scale3 s, Param param) {
+  const int64_t t = sorted_slot(total);
+  if (t < 0) return;
+  const float2 pos = sorted[t];
+  trace_fluvial(F, P, pos.x, pos.y, N, d, s, param);
+}
+
+__global__ void __launch_bounds__(kPBlock)
+    k_debris_sorted(DebrisPlanes P, const float2* __restrict__ sorted,
+                    const uint32_t* __restrict__ total, int64_t N, PackedFields F, Dom d, Scale3 s,
+                    Param param) {
+  const int64_t t = sorted_slot(total);
+  if (t < 0) return;
+  const float2 pos = sorted[t];
+  trace_debris(F, P, pos.x, pos.y, N, d, s, param);
+}
+
 static Scale3 s3p(const float* s) { return Scale3{s[0], s[1], s[2]}; }
+
+static bool use_staged(int64_t N) {
+  if (g_particle_mode == 1) return false;
+  if (g_particle_mode == 2) return true;
+  return N >= 1024;
+}
+
+// Shared staging: pack the fields, bucket the spawn points.  Returns device
+// pointers into the per-device workspace (valid until the next staged call).
+struct Staged {
+  float4* p4;
+  float2* sorted;
+  uint32_t* total;
+};
+
+static int stage(Staged* out, soil_rng* rng, int64_t N, const float* layers,
+                 const float* velocity, const Dom& d, Scale3 s, const Param& p, hipStream_t st) {
+  const int64_t tiles_w = (d.W + kTile - 1) / kTile, tiles_h = (d.rows + kTile - 1) / kTile;
+  const int64_t tiles = tiles_w * tiles_h;
+  auto align = [](size_t b) { return (b + 255) & ~static_cast<size_t>(255); };
+  const size_t b_p4 = align(sizeof(float4) * d.rows * d.W);
+  const size_t b_pos = align(sizeof(float2) * N);
+  const size_t b_cnt = align(sizeof(uint32_t) * (tiles + 1));
+  void* base = nullptr;
+  int rc = workspace_get(1, b_p4 + 2 * b_pos + 3 * b_cnt, &base);
+  if (rc != SOIL_OK) return rc;
+  char* w = static_cast<char*>(base);
+  out->p4 = reinterpret_cast<float4*>(w);      w += b_p4;
+  float2* spawn = reinterpret_cast<float2*>(w); w += b_pos;
+  out->sorted = reinterpret_cast<float2*>(w);  w += b_pos;
+  uint32_t* count = reinterpret_cast<uint32_t*>(w); w += b_cnt;
+  uint32_t* fill = reinterpret_cast<uint32_t*>(w);  w += b_cnt;
+  uint32_t* start = reinterpret_cast<uint32_t*>(w);
+  out->total = start + tiles;
+
+  const int64_t lo = stencil_lo(d), hi = stencil_hi(d);
+  const int64_t cells = (hi - lo + 1) * d.W;
+  if (cells > 0)
+    k_pack_fields<<<blocks_for(cells, kPBlock), kPBlock, 0, st>>>(
+        out->p4, reinterpret_cast<const float2*>(layers),
+        reinterpret_cast<const float2*>(velocity), d, s, p.exitSlope, lo, cells);
+  SOIL_HIP(hipMemsetAsync(count, 0, 2 * b_cnt, st));  // count and fill are adjacent
+  k_spawn_count<<<blocks_for(N, kPBlock), kPBlock, 0, st>>>(spawn, count, rng, N, d, tiles_w);
+  k_tile_scan<<<1, 1024, 0, st>>>(start, count, tiles);
+  k_spawn_scatter<<<blocks_for(N, kPBlock), kPBlock, 0, st>>>(out->sorted, fill, start, spawn, N,
+                                                              d, tiles_w);
+  SOIL_LAUNCH_CHECK();
+  return SOIL_OK;
+}
 
 static int launch_particles_fluvial(float* waterFlux, float* massFlux, float* velocityFlux,
                                     float* albedoFlux, soil_rng* rng, int64_t N,
                                     const float* layers, const float* waterSource,
                                     const float* waterHeight, const float* velocity,
-                                    const float* albedoSource, const Dom& d, Scale3 s,
-                                    const Param& p, hipStream_t st) {
+                                    const float* albedoSource, float* remote0, const Dom& d,
+                                    Scale3 s, const Param& p, hipStream_t st) {
   if (N <= 0) return SOIL_OK;
-  k_particles_fluvial<<<blocks_for(N, kPBlock), kPBlock, 0, st>>>(
-      waterFlux, massFlux, velocityFlux, albedoFlux, rng, N,
-      reinterpret_cast<const float2*>(layers), waterSource, waterHeight,
-      reinterpret_cast<const float2*>(velocity), albedoSource, d, s, p);
+  const FluvialPlanes P{waterFlux,   massFlux,     velocityFlux, albedoFlux,
+                        waterSource, waterHeight, albedoSource, remote0};
+  if (use_staged(N)) {
+    Staged sg;
+    int rc = stage(&sg, rng, N, layers, velocity, d, s, p, st);
+    if (rc != SOIL_OK) return rc;
+    k_fluvial_sorted<<<blocks_for(N, kPBlock) + 8, kPBlock, 0, st>>>(
+        P, sg.sorted, sg.total, N, PackedFields{sg.p4}, d, s, p);
+  } else {
+    const DirectFields F{reinterpret_cast<const float2*>(layers),
+                         reinterpret_cast<const float2*>(velocity), d, s, p.exitSlope};
+    k_fluvial_direct<<<blocks_for(N, kPBlock), kPBlock, 0, st>>>(P, rng, N, F, p);
+  }
   SOIL_LAUNCH_CHECK();
   return SOIL_OK;
 }
 
 static int launch_particles_debris(float* massFlux, float* velocityFlux, float* albedoFlux,
                                    soil_rng* rng, int64_t N, const float* layers,
-                                   const float* velocity, const float* albedoSource, const Dom& d,
-                                   Scale3 s, const Param& p, hipStream_t st) {
+                                   const float* velocity, const float* albedoSource,
+                                   float* remote0, const Dom& d, Scale3 s, const Param& p,
+                                   hipStream_t st) {
   if (N <= 0) return SOIL_OK;
-  k_particles_debris<<<blocks_for(N, kPBlock), kPBlock, 0, st>>>(
-      massFlux, velocityFlux, albedoFlux, rng, N, reinterpret_cast<const float2*>(layers),
-      reinterpret_cast<const float2*>(velocity), albedoSource, d, s, p);
+  const DebrisPlanes P{massFlux, velocityFlux, albedoFlux, albedoSource, remote0};
+  if (use_staged(N)) {
+    Staged sg;
+    int rc = stage(&sg, rng, N, layers, velocity, d, s, p, st);
+    if (rc != SOIL_OK) return rc;
+    k_debris_sorted<<<blocks_for(N, kPBlock) + 8, kPBlock, 0, st>>>(
+        P, sg.sorted, sg.total, N, PackedFields{sg.p4}, d, s, p);
+  } else {
+    const DirectFields F{reinterpret_cast<const float2*>(layers),
+                         reinterpret_cast<const float2*>(velocity), d, s, p.exitSlope};
+    k_debris_direct<<<blocks_for(N, kPBlock), kPBlock, 0, st>>>(P, rng, N, F, p);
+  }
   SOIL_LAUNCH_CHECK();
   return SOIL_OK;
 }
@@ -285,6 +543,12 @@ static int launch_particles_debris(float* massFlux, float* velocityFlux, float* 
 using namespace soil;
 
 extern "C" {
+
+int soil_set_particle_mode(int mode) {
+  SOIL_REQUIRE(mode >= 0 && mode <= 2, "particle mode: 0 auto, 1 direct, 2 staged");
+  g_particle_mode = mode;
+  return SOIL_OK;
+}
 
 int64_t soil_ghost_rows(const soil_param* param) {
   const double travel = 1.41421356237309515 * static_cast<double>(param ? param->maxage : 512);
@@ -308,8 +572,8 @@ int soil_transport_fluvial(const float* layers, const float* rainfall, float* wa
   const Dom d = full_domain(H, W);
   const Scale3 s = s3p(scale);
   int rc = launch_particles_fluvial(waterFlux, massFlux, velocityFlux, albedoFlux, rng, N, layers,
-                                    rainfall, waterHeight, velocity, albedoSource, d, s, *param,
-                                    as_stream(stream));  // erosion.cu:209
+                                    rainfall, waterHeight, velocity, albedoSource, nullptr, d, s,
+                                    *param, as_stream(stream));  // erosion.cu:209
   if (rc != SOIL_OK) return rc;
   return launch_normalize_fluvial(waterFlux, massFlux, velocityFlux, albedoFlux, layers, rainfall,
                                   waterHeight, mass, velocity, albedoSource, d, s, *param,
@@ -331,7 +595,8 @@ int soil_transport_debris(const float* layers, float* velocity, float* velocityF
   const Dom d = full_domain(H, W);
   const Scale3 s = s3p(scale);
   int rc = launch_particles_debris(massFlux, velocityFlux, albedoFlux, rng, N, layers, velocity,
-                                   albedoSource, d, s, *param, as_stream(stream));  // :412
+                                   albedoSource, nullptr, d, s, *param,
+                                   as_stream(stream));  // :412
   if (rc != SOIL_OK) return rc;
   return launch_normalize_debris(massFlux, velocityFlux, albedoFlux, layers, mass, velocity,
                                  albedoSource, d, s, *param, as_stream(stream));  // :424
@@ -340,7 +605,7 @@ int soil_transport_debris(const float* layers, float* velocity, float* velocityF
 int soil_particles_fluvial_slab(float* waterFlux, float* massFlux, float* velocityFlux,
                                 float* albedoFlux, soil_rng* rng, int64_t N, const float* layers,
                                 const float* rainfall, const float* waterHeight,
-                                const float* velocity, const float* albedoSource,
+                                const float* velocity, const float* albedoSource, float* remote0,
                                 const soil_domain* dom, const float scale[3],
                                 const soil_param* param, void* stream) {
   SOIL_DEVICE();
@@ -354,13 +619,13 @@ int soil_particles_fluvial_slab(float* waterFlux, float* massFlux, float* veloci
   int rc = check_domain(d);
   if (rc != SOIL_OK) return rc;
   return launch_particles_fluvial(waterFlux, massFlux, velocityFlux, albedoFlux, rng, N, layers,
-                                  rainfall, waterHeight, velocity, albedoSource, d, s3p(scale),
-                                  *param, as_stream(stream));
+                                  rainfall, waterHeight, velocity, albedoSource, remote0, d,
+                                  s3p(scale), *param, as_stream(stream));
 }
 
 int soil_particles_debris_slab(float* massFlux, float* velocityFlux, float* albedoFlux,
                                soil_rng* rng, int64_t N, const float* layers,
-                               const float* velocity, const float* albedoSource,
+                               const float* velocity, const float* albedoSource, float* remote0,
                                const soil_domain* dom, const float scale[3],
                                const soil_param* param, void* stream) {
   SOIL_DEVICE();
@@ -373,7 +638,8 @@ int soil_particles_debris_slab(float* massFlux, float* velocityFlux, float* albe
   int rc = check_domain(d);
   if (rc != SOIL_OK) return rc;
   return launch_particles_debris(massFlux, velocityFlux, albedoFlux, rng, N, layers, velocity,
-                                 albedoSource, d, s3p(scale), *param, as_stream(stream));
+                                 albedoSource, remote0, d, s3p(scale), *param,
+                                 as_stream(stream));
 }
 
 }  // extern "C"

@@ -204,30 +204,6 @@ __global__ void __launch_bounds__(kGBlock)
   }
 }
 
-// per-device scratch for accumulate
-struct Workspace {
-  void* base = nullptr;
-  size_t bytes = 0;
-};
-static std::mutex g_ws_mutex;
-static std::unordered_map<int, Workspace> g_ws;
-
-static int workspace_get(size_t bytes, void** out) {
-  int dev = 0;
-  SOIL_HIP(hipGetDevice(&dev));
-  std::lock_guard<std::mutex> lock(g_ws_mutex);
-  Workspace& w = g_ws[dev];
-  if (w.bytes < bytes) {
-    if (w.base) SOIL_HIP(hipFree(w.base));
-    w.base = nullptr;
-    w.bytes = 0;
-    SOIL_HIP(hipMalloc(&w.base, bytes));
-    w.bytes = bytes;
-  }
-  *out = w.base;
-  return SOIL_OK;
-}
-
 template <int K>
 static int accumulate_impl(float* out, const int32_t* graph, const float* source,
                            const float* decayIn, int64_t H, int64_t W, hipStream_t st) {
@@ -235,7 +211,7 @@ static int accumulate_impl(float* out, const int32_t* graph, const float* source
   auto align = [](size_t b) { return (b + 255) & ~static_cast<size_t>(255); };
   const size_t b1 = align(sizeof(float) * elem), bK = align(sizeof(float) * elem * K);
   void* base = nullptr;
-  int rc = workspace_get(4 * b1 + 4 * bK, &base);
+  int rc = workspace_get(0, 4 * b1 + 4 * bK, &base);
   if (rc != SOIL_OK) return rc;
   char* p = static_cast<char*>(base);
   Acc A, B;
@@ -347,15 +323,7 @@ int soil_accumulate(float* out, const int32_t* graph, const float* source, const
 
 int soil_workspace_release(void) {
   SOIL_DEVICE();
-  int dev = 0;
-  SOIL_HIP(hipGetDevice(&dev));
-  std::lock_guard<std::mutex> lock(g_ws_mutex);
-  auto it = g_ws.find(dev);
-  if (it != g_ws.end()) {
-    if (it->second.base) SOIL_HIP(hipFree(it->second.base));
-    g_ws.erase(it);
-  }
-  return SOIL_OK;
+  return workspace_release_all();
 }
 
 }  // extern "C"

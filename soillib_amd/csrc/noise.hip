@@ -122,9 +122,9 @@ SOIL_HD float noise_cell(int64_t n, int64_t W, const NoiseSetup& q) {
 }
 
 __global__ void __launch_bounds__(kNBlock)
-    k_noise(float* __restrict__ out, int64_t cells, int64_t W, NoiseSetup q) {
+    k_noise(float* __restrict__ out, int64_t cells, int64_t W, int64_t first_cell, NoiseSetup q) {
   const int64_t n = static_cast<int64_t>(blockIdx.x) * kNBlock + threadIdx.x;
-  if (n < cells) out[n] = noise_cell(n, W, q);
+  if (n < cells) out[n] = noise_cell(first_cell + n, W, q);
 }
 
 static NoiseSetup make_setup(const soil_noise_param* p) {
@@ -167,8 +167,19 @@ int soil_noise(float* out, int64_t H, int64_t W, const soil_noise_param* p, void
   SOIL_DEVICE();
   SOIL_REQUIRE(out && p, "noise: null argument");
   SOIL_REQUIRE(H > 0 && W > 0, "noise: empty grid");  // noise.hpp:44-45 rejects non-2D shapes
-  k_noise<<<blocks_for(H * W, kNBlock), kNBlock, 0, as_stream(stream)>>>(out, H * W, W,
+  k_noise<<<blocks_for(H * W, kNBlock), kNBlock, 0, as_stream(stream)>>>(out, H * W, W, 0,
                                                                          make_setup(p));
+  SOIL_LAUNCH_CHECK();
+  return SOIL_OK;
+}
+
+int soil_noise_window(float* out, int64_t rows, int64_t W, int64_t x0,
+                      const soil_noise_param* p, void* stream) {
+  SOIL_DEVICE();
+  SOIL_REQUIRE(out && p, "noise_window: null argument");
+  SOIL_REQUIRE(rows > 0 && W > 0 && x0 >= 0, "noise_window: bad window");
+  k_noise<<<blocks_for(rows * W, kNBlock), kNBlock, 0, as_stream(stream)>>>(out, rows * W, W,
+                                                                            x0 * W, make_setup(p));
   SOIL_LAUNCH_CHECK();
   return SOIL_OK;
 }

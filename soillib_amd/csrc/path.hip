@@ -14,7 +14,7 @@ __device__ __forceinline__ float2 bilinear(const float2* __restrict__ flow, int6
   const float rx = static_cast<float>(H), ry = static_cast<float>(W);
   const float nan = __builtin_nanf("");
   if (px < 0 || py < 0 || px > rx - 1 || py > ry - 1) return make_float2(nan, nan);  // :167-170
-  const int64_t ix = static_cast<int64_t>(px), iy = static_cast<int64_t>(py);        // :156-159
+  const int64_t ix = cell_of(px), iy = cell_of(py);        // :156-159
   float wx = px - floorf(px), wy = py - floorf(py);                                  // :160
   int64_t i00 = ix * W + iy, i01 = ix * W + (iy + 1);                                // :162-165
   int64_t i10 = (ix + 1) * W + iy, i11 = (ix + 1) * W + (iy + 1);
@@ -57,7 +57,7 @@ __global__ void __launch_bounds__(kUBlock)
   // a draw of exactly 1 lands on the far edge; the reference then reads out of
   // bounds at :90 (undefined) — the sample is dropped instead
   if (oob_hw(H, W, px, py)) return;
-  int64_t ind = static_cast<int64_t>(px) * W + static_cast<int64_t>(py);  // :84
+  int64_t ind = cell_of(px) * W + cell_of(py);  // :84
   const float L = sqrtf(s.x * s.x + s.y * s.y);                           // :87
   const float A = s.x * s.y;                                              // :88
   const float P = 1.0f / (A * static_cast<float>(H * W));                 // :89
@@ -70,7 +70,7 @@ __global__ void __launch_bounds__(kUBlock)
   int step = 0;
   while (!oob_hw(H, W, px, py) && epsilon < fabsf(att) &&
          static_cast<float>(++step) < maxstep) {  // :104
-    const int64_t nind = static_cast<int64_t>(px) * W + static_cast<int64_t>(py);  // :107
+    const int64_t nind = cell_of(px) * W + cell_of(py);  // :107
     if (nind != ind) {                                                             // :108-116
       ind = nind;
 #pragma unroll

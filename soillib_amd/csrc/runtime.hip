@@ -2,6 +2,9 @@
 // element-wise ops of the C ABI (include/soil_hip.h §runtime).
 #include <cstdio>
 #include <cstring>
+#include <map>
+#include <mutex>
+#include <utility>
 
 #include "common.hpp"
 
@@ -47,6 +50,52 @@ int check_domain(const Dom& d) {
                "domain: first computed row has no ghost row above it");
   SOIL_REQUIRE(d.r0 == d.r1 || d.r1 < d.rows || d.x0 + d.rows == d.H,
                "domain: last computed row has no ghost row below it");
+  return SOIL_OK;
+}
+
+// ---- per-device workspace ------------------------------------------------------
+
+struct WsBlock {
+  void* base = nullptr;
+  size_t bytes = 0;
+};
+static std::mutex g_ws_mutex;
+static std::map<std::pair<int, int>, WsBlock> g_ws;  // (device, slot) -> block
+
+int workspace_get(int slot, size_t bytes, void** out) {
+  int dev = 0;
+  SOIL_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(g_ws_mutex);
+  WsBlock& w = g_ws[{dev, slot}];
+  if (w.bytes < bytes) {
+    if (w.base) {
+      SOIL_HIP(hipDeviceSynchronize());  // nobody may still be reading the old block
+      SOIL_HIP(hipFree(w.base));
+    }
+    w.base = nullptr;
+    w.bytes = 0;
+    SOIL_HIP(hipMalloc(&w.base, bytes));
+    w.bytes = bytes;
+  }
+  *out = w.base;
+  return SOIL_OK;
+}
+
+int workspace_release_all() {
+  int dev = 0;
+  SOIL_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(g_ws_mutex);
+  for (auto it = g_ws.begin(); it != g_ws.end();) {
+    if (it->first.first == dev) {
+      if (it->second.base) {
+        SOIL_HIP(hipDeviceSynchronize());
+        SOIL_HIP(hipFree(it->second.base));
+      }
+      it = g_ws.erase(it);
+    } else {
+      ++it;
+    }
+  }
   return SOIL_OK;
 }
 

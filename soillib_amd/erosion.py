@@ -77,15 +77,15 @@ class ErosionModel:
         _abi.check(L.soil_particles_fluvial_slab(
             self.waterFlux.c_ptr, self.massFlux.c_ptr, self.velocityFlux.c_ptr, None,
             self.rng.c_ptr, self.N, self.layers.c_ptr, self.rainfall.c_ptr,
-            self.waterHeight.c_ptr, self.velocity.c_ptr, None, C.byref(self.dom), self._scale(),
-            self.param._ref(), _abi.stream()))
+            self.waterHeight.c_ptr, self.velocity.c_ptr, None, None, C.byref(self.dom),
+            self._scale(), self.param._ref(), _abi.stream()))
 
     def particles_debris(self):
         L = _abi.lib()
         _abi.check(L.soil_particles_debris_slab(
             self.debrisFlux.c_ptr, self.debrisVelocityFlux.c_ptr, None, self.rng.c_ptr, self.N,
-            self.layers.c_ptr, self.debrisVelocity.c_ptr, None, C.byref(self.dom), self._scale(),
-            self.param._ref(), _abi.stream()))
+            self.layers.c_ptr, self.debrisVelocity.c_ptr, None, None, C.byref(self.dom),
+            self._scale(), self.param._ref(), _abi.stream()))
 
     def cells_fused(self, r0=None, r1=None):
         """Fused cell phase on local rows [r0, r1) (default: the owned rows)."""

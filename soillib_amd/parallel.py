@@ -1,0 +1,326 @@
+"""Row-slab sharding of the erosion step across the GPUs of one node.
+
+One process per GPU (torch.distributed; backend "nccl" == RCCL over xGMI).
+Rank r owns global rows [r*S, (r+1)*S) of a (world*S, W) grid and holds G ghost
+rows on each interior side, G = soil_ghost_rows(param) = ceil(sqrt(2)*maxage)+2:
+one particle step moves at most sqrt(2) cells (erosion_map.cu:61-76), so no
+trajectory born in the owned rows can leave the slab.  That makes the sharded
+step EXACT (same trajectories, same deposits as the single-GPU run; only the
+fp32 summation order of the flux differs) with nearest-neighbour traffic only:
+
+  per step                         exchanged with each neighbour
+  1 particles (own spawn rows)     -
+  2 flux halo-accumulate           G rows x 7 floats (5 flux planes) -> added
+  3 fused cell phase, owned rows   (interior rows overlap with 2 on a 2nd stream)
+  4 field halo                     G rows of layers, velocity, waterHeight,
+                                   debrisVelocity -> neighbour's ghost rows
+
+Every rank replays all world*N particle streams (two Philox draws each) and
+traces the ones whose spawn row it owns (soil_particles_*_slab), so the set of
+trajectories is identical to a single-GPU run of the global grid.  One corner
+is NOT reproduced: the reference's NaN walkers
+deposit into global cell (0,0); a rank that does not hold global row 0 drops
+its own NaN walkers instead.
+
+The runner is written against a small `ops` interface so that the exchange and
+partition logic can be tested on CPU (gloo) with the oracle as the compute
+back-end (tests/test_parallel_gloo.py); the product back-end is HipOps — HIP
+kernels through the C ABI, torch only for allocation and communication.
+"""
+import ctypes as C
+import os
+
+FIELD_PLANES = ("layers", "velocity", "waterHeight", "debrisVelocity")
+FLUX_PLANES = ("waterFlux", "massFlux", "velocityFlux", "debrisFlux", "debrisVelocityFlux")
+PLANE_CHANNELS = {
+    "layers": 2, "layers_next": 2, "height": 1, "uplift": 1, "rainfall": 1, "waterHeight": 1,
+    "waterFlux": 1, "mass": 1, "massFlux": 1, "velocity": 2, "velocityFlux": 2, "debris": 1,
+    "debrisFlux": 1, "debrisVelocity": 2, "debrisVelocityFlux": 2,
+}
+
+
+def slab_layout(rank, world, S, G):
+    """Rows a rank holds: (x0, rows, r0, r1) — global row of local row 0, local
+    row count, owned local row range."""
+    H = world * S
+    o0, o1 = rank * S, (rank + 1) * S
+    x0 = max(0, o0 - G)
+    x1 = min(H, o1 + G)
+    return x0, x1 - x0, o0 - x0, o1 - x0
+
+
+class HipOps:
+    """Product back-end: torch CUDA tensors for storage, HIP kernels via the C ABI."""
+
+    def __init__(self, local_rank):
+        import torch
+        from . import _abi
+        self.torch, self.abi, self.lib = torch, _abi, _abi.lib()
+        torch.cuda.set_device(local_rank)
+        _abi.check(self.lib.soil_set_device(local_rank))
+        self.device = torch.device("cuda", local_rank)
+        self.main = torch.cuda.current_stream()
+        self.comm = torch.cuda.Stream()
+
+    def alloc(self, shape, kind="f32"):
+        t = self.torch
+        if kind == "rng":
+            return t.zeros((shape[0], 2), dtype=t.int64, device=self.device)
+        return t.zeros(tuple(shape), dtype=t.float32, device=self.device)
+
+    def _stream(self):
+        return C.c_void_p(self.torch.cuda.current_stream().cuda_stream)
+
+    @staticmethod
+    def _p(t):
+        return C.c_void_p(t.data_ptr())
+
+    def seed(self, rng, seed, offset):
+        self.abi.check(self.lib.soil_rng_seed(self._p(rng), rng.shape[0], seed, offset,
+                                              self._stream()))
+
+    def fill(self, t, value):
+        self.abi.check(self.lib.soil_set_f32(self._p(t), float(value), t.numel(), self._stream()))
+
+    def zero(self, t):
+        self.fill(t, 0.0)
+
+    def add(self, dst, src):
+        self.abi.check(self.lib.soil_add_f32(self._p(dst), self._p(src), dst.numel(),
+                                             self._stream()))
+
+    def copy(self, dst, src):
+        self.abi.check(self.lib.soil_memcpy_d2d(self._p(dst), self._p(src),
+                                                dst.numel() * dst.element_size(), self._stream()))
+
+    def noise_rows(self, out, H, W, x0, seed):
+        """Bedrock rows [x0, x0+rows) of the global soil.noise heightmap."""
+        from . import _abi
+        p = _abi.NoiseParam()
+        self.lib.soil_noise_param_default(C.byref(p))
+        p.seed = seed
+        p.ext[0], p.ext[1] = float(H), float(W)
+        # noise is a pure function of the global cell index: generate the whole
+        # columns x rows window by offsetting the row origin
+        self.abi.check(self.lib.soil_noise_window(self._p(out), out.shape[0], W, x0, C.byref(p),
+                                                  self._stream()))
+
+    def layers_from_bedrock(self, layers, bed):
+        self.abi.check(self.lib.soil_layers_from_planes(self._p(layers), self._p(bed), None,
+                                                        bed.numel(), self._stream()))
+
+    def particles_fluvial(self, P, rng, N, dom, scale, param, remote0):
+        self.abi.check(self.lib.soil_particles_fluvial_slab(
+            self._p(P["waterFlux"]), self._p(P["massFlux"]), self._p(P["velocityFlux"]), None,
+            self._p(rng), N, self._p(P["layers"]), self._p(P["rainfall"]),
+            self._p(P["waterHeight"]), self._p(P["velocity"]), None, self._p(remote0),
+            C.byref(dom), self.abi.vec(scale, 3), param._ref(), self._stream()))
+
+    def particles_debris(self, P, rng, N, dom, scale, param, remote0):
+        self.abi.check(self.lib.soil_particles_debris_slab(
+            self._p(P["debrisFlux"]), self._p(P["debrisVelocityFlux"]), None, self._p(rng), N,
+            self._p(P["layers"]), self._p(P["debrisVelocity"]), None, self._p(remote0),
+            C.byref(dom), self.abi.vec(scale, 3), param._ref(), self._stream()))
+
+    def add_cell0(self, P, remote0):
+        """Global cell (0,0) += the all-reduced deposits of the other ranks' NaN walkers."""
+        for plane, lo, n in (("waterFlux", 0, 1), ("massFlux", 1, 1), ("velocityFlux", 2, 2),
+                             ("debrisFlux", 4, 1), ("debrisVelocityFlux", 5, 2)):
+            self.abi.check(self.lib.soil_add_f32(self._p(P[plane]),
+                                                 C.c_void_p(remote0.data_ptr() + 4 * lo), n,
+                                                 self._stream()))
+
+    def cells(self, P, dom, r0, r1, scale, param):
+        if r1 <= r0:
+            return
+        planes = self.abi.ErosionPlanes()
+        for name in self.abi._PLANES:
+            setattr(planes, name, P[name].data_ptr())
+        d = self.abi.Domain(dom.H, dom.W, dom.x0, dom.rows, r0, r1)
+        self.abi.check(self.lib.soil_erode_cells_fused(C.byref(planes), C.byref(d),
+                                                       self.abi.vec(scale, 3), param._ref(),
+                                                       self._stream()))
+
+    # -- stream plumbing for overlap ---------------------------------------
+    def fork_comm(self):
+        """Make the communication stream wait for everything queued so far."""
+        self.comm.wait_stream(self.torch.cuda.current_stream())
+        return self.torch.cuda.stream(self.comm)
+
+    def join_comm(self):
+        self.torch.cuda.current_stream().wait_stream(self.comm)
+
+    def sync(self):
+        self.torch.cuda.synchronize()
+
+
+class SlabRunner:
+    """The sharded erosion model; `step()` advances the global grid by one step."""
+
+    def __init__(self, rows_per_rank, W, param, particles_div=8, seed=0, ops=None, scale=None,
+                 noise_seed=3.0, init=True):
+        import torch.distributed as dist
+        self.dist = dist
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if ops is None:
+            ops = HipOps(local_rank)
+        self.ops = ops
+        if not dist.is_initialized():
+            backend = "nccl" if isinstance(ops, HipOps) else "gloo"
+            kw = {}
+            if backend == "nccl":
+                kw["device_id"] = ops.device
+            dist.init_process_group(backend=backend, **kw)
+        self.S, self.W, self.param = int(rows_per_rank), int(W), param
+        self.H = self.world * self.S
+        self.scale = list(scale) if scale is not None else [20.0 / self.H, 20.0 / self.W, 4.0]
+        self.G = int(ops.ghost_rows(param)) if hasattr(ops, "ghost_rows") else self._ghost(param)
+        if self.world > 1 and self.G > self.S:
+            raise ValueError("ghost depth %d exceeds the %d rows a neighbour owns" %
+                             (self.G, self.S))
+        self.x0, self.rows, self.r0, self.r1 = slab_layout(self.rank, self.world, self.S, self.G)
+        self.N = self.H * self.W // int(particles_div)   # particles of the GLOBAL grid
+        self.seed = int(seed)
+        self.step_index = 0
+        self.dom = self._domain(self.r0, self.r1)
+        self.P = {name: ops.alloc((self.rows, self.W, ch) if ch > 1 else (self.rows, self.W))
+                  for name, ch in PLANE_CHANNELS.items()}
+        self.rng = ops.alloc((self.N,), "rng")
+        self.remote0 = ops.alloc((8,))
+        self.up = self.rank - 1 if self.rank > 0 else None
+        self.down = self.rank + 1 if self.rank < self.world - 1 else None
+        # staging buffers for the flux halo-accumulate (one per plane and side)
+        self.gu, self.gd = self.r0, self.rows - self.r1      # ghost rows above / below
+        self.stage = {}
+        for name in FLUX_PLANES:
+            ch = PLANE_CHANNELS[name]
+            tail = (self.W, ch) if ch > 1 else (self.W,)
+            self.stage[name] = (ops.alloc((self._peer_ghost(self.up),) + tail) if self.up is not None else None,
+                                ops.alloc((self._peer_ghost(self.down),) + tail) if self.down is not None else None)
+        if init:
+            bed = ops.alloc((self.rows, self.W))
+            ops.noise_rows(bed, self.H, self.W, self.x0, noise_seed)
+            ops.layers_from_bedrock(self.P["layers"], bed)
+            self.fill(self.P["rainfall"], 1.0)
+
+    # -- helpers -------------------------------------------------------------
+    def _ghost(self, param):
+        from . import _abi
+        return _abi.lib().soil_ghost_rows(param._ref())
+
+    def _domain(self, r0, r1):
+        from . import _abi
+        return _abi.Domain(self.H, self.W, self.x0, self.rows, r0, r1)
+
+    def _peer_ghost(self, peer):
+        """Ghost rows the neighbour `peer` holds on the side facing this rank."""
+        if peer is None:
+            return 0
+        x0, rows, r0, r1 = slab_layout(peer, self.world, self.S, self.G)
+        return r0 if peer > self.rank else rows - r1
+
+    def fill(self, t, value):
+        self.ops.fill(t, value)
+
+    # -- halo exchanges --------------------------------------------------------
+    def _exchange(self, sends, recvs):
+        """sends/recvs: lists of (tensor_view, peer).  One batched group per call."""
+        dist = self.dist
+        ops_ = [dist.P2POp(dist.isend, t, peer) for t, peer in sends] + \
+               [dist.P2POp(dist.irecv, t, peer) for t, peer in recvs]
+        if not ops_:
+            return []
+        return dist.batch_isend_irecv(ops_)
+
+    def flux_exchange_start(self):
+        """Ship the flux deposited into my ghost rows to their owners."""
+        sends, recvs = [], []
+        for name in FLUX_PLANES:
+            t = self.P[name]
+            su, sd = self.stage[name]
+            if self.up is not None:
+                sends.append((t[0:self.gu], self.up))
+                recvs.append((su, self.up))
+            if self.down is not None:
+                sends.append((t[self.r1:self.rows], self.down))
+                recvs.append((sd, self.down))
+        return self._exchange(sends, recvs)
+
+    def flux_exchange_finish(self, reqs):
+        for r in reqs:
+            r.wait()
+        for name in FLUX_PLANES:
+            t = self.P[name]
+            su, sd = self.stage[name]
+            if su is not None:      # the up neighbour's lower ghost rows = my first owned rows
+                self.ops.add(t[self.r0:self.r0 + su.shape[0]], su)
+                self.ops.zero(t[0:self.gu])
+            if sd is not None:
+                self.ops.add(t[self.r1 - sd.shape[0]:self.r1], sd)
+                self.ops.zero(t[self.r1:self.rows])
+
+    def field_exchange(self, layers_key="layers"):
+        """Refresh the ghost rows of the fields the next step's particles read."""
+        sends, recvs = [], []
+        for name in FIELD_PLANES:
+            t = self.P[layers_key if name == "layers" else name]
+            if self.up is not None:
+                n = self._peer_ghost(self.up)
+                sends.append((t[self.r0:self.r0 + n], self.up))
+                recvs.append((t[0:self.gu], self.up))
+            if self.down is not None:
+                n = self._peer_ghost(self.down)
+                sends.append((t[self.r1 - n:self.r1], self.down))
+                recvs.append((t[self.r1:self.rows], self.down))
+        for r in self._exchange(sends, recvs):
+            r.wait()
+
+    # -- one step ---------------------------------------------------------------
+    def step(self, ev=None):
+        ops, P = self.ops, self.P
+        ops.seed(self.rng, self.seed, self.step_index * self.N)
+        ops.zero(self.remote0)
+        if ev: ev.record(0)
+        ops.particles_fluvial(P, self.rng, self.N, self.dom, self.scale, self.param, self.remote0)
+        if ev: ev.record(1)
+        ops.particles_debris(P, self.rng, self.N, self.dom, self.scale, self.param, self.remote0)
+        if ev: ev.record(2)
+        if self.world == 1:
+            ops.cells(P, self.dom, self.r0, self.r1, self.scale, self.param)
+        else:
+            # NaN walkers of the other ranks -> global cell (0,0) (8 floats, latency only)
+            self.dist.all_reduce(self.remote0)
+            if self.rank == 0:
+                ops.add_cell0(P, self.remote0)
+            # rows whose flux is complete without the neighbours' contribution
+            i0 = min(self.r1, self.r0 + (self._peer_ghost(self.up) if self.up is not None else 0))
+            i1 = max(i0, self.r1 - (self._peer_ghost(self.down) if self.down is not None else 0))
+            with ops.fork_comm():
+                reqs = self.flux_exchange_start()
+            ops.cells(P, self.dom, i0, i1, self.scale, self.param)      # overlaps the exchange
+            with ops.fork_comm():
+                self.flux_exchange_finish(reqs)
+            ops.join_comm()
+            ops.cells(P, self.dom, self.r0, i0, self.scale, self.param)
+            ops.cells(P, self.dom, i1, self.r1, self.scale, self.param)
+            self.field_exchange("layers_next")
+        if ev: ev.record(3)
+        P["layers"], P["layers_next"] = P["layers_next"], P["layers"]
+        self.step_index += 1
+
+    # -- bench plumbing ----------------------------------------------------------
+    def sync(self):
+        self.ops.sync()
+
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+
+    def max_over_ranks(self, value):
+        import torch
+        t = torch.tensor([float(value)], dtype=torch.float64,
+                         device=getattr(self.ops, "device", "cpu"))
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())

@@ -251,14 +251,22 @@ def test_albedo_ops_bit_exact(hip, oracle):
 def _flux_close(got, want, what):
     """Same trajectories, different fp32 summation order: compare against the
     magnitude accumulated in each cell."""
-    scale = np.abs(want).max() + 1e-30
+    scale = np.nanmax(np.abs(want)) + 1e-30
     np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-6 * scale, err_msg=what)
     assert ((got != 0) == (want != 0)).all(), what + ": different set of visited cells"
 
 
-@pytest.mark.parametrize("H,W,N", [(64, 64, 4096), (96, 40, 3000)])
+@pytest.fixture(params=["direct", "staged"])
+def particle_mode(request, hip):
+    """Both launch shapes of the particle kernels (soil_set_particle_mode)."""
+    assert hip.soil_set_particle_mode({"direct": 1, "staged": 2}[request.param]) == 0
+    yield request.param
+    hip.soil_set_particle_mode(0)
+
+
+@pytest.mark.parametrize("H,W,N", [(64, 64, 4096), (96, 40, 3000), (33, 50, 700)])
 @pytest.mark.parametrize("which", ["default", "script"])
-def test_transport_fluvial_parity(hip, oracle, H, W, N, which):
+def test_transport_fluvial_parity(hip, oracle, particle_mode, H, W, N, which):
     from soillib_amd import soil
     op = oracle.default_param()
     if which == "script":
@@ -292,12 +300,12 @@ def test_transport_fluvial_parity(hip, oracle, H, W, N, which):
         _flux_close(to_np(g[k]), o[k], "fluvial flux " + k)
     for k in ("wh", "m", "v"):
         np.testing.assert_allclose(to_np(g[k]), o[k], rtol=3e-5,
-                                   atol=3e-6 * (np.abs(o[k]).max() + 1e-30), err_msg=k)
+                                   atol=3e-6 * (np.nanmax(np.abs(o[k])) + 1e-30), err_msg=k)
     np.testing.assert_allclose(to_np(g["af"]), o["af"], rtol=1e-3, atol=1e-5)
 
 
-@pytest.mark.parametrize("H,W,N", [(64, 64, 4096), (40, 96, 3000)])
-def test_transport_debris_parity(hip, oracle, H, W, N):
+@pytest.mark.parametrize("H,W,N", [(64, 64, 4096), (40, 96, 3000), (50, 33, 700)])
+def test_transport_debris_parity(hip, oracle, particle_mode, H, W, N):
     from soillib_amd import soil
     op = script_param(oracle.default_param())
     op.maxage = 128
@@ -322,7 +330,60 @@ def test_transport_debris_parity(hip, oracle, H, W, N):
         _flux_close(to_np(g[k]), o[k], "debris flux " + k)
     for k in ("m", "v"):
         np.testing.assert_allclose(to_np(g[k]), o[k], rtol=3e-5,
-                                   atol=3e-6 * (np.abs(o[k]).max() + 1e-30), err_msg=k)
+                                   atol=3e-6 * (np.nanmax(np.abs(o[k])) + 1e-30), err_msg=k)
+
+
+def test_particles_on_slabs_equal_whole_grid(hip, oracle, particle_mode):
+    """soil_particles_*_slab on three row slabs (ghost depth from soil_ghost_rows) deposit
+    exactly what one launch on the whole grid deposits, NaN walkers included (remote0)."""
+    from soillib_amd import _abi
+    H, W, N = 96, 48, 6000
+    op = script_param(oracle.default_param())
+    op.maxage = 8
+    op.critSlopeBedrock = 0.05
+    pp = product_param(op)
+    G = int(hip.soil_ghost_rows(pp._ref()))
+    assert G == int(np.ceil(np.sqrt(2.0) * 8)) + 2
+    scale = (20.0 / H, 20.0 / W, 4.0)
+    layers = terrain(oracle, H, W, sediment=0.01)
+    rain = np.ones((H, W), np.float32)
+    z1, z2 = np.zeros((H, W), np.float32), np.zeros((H, W, 2), np.float32)
+
+    def run(x0, rows, r0, r1):
+        sl = slice(x0, x0 + rows)
+        g = dict(wf=to_gpu(z1[sl]), mf=to_gpu(z1[sl]), vf=to_gpu(z2[sl]), df=to_gpu(z1[sl]),
+                 dvf=to_gpu(z2[sl]), rem=to_gpu(np.zeros(8, np.float32)))
+        rng = rng_to_gpu(oracle.rng_seed(N, 2, 0))
+        dom = _abi.Domain(H, W, x0, rows, r0, r1)
+        lay, rn, zz1, zz2 = to_gpu(layers[sl]), to_gpu(rain[sl]), to_gpu(z1[sl]), to_gpu(z2[sl])
+        _abi.check(hip.soil_particles_fluvial_slab(
+            g["wf"].c_ptr, g["mf"].c_ptr, g["vf"].c_ptr, None, rng.c_ptr, N, lay.c_ptr, rn.c_ptr,
+            zz1.c_ptr, zz2.c_ptr, None, g["rem"].c_ptr, C.byref(dom), _abi.vec(scale, 3),
+            pp._ref(), None))
+        _abi.check(hip.soil_particles_debris_slab(
+            g["df"].c_ptr, g["dvf"].c_ptr, None, rng.c_ptr, N, lay.c_ptr, zz2.c_ptr, None,
+            g["rem"].c_ptr, C.byref(dom), _abi.vec(scale, 3), pp._ref(), None))
+        assert (to_np(rng)["offset"] == 4).all()     # every stream advanced, owned or not
+        return {k: to_np(v) for k, v in g.items()}
+
+    whole = run(0, H, 0, H)
+    assert (whole["rem"] == 0).all() and np.isnan(whole["wf"][0, 0])
+    acc = {k: np.zeros_like(v, dtype=np.float64) for k, v in whole.items()}
+    for (o0, o1) in [(0, 32), (32, 64), (64, 96)]:
+        x0, x1 = max(0, o0 - G), min(H, o1 + G)
+        part = run(x0, x1 - x0, o0 - x0, o1 - x0)
+        for k in ("wf", "mf", "vf", "df", "dvf"):
+            acc[k][x0:x1] += part[k]
+        acc["rem"] += part["rem"]
+    # the owner of global row 0 receives the parked NaN-walker deposits
+    acc["wf"][0, 0] += acc["rem"][0]
+    acc["mf"][0, 0] += acc["rem"][1]
+    acc["vf"][0, 0] += acc["rem"][2:4]
+    acc["df"][0, 0] += acc["rem"][4]
+    acc["dvf"][0, 0] += acc["rem"][5:7]
+    for k in ("wf", "mf", "vf", "df", "dvf"):
+        np.testing.assert_allclose(acc[k], whole[k], rtol=2e-5,
+                                   atol=2e-6 * (np.nanmax(np.abs(whole[k])) + 1e-30), err_msg=k)
 
 
 def test_erosion_model_fused_equals_unfused_and_oracle(hip, oracle):
@@ -364,7 +425,7 @@ def test_erosion_model_fused_equals_unfused_and_oracle(hip, oracle):
         for name, key in (("layers", "layers"), ("waterHeight", "wh"), ("velocity", "v"),
                           ("debrisVelocity", "dv"), ("mass", "m")):
             ga, gb = to_np(getattr(a, name)), to_np(getattr(b, name))
-            tol = dict(rtol=1e-4, atol=1e-5 * (np.abs(st[key]).max() + 1e-30))
+            tol = dict(rtol=1e-4, atol=1e-5 * (np.nanmax(np.abs(st[key])) + 1e-30))
             np.testing.assert_allclose(ga, gb, err_msg="fused vs unfused " + name, **tol)
             np.testing.assert_allclose(ga, st[key], err_msg="fused vs oracle " + name, **tol)
     assert np.abs(st["layers"] - layers0).max() > 0          # the terrain really eroded

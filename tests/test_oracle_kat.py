@@ -330,8 +330,13 @@ def test_fluvial_particles_deposit_only_downstream(oracle):
     steps = oracle.particles_fluvial(wf, mf, vf, None, rng, layers, rain, z1, z2, None, scale, p)
     assert (rng["offset"] == 2).all()                # two draws per particle (erosion.cu:57-58)
     assert 0 < steps <= N * (p.maxage - 1)           # ++iter < maxage (Appendix B7)
-    assert (wf >= 0).all() and wf.sum() > 0
-    assert (mf == 0).all()                           # zero velocity field -> shear 0 -> no suspension
+    # Reference quirk, restated: with a zero velocity field every particle spawned on a
+    # pit cell (grad = 0) has speed 0/sqrt(0) = NaN (erosion.cu:77-79), is never "oob", and
+    # dumps NaN into cell (0,0) (CUDA converts NaN -> 0 when flattening the position).
+    assert np.isnan(wf[0, 0])
+    rest = wf.ravel()[1:]
+    assert (rest >= 0).all() and rest.sum() > 0
+    assert (mf.ravel()[1:] == 0).all()               # zero velocity field -> shear 0 -> no suspension
     # the same call again continues the stream: different spawn points, different flux
     wf2 = z1.copy()
     oracle.particles_fluvial(wf2, z1.copy(), z2.copy(), None, rng, layers, rain, z1, z2, None,
@@ -363,4 +368,7 @@ def test_slab_particles_partition_exactly(oracle):
                                  np.ascontiguousarray(rain[sl]), np.zeros((rows, W), np.float32),
                                  np.zeros((rows, W, 2), np.float32), None, scale, p, dom=dom)
         parts[sl] += wf
-    np.testing.assert_allclose(parts, full, rtol=1e-5, atol=1e-9)
+    # cell (0,0) collects the NaN walkers (see above); a slab that does not hold global
+    # row 0 has to drop its own, so that one cell is compared for NaN-ness only
+    assert np.isnan(full[0, 0])
+    np.testing.assert_allclose(parts.ravel()[1:], full.ravel()[1:], rtol=1e-5, atol=1e-9)

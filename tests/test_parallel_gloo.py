@@ -1,0 +1,103 @@
+"""Multi-process (gloo, CPU) test of the row-slab sharding logic.
+
+world_size 2 and 3 jobs run soillib_amd.parallel.SlabRunner with the oracle as
+compute back-end (tests/parallel_worker.py); the owned rows of all ranks,
+stitched together, must equal a single-domain oracle run of the same global
+grid: same trajectories and deposits, fp32 flux summation order aside.
+"""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from util import script_param
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _single_domain(oracle, H, W, steps, maxage):
+    p = script_param(oracle.default_param())
+    p.maxage = maxage
+    scale = (20.0 / H, 20.0 / W, 4.0)
+    N = H * W // 8
+    layers = np.zeros((H, W, 2), np.float32)
+    layers[..., 0] = oracle.noise(H, W, seed=3.0, ext=(float(H), float(W)))
+    z1 = lambda: np.zeros((H, W), np.float32)
+    z2 = lambda: np.zeros((H, W, 2), np.float32)
+    st = dict(layers=layers, waterHeight=z1(), velocity=z2(), debrisVelocity=z2(), debris=z1(),
+              height=z1())
+    rain = np.ones((H, W), np.float32)
+    for step in range(steps):
+        rng = oracle.rng_seed(N, 0, step * N)
+        wf, mf, vf, df, dvf = z1(), z1(), z2(), z1(), z2()
+        oracle.particles_fluvial(wf, mf, vf, None, rng, st["layers"], rain, st["waterHeight"],
+                                 st["velocity"], None, scale, p)
+        oracle.particles_debris(df, dvf, None, rng, st["layers"], st["debrisVelocity"], None,
+                                scale, p)
+        r = oracle.erode_cells(st["layers"], z1(), rain, wf, mf, vf, df, dvf, scale, p)
+        st = dict(layers=r["layers_next"], waterHeight=r["waterHeight"], velocity=r["velocity"],
+                  debrisVelocity=r["debrisVelocity"], debris=r["debris"], height=r["height"])
+    return st
+
+
+@pytest.mark.parametrize("world,S,W,maxage", [(2, 24, 32, 8), (3, 16, 24, 6)])
+def test_slab_runner_matches_single_domain(oracle, tmp_path, world, S, W, maxage):
+    steps = 2
+    port = _free_port()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen(
+            [sys.executable, os.path.join(ROOT, "tests", "parallel_worker.py"), str(tmp_path),
+             str(S), str(W), str(steps), str(maxage)], env=env, stdout=subprocess.PIPE,
+            stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    for p, out in zip(procs, outs):
+        assert p.returncode == 0, out[-3000:]
+
+    H = world * S
+    want = _single_domain(oracle, H, W, steps, maxage)
+    got = {k: [] for k in ("layers", "waterHeight", "velocity", "debris", "height")}
+    for rank in range(world):
+        d = np.load(os.path.join(str(tmp_path), "rank%d.npz" % rank))
+        assert int(d["H"]) == H
+        G = int(d["G"])
+        assert G == int(np.ceil(np.sqrt(2.0) * maxage)) + 2 and G <= S
+        for k in got:
+            got[k].append(d[k])
+        # ghost rows of the layer plane hold the neighbours' updated rows
+        x0, rows = int(d["x0"]), int(d["rows"])
+        np.testing.assert_allclose(d["ghost_layers"], want["layers"][x0:x0 + rows], rtol=2e-5,
+                                   atol=1e-6)
+    for k in got:
+        full = np.concatenate(got[k], axis=0)
+        w = want[k]
+        # includes global cell (0,0): the NaN walkers of every rank reach it through the
+        # all-reduced `remote0` buffer, exactly as in the single-domain run
+        np.testing.assert_allclose(full, w, rtol=2e-5, atol=1e-6 * (np.nanmax(np.abs(w)) + 1e-30),
+                                   err_msg=k)
+    assert np.isnan(want["waterHeight"][0, 0])      # the quirk is live on this terrain
+
+
+def test_slab_layout_partitions_rows():
+    from soillib_amd.parallel import slab_layout
+    for world, S, G in [(1, 16, 5), (2, 16, 5), (4, 32, 32), (8, 8192, 365)]:
+        covered = []
+        for r in range(world):
+            x0, rows, r0, r1 = slab_layout(r, world, S, G)
+            assert r1 - r0 == S and x0 + r0 == r * S
+            assert x0 == max(0, r * S - G) and x0 + rows == min(world * S, (r + 1) * S + G)
+            covered.extend(range(x0 + r0, x0 + r1))
+        assert covered == list(range(world * S))
