@@ -294,10 +294,13 @@ int soil_particles_debris_slab(float* massFlux, float* velocityFlux, float* albe
                                const float* velocity, const float* albedoSource, float* remote0,
                                const soil_domain* dom, const float scale[3],
                                const soil_param* param, void* stream);
-/* Launch shape of the particle kernels: 0 = auto (staged for N >= 1024),
- * 1 = direct (the reference's: thread n = particle n, 5-point stencil gathers),
- * 2 = staged (packed field plane + tile-ordered particles).  Results are the
- * same up to the order of the fp32 atomic additions; for ablation and tests. */
+/* Launch shape of the particle kernels: 0 = auto, 1 = direct (the reference's:
+ * thread n = particle n, 5-point stencil gathers), 2 = staged (packed field
+ * plane + tile-ordered particles), 3 = tiled (per-tile particle queues advanced
+ * against LDS-resident field and flux tiles; no colour planes).  Auto picks
+ * tiled for N >= 32768 without albedo, staged for N >= 1024, else direct.  All
+ * shapes produce the same trajectories and deposits; only the order of the
+ * fp32 additions into a cell differs.  For ablation and tests. */
 int soil_set_particle_mode(int mode);
 /* Ghost rows a slab needs on each interior side so that no trajectory can
  * leave it: ceil(sqrt(2) * maxage) + 2 (one __stepsize step moves a particle

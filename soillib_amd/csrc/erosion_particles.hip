@@ -19,7 +19,7 @@
 //     wave and the waves of an XCD share cache lines for most of their walk.
 // The reference's launch shape (thread n = particle n, direct stencil gathers)
 // is kept as `direct` mode for ablation (soil_set_particle_mode).
-#include "cell_math.hpp"
+#include "particles_common.hpp"
 
 namespace soil {
 
@@ -36,27 +36,7 @@ int launch_normalize_debris(const float* massFlux, const float* velocityFlux, fl
                             const float* albedoSource, const Dom& d, Scale3 s, const Param& p,
                             hipStream_t st);
 
-static int g_particle_mode = 0;  // 0 auto, 1 direct, 2 staged
-
-__device__ __forceinline__ bool oob(const Dom& d, float px, float py) {  // erosion_map.cu:29-40
-  if (px < 0) return true;
-  if (py < 0) return true;
-  if (px >= static_cast<float>(d.H)) return true;
-  if (py >= static_cast<float>(d.W)) return true;
-  return false;
-}
-
-// local rows whose 5-point stencil lies inside the rows this slab holds
-__device__ __host__ __forceinline__ int64_t stencil_lo(const Dom& d) { return (d.x0 == 0) ? 0 : 1; }
-__device__ __host__ __forceinline__ int64_t stencil_hi(const Dom& d) {  // inclusive
-  return (d.x0 + d.rows == d.H) ? d.rows - 1 : d.rows - 2;
-}
-// A slab traces a particle only while its cell's stencil is available
-// (soil_hip.h, soil_particles_*_slab).
-__device__ __forceinline__ bool slab_escape(const Dom& d, int64_t gx) {
-  const int64_t lx = gx - d.x0;
-  return lx < stencil_lo(d) || lx > stencil_hi(d);
-}
+static int g_particle_mode = 0;  // 0 auto, 1 direct, 2 staged, 3 tiled
 
 // ---- where a step gets grad(cell) and velocity(cell) from -------------------
 
@@ -82,22 +62,6 @@ struct PackedFields {  // one 16-byte gather per step
     vel = make_float2(v.z, v.w);
   }
 };
-
-// first two draws of particle n: spawn position (erosion.cu:56-59 / :269-272)
-__device__ __forceinline__ float2 spawn_position(soil_rng* __restrict__ rng, int64_t n,
-                                                 const Dom& d) {
-  soil_rng st = rng[n];
-  const float u1 = rng_uniform_at(st.seed, static_cast<uint64_t>(n), st.offset);
-  const float u2 = rng_uniform_at(st.seed, static_cast<uint64_t>(n), st.offset + 1);
-  st.offset += 2;
-  rng[n] = st;  // the state persists in the tensor, like curandState
-  return make_float2(0.5f + u1 * static_cast<float>(d.H - 1),
-                     0.5f + u2 * static_cast<float>(d.W - 1));
-}
-__device__ __forceinline__ bool owns_spawn(const Dom& d, float px) {
-  const int64_t sx = cell_of(px) - d.x0;
-  return sx >= d.r0 && sx < d.r1;
-}
 
 struct FluvialPlanes {
   float* __restrict__ waterFlux;
@@ -371,7 +335,7 @@ __global__ void __launch_bounds__(kPBlock)
 
 // pass 2: exclusive scan of the tile counts (one work-group; tiles <= a few 1e5)
 __global__ void __launch_bounds__(1024)
-    k_tile_scan(uint32_t* __restrict__ start, const uint32_t* __restrict__ count, int64_t tiles) {
+    k_tile_scan(uint32_t* start, const uint32_t* count, int64_t tiles) {
   __shared__ uint32_t part[1024];
   const int tid = threadIdx.x;
   const int64_t chunk = (tiles + 1023) / 1024;
@@ -448,6 +412,13 @@ static bool use_staged(int64_t N) {
   if (g_particle_mode == 2) return true;
   return N >= 1024;
 }
+// the tiled shape keeps 9 floats per cell in LDS and has no room for the three
+// albedo accumulators, so colour transport stays on the staged shape
+static bool use_tiled(int64_t N, const void* albedoFlux) {
+  if (albedoFlux) return false;
+  if (g_particle_mode == 3) return true;
+  return g_particle_mode == 0 && N >= 32768;
+}
 
 // Shared staging: pack the fields, bucket the spawn points.  Returns device
 // pointers into the per-device workspace (valid until the next staged call).
@@ -499,6 +470,9 @@ static int launch_particles_fluvial(float* waterFlux, float* massFlux, float* ve
                                     const float* albedoSource, float* remote0, const Dom& d,
                                     Scale3 s, const Param& p, hipStream_t st) {
   if (N <= 0) return SOIL_OK;
+  if (use_tiled(N, albedoFlux))
+    return launch_fluvial_tiled(waterFlux, massFlux, velocityFlux, rng, N, layers, waterSource,
+                                waterHeight, velocity, remote0, d, s, p, st);
   const FluvialPlanes P{waterFlux,   massFlux,     velocityFlux, albedoFlux,
                         waterSource, waterHeight, albedoSource, remote0};
   if (use_staged(N)) {
@@ -522,6 +496,9 @@ static int launch_particles_debris(float* massFlux, float* velocityFlux, float* 
                                    float* remote0, const Dom& d, Scale3 s, const Param& p,
                                    hipStream_t st) {
   if (N <= 0) return SOIL_OK;
+  if (use_tiled(N, albedoFlux))
+    return launch_debris_tiled(massFlux, velocityFlux, rng, N, layers, velocity, remote0, d, s, p,
+                               st);
   const DebrisPlanes P{massFlux, velocityFlux, albedoFlux, albedoSource, remote0};
   if (use_staged(N)) {
     Staged sg;
@@ -545,7 +522,7 @@ using namespace soil;
 extern "C" {
 
 int soil_set_particle_mode(int mode) {
-  SOIL_REQUIRE(mode >= 0 && mode <= 2, "particle mode: 0 auto, 1 direct, 2 staged");
+  SOIL_REQUIRE(mode >= 0 && mode <= 3, "particle mode: 0 auto, 1 direct, 2 staged, 3 tiled");
   g_particle_mode = mode;
   return SOIL_OK;
 }

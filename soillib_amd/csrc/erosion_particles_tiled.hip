@@ -1,0 +1,566 @@
+// erosion_particles_tiled.hip — the MI355X launch shape of the particle
+// transport (__transport_fluvial erosion.cu:29-141, __transport_debris :245-351).
+//
+// Why: with one lane per streamline and global gathers/atomics every step, the
+// phase is bound by random 64-byte HBM traffic with zero cache reuse (measured:
+// profiles/r01_first — ~1.1 TB of HBM traffic per fluvial launch at 8192^2).
+// Every step only needs data of the cell the particle stands on, and every cell
+// is visited ~30 times per launch, so the work is re-organised around cells:
+//
+//   * a streaming pre-pass packs {__glocal gradient, velocity} of every cell
+//     into one float4 plane (evaluated once per cell instead of once per visit);
+//   * the grid is cut into 64x64-cell tiles; a tile's packed fields, its water
+//     height and its flux accumulators live in the 160 KiB LDS of one
+//     work-group (9 floats/cell = 144 KiB for fluvial);
+//   * particles are kept in per-tile queues of 64-byte records.  A work-group
+//     advances the particles of its tile step by step against LDS (gather =
+//     one ds_read_b128, deposits = ds_add_f32) until they die, step onto
+//     another tile or use up the round's step budget; survivors are written
+//     back into the slots their queue occupied, counting-sorted by destination
+//     tile, and resumed in the next round;
+//   * at the end of a round the tile's flux is added to the global planes with
+//     coalesced, non-atomic read-modify-writes (one work-group per tile);
+//   * once few particles are left, one last launch walks them to the end
+//     against global memory (no more rounds for a handful of stragglers).
+//
+// A particle executes exactly the instruction sequence of the reference loop —
+// state is only ever parked at the top of an iteration, before `++iter` — so
+// every trajectory and every deposit is bit-identical to the direct launch
+// shape; only the order of the fp32 additions into a cell differs.
+#include <cstdlib>
+
+#include "particles_common.hpp"
+
+namespace soil {
+
+constexpr int kTS = 64;             // tile edge in cells
+constexpr int kTCells = kTS * kTS;  // 4096
+constexpr int kTBlock = 512;        // threads of a tile work-group
+constexpr int kPerThread = kTCells / kTBlock;
+
+enum Kind { FLUVIAL = 0, DEBRIS = 1 };
+
+struct alignas(16) PRec {  // parked particle, 64 bytes
+  float px, py, spx, spy;
+  float a0, a1, a2, s0;  // fluvial: att_w att_m att_v source_w | debris: att_d att_v - source_d
+  float s1, svx, svy;    // fluvial: source_m, source_v        | debris: -, source_v
+  int32_t iter;          // < 0: empty slot
+  int64_t ind;           // global flat index of the last cell deposited into (erosion.cu:60,105)
+  int32_t pad[2];
+};
+static_assert(sizeof(PRec) == 64, "PRec must be one 64-byte line");
+
+// float -> cell coordinate, 32-bit flavour of cell_of (positions are < 2^31)
+__device__ __forceinline__ int cell32(float f) { return (f != f) ? 0 : static_cast<int>(f); }
+
+__device__ __forceinline__ int64_t tile_id(int x0, float px, float py, int tiles_w) {
+  const int lx = cell32(px) - x0, cy = cell32(py);
+  return static_cast<int64_t>(lx / kTS) * tiles_w + cy / kTS;
+}
+
+// per-launch constants of the step (erosion.cu:63-72 / :276-283), hoisted
+struct StepConst {
+  float Hf, Wf, eps, g, lenL, nu, tau, kd, fD, evap, theta, kdd, kds, tau_y, fx, fy;
+  int x0, lo, hi, W;  // slab origin, rows with a full stencil (local, inclusive), width
+  uint32_t maxage;
+};
+
+template <int KIND>
+__device__ __forceinline__ StepConst make_const(const Dom& d, Scale3 s, const Param& p) {
+  StepConst k;
+  k.Hf = static_cast<float>(d.H);
+  k.Wf = static_cast<float>(d.W);
+  k.eps = 1E-12f;
+  k.g = p.gravity;
+  k.lenL = length2(s.x, s.y);
+  k.nu = (KIND == FLUVIAL) ? p.viscosityWater : p.viscosityDebris;
+  k.tau = (KIND == FLUVIAL) ? p.bedShearWater : p.bedShearDebris;
+  k.kd = p.depositionRateFluvial * 1.33f;
+  k.fD = p.frictionFactor / 8.0f;
+  k.evap = p.evapRate;
+  k.theta = p.critSlopeBedrock;
+  k.kdd = p.depositionRateDebris;
+  k.kds = p.suspensionRateDebris;
+  k.tau_y = p.yieldStress;
+  k.fx = p.force[0];
+  k.fy = p.force[1];
+  k.x0 = static_cast<int>(d.x0);
+  k.lo = static_cast<int>(stencil_lo(d));
+  k.hi = static_cast<int>(stencil_hi(d));
+  k.W = static_cast<int>(d.W);
+  k.maxage = p.maxage > 0x7fffffffull ? 0x7fffffffu : static_cast<uint32_t>(p.maxage);
+  return k;
+}
+
+// The body of one loop iteration AFTER the bookkeeping at its top (oob, ++iter,
+// escape) and the deposit: erosion.cu:116-137 / :321-347.  `f` = {grad, vel} of
+// the current cell, `wh` its water height.  Returns false when the walk ends.
+template <int KIND>
+__device__ __forceinline__ bool advance(PRec& r, const float4 f, const float wh,
+                                        const StepConst& k) {
+  const float v_norm = length2(r.spx, r.spy);            // :116 / :321
+  const float ux = r.spx / v_norm, uy = r.spy / v_norm;  // :117 / :322
+  const float v_step = stepsize(r.px, r.py, ux, uy);     // :118 / :323
+  const float dL = v_step * k.lenL;                      // :119 / :324
+  const float ds = dL / v_norm;                          // :120 / :325
+  if (v_norm < k.eps) return false;                      // :121-122 / :326-327
+  if (KIND == FLUVIAL) {
+    const float ax = -(k.g * f.x) + k.nu * f.z + k.fx;  // :126
+    const float ay = -(k.g * f.y) + k.nu * f.w + k.fy;
+    const float w0 = 1.0f / (1.0f + dL * (k.tau + k.nu));  // :127
+    const float w1 = dL / (1.0f + dL * (k.tau + k.nu));
+    r.spx = w0 * r.spx + w1 * ax;
+    r.spy = w0 * r.spy + w1 * ay;
+    const float decay_v = 0.125f * k.fD / (k.eps + wh);  // :132
+    r.a1 = r.a1 * expf_(-ds * k.kd);                     // att_m :134
+    r.a0 = r.a0 * expf_(-ds * k.evap);                   // att_w :135
+    r.a2 = r.a2 * expf_(-dL * decay_v);                  // att_v :136
+  } else {
+    const float debrisHeight = k.eps + r.a0 * r.s0;  // :331
+    const float ax = -(k.g * f.x) + k.nu * f.z;      // :332
+    const float ay = -(k.g * f.y) + k.nu * f.w;
+    const float decay = k.nu + k.tau / debrisHeight;  // :333
+    const float w = 1.0f / (1.0f + dL * decay);       // :334
+    r.spx = w * r.spx + w * dL * ax;                  // :335
+    r.spy = w * r.spy + w * dL * ay;
+    const float excessSlope = length2(f.x, f.y) - k.theta;                    // :339
+    const float excessStress = k.g * (excessSlope - k.tau_y / debrisHeight);  // :340
+    const float shearRate = (excessStress < 0.0f) ? k.kdd : k.kds;            // :341
+    const float decay_d = ds * shearRate * excessStress / v_norm;             // :342
+    const float decay_v = k.nu + k.tau / debrisHeight;                        // :343
+    r.a0 = r.a0 * expf_(decay_d);                                             // :345
+    r.a1 = r.a1 * expf_(-dL * decay_v);                                       // :346
+  }
+  r.px += v_step * ux;  // :137 / :347
+  r.py += v_step * uy;
+  return true;
+}
+
+// a NaN walker's deposit for global cell (0,0) held by another rank (soil_hip.h)
+template <int KIND>
+__device__ __forceinline__ void park_remote(const PRec& r, float* __restrict__ remote0) {
+  if (!(r.px != r.px) || !remote0 || r.ind == 0) return;
+  if (KIND == FLUVIAL) {
+    atomicAdd(&remote0[0], r.a0 * r.s0);
+    atomicAdd(&remote0[1], r.a1 * r.s1);
+    atomicAdd(&remote0[2], r.a2 * r.svx);
+    atomicAdd(&remote0[3], r.a2 * r.svy);
+  } else {
+    atomicAdd(&remote0[4], r.a0 * r.s0);
+    atomicAdd(&remote0[5], r.a1 * r.svx);
+    atomicAdd(&remote0[6], r.a1 * r.svy);
+  }
+}
+
+// ---- pre-pass: p4[cell] = {__glocal(cell), velocity[cell]} ------------------------
+
+__global__ void __launch_bounds__(256)
+    k_tiled_pack(float4* __restrict__ p4, const float2* __restrict__ layers,
+                 const float2* __restrict__ velocity, Dom d, Scale3 s, float exitSlope,
+                 int64_t row_lo, int64_t cells) {
+  const int64_t t = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (t >= cells) return;
+  const int64_t lx = row_lo + t / d.W, y = t % d.W;
+  const int64_t l = lx * d.W + y;
+  const float2 g = glocal(layers, d, s, d.x0 + lx, y, exitSlope);
+  const float2 v = velocity[l];
+  p4[l] = make_float4(g.x, g.y, v.x, v.y);
+}
+
+// ---- spawn: draws, ownership, trajectory initialisation (erosion.cu:49-96 / :262-302)
+
+template <int KIND>
+__global__ void __launch_bounds__(256)
+    k_tiled_spawn(PRec* __restrict__ recs, uint32_t* __restrict__ count,
+                  soil_rng* __restrict__ rng, int64_t N, const float4* __restrict__ p4,
+                  const float* __restrict__ waterSource, Dom d, Scale3 s, Param param,
+                  int tiles_w) {
+  const int64_t n = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (n >= N) return;
+  PRec r;
+  r.iter = -1;
+  const float2 pos = spawn_position(rng, n, d);
+  if (owns_spawn(d, pos.x)) {
+    const float A = s.x * s.y;
+    const float Pr = 1.0f / (A * static_cast<float>(d.H * d.W));
+    const float Q = 1.0f / (Pr * static_cast<float>(N));
+    const float eps = 1E-12f;
+    const int64_t cx = cell_of(pos.x), cy = cell_of(pos.y);
+    const int64_t ind = cx * d.W + cy;
+    const int64_t l = ind - d.x0 * d.W;
+    const float g = param.gravity;
+    const float4 f = p4[l];
+    const float2 grad = make_float2(f.x, f.y), vel = make_float2(f.z, f.w);
+    float spx, spy;
+    if (KIND == FLUVIAL) {
+      const float nu = param.viscosityWater;
+      spx = -(g * grad.x) + nu * vel.x + param.force[0];  // :77
+      spy = -(g * grad.y) + nu * vel.y + param.force[1];
+    } else {
+      const float nu = param.viscosityDebris;
+      spx = -(g * grad.x) + nu * vel.x;  // :288
+      spy = -(g * grad.y) + nu * vel.y;
+    }
+    const float den = sqrtf(length2(s.x * spx, s.y * spy));  // :78 / :289
+    spx = spx / den;
+    spy = spy / den;
+    if (!(length2(spx, spy) < eps)) {  // :79-80 / :290-291 (a NaN speed walks on)
+      r.px = pos.x;
+      r.py = pos.y;
+      r.spx = spx;
+      r.spy = spy;
+      r.ind = ind;
+      r.iter = 0;
+      r.pad[0] = r.pad[1] = 0;
+      if (KIND == FLUVIAL) {
+        const float nu = param.viscosityWater;
+        const float ks = param.suspensionRateFluvial / 64.0f;  // :68
+        const float fD = param.frictionFactor / 8.0f;          // :70
+        const float v = length2(vel.x, vel.y);                 // :83
+        const float shear = 0.125f * fD * param.densityWater * v * v;                       // :84
+        const float power = powf_(shear * length2(grad.x, grad.y), param.fluvialExponent);  // :85
+        r.a0 = 1.0f;                                  // att_w
+        r.a1 = 1.0f;                                  // att_m
+        r.a2 = 1.0f;                                  // att_v
+        r.s0 = Q * param.rainfall * waterSource[l];   // source_w :89
+        r.s1 = Q * ks * power;                        // source_m :88
+        r.svx = Q * (-(g * grad.x) + nu * vel.x);     // :90
+        r.svy = Q * (-(g * grad.y) + nu * vel.y);
+      } else {
+        const float nu = param.viscosityDebris;
+        const float excessSlope0 = length2(grad.x, grad.y) - param.critSlopeBedrock;  // :294
+        const float suspend = fmaxf(0.0f, param.landslideRateDebris * excessSlope0);  // :295
+        r.a0 = 1.0f;                              // att_d
+        r.a1 = 1.0f;                              // att_v
+        r.a2 = 0.0f;
+        r.s0 = Q * suspend;                       // source_d :297
+        r.s1 = 0.0f;
+        r.svx = Q * (-g * grad.x + nu * vel.x);   // :298
+        r.svy = Q * (-g * grad.y + nu * vel.y);
+      }
+      atomicAdd(&count[tile_id(static_cast<int>(d.x0), pos.x, pos.y, tiles_w)], 1u);
+    }
+  }
+  recs[n] = r;
+}
+
+// ---- counting sort of a record list by tile -----------------------------------------
+
+__global__ void __launch_bounds__(256)
+    k_tiled_scatter(PRec* __restrict__ sorted, uint32_t* __restrict__ fill,
+                    const uint32_t* __restrict__ start, const PRec* __restrict__ src,
+                    int64_t n_src, int x0, int tiles_w) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (i >= n_src) return;
+  const PRec r = src[i];
+  if (r.iter < 0) return;
+  const int64_t tile = tile_id(x0, r.px, r.py, tiles_w);
+  sorted[start[tile] + atomicAdd(&fill[tile], 1u)] = r;
+}
+
+// convergent wave-aggregated slot allocation: every lane calls it
+__device__ __forceinline__ uint32_t wave_append(uint32_t* counter, bool pred) {
+  const uint64_t mask = __ballot(pred);
+  if (mask == 0) return 0;
+  const int lane = threadIdx.x & 63;
+  const int leader = __ffsll(static_cast<long long>(mask)) - 1;
+  uint32_t base = 0;
+  if (lane == leader) base = atomicAdd(counter, static_cast<uint32_t>(__popcll(mask)));
+  base = __shfl(base, leader, 64);
+  return base + static_cast<uint32_t>(__popcll(mask & ((1ull << lane) - 1ull)));
+}
+
+// ---- one round: advance the particles of one tile against LDS ---------------------
+
+template <int KIND>
+__global__ void __launch_bounds__(kTBlock)
+    k_tiled_round(PRec* __restrict__ out, uint32_t* __restrict__ count_next,
+                  const PRec* __restrict__ in, const uint32_t* __restrict__ start,
+                  const uint32_t* __restrict__ count, float* __restrict__ flux0,
+                  float* __restrict__ flux1, float2* __restrict__ fluxV,
+                  const float4* __restrict__ p4, const float* __restrict__ waterHeight,
+                  float* __restrict__ remote0, Dom d, Scale3 s, Param param, int tiles_w,
+                  int steps_per_round) {
+  const int tile = blockIdx.x;
+  const uint32_t cnt = count[tile];
+  if (cnt == 0) return;
+  const uint32_t first = start[tile];
+  const int row0 = (tile / tiles_w) * kTS, col0 = (tile % tiles_w) * kTS;  // local row, column
+
+  __shared__ float4 s_fld[kTCells];                      // {gx, gy, vx, vy}
+  __shared__ float s_wh[KIND == FLUVIAL ? kTCells : 1];  // water height
+  __shared__ float4 s_flx[kTCells];  // fluvial {water, mass, vx, vy} | debris {mass, vx, vy, -}
+  __shared__ uint32_t s_next, s_out;
+  const int tid = threadIdx.x;
+  if (tid == 0) {
+    s_next = 0;
+    s_out = 0;
+  }
+  const StepConst k = make_const<KIND>(d, s, param);
+
+  {  // stage the tile: all global loads first, then the LDS stores
+    float4 fv[kPerThread];
+    float wv[kPerThread];
+#pragma unroll
+    for (int j = 0; j < kPerThread; ++j) {
+      const int c = tid + j * kTBlock;
+      const int lx = row0 + c / kTS, y = col0 + c % kTS;
+      const bool ok = lx >= k.lo && lx <= k.hi && y < k.W;
+      const int64_t l = static_cast<int64_t>(lx) * k.W + y;
+      fv[j] = ok ? p4[l] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      wv[j] = (KIND == FLUVIAL && ok) ? waterHeight[l] : 0.0f;
+    }
+#pragma unroll
+    for (int j = 0; j < kPerThread; ++j) {
+      const int c = tid + j * kTBlock;
+      s_fld[c] = fv[j];
+      if (KIND == FLUVIAL) s_wh[c] = wv[j];
+      s_flx[c] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+  }
+  __syncthreads();
+
+  bool have = false, drained = false;
+  int budget = 0;  // steps this lane may still spend on its particle in this round
+  PRec r;
+  r.iter = -1;
+  for (;;) {
+    if (!have && !drained) {  // take the next particle of this tile's queue
+      const uint32_t i = atomicAdd(&s_next, 1u);
+      if (i < cnt) {
+        r = in[first + i];
+        have = true;
+        budget = steps_per_round;
+      } else {
+        drained = true;
+      }
+    }
+    if (!__any(have)) break;
+
+    bool park = false;
+    if (have) {
+      // top of the reference loop: while(!__oob(pos) && ++iter < maxage)  (:100 / :306)
+      if (r.px < 0 || r.py < 0 || r.px >= k.Hf || r.py >= k.Wf) {  // __oob, erosion_map.cu:29-40
+        have = false;
+      } else {
+        const int cx = cell32(r.px), cy = cell32(r.py);
+        const int lx = cx - k.x0;
+        const bool esc = lx < k.lo || lx > k.hi;  // slab_escape
+        const int tr = lx - row0, tc = cy - col0;
+        const bool inside =
+            esc || (static_cast<unsigned>(tr) < kTS && static_cast<unsigned>(tc) < kTS);
+        if (!inside || budget == 0) {
+          // the particle stands on another tile, or its round budget is used
+          // up: park it (state untouched) and resume next round
+          park = true;
+          have = false;
+        } else if (static_cast<uint32_t>(++r.iter) >= k.maxage) {
+          have = false;
+        } else if (esc) {
+          park_remote<KIND>(r, remote0);
+          have = false;
+        } else {
+          --budget;
+          const int c = tr * kTS + tc;
+          const float4 f = s_fld[c];  // issued early: its latency hides under the deposit
+          const float wh = (KIND == FLUVIAL) ? s_wh[c] : 0.0f;
+          const int64_t nind = static_cast<int64_t>(cx) * k.W + cy;  // :103 / :309
+          if (nind != r.ind) {                                       // :104-113 / :310-318
+            r.ind = nind;
+            float* a = reinterpret_cast<float*>(&s_flx[c]);
+            if (KIND == FLUVIAL) {
+              atomicAdd(a + 0, r.a0 * r.s0);
+              atomicAdd(a + 1, r.a1 * r.s1);
+              atomicAdd(a + 2, r.a2 * r.svx);
+              atomicAdd(a + 3, r.a2 * r.svy);
+            } else {
+              atomicAdd(a + 0, r.a0 * r.s0);
+              atomicAdd(a + 1, r.a1 * r.svx);
+              atomicAdd(a + 2, r.a1 * r.svy);
+            }
+          }
+          have = advance<KIND>(r, f, wh, k);
+        }
+      }
+    }
+    // survivors go back into the slots this tile's queue occupied (same range of
+    // the other list): no global allocation, one LDS counter per work-group
+    const uint32_t slot = wave_append(&s_out, park);
+    if (park) {
+      out[first + slot] = r;
+      atomicAdd(&count_next[tile_id(k.x0, r.px, r.py, tiles_w)], 1u);
+    }
+  }
+  __syncthreads();
+  for (uint32_t j = s_out + tid; j < cnt; j += kTBlock) out[first + j].iter = -1;  // unused slots
+
+  // flush the tile's flux into the global planes: one work-group per tile per
+  // round, so plain coalesced read-modify-writes suffice; loads first
+  {
+    float g0[kPerThread], g1[kPerThread];
+    float2 gv[kPerThread];
+    bool ok[kPerThread];
+#pragma unroll
+    for (int j = 0; j < kPerThread; ++j) {
+      const int c = tid + j * kTBlock;
+      const int lx = row0 + c / kTS, y = col0 + c % kTS;
+      ok[j] = lx < static_cast<int>(d.rows) && y < k.W;
+      const int64_t l = static_cast<int64_t>(lx) * k.W + y;
+      g0[j] = ok[j] ? flux0[l] : 0.0f;
+      g1[j] = (KIND == FLUVIAL && ok[j]) ? flux1[l] : 0.0f;
+      gv[j] = ok[j] ? fluxV[l] : make_float2(0.0f, 0.0f);
+    }
+#pragma unroll
+    for (int j = 0; j < kPerThread; ++j) {
+      if (!ok[j]) continue;
+      const int c = tid + j * kTBlock;
+      const int lx = row0 + c / kTS, y = col0 + c % kTS;
+      const int64_t l = static_cast<int64_t>(lx) * k.W + y;
+      const float4 a = s_flx[c];
+      if (KIND == FLUVIAL) {
+        if (a.x != 0.0f) flux0[l] = g0[j] + a.x;
+        if (a.y != 0.0f) flux1[l] = g1[j] + a.y;
+        if (a.z != 0.0f || a.w != 0.0f) fluxV[l] = make_float2(gv[j].x + a.z, gv[j].y + a.w);
+      } else {
+        if (a.x != 0.0f) flux0[l] = g0[j] + a.x;
+        if (a.y != 0.0f || a.z != 0.0f) fluxV[l] = make_float2(gv[j].x + a.y, gv[j].y + a.z);
+      }
+    }
+  }
+}
+
+// ---- the last launch: walk the remaining particles to the end against HBM ----------
+
+template <int KIND>
+__global__ void __launch_bounds__(256)
+    k_tiled_finish(const PRec* __restrict__ recs, int64_t n, float* __restrict__ flux0,
+                   float* __restrict__ flux1, float* __restrict__ fluxV,
+                   const float4* __restrict__ p4, const float* __restrict__ waterHeight,
+                   float* __restrict__ remote0, Dom d, Scale3 s, Param param) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (i >= n) return;
+  PRec r = recs[i];
+  if (r.iter < 0) return;
+  const StepConst k = make_const<KIND>(d, s, param);
+  const int64_t base = static_cast<int64_t>(k.x0) * k.W;
+  for (;;) {
+    if (r.px < 0 || r.py < 0 || r.px >= k.Hf || r.py >= k.Wf) break;
+    const int cx = cell32(r.px), cy = cell32(r.py);
+    const int lx = cx - k.x0;
+    const bool esc = lx < k.lo || lx > k.hi;
+    if (static_cast<uint32_t>(++r.iter) >= k.maxage) break;
+    if (esc) {
+      park_remote<KIND>(r, remote0);
+      break;
+    }
+    const int64_t nind = static_cast<int64_t>(cx) * k.W + cy;
+    const int64_t l = nind - base;
+    const float4 f = p4[l];
+    const float wh = (KIND == FLUVIAL) ? waterHeight[l] : 0.0f;
+    if (nind != r.ind) {
+      r.ind = nind;
+      if (KIND == FLUVIAL) {
+        atomicAdd(&flux0[l], r.a0 * r.s0);
+        atomicAdd(&flux1[l], r.a1 * r.s1);
+        atomicAdd(&fluxV[2 * l], r.a2 * r.svx);
+        atomicAdd(&fluxV[2 * l + 1], r.a2 * r.svy);
+      } else {
+        atomicAdd(&flux0[l], r.a0 * r.s0);
+        atomicAdd(&fluxV[2 * l], r.a1 * r.svx);
+        atomicAdd(&fluxV[2 * l + 1], r.a1 * r.svy);
+      }
+    }
+    if (!advance<KIND>(r, f, wh, k)) break;
+  }
+}
+
+static int env_int(const char* name, int fallback) {
+  const char* e = std::getenv(name);
+  const int v = e ? std::atoi(e) : fallback;
+  return v > 0 ? v : fallback;
+}
+
+template <int KIND>
+static int run_tiled(float* flux0, float* flux1, float* fluxV, soil_rng* rng, int64_t N,
+                     const float* layers, const float* waterSource, const float* waterHeight,
+                     const float* velocity, float* remote0, const Dom& d, Scale3 s, const Param& p,
+                     hipStream_t st) {
+  const int tiles_w = static_cast<int>((d.W + kTS - 1) / kTS);
+  const int tiles_h = static_cast<int>((d.rows + kTS - 1) / kTS);
+  const int64_t tiles = static_cast<int64_t>(tiles_w) * tiles_h;
+  auto align = [](size_t b) { return (b + 255) & ~static_cast<size_t>(255); };
+  const size_t b_rec = align(sizeof(PRec) * N), b_cnt = align(sizeof(uint32_t) * (tiles + 1));
+  const size_t b_p4 = align(sizeof(float4) * d.rows * d.W);
+  void* base = nullptr;
+  int rc = workspace_get(2, 2 * b_rec + 4 * b_cnt + b_p4, &base);
+  if (rc != SOIL_OK) return rc;
+  char* w = static_cast<char*>(base);
+  PRec* listA = reinterpret_cast<PRec*>(w);  w += b_rec;   // spawn output / survivors
+  PRec* listB = reinterpret_cast<PRec*>(w);  w += b_rec;   // sorted by tile
+  float4* p4 = reinterpret_cast<float4*>(w);  w += b_p4;
+  uint32_t* count = reinterpret_cast<uint32_t*>(w);       w += b_cnt;
+  uint32_t* count_next = reinterpret_cast<uint32_t*>(w);  w += b_cnt;
+  uint32_t* start = reinterpret_cast<uint32_t*>(w);       w += b_cnt;
+  uint32_t* fill = reinterpret_cast<uint32_t*>(w);
+
+  // steps a particle may take per round: bounds the time a work-group waits for
+  // its longest walker; and the population below which the rounds stop paying
+  static const int steps_per_round = env_int("SOIL_TILED_STEPS", 64);
+  static const int tail = env_int("SOIL_TILED_TAIL", 200000);
+
+  const int64_t lo = stencil_lo(d), hi = stencil_hi(d);
+  const int64_t cells = (hi - lo + 1) * d.W;
+  if (cells > 0)
+    k_tiled_pack<<<blocks_for(cells, 256), 256, 0, st>>>(
+        p4, reinterpret_cast<const float2*>(layers), reinterpret_cast<const float2*>(velocity), d,
+        s, p.exitSlope, lo, cells);
+  SOIL_HIP(hipMemsetAsync(count, 0, b_cnt, st));
+  k_tiled_spawn<KIND><<<blocks_for(N, 256), 256, 0, st>>>(listA, count, rng, N, p4, waterSource, d,
+                                                          s, p, tiles_w);
+  SOIL_LAUNCH_CHECK();
+  int64_t n_src = N;  // length of listA to look at (spawn output, then survivor slots)
+  const uint64_t max_rounds = p.maxage + 2;  // every live particle advances >= 1 step per round
+  for (uint64_t round = 0; round < max_rounds; ++round) {
+    k_tile_scan<<<1, 1024, 0, st>>>(start, count, tiles);
+    uint32_t live = 0;  // particles queued for this round = start[tiles]
+    SOIL_HIP(hipMemcpyAsync(&live, start + tiles, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    SOIL_HIP(hipStreamSynchronize(st));
+    if (live == 0) break;
+    if (static_cast<int64_t>(live) <= tail && round > 0) {
+      k_tiled_finish<KIND><<<blocks_for(n_src, 256), 256, 0, st>>>(
+          listA, n_src, flux0, flux1, fluxV, p4, waterHeight, remote0, d, s, p);
+      SOIL_LAUNCH_CHECK();
+      break;
+    }
+    SOIL_HIP(hipMemsetAsync(fill, 0, b_cnt, st));
+    k_tiled_scatter<<<blocks_for(n_src, 256), 256, 0, st>>>(listB, fill, start, listA, n_src,
+                                                            static_cast<int>(d.x0), tiles_w);
+    SOIL_HIP(hipMemsetAsync(count_next, 0, b_cnt, st));
+    k_tiled_round<KIND><<<static_cast<unsigned>(tiles), kTBlock, 0, st>>>(
+        listA, count_next, listB, start, count, flux0, flux1, reinterpret_cast<float2*>(fluxV), p4,
+        waterHeight, remote0, d, s, p, tiles_w, steps_per_round);
+    SOIL_LAUNCH_CHECK();
+    n_src = live;
+    uint32_t* t = count;
+    count = count_next;
+    count_next = t;
+  }
+  return SOIL_OK;
+}
+
+int launch_fluvial_tiled(float* waterFlux, float* massFlux, float* velocityFlux, soil_rng* rng,
+                         int64_t N, const float* layers, const float* waterSource,
+                         const float* waterHeight, const float* velocity, float* remote0,
+                         const Dom& d, Scale3 s, const Param& p, hipStream_t st) {
+  return run_tiled<FLUVIAL>(waterFlux, massFlux, velocityFlux, rng, N, layers, waterSource,
+                            waterHeight, velocity, remote0, d, s, p, st);
+}
+
+int launch_debris_tiled(float* massFlux, float* velocityFlux, soil_rng* rng, int64_t N,
+                        const float* layers, const float* velocity, float* remote0, const Dom& d,
+                        Scale3 s, const Param& p, hipStream_t st) {
+  return run_tiled<DEBRIS>(massFlux, nullptr, velocityFlux, rng, N, layers, nullptr, nullptr,
+                           velocity, remote0, d, s, p, st);
+}
+
+}  // namespace soil

@@ -1,0 +1,59 @@
+// particles_common.hpp — pieces shared by the particle-transport launch shapes
+// (erosion_particles.hip: direct / staged; erosion_particles_tiled.hip: tiled).
+#pragma once
+
+#include "cell_math.hpp"
+
+namespace soil {
+
+__device__ __forceinline__ bool oob(const Dom& d, float px, float py) {  // erosion_map.cu:29-40
+  if (px < 0) return true;
+  if (py < 0) return true;
+  if (px >= static_cast<float>(d.H)) return true;
+  if (py >= static_cast<float>(d.W)) return true;
+  return false;
+}
+
+// local rows whose 5-point stencil lies inside the rows this slab holds
+__device__ __host__ __forceinline__ int64_t stencil_lo(const Dom& d) { return (d.x0 == 0) ? 0 : 1; }
+__device__ __host__ __forceinline__ int64_t stencil_hi(const Dom& d) {  // inclusive
+  return (d.x0 + d.rows == d.H) ? d.rows - 1 : d.rows - 2;
+}
+// A slab traces a particle only while its cell's stencil is available
+// (soil_hip.h, soil_particles_*_slab).
+__device__ __forceinline__ bool slab_escape(const Dom& d, int64_t gx) {
+  const int64_t lx = gx - d.x0;
+  return lx < stencil_lo(d) || lx > stencil_hi(d);
+}
+
+// first two draws of particle n: spawn position (erosion.cu:56-59 / :269-272)
+__device__ __forceinline__ float2 spawn_position(soil_rng* __restrict__ rng, int64_t n,
+                                                 const Dom& d) {
+  soil_rng st = rng[n];
+  const float u1 = rng_uniform_at(st.seed, static_cast<uint64_t>(n), st.offset);
+  const float u2 = rng_uniform_at(st.seed, static_cast<uint64_t>(n), st.offset + 1);
+  st.offset += 2;
+  rng[n] = st;  // the state persists in the tensor, like curandState
+  return make_float2(0.5f + u1 * static_cast<float>(d.H - 1),
+                     0.5f + u2 * static_cast<float>(d.W - 1));
+}
+__device__ __forceinline__ bool owns_spawn(const Dom& d, float px) {
+  const int64_t sx = cell_of(px) - d.x0;
+  return sx >= d.r0 && sx < d.r1;
+}
+
+// exclusive scan of per-tile counts, start[tiles] = total (one 1024-thread group;
+// defined in erosion_particles.hip)
+__global__ void __launch_bounds__(1024)
+    k_tile_scan(uint32_t* start, const uint32_t* count, int64_t tiles);
+
+// tiled launch shape (erosion_particles_tiled.hip)
+int launch_fluvial_tiled(float* waterFlux, float* massFlux, float* velocityFlux, soil_rng* rng,
+                         int64_t N, const float* layers, const float* waterSource,
+                         const float* waterHeight, const float* velocity, float* remote0,
+                         const Dom& d, Scale3 s, const Param& p, hipStream_t st);
+int launch_debris_tiled(float* massFlux, float* velocityFlux, soil_rng* rng, int64_t N,
+                        const float* layers, const float* velocity, float* remote0, const Dom& d,
+                        Scale3 s, const Param& p, hipStream_t st);
+
+}  // namespace soil

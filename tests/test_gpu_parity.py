@@ -256,15 +256,15 @@ def _flux_close(got, want, what):
     assert ((got != 0) == (want != 0)).all(), what + ": different set of visited cells"
 
 
-@pytest.fixture(params=["direct", "staged"])
+@pytest.fixture(params=["direct", "staged", "tiled"])
 def particle_mode(request, hip):
     """Both launch shapes of the particle kernels (soil_set_particle_mode)."""
-    assert hip.soil_set_particle_mode({"direct": 1, "staged": 2}[request.param]) == 0
+    assert hip.soil_set_particle_mode({"direct": 1, "staged": 2, "tiled": 3}[request.param]) == 0
     yield request.param
     hip.soil_set_particle_mode(0)
 
 
-@pytest.mark.parametrize("H,W,N", [(64, 64, 4096), (96, 40, 3000), (33, 50, 700)])
+@pytest.mark.parametrize("H,W,N", [(64, 64, 4096), (96, 40, 3000), (33, 50, 700), (200, 136, 20000)])
 @pytest.mark.parametrize("which", ["default", "script"])
 def test_transport_fluvial_parity(hip, oracle, particle_mode, H, W, N, which):
     from soillib_amd import soil
@@ -304,7 +304,7 @@ def test_transport_fluvial_parity(hip, oracle, particle_mode, H, W, N, which):
     np.testing.assert_allclose(to_np(g["af"]), o["af"], rtol=1e-3, atol=1e-5)
 
 
-@pytest.mark.parametrize("H,W,N", [(64, 64, 4096), (40, 96, 3000), (50, 33, 700)])
+@pytest.mark.parametrize("H,W,N", [(64, 64, 4096), (40, 96, 3000), (50, 33, 700), (136, 200, 20000)])
 def test_transport_debris_parity(hip, oracle, particle_mode, H, W, N):
     from soillib_amd import soil
     op = script_param(oracle.default_param())
