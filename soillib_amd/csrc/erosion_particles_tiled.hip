@@ -244,18 +244,28 @@ __global__ void __launch_bounds__(256)
   recs[n] = r;
 }
 
-// ---- counting sort of a record list by tile -----------------------------------------
-
-__global__ void __launch_bounds__(256)
-    k_tiled_scatter(PRec* __restrict__ sorted, uint32_t* __restrict__ fill,
-                    const uint32_t* __restrict__ start, const PRec* __restrict__ src,
-                    int64_t n_src, int x0, int tiles_w) {
-  const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
-  if (i >= n_src) return;
-  const PRec r = src[i];
-  if (r.iter < 0) return;
-  const int64_t tile = tile_id(x0, r.px, r.py, tiles_w);
-  sorted[start[tile] + atomicAdd(&fill[tile], 1u)] = r;
+// Convergent per-key aggregation of atomicAdd(&counter[key], 1): lanes of a wave
+// that share a key are served by one atomic.  Queue order makes neighbouring
+// lanes share their tile most of the time, so this removes ~95 % of the atomics
+// (and their same-address serialisation in L2).  Every lane of the wave must
+// call it; returns the lane's slot (old value + rank among its key group).
+__device__ __forceinline__ uint32_t wave_key_append(uint32_t* __restrict__ counter, bool valid,
+                                                    int64_t key) {
+  const int lane = threadIdx.x & 63;
+  uint64_t todo = __ballot(valid);
+  uint32_t slot = 0;
+  while (todo) {
+    const int leader = __ffsll(static_cast<long long>(todo)) - 1;
+    const int64_t k0 = __shfl(key, leader, 64);
+    const uint64_t group = __ballot(valid && key == k0);
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(&counter[k0], static_cast<uint32_t>(__popcll(group)));
+    base = __shfl(base, leader, 64);
+    if (valid && key == k0)
+      slot = base + static_cast<uint32_t>(__popcll(group & ((1ull << lane) - 1ull)));
+    todo &= ~group;
+  }
+  return slot;
 }
 
 // convergent wave-aggregated slot allocation: every lane calls it
@@ -268,6 +278,22 @@ __device__ __forceinline__ uint32_t wave_append(uint32_t* counter, bool pred) {
   if (lane == leader) base = atomicAdd(counter, static_cast<uint32_t>(__popcll(mask)));
   base = __shfl(base, leader, 64);
   return base + static_cast<uint32_t>(__popcll(mask & ((1ull << lane) - 1ull)));
+}
+
+// ---- counting sort of a record list by tile -----------------------------------------
+
+__global__ void __launch_bounds__(256)
+    k_tiled_scatter(PRec* __restrict__ sorted, uint32_t* __restrict__ fill,
+                    const uint32_t* __restrict__ start, const PRec* __restrict__ src,
+                    int64_t n_src, int x0, int tiles_w) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  PRec r;
+  r.iter = -1;
+  if (i < n_src) r = src[i];
+  const bool valid = r.iter >= 0;
+  const int64_t tile = valid ? tile_id(x0, r.px, r.py, tiles_w) : 0;
+  const uint32_t slot = wave_key_append(fill, valid, tile);
+  if (valid) sorted[start[tile] + slot] = r;
 }
 
 // ---- one round: advance the particles of one tile against LDS ---------------------
@@ -289,7 +315,11 @@ __global__ void __launch_bounds__(kTBlock)
 
   __shared__ float4 s_fld[kTCells];                      // {gx, gy, vx, vy}
   __shared__ float s_wh[KIND == FLUVIAL ? kTCells : 1];  // water height
-  __shared__ float4 s_flx[kTCells];  // fluvial {water, mass, vx, vy} | debris {mass, vx, vy, -}
+  // flux accumulators as separate planes: lane addresses c map to 32 distinct
+  // banks (an AoS float4 would put every lane of a ds_add_f32 on 8 banks)
+  __shared__ float s_f0[kTCells];                        // fluvial water | debris mass
+  __shared__ float s_f1[KIND == FLUVIAL ? kTCells : 1];  // fluvial mass
+  __shared__ float s_fx[kTCells], s_fy[kTCells];         // velocity flux
   __shared__ uint32_t s_next, s_out;
   const int tid = threadIdx.x;
   if (tid == 0) {
@@ -315,19 +345,34 @@ __global__ void __launch_bounds__(kTBlock)
       const int c = tid + j * kTBlock;
       s_fld[c] = fv[j];
       if (KIND == FLUVIAL) s_wh[c] = wv[j];
-      s_flx[c] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      s_f0[c] = 0.0f;
+      if (KIND == FLUVIAL) s_f1[c] = 0.0f;
+      s_fx[c] = 0.0f;
+      s_fy[c] = 0.0f;
     }
   }
   __syncthreads();
 
-  bool have = false, drained = false;
+  // A lane that has to park its particle keeps the record in registers and idles;
+  // the record is written out only when the lane takes another particle or the
+  // loop is over.  That keeps global-memory traffic (and the vmcnt waits it
+  // causes for the whole wave) out of the stepping loop: a 64x64 tile starts a
+  // round with ~512 particles = one per lane, so refills are the exception.
+  bool have = false, drained = false, parked = false;
   int budget = 0;  // steps this lane may still spend on its particle in this round
   PRec r;
   r.iter = -1;
+  auto write_out = [&]() {
+    const uint32_t slot = atomicAdd(&s_out, 1u);  // slots this tile's queue occupied
+    out[first + slot] = r;
+    atomicAdd(&count_next[tile_id(k.x0, r.px, r.py, tiles_w)], 1u);
+    parked = false;
+  };
   for (;;) {
     if (!have && !drained) {  // take the next particle of this tile's queue
       const uint32_t i = atomicAdd(&s_next, 1u);
       if (i < cnt) {
+        if (parked) write_out();
         r = in[first + i];
         have = true;
         budget = steps_per_round;
@@ -337,7 +382,6 @@ __global__ void __launch_bounds__(kTBlock)
     }
     if (!__any(have)) break;
 
-    bool park = false;
     if (have) {
       // top of the reference loop: while(!__oob(pos) && ++iter < maxage)  (:100 / :306)
       if (r.px < 0 || r.py < 0 || r.px >= k.Hf || r.py >= k.Wf) {  // __oob, erosion_map.cu:29-40
@@ -352,7 +396,7 @@ __global__ void __launch_bounds__(kTBlock)
         if (!inside || budget == 0) {
           // the particle stands on another tile, or its round budget is used
           // up: park it (state untouched) and resume next round
-          park = true;
+          parked = true;
           have = false;
         } else if (static_cast<uint32_t>(++r.iter) >= k.maxage) {
           have = false;
@@ -367,29 +411,27 @@ __global__ void __launch_bounds__(kTBlock)
           const int64_t nind = static_cast<int64_t>(cx) * k.W + cy;  // :103 / :309
           if (nind != r.ind) {                                       // :104-113 / :310-318
             r.ind = nind;
-            float* a = reinterpret_cast<float*>(&s_flx[c]);
             if (KIND == FLUVIAL) {
-              atomicAdd(a + 0, r.a0 * r.s0);
-              atomicAdd(a + 1, r.a1 * r.s1);
-              atomicAdd(a + 2, r.a2 * r.svx);
-              atomicAdd(a + 3, r.a2 * r.svy);
+              atomicAdd(&s_f0[c], r.a0 * r.s0);
+              atomicAdd(&s_f1[c], r.a1 * r.s1);
+              atomicAdd(&s_fx[c], r.a2 * r.svx);
+              atomicAdd(&s_fy[c], r.a2 * r.svy);
             } else {
-              atomicAdd(a + 0, r.a0 * r.s0);
-              atomicAdd(a + 1, r.a1 * r.svx);
-              atomicAdd(a + 2, r.a1 * r.svy);
+              atomicAdd(&s_f0[c], r.a0 * r.s0);
+              atomicAdd(&s_fx[c], r.a1 * r.svx);
+              atomicAdd(&s_fy[c], r.a1 * r.svy);
             }
           }
           have = advance<KIND>(r, f, wh, k);
         }
       }
     }
-    // survivors go back into the slots this tile's queue occupied (same range of
-    // the other list): no global allocation, one LDS counter per work-group
-    const uint32_t slot = wave_append(&s_out, park);
-    if (park) {
-      out[first + slot] = r;
-      atomicAdd(&count_next[tile_id(k.x0, r.px, r.py, tiles_w)], 1u);
-    }
+  }
+  {  // everything still parked goes out together (convergent: aggregate the counters)
+    const uint32_t slot = wave_append(&s_out, parked);
+    const int64_t dest = parked ? tile_id(k.x0, r.px, r.py, tiles_w) : 0;
+    (void)wave_key_append(count_next, parked, dest);
+    if (parked) out[first + slot] = r;
   }
   __syncthreads();
   for (uint32_t j = s_out + tid; j < cnt; j += kTBlock) out[first + j].iter = -1;  // unused slots
@@ -416,15 +458,13 @@ __global__ void __launch_bounds__(kTBlock)
       const int c = tid + j * kTBlock;
       const int lx = row0 + c / kTS, y = col0 + c % kTS;
       const int64_t l = static_cast<int64_t>(lx) * k.W + y;
-      const float4 a = s_flx[c];
+      const float a0 = s_f0[c], ax = s_fx[c], ay = s_fy[c];
+      if (a0 != 0.0f) flux0[l] = g0[j] + a0;
       if (KIND == FLUVIAL) {
-        if (a.x != 0.0f) flux0[l] = g0[j] + a.x;
-        if (a.y != 0.0f) flux1[l] = g1[j] + a.y;
-        if (a.z != 0.0f || a.w != 0.0f) fluxV[l] = make_float2(gv[j].x + a.z, gv[j].y + a.w);
-      } else {
-        if (a.x != 0.0f) flux0[l] = g0[j] + a.x;
-        if (a.y != 0.0f || a.z != 0.0f) fluxV[l] = make_float2(gv[j].x + a.y, gv[j].y + a.z);
+        const float a1 = s_f1[c];
+        if (a1 != 0.0f) flux1[l] = g1[j] + a1;
       }
+      if (ax != 0.0f || ay != 0.0f) fluxV[l] = make_float2(gv[j].x + ax, gv[j].y + ay);
     }
   }
 }
@@ -505,7 +545,7 @@ static int run_tiled(float* flux0, float* flux1, float* fluxV, soil_rng* rng, in
 
   // steps a particle may take per round: bounds the time a work-group waits for
   // its longest walker; and the population below which the rounds stop paying
-  static const int steps_per_round = env_int("SOIL_TILED_STEPS", 64);
+  static const int steps_per_round = env_int("SOIL_TILED_STEPS", 32);
   static const int tail = env_int("SOIL_TILED_TAIL", 200000);
 
   const int64_t lo = stencil_lo(d), hi = stencil_hi(d);
