@@ -4,6 +4,8 @@
 //   __normalize_fluvial erosion.cu:143-187   __normalize_debris :353-393
 //   __transfer :453-574   __mass_creep :633-710   __layer_merge :733-745
 //   __albedo_layer :759-791   __albedo_stratum :794-826   __albedo_discharge :857-875
+#include <cstdlib>
+
 #include "cell_math.hpp"
 
 namespace soil {
@@ -236,9 +238,25 @@ struct Planes {  // soil_erosion_planes by value, typed
 struct Row4 {  // four consecutive float2
   float2 v[kVec];
 };
+typedef float v4f __attribute__((ext_vector_type(4)));
+// streaming accesses: planes that are read or written exactly once per step
+// bypass the caches' retention policy (nontemporal), the layer rows that the
+// neighbouring rows re-read do not
+template <bool NT>
+__device__ __forceinline__ v4f ldv(const float* __restrict__ p) {
+  const v4f* q = reinterpret_cast<const v4f*>(p);
+  return NT ? __builtin_nontemporal_load(q) : *q;
+}
+template <bool NT>
+__device__ __forceinline__ void stv(float* __restrict__ p, v4f v) {
+  v4f* q = reinterpret_cast<v4f*>(p);
+  if (NT) __builtin_nontemporal_store(v, q);
+  else *q = v;
+}
+template <bool NT = false>
 __device__ __forceinline__ Row4 load_row4(const float2* __restrict__ p) {
-  const float4 a = reinterpret_cast<const float4*>(p)[0];
-  const float4 b = reinterpret_cast<const float4*>(p)[1];
+  const float* f = reinterpret_cast<const float*>(p);
+  const v4f a = ldv<NT>(f), b = ldv<NT>(f + 4);
   Row4 r;
   r.v[0] = make_float2(a.x, a.y);
   r.v[1] = make_float2(a.z, a.w);
@@ -246,19 +264,23 @@ __device__ __forceinline__ Row4 load_row4(const float2* __restrict__ p) {
   r.v[3] = make_float2(b.z, b.w);
   return r;
 }
+template <bool NT = false>
 __device__ __forceinline__ void store_row4(float2* __restrict__ p, const Row4& r) {
-  reinterpret_cast<float4*>(p)[0] = make_float4(r.v[0].x, r.v[0].y, r.v[1].x, r.v[1].y);
-  reinterpret_cast<float4*>(p)[1] = make_float4(r.v[2].x, r.v[2].y, r.v[3].x, r.v[3].y);
+  float* f = reinterpret_cast<float*>(p);
+  stv<NT>(f, v4f{r.v[0].x, r.v[0].y, r.v[1].x, r.v[1].y});
+  stv<NT>(f + 4, v4f{r.v[2].x, r.v[2].y, r.v[3].x, r.v[3].y});
 }
+template <bool NT = false>
 __device__ __forceinline__ void load4(const float* __restrict__ p, float o[kVec]) {
-  const float4 a = *reinterpret_cast<const float4*>(p);
+  const v4f a = ldv<NT>(p);
   o[0] = a.x;
   o[1] = a.y;
   o[2] = a.z;
   o[3] = a.w;
 }
+template <bool NT = false>
 __device__ __forceinline__ void store4(float* __restrict__ p, const float o[kVec]) {
-  *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]);
+  stv<NT>(p, v4f{o[0], o[1], o[2], o[3]});
 }
 
 // The arithmetic of one cell of the fused step; shared by the vector and the
@@ -285,7 +307,7 @@ __device__ __forceinline__ CellResult fused_cell(const Nbhd& nb, float uplift, f
   return r;
 }
 
-template <bool XCD_REMAP>
+template <bool XCD_REMAP, bool NT>
 __global__ void __launch_bounds__(kBlock)
     k_erode_cells_fused(Planes P, Dom d, Scale3 s, Param p, int64_t groups_per_row,
                         int64_t total_groups) {
@@ -327,13 +349,13 @@ __global__ void __launch_bounds__(kBlock)
   if (!active) return;
 
   float uplift[kVec], rain[kVec], wflux[kVec], mflux[kVec], dflux[kVec];
-  load4(P.uplift + n0, uplift);
-  load4(P.rainfall + n0, rain);
-  load4(P.waterFlux + n0, wflux);
-  load4(P.massFlux + n0, mflux);
-  load4(P.debrisFlux + n0, dflux);
-  const Row4 vflux = load_row4(P.velocityFlux + n0);
-  const Row4 dvflux = load_row4(P.debrisVelocityFlux + n0);
+  load4<NT>(P.uplift + n0, uplift);
+  load4<NT>(P.rainfall + n0, rain);
+  load4<NT>(P.waterFlux + n0, wflux);
+  load4<NT>(P.massFlux + n0, mflux);
+  load4<NT>(P.debrisFlux + n0, dflux);
+  const Row4 vflux = load_row4<NT>(P.velocityFlux + n0);
+  const Row4 dvflux = load_row4<NT>(P.debrisVelocityFlux + n0);
 
   Row4 o_layers, o_vel, o_dvel;
   float o_h[kVec], o_wh[kVec], o_m[kVec], o_d[kVec];
@@ -360,23 +382,23 @@ __global__ void __launch_bounds__(kBlock)
     o_dvel.v[k] = r.db.velocity;
   }
 
-  store_row4(P.layers_next + n0, o_layers);
-  if (P.height) store4(P.height + n0, o_h);
-  store4(P.waterHeight + n0, o_wh);
-  store4(P.mass + n0, o_m);
-  store_row4(P.velocity + n0, o_vel);
-  store4(P.debris + n0, o_d);
-  store_row4(P.debrisVelocity + n0, o_dvel);
+  store_row4<NT>(P.layers_next + n0, o_layers);
+  if (P.height) store4<NT>(P.height + n0, o_h);
+  store4<NT>(P.waterHeight + n0, o_wh);
+  store4<NT>(P.mass + n0, o_m);
+  store_row4<NT>(P.velocity + n0, o_vel);
+  store4<NT>(P.debris + n0, o_d);
+  store_row4<NT>(P.debrisVelocity + n0, o_dvel);
   // re-zero the flux planes for the next step's atomics
   const float z[kVec] = {0.0f, 0.0f, 0.0f, 0.0f};
   Row4 z2;
 #pragma unroll
   for (int k = 0; k < kVec; ++k) z2.v[k] = make_float2(0.0f, 0.0f);
-  store4(P.waterFlux + n0, z);
-  store4(P.massFlux + n0, z);
-  store4(P.debrisFlux + n0, z);
-  store_row4(P.velocityFlux + n0, z2);
-  store_row4(P.debrisVelocityFlux + n0, z2);
+  store4<NT>(P.waterFlux + n0, z);
+  store4<NT>(P.massFlux + n0, z);
+  store4<NT>(P.debrisFlux + n0, z);
+  store_row4<NT>(P.velocityFlux + n0, z2);
+  store_row4<NT>(P.debrisVelocityFlux + n0, z2);
 }
 
 // scalar path for W % 4 != 0 (ragged widths): one thread per cell
@@ -600,12 +622,16 @@ int soil_erode_cells_fused(const soil_erosion_planes* pl, const soil_domain* dom
     const int64_t groups_per_row = d.W / kVec;
     const int64_t total = (d.r1 - d.r0) * groups_per_row;
     const unsigned nblk = blocks_for(total, kBlock);
-    if (nblk % 8 == 0 && nblk >= 64)
-      k_erode_cells_fused<true><<<nblk, kBlock, 0, st>>>(P, d, s3(scale), *param, groups_per_row,
-                                                         total);
+    static const bool nt = [] { const char* e = std::getenv("SOIL_CELLS_NT"); return e && e[0] == '1'; }();  // measured slower than plain accesses; kept for A/B
+    const bool remap = nblk % 8 == 0 && nblk >= 64;
+    if (remap && nt)
+      k_erode_cells_fused<true, true><<<nblk, kBlock, 0, st>>>(P, d, s3(scale), *param, groups_per_row, total);
+    else if (remap)
+      k_erode_cells_fused<true, false><<<nblk, kBlock, 0, st>>>(P, d, s3(scale), *param, groups_per_row, total);
+    else if (nt)
+      k_erode_cells_fused<false, true><<<nblk, kBlock, 0, st>>>(P, d, s3(scale), *param, groups_per_row, total);
     else
-      k_erode_cells_fused<false><<<nblk, kBlock, 0, st>>>(P, d, s3(scale), *param, groups_per_row,
-                                                          total);
+      k_erode_cells_fused<false, false><<<nblk, kBlock, 0, st>>>(P, d, s3(scale), *param, groups_per_row, total);
   } else {
     k_erode_cells_fused_scalar<<<blocks_for(cells, kBlock), kBlock, 0, st>>>(P, d, s3(scale),
                                                                               *param);
