@@ -160,7 +160,7 @@ def main():
 
     S = args.size
     param = script_param(soil)
-    if world > 1:
+    if world > 1 or os.environ.get("SOIL_BENCH_FORCE_SLAB") == "1":
         from soillib_amd import parallel
         runner = parallel.SlabRunner(rows_per_rank=S, W=S, param=param,
                                      particles_div=args.particles_div, seed=0)

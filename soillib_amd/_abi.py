@@ -123,10 +123,29 @@ SIGNATURES = {
 _lib = None
 
 
+def _load_torch_runtime_first():
+    """PyTorch-ROCm wheels bundle their own HIP/HSA runtime (torch/lib/libamdhip64.so).
+    Two HIP runtimes in one process do not share the device: whichever initialises
+    second sees "no GPU" (measured on the MI355X box).  libsoil_hip.so only asks for
+    the SONAME libamdhip64.so.7, so when torch is imported FIRST the dynamic linker
+    binds it to torch's already-loaded runtime and both live happily on one runtime
+    (tensors can then be aliased both ways, RCCL works on our buffers).  torch is
+    this package's plumbing for multi-GPU runs anyway, so it goes first whenever it
+    is installed; SOIL_NO_TORCH=1 opts out (pure C-ABI use on the system ROCm)."""
+    import sys
+    if os.environ.get("SOIL_NO_TORCH") == "1" or "torch" in sys.modules:
+        return
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+
+
 def lib():
     """Loads libsoil_hip.so (fails loudly if it has not been built)."""
     global _lib
     if _lib is None:
+        _load_torch_runtime_first()
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(
                 "libsoil_hip.so is missing (%s): build it with `python -m soillib_amd.build`; "

@@ -17,10 +17,10 @@ fp32 summation order of the flux differs) with nearest-neighbour traffic only:
 
 Every rank replays all world*N particle streams (two Philox draws each) and
 traces the ones whose spawn row it owns (soil_particles_*_slab), so the set of
-trajectories is identical to a single-GPU run of the global grid.  One corner
-is NOT reproduced: the reference's NaN walkers
-deposit into global cell (0,0); a rank that does not hold global row 0 drops
-its own NaN walkers instead.
+trajectories is identical to a single-GPU run of the global grid.  Even the
+reference's NaN walkers, whose one deposit belongs
+to global cell (0,0), are reproduced: a rank that does not hold global row 0
+parks those deposits in an 8-float buffer that is all-reduced to the owner.
 
 The runner is written against a small `ops` interface so that the exchange and
 partition logic can be tested on CPU (gloo) with the oracle as the compute
@@ -158,16 +158,22 @@ class SlabRunner:
     """The sharded erosion model; `step()` advances the global grid by one step."""
 
     def __init__(self, rows_per_rank, W, param, particles_div=8, seed=0, ops=None, scale=None,
-                 noise_seed=3.0, init=True):
-        import torch.distributed as dist
+                 noise_seed=3.0, init=True, comm=None, rank=None, world=None):
+        """`comm` is a torch.distributed-like module (P2POp, isend, irecv,
+        batch_isend_irecv, all_reduce, barrier); the default is torch.distributed
+        itself.  Tests inject an in-process stand-in to drive several slabs on one GPU."""
+        if comm is None:
+            import torch.distributed as dist
+        else:
+            dist = comm
         self.dist = dist
-        self.rank = int(os.environ.get("RANK", "0"))
-        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0")) if rank is None else int(rank)
+        self.world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else int(world)
         local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         if ops is None:
             ops = HipOps(local_rank)
         self.ops = ops
-        if not dist.is_initialized():
+        if comm is None and not dist.is_initialized():
             backend = "nccl" if isinstance(ops, HipOps) else "gloo"
             kw = {}
             if backend == "nccl":

@@ -1,0 +1,189 @@
+"""GPU tests of the sharded erosion step (soillib_amd.parallel.SlabRunner + HipOps).
+
+Only one GPU is available to the test box, so N slabs are driven by N threads of
+one process against an in-process stand-in for torch.distributed that moves the
+halo rows with device copies (stream-ordered through events).  Everything else —
+HipOps, the slab kernels, the exchange schedule with its second stream — is the
+product code that runs under RCCL on a real node.
+"""
+import queue
+import threading
+
+import numpy as np
+import pytest
+
+from util import product_param, script_param, to_gpu, to_np
+
+pytestmark = pytest.mark.gpu
+
+
+class LocalComm:
+    """torch.distributed look-alike for `world` runners living in one process."""
+
+    class ReduceOp:
+        SUM, MAX = "sum", "max"
+
+    class P2POp:
+        def __init__(self, op, tensor, peer):
+            self.op, self.tensor, self.peer = op, tensor, peer
+
+    isend, irecv = "isend", "irecv"
+
+    class _Req:
+        def __init__(self, fn=None):
+            self.fn = fn
+
+        def wait(self):
+            if self.fn:
+                self.fn()
+
+    class _Shared:
+        def __init__(self, world):
+            self.world = world
+            self.q = {(a, b): queue.Queue() for a in range(world) for b in range(world)}
+            self.bar = threading.Barrier(world)
+            self.red = [None] * world
+
+    def __init__(self, shared, rank):
+        self.s, self.rank = shared, rank
+
+    def batch_isend_irecv(self, ops):
+        import torch
+        reqs = []
+        for o in ops:                          # sends first: never blocks
+            if o.op == "isend":
+                ev = torch.cuda.Event()
+                ev.record()                    # the data is ready once the sender's stream gets here
+                done = threading.Event()
+                self.s.q[(self.rank, o.peer)].put((o.tensor, ev, done))
+                reqs.append(self._Req(done.wait))
+        for o in ops:
+            if o.op == "irecv":
+                src, ev, done = self.s.q[(o.peer, self.rank)].get(timeout=120)
+                torch.cuda.current_stream().wait_event(ev)
+                o.tensor.copy_(src)
+                torch.cuda.current_stream().synchronize()   # the sender may reuse its rows now
+                done.set()
+                reqs.append(self._Req())
+        return reqs
+
+    def all_reduce(self, t, op="sum"):
+        import torch
+        torch.cuda.synchronize()
+        self.s.red[self.rank] = t.clone()
+        self.s.bar.wait()
+        stack = torch.stack(self.s.red)
+        res = stack.max(0).values if op == "max" else stack.sum(0)
+        self.s.bar.wait()
+        t.copy_(res)
+
+    def barrier(self):
+        self.s.bar.wait()
+
+
+def _run_world(world, S, W, param, steps, maxage):
+    import torch
+    from soillib_amd.parallel import SlabRunner
+    shared = LocalComm._Shared(world)
+    out, errs = [None] * world, []
+    dev_lock = threading.Lock()
+
+    def worker(rank):
+        try:
+            torch.cuda.set_device(0)
+            r = SlabRunner(rows_per_rank=S, W=W, param=param, particles_div=8, seed=0,
+                           comm=LocalComm(shared, rank), rank=rank, world=world)
+            # the particle launches stage through ONE per-device workspace; ranks that
+            # share a device (only in this test) must not interleave them
+            for name in ("particles_fluvial", "particles_debris"):
+                fn = getattr(r.ops, name)
+
+                def locked(*a, _fn=fn, **kw):
+                    with dev_lock:
+                        _fn(*a, **kw)
+                        r.ops.sync()
+                setattr(r.ops, name, locked)
+            for _ in range(steps):
+                r.step()
+            r.sync()
+            own = slice(r.r0, r.r1)
+            out[rank] = {k: r.P[k][own].cpu().numpy() for k in
+                         ("layers", "waterHeight", "velocity", "debris", "height")}
+            assert r.max_over_ranks(float(rank)) == world - 1
+        except Exception as e:  # surface worker failures in the main thread
+            errs.append(e)
+            try:
+                shared.bar.abort()
+            except Exception:
+                pass
+    ts = [threading.Thread(target=worker, args=(k,)) for k in range(world)]
+    [t.start() for t in ts]
+    [t.join(300) for t in ts]
+    if errs:
+        raise errs[0]
+    return {k: np.concatenate([o[k] for o in out], axis=0) for k in out[0]}
+
+
+@pytest.mark.parametrize("world,S,W,maxage", [(2, 64, 128, 16), (3, 64, 64, 24)])
+def test_slab_runner_on_one_gpu_matches_single_domain(hip, oracle, world, S, W, maxage):
+    from soillib_amd import silt, soil
+    from soillib_amd.erosion import ErosionModel
+    op = script_param(oracle.default_param())
+    op.maxage = maxage
+    pp = product_param(op)
+    steps = 3
+    H = world * S
+    got = _run_world(world, S, W, pp, steps, maxage)
+
+    scale = (20.0 / H, 20.0 / W, 4.0)
+    m = ErosionModel(H, W, scale, pp, H * W // 8, seed=0)
+    npar = soil.noise_t()
+    npar.seed = 3.0
+    npar.ext = [H, W]
+    bed = soil.noise(silt.shape(H, W), npar, host=silt.gpu)
+    layers0 = np.zeros((H, W, 2), np.float32)
+    layers0[..., 0] = to_np(bed)
+    m.set_layers(to_gpu(layers0))
+    silt.set(m.rainfall, 1.0)
+    for _ in range(steps):
+        m.step()
+    want = {k: to_np(getattr(m, k)) for k in got}
+    assert np.abs(want["layers"] - layers0).max() > 0
+    for k in got:
+        np.testing.assert_allclose(got[k], want[k], rtol=1e-4,
+                                   atol=1e-5 * (np.nanmax(np.abs(want[k])) + 1e-30), err_msg=k)
+
+
+def test_slab_runner_world1_is_the_plain_model(hip, oracle):
+    """world = 1 through torch.distributed itself (nccl, one rank)."""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import os, sys, numpy as np
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+from soillib_amd import soil, parallel
+from soillib_amd.erosion import ErosionModel
+from soillib_amd import silt
+p = soil.param_t(); p.maxage = 32; p.timeStep = 1000.0
+r = parallel.SlabRunner(rows_per_rank=128, W=128, param=p, particles_div=8, seed=0)
+for _ in range(2): r.step()
+r.sync()
+m = ErosionModel(128, 128, r.scale, p, 128 * 128 // 8, seed=0)
+n = soil.noise_t(); n.seed = 3.0; n.ext = [128, 128]
+bed = soil.noise(silt.shape(128, 128), n, host=silt.gpu)
+from soillib_amd import _abi
+_abi.check(_abi.lib().soil_layers_from_planes(m.layers.c_ptr, bed.c_ptr, None, bed.elem(), None))
+silt.set(m.rainfall, 1.0)
+for _ in range(2): m.step()
+a = r.P["layers"].cpu().numpy(); b = m.layers.cpu().numpy()
+np.testing.assert_allclose(a, b, rtol=1e-4, atol=1e-6)
+assert r.max_over_ranks(3.0) == 3.0
+print("WORLD1_OK")
+"""
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT="29617")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True,
+                         text=True, timeout=600)
+    assert "WORLD1_OK" in res.stdout, res.stdout[-2000:] + res.stderr[-3000:]
