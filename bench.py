@@ -218,6 +218,8 @@ def main():
     if world > 1:
         elapsed = runner.max_over_ranks(elapsed)
 
+    if world > 1 or os.environ.get("SOIL_BENCH_FORCE_SLAB") == "1":
+        runner.shutdown()
     if rank != 0:
         return
     K = args.steps
@@ -259,7 +261,11 @@ def main():
     }
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.cpu_size)
-    print(json.dumps(out))
+    try:  # anything RCCL/HIP left in the C stdio buffer goes out BEFORE the result line
+        C.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    print(json.dumps(out), flush=True)
 
 
 def _interleave(lib, _abi, layers, bed):

@@ -324,6 +324,14 @@ class SlabRunner:
         if self.world > 1:
             self.dist.barrier()
 
+    def shutdown(self):
+        """Tear the process group down (only when it is torch.distributed itself)."""
+        d = self.dist
+        if hasattr(d, "is_initialized") and d.is_initialized():
+            self.sync()
+            d.barrier()
+            d.destroy_process_group()
+
     def max_over_ranks(self, value):
         import torch
         t = torch.tensor([float(value)], dtype=torch.float64,
