@@ -1,0 +1,238 @@
+// soil.hpp — header-only C++ host mirror of the reference's operator API over the
+// C ABI (soil_hip.h).  Same function names, argument order and meaning as the
+// free functions of `namespace soil` in the reference:
+//   source/soillib/model/path/erosion.hpp:69-166   graph/graph.hpp:49-63
+//   model/grad/grad.hpp:11-17   model/filter/filter.hpp:11   model/path/path.hpp:30-37
+//   op/noise.hpp:42
+// plus the sliver of `silt` those signatures need (shape, tensor_t<T>, host_t,
+// rng): ref-counted device buffers that can be passed by value like the
+// reference's handles.  Errors of the C ABI become C++ exceptions, as the
+// reference throws std::invalid_argument / silt::error::mismatch_host.
+//
+//   g++ -std=c++17 -Iinclude app.cpp -Lsoillib_amd/lib -lsoil_hip
+#pragma once
+
+#include <array>
+#include <cstdint>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "soil_hip.h"
+
+namespace silt {
+
+enum host_t { CPU = 0, GPU = 1 };
+using rng = soil_rng;  // erosion.hpp:6 uses curandState; see DESIGN.md §4
+struct vec2 { float x, y; };
+struct vec3 { float x, y, z; };
+
+namespace error {
+struct mismatch_host : std::runtime_error {
+  mismatch_host(host_t want, host_t got)
+      : std::runtime_error(std::string("mismatch_host: expected ") + (want == GPU ? "GPU" : "CPU") +
+                           ", got " + (got == GPU ? "GPU" : "CPU")) {}
+};
+}  // namespace error
+
+inline void check(int rc) {
+  if (rc == SOIL_OK) return;
+  if (rc == SOIL_ERR_INVALID_ARGUMENT) throw std::invalid_argument(soil_last_error());
+  if (rc == SOIL_ERR_OUT_OF_MEMORY) throw std::bad_alloc();
+  throw std::runtime_error(soil_last_error());
+}
+
+class shape {  // dense row-major, flatten((x, y)) = x*shape[1] + y
+ public:
+  shape() = default;
+  shape(int64_t a) : n_(1), d_{a, 1, 1, 1} {}
+  shape(int64_t a, int64_t b) : n_(2), d_{a, b, 1, 1} {}
+  shape(int64_t a, int64_t b, int64_t c) : n_(3), d_{a, b, c, 1} {}
+  int64_t operator[](int i) const { return i < n_ ? d_[i] : 1; }
+  int dim() const { return n_; }
+  int64_t elem() const { return d_[0] * d_[1] * d_[2] * d_[3]; }
+ private:
+  int n_ = 0;
+  std::array<int64_t, 4> d_{0, 1, 1, 1};
+};
+
+template <typename T>
+class tensor_t {  // shared handle to a GPU buffer (host tensors: std::vector on the caller's side)
+ public:
+  tensor_t() = default;
+  tensor_t(const shape& s, host_t host = GPU) : shape_(s) {
+    if (host != GPU) throw error::mismatch_host(GPU, host);
+    void* p = nullptr;
+    check(soil_malloc(&p, sizeof(T) * static_cast<size_t>(s.elem())));
+    mem_ = std::shared_ptr<void>(p, [](void* q) { soil_free(q); });
+  }
+  static tensor_t from_host(const std::vector<T>& v, const shape& s) {
+    tensor_t t(s, GPU);
+    check(soil_memcpy_h2d(t.data(), v.data(), sizeof(T) * v.size(), nullptr));
+    return t;
+  }
+  std::vector<T> to_host() const {
+    std::vector<T> v(static_cast<size_t>(elem()));
+    check(soil_memcpy_d2h(v.data(), data(), sizeof(T) * v.size(), nullptr));
+    return v;
+  }
+  T* data() const { return static_cast<T*>(mem_.get()); }
+  const silt::shape& shape() const { return shape_; }
+  int64_t elem() const { return shape_.elem(); }
+  host_t host() const { return GPU; }
+ private:
+  std::shared_ptr<void> mem_;
+  silt::shape shape_;
+};
+
+inline void set(tensor_t<float> t, float v) { check(soil_set_f32(t.data(), v, t.elem(), nullptr)); }
+inline void set(tensor_t<int> t, int v) { check(soil_set_i32(t.data(), v, t.elem(), nullptr)); }
+inline void add(tensor_t<float> a, tensor_t<float> b) { check(soil_add_f32(a.data(), b.data(), a.elem(), nullptr)); }
+inline void multiply(tensor_t<float> a, float v) { check(soil_multiply_f32(a.data(), v, a.elem(), nullptr)); }
+inline void seed(tensor_t<rng> r, uint64_t seed, uint64_t offset) {
+  check(soil_rng_seed(r.data(), r.elem(), seed, offset, nullptr));
+}
+
+}  // namespace silt
+
+namespace soil {
+
+struct param_t : soil_param {  // erosion.hpp:17-58, defaults included
+  param_t() { soil_param_default(this); }
+};
+enum edge_t { D4 = SOIL_D4, D8 = SOIL_D8 };  // graph.hpp:11-14
+using silt::check;
+using F = silt::tensor_t<float>;
+
+namespace detail {
+struct s3 { float v[3]; s3(silt::vec3 s) : v{s.x, s.y, s.z} {} };
+struct s2 { float v[2]; s2(silt::vec2 s) : v{s.x, s.y} {} };
+}  // namespace detail
+
+// ---- erosion.hpp:69-133 ---------------------------------------------------------------------
+inline void transport_fluvial(F layers, F rainfall, F discharge, F discharge_track, F mass,
+                              F mass_track, F momentum, F momentum_track, F albedo_bedrock,
+                              F albedo_transport, F albedo_surface, silt::tensor_t<silt::rng> rng,
+                              const silt::vec3 scale, const param_t param) {
+  const auto s = layers.shape();
+  check(soil_transport_fluvial(layers.data(), rainfall.data(), discharge.data(),
+                               discharge_track.data(), mass.data(), mass_track.data(),
+                               momentum.data(), momentum_track.data(), albedo_bedrock.data(),
+                               albedo_transport.data(), albedo_surface.data(), rng.data(),
+                               rng.elem(), s[0], s[1], detail::s3(scale).v, &param, nullptr));
+}
+inline void transport_debris(F layers, F velocity, F velocity_track, F mass, F mass_track,
+                             F albedo_bedrock, F albedo_transport, F albedo_surface,
+                             silt::tensor_t<silt::rng> rng, const silt::vec3 scale,
+                             const param_t param) {
+  const auto s = layers.shape();
+  check(soil_transport_debris(layers.data(), velocity.data(), velocity_track.data(), mass.data(),
+                              mass_track.data(), albedo_bedrock.data(), albedo_transport.data(),
+                              albedo_surface.data(), rng.data(), rng.elem(), s[0], s[1],
+                              detail::s3(scale).v, &param, nullptr));
+}
+inline void mass_transfer(F delta, F layers, const F uplift, const F discharge, const F mass,
+                          const F momentum, const F debris, const F momentumDebris,
+                          F albedo_bedrock, F albedo_transport_fluvial, F albedo_transport_debris,
+                          F albedo_surface, const silt::vec3 scale, const param_t param) {
+  const auto s = uplift.shape();
+  check(soil_mass_transfer(delta.data(), layers.data(), uplift.data(), discharge.data(),
+                           mass.data(), momentum.data(), debris.data(), momentumDebris.data(),
+                           albedo_bedrock.data(), albedo_transport_fluvial.data(),
+                           albedo_transport_debris.data(), albedo_surface.data(), s[0], s[1],
+                           detail::s3(scale).v, &param, nullptr));
+}
+inline void mass_creep(F delta, const F layers, const silt::vec3 scale, const param_t param) {
+  const auto s = layers.shape();
+  check(soil_mass_creep(delta.data(), layers.data(), s[0], s[1], detail::s3(scale).v, &param, nullptr));
+}
+inline void layer_merge(F height, const F layers) {
+  check(soil_layer_merge(height.data(), layers.data(), height.elem(), nullptr));
+}
+
+// ---- graph.hpp:49-63 ------------------------------------------------------------------------
+inline silt::tensor_t<int> direction(const F height, const edge_t edge) {
+  silt::tensor_t<int> out(height.shape(), silt::GPU);
+  check(soil_direction(out.data(), height.data(), height.shape()[0], height.shape()[1], edge, nullptr));
+  return out;
+}
+inline silt::tensor_t<int> steepest(const F height, const edge_t edge) {
+  silt::tensor_t<int> out(height.shape(), silt::GPU);
+  check(soil_steepest(out.data(), height.data(), height.shape()[0], height.shape()[1], edge, nullptr));
+  return out;
+}
+inline silt::tensor_t<int> random_weighted(const F height, const edge_t edge, const size_t seed,
+                                           const size_t offset, const float T) {
+  silt::tensor_t<int> out(height.shape(), silt::GPU);
+  check(soil_random_weighted(out.data(), height.data(), height.shape()[0], height.shape()[1], edge,
+                             seed, offset, T, nullptr));
+  return out;
+}
+inline F accumulate(const silt::tensor_t<int> graph, const F source, const edge_t edge) {
+  F out(graph.shape(), silt::GPU);
+  check(soil_accumulate(out.data(), graph.data(), source.data(), nullptr, graph.shape()[0],
+                        graph.shape()[1], edge, nullptr));
+  return out;
+}
+inline F accumulate_decay(const silt::tensor_t<int> graph, const F source, const F decay,
+                          const edge_t edge) {
+  F out(graph.shape(), silt::GPU);
+  check(soil_accumulate(out.data(), graph.data(), source.data(), decay.data(), graph.shape()[0],
+                        graph.shape()[1], edge, nullptr));
+  return out;
+}
+inline F slope(const F tensor, const silt::tensor_t<int> flow, const silt::vec2 scale) {
+  F out(tensor.shape(), silt::GPU);
+  check(soil_slope(out.data(), tensor.data(), flow.data(), tensor.shape()[0], tensor.shape()[1],
+                   detail::s2(scale).v, nullptr));
+  return out;
+}
+
+// ---- grad.hpp:11-17, filter.hpp:11 ------------------------------------------------------------
+inline F gradient(const F& tensor, const silt::vec2 scale) {
+  F out(silt::shape(tensor.shape()[0], tensor.shape()[1], 2), silt::GPU);
+  check(soil_gradient(out.data(), tensor.data(), tensor.shape()[0], tensor.shape()[1],
+                      detail::s2(scale).v, nullptr));
+  return out;
+}
+inline F negslope(const F& tensor, const silt::vec2 scale) {
+  F out(silt::shape(tensor.shape()[0], tensor.shape()[1]), silt::GPU);
+  check(soil_negslope(out.data(), tensor.data(), tensor.shape()[0], tensor.shape()[1],
+                      detail::s2(scale).v, nullptr));
+  return out;
+}
+inline F laplacian(const F& tensor, const silt::vec2 scale) {
+  F out(tensor.shape(), silt::GPU);
+  check(soil_laplacian(out.data(), tensor.data(), tensor.shape()[0], tensor.shape()[1],
+                       static_cast<int>(tensor.shape()[2]), detail::s2(scale).v, nullptr));
+  return out;
+}
+inline F gaussian_blur(F tensor, const float sigma) {  // blurs in place, returns its input (filter.cu:90)
+  F scratch(tensor.shape(), silt::GPU);
+  check(soil_gaussian_blur(tensor.data(), scratch.data(), tensor.shape()[0], tensor.shape()[1],
+                           static_cast<int>(tensor.shape()[2]), sigma, nullptr));
+  return tensor;
+}
+
+// ---- path.hpp:30-37, noise.hpp:14-56 -----------------------------------------------------------
+inline F solve_uniform(const F flow, const F source, const F decay, silt::tensor_t<silt::rng> rng,
+                       const silt::vec2 scale, const size_t count) {
+  F flux(source.shape(), silt::GPU);
+  check(soil_solve_uniform(flux.data(), flow.data(), source.data(), decay.data(), rng.data(),
+                           rng.elem(), source.shape()[0], source.shape()[1],
+                           static_cast<int>(source.shape()[2]), detail::s2(scale).v, count, nullptr));
+  return flux;
+}
+struct noise_param_t : soil_noise_param {
+  noise_param_t() { soil_noise_param_default(this); }
+};
+inline F noise(const silt::shape shape, noise_param_t param) {  // generated straight into HBM
+  if (shape.dim() != 2)
+    throw std::invalid_argument("can't extract a full noise buffer from a non-2D index");
+  F out(shape, silt::GPU);
+  check(soil_noise(out.data(), shape[0], shape[1], &param, nullptr));
+  return out;
+}
+
+}  // namespace soil
