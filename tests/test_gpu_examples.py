@@ -89,7 +89,7 @@ def test_erosion_gpu_script_sequence(hip):
     dis = data.discharge.cpu().numpy()
     assert h1.shape == (256, 256) and np.isfinite(h1).all() and np.isfinite(sed).all()
     assert np.abs(h1 - h0).max() > 0              # the terrain eroded
-    assert (sed >= 0).all()
+    assert (sed >= -1e-6).all()                    # (-y*sz)/sz may miss -y by an ulp (erosion.cu:538-539)
     assert np.nanmax(dis) > 0 and np.isfinite(dis.ravel()[1:]).all()
     for t in (track.discharge, track.mass, track.momentum, track.debris, track.debris_momentum):
         assert (t.cpu().numpy() == 0).all()       # flux planes are left zeroed for the next step
