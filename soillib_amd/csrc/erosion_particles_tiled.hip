@@ -27,6 +27,7 @@
 // state is only ever parked at the top of an iteration, before `++iter` — so
 // every trajectory and every deposit is bit-identical to the direct launch
 // shape; only the order of the fp32 additions into a cell differs.
+#include <cstdio>
 #include <cstdlib>
 
 #include "particles_common.hpp"
@@ -411,6 +412,11 @@ __global__ void __launch_bounds__(kTBlock)
           const int64_t nind = static_cast<int64_t>(cx) * k.W + cy;  // :103 / :309
           if (nind != r.ind) {                                       // :104-113 / :310-318
             r.ind = nind;
+            // ds_add_f32 runs at ~2.6 cycles per LANE on gfx950 (tools/microbench/
+            // lds_atomic.hip: 170 cycles per wave instruction vs 6 for ds_add_u32); a
+            // compare-and-swap formulation is 4x cheaper for the LDS pipe but makes the
+            // wave wait twice per step, and measured no faster in this kernel (2 waves
+            // per SIMD cannot hide it), so the fire-and-forget native atomic stays
             if (KIND == FLUVIAL) {
               atomicAdd(&s_f0[c], r.a0 * r.s0);
               atomicAdd(&s_f1[c], r.a1 * r.s1);
@@ -547,6 +553,7 @@ static int run_tiled(float* flux0, float* flux1, float* fluxV, soil_rng* rng, in
   // its longest walker; and the population below which the rounds stop paying
   static const int steps_per_round = env_int("SOIL_TILED_STEPS", 32);
   static const int tail = env_int("SOIL_TILED_TAIL", 200000);
+  static const bool verbose = std::getenv("SOIL_TILED_VERBOSE") != nullptr;
 
   const int64_t lo = stencil_lo(d), hi = stencil_hi(d);
   const int64_t cells = (hi - lo + 1) * d.W;
@@ -565,6 +572,8 @@ static int run_tiled(float* flux0, float* flux1, float* fluxV, soil_rng* rng, in
     uint32_t live = 0;  // particles queued for this round = start[tiles]
     SOIL_HIP(hipMemcpyAsync(&live, start + tiles, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     SOIL_HIP(hipStreamSynchronize(st));
+    if (verbose) std::fprintf(stderr, "[tiled kind %d] round %llu: %u live\n", KIND,
+                              static_cast<unsigned long long>(round), live);
     if (live == 0) break;
     if (static_cast<int64_t>(live) <= tail && round > 0) {
       k_tiled_finish<KIND><<<blocks_for(n_src, 256), 256, 0, st>>>(
