@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsoil_hip.so")
+LIB_PATH = os.environ.get("SOIL_LIB") or os.path.join(_HERE, "lib", "libsoil_hip.so")
 
 SOIL_OK = 0
 SOIL_ERR_INVALID_ARGUMENT = -1

@@ -307,8 +307,8 @@ __device__ __forceinline__ CellResult fused_cell(const Nbhd& nb, float uplift, f
   return r;
 }
 
-template <bool XCD_REMAP, bool NT>
-__global__ void __launch_bounds__(kBlock)
+template <bool XCD_REMAP, bool NT, int BLOCK = kBlock>
+__global__ void __launch_bounds__(BLOCK)
     k_erode_cells_fused(Planes P, Dom d, Scale3 s, Param p, int64_t groups_per_row,
                         int64_t total_groups) {
   // group = kVec consecutive cells of one row; one thread per group
@@ -319,7 +319,7 @@ __global__ void __launch_bounds__(kBlock)
     const int64_t per = gridDim.x / 8;
     blk = (blk % 8) * per + blk / 8;
   }
-  const int64_t g = blk * kBlock + threadIdx.x;
+  const int64_t g = blk * BLOCK + threadIdx.x;
   const bool active = g < total_groups;
   const int64_t gsafe = active ? g : total_groups - 1;
   const int64_t lx = d.r0 + gsafe / groups_per_row;
@@ -328,26 +328,12 @@ __global__ void __launch_bounds__(kBlock)
   const int64_t n0 = lx * d.W + y0;
   const int lane = threadIdx.x & 63;
 
+  // every streaming load is issued before anything waits on one of them (the
+  // shuffles below need `c`): 13 x 16-byte loads in flight per lane
   const bool has_n0 = gx - 1 >= 0, has_p0 = gx + 1 < d.H;
   const Row4 c = load_row4(P.layers + n0);
   const Row4 up = has_n0 ? load_row4(P.layers + n0 - d.W) : c;
   const Row4 dn = has_p0 ? load_row4(P.layers + n0 + d.W) : c;
-
-  // y-neighbours across the group boundary: previous lane's v[3], next lane's v[0]
-  float2 left, right;
-  left.x = __shfl_up(c.v[3].x, 1, 64);
-  left.y = __shfl_up(c.v[3].y, 1, 64);
-  right.x = __shfl_down(c.v[0].x, 1, 64);
-  right.y = __shfl_down(c.v[0].y, 1, 64);
-  const bool has_left = y0 - 1 >= 0, has_right = y0 + kVec < d.W;
-  // lanes at a wave edge, or whose shuffle partner sits on another row, reload
-  const bool left_ok = lane != 0 && (gsafe % groups_per_row) != 0;
-  const bool right_ok = lane != 63 && (gsafe % groups_per_row) != groups_per_row - 1;
-  if (has_left && !left_ok) left = P.layers[n0 - 1];
-  if (has_right && !right_ok) right = P.layers[n0 + kVec];
-
-  if (!active) return;
-
   float uplift[kVec], rain[kVec], wflux[kVec], mflux[kVec], dflux[kVec];
   load4<NT>(P.uplift + n0, uplift);
   load4<NT>(P.rainfall + n0, rain);
@@ -356,6 +342,23 @@ __global__ void __launch_bounds__(kBlock)
   load4<NT>(P.debrisFlux + n0, dflux);
   const Row4 vflux = load_row4<NT>(P.velocityFlux + n0);
   const Row4 dvflux = load_row4<NT>(P.debrisVelocityFlux + n0);
+  const bool has_left = y0 - 1 >= 0, has_right = y0 + kVec < d.W;
+  // lanes at a wave edge, or whose shuffle partner sits on another row, reload
+  const bool left_ok = lane != 0 && (gsafe % groups_per_row) != 0;
+  const bool right_ok = lane != 63 && (gsafe % groups_per_row) != groups_per_row - 1;
+  float2 left = make_float2(0.0f, 0.0f), right = make_float2(0.0f, 0.0f);
+  if (has_left && !left_ok) left = P.layers[n0 - 1];
+  if (has_right && !right_ok) right = P.layers[n0 + kVec];
+
+  // y-neighbours across the group boundary: previous lane's v[3], next lane's v[0]
+  {
+    const float lx_ = __shfl_up(c.v[3].x, 1, 64), ly_ = __shfl_up(c.v[3].y, 1, 64);
+    const float rx_ = __shfl_down(c.v[0].x, 1, 64), ry_ = __shfl_down(c.v[0].y, 1, 64);
+    if (left_ok) left = make_float2(lx_, ly_);
+    if (right_ok) right = make_float2(rx_, ry_);
+  }
+
+  if (!active) return;
 
   Row4 o_layers, o_vel, o_dvel;
   float o_h[kVec], o_wh[kVec], o_m[kVec], o_d[kVec];
@@ -623,8 +626,13 @@ int soil_erode_cells_fused(const soil_erosion_planes* pl, const soil_domain* dom
     const int64_t total = (d.r1 - d.r0) * groups_per_row;
     const unsigned nblk = blocks_for(total, kBlock);
     static const bool nt = [] { const char* e = std::getenv("SOIL_CELLS_NT"); return e && e[0] == '1'; }();  // measured slower than plain accesses; kept for A/B
-    const bool remap = nblk % 8 == 0 && nblk >= 64;
-    if (remap && nt)
+    static const int variant = [] { const char* e = std::getenv("SOIL_CELLS_VARIANT"); return e ? std::atoi(e) : 0; }();
+    const bool remap = nblk % 8 == 0 && nblk >= 64 && variant != 2;
+    if (variant == 1 && (total % 512) == 0 && ((total / 512) % 8) == 0)
+      k_erode_cells_fused<true, false, 512><<<static_cast<unsigned>(total / 512), 512, 0, st>>>(P, d, s3(scale), *param, groups_per_row, total);
+    else if (variant == 3 && (total % 128) == 0 && ((total / 128) % 8) == 0)
+      k_erode_cells_fused<true, false, 128><<<static_cast<unsigned>(total / 128), 128, 0, st>>>(P, d, s3(scale), *param, groups_per_row, total);
+    else if (remap && nt)
       k_erode_cells_fused<true, true><<<nblk, kBlock, 0, st>>>(P, d, s3(scale), *param, groups_per_row, total);
     else if (remap)
       k_erode_cells_fused<true, false><<<nblk, kBlock, 0, st>>>(P, d, s3(scale), *param, groups_per_row, total);
