@@ -34,10 +34,11 @@
 
 namespace soil {
 
-constexpr int kTS = 64;             // tile edge in cells
-constexpr int kTCells = kTS * kTS;  // 4096
-constexpr int kTBlock = 512;        // threads of a tile work-group
-constexpr int kPerThread = kTCells / kTBlock;
+// A tile is TR rows x TC columns of cells (powers of two) and is worked on by
+// TR*TC/8 threads: the acceptance workload spawns one particle per 8 cells
+// (SURVEY 8d), so a round starts with about one particle per lane.
+constexpr int kPerThread = 8;  // cells per thread of a tile work-group
+struct TileShape { int shift_r, shift_c; };  // log2(TR), log2(TC)
 
 enum Kind { FLUVIAL = 0, DEBRIS = 1 };
 
@@ -54,9 +55,9 @@ static_assert(sizeof(PRec) == 64, "PRec must be one 64-byte line");
 // float -> cell coordinate, 32-bit flavour of cell_of (positions are < 2^31)
 __device__ __forceinline__ int cell32(float f) { return (f != f) ? 0 : static_cast<int>(f); }
 
-__device__ __forceinline__ int64_t tile_id(int x0, float px, float py, int tiles_w) {
-  const int lx = cell32(px) - x0, cy = cell32(py);
-  return static_cast<int64_t>(lx / kTS) * tiles_w + cy / kTS;
+__device__ __forceinline__ int64_t tile_id(int x0, float px, float py, int tiles_w, TileShape ts) {
+  const int lx = cell32(px) - x0, cy = cell32(py);  // lx >= 0: parked particles stand on owned rows
+  return static_cast<int64_t>(lx >> ts.shift_r) * tiles_w + (cy >> ts.shift_c);
 }
 
 // per-launch constants of the step (erosion.cu:63-72 / :276-283), hoisted
@@ -175,7 +176,7 @@ __global__ void __launch_bounds__(256)
     k_tiled_spawn(PRec* __restrict__ recs, uint32_t* __restrict__ count,
                   soil_rng* __restrict__ rng, int64_t N, const float4* __restrict__ p4,
                   const float* __restrict__ waterSource, Dom d, Scale3 s, Param param,
-                  int tiles_w) {
+                  int tiles_w, TileShape ts) {
   const int64_t n = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
   if (n >= N) return;
   PRec r;
@@ -239,7 +240,7 @@ __global__ void __launch_bounds__(256)
         r.svx = Q * (-g * grad.x + nu * vel.x);   // :298
         r.svy = Q * (-g * grad.y + nu * vel.y);
       }
-      atomicAdd(&count[tile_id(static_cast<int>(d.x0), pos.x, pos.y, tiles_w)], 1u);
+      atomicAdd(&count[tile_id(static_cast<int>(d.x0), pos.x, pos.y, tiles_w, ts)], 1u);
     }
   }
   recs[n] = r;
@@ -286,21 +287,55 @@ __device__ __forceinline__ uint32_t wave_append(uint32_t* counter, bool pred) {
 __global__ void __launch_bounds__(256)
     k_tiled_scatter(PRec* __restrict__ sorted, uint32_t* __restrict__ fill,
                     const uint32_t* __restrict__ start, const PRec* __restrict__ src,
-                    int64_t n_src, int x0, int tiles_w) {
+                    int64_t n_src, int x0, int tiles_w, TileShape ts) {
   const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
   PRec r;
   r.iter = -1;
   if (i < n_src) r = src[i];
   const bool valid = r.iter >= 0;
-  const int64_t tile = valid ? tile_id(x0, r.px, r.py, tiles_w) : 0;
+  const int64_t tile = valid ? tile_id(x0, r.px, r.py, tiles_w, ts) : 0;
   const uint32_t slot = wave_key_append(fill, valid, tile);
   if (valid) sorted[start[tile] + slot] = r;
 }
 
 // ---- one round: advance the particles of one tile against LDS ---------------------
 
-template <int KIND>
-__global__ void __launch_bounds__(kTBlock)
+// Float adds on LDS words by compare-and-swap, split in two halves so that the
+// swaps' round trip hides under the step arithmetic: begin() reads the old words
+// and issues one swap per plane, finish() (after the step) looks at the results
+// and only a lane that lost a race retries.  ds_add_f32 needs no such care but
+// occupies the LDS pipe ~170 cycles per wave instruction on gfx950 (2.6 per lane;
+// tools/microbench/lds_atomic.hip), a ds_cmpst ~6.
+template <int NP>
+struct CasDeposit {
+  float* p[NP];
+  float v[NP];
+  uint32_t o[NP], g[NP];
+  bool pending = false;
+  static __device__ __forceinline__ uint32_t swap(float* q, uint32_t expect, float add) {
+    return atomicCAS(reinterpret_cast<uint32_t*>(q), expect, f2bits(bits2f(expect) + add));
+  }
+  __device__ __forceinline__ void begin() {
+#pragma unroll
+    for (int j = 0; j < NP; ++j) o[j] = f2bits(*p[j]);
+#pragma unroll
+    for (int j = 0; j < NP; ++j) g[j] = swap(p[j], o[j], v[j]);
+    pending = true;
+  }
+  __device__ __forceinline__ void finish() {
+    if (!pending) return;
+#pragma unroll
+    for (int j = 0; j < NP; ++j)
+      while (g[j] != o[j]) {
+        o[j] = g[j];
+        g[j] = swap(p[j], o[j], v[j]);
+      }
+    pending = false;
+  }
+};
+
+template <int KIND, int DEP, int TR, int TC>
+__global__ void __launch_bounds__(TR * TC / kPerThread)
     k_tiled_round(PRec* __restrict__ out, uint32_t* __restrict__ count_next,
                   const PRec* __restrict__ in, const uint32_t* __restrict__ start,
                   const uint32_t* __restrict__ count, float* __restrict__ flux0,
@@ -308,19 +343,19 @@ __global__ void __launch_bounds__(kTBlock)
                   const float4* __restrict__ p4, const float* __restrict__ waterHeight,
                   float* __restrict__ remote0, Dom d, Scale3 s, Param param, int tiles_w,
                   int steps_per_round) {
+  constexpr int kCells = TR * TC, kBlock = kCells / kPerThread;
+  constexpr TileShape ts = {__builtin_ctz(TR), __builtin_ctz(TC)};
   const int tile = blockIdx.x;
   const uint32_t cnt = count[tile];
   if (cnt == 0) return;
   const uint32_t first = start[tile];
-  const int row0 = (tile / tiles_w) * kTS, col0 = (tile % tiles_w) * kTS;  // local row, column
+  const int row0 = (tile / tiles_w) * TR, col0 = (tile % tiles_w) * TC;  // local row, column
 
-  __shared__ float4 s_fld[kTCells];                      // {gx, gy, vx, vy}
-  __shared__ float s_wh[KIND == FLUVIAL ? kTCells : 1];  // water height
   // flux accumulators as separate planes: lane addresses c map to 32 distinct
-  // banks (an AoS float4 would put every lane of a ds_add_f32 on 8 banks)
-  __shared__ float s_f0[kTCells];                        // fluvial water | debris mass
-  __shared__ float s_f1[KIND == FLUVIAL ? kTCells : 1];  // fluvial mass
-  __shared__ float s_fx[kTCells], s_fy[kTCells];         // velocity flux
+  // banks (an AoS float4 would put every lane of a deposit on 8 banks)
+  __shared__ float s_f0[kCells];                        // fluvial water | debris mass
+  __shared__ float s_f1[KIND == FLUVIAL ? kCells : 1];  // fluvial mass
+  __shared__ float s_fx[kCells], s_fy[kCells];          // velocity flux
   __shared__ uint32_t s_next, s_out;
   const int tid = threadIdx.x;
   if (tid == 0) {
@@ -328,37 +363,20 @@ __global__ void __launch_bounds__(kTBlock)
     s_out = 0;
   }
   const StepConst k = make_const<KIND>(d, s, param);
-
-  {  // stage the tile: all global loads first, then the LDS stores
-    float4 fv[kPerThread];
-    float wv[kPerThread];
 #pragma unroll
-    for (int j = 0; j < kPerThread; ++j) {
-      const int c = tid + j * kTBlock;
-      const int lx = row0 + c / kTS, y = col0 + c % kTS;
-      const bool ok = lx >= k.lo && lx <= k.hi && y < k.W;
-      const int64_t l = static_cast<int64_t>(lx) * k.W + y;
-      fv[j] = ok ? p4[l] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-      wv[j] = (KIND == FLUVIAL && ok) ? waterHeight[l] : 0.0f;
-    }
-#pragma unroll
-    for (int j = 0; j < kPerThread; ++j) {
-      const int c = tid + j * kTBlock;
-      s_fld[c] = fv[j];
-      if (KIND == FLUVIAL) s_wh[c] = wv[j];
-      s_f0[c] = 0.0f;
-      if (KIND == FLUVIAL) s_f1[c] = 0.0f;
-      s_fx[c] = 0.0f;
-      s_fy[c] = 0.0f;
-    }
+  for (int j = 0; j < kPerThread; ++j) {
+    const int c = tid + j * kBlock;
+    s_f0[c] = 0.0f;
+    if (KIND == FLUVIAL) s_f1[c] = 0.0f;
+    s_fx[c] = 0.0f;
+    s_fy[c] = 0.0f;
   }
   __syncthreads();
 
   // A lane that has to park its particle keeps the record in registers and idles;
   // the record is written out only when the lane takes another particle or the
-  // loop is over.  That keeps global-memory traffic (and the vmcnt waits it
-  // causes for the whole wave) out of the stepping loop: a 64x64 tile starts a
-  // round with ~512 particles = one per lane, so refills are the exception.
+  // loop is over: a tile starts a round with about one particle per lane, so
+  // refills are the exception.
   bool have = false, drained = false, parked = false;
   int budget = 0;  // steps this lane may still spend on its particle in this round
   PRec r;
@@ -366,7 +384,7 @@ __global__ void __launch_bounds__(kTBlock)
   auto write_out = [&]() {
     const uint32_t slot = atomicAdd(&s_out, 1u);  // slots this tile's queue occupied
     out[first + slot] = r;
-    atomicAdd(&count_next[tile_id(k.x0, r.px, r.py, tiles_w)], 1u);
+    atomicAdd(&count_next[tile_id(k.x0, r.px, r.py, tiles_w, ts)], 1u);
     parked = false;
   };
   for (;;) {
@@ -393,7 +411,7 @@ __global__ void __launch_bounds__(kTBlock)
         const bool esc = lx < k.lo || lx > k.hi;  // slab_escape
         const int tr = lx - row0, tc = cy - col0;
         const bool inside =
-            esc || (static_cast<unsigned>(tr) < kTS && static_cast<unsigned>(tc) < kTS);
+            esc || (static_cast<unsigned>(tr) < TR && static_cast<unsigned>(tc) < TC);
         if (!inside || budget == 0) {
           // the particle stands on another tile, or its round budget is used
           // up: park it (state untouched) and resume next round
@@ -406,41 +424,57 @@ __global__ void __launch_bounds__(kTBlock)
           have = false;
         } else {
           --budget;
-          const int c = tr * kTS + tc;
-          const float4 f = s_fld[c];  // issued early: its latency hides under the deposit
-          const float wh = (KIND == FLUVIAL) ? s_wh[c] : 0.0f;
+          // the cell's fields come from the packed plane through L1/L2 (the tile's
+          // 80 KiB are touched ~4x per round); issued first, the gather's latency
+          // hides under the deposit and the other waves of the SIMD
+          const int64_t lcell = static_cast<int64_t>(lx) * k.W + cy;
+          const float4 f = p4[lcell];
+          const float wh = (KIND == FLUVIAL) ? waterHeight[lcell] : 0.0f;
+          CasDeposit<KIND == FLUVIAL ? 4 : 3> dep;
+          const int c = tr * TC + tc;
           const int64_t nind = static_cast<int64_t>(cx) * k.W + cy;  // :103 / :309
           if (nind != r.ind) {                                       // :104-113 / :310-318
             r.ind = nind;
-            // ds_add_f32 runs at ~2.6 cycles per LANE on gfx950 (tools/microbench/
-            // lds_atomic.hip: 170 cycles per wave instruction vs 6 for ds_add_u32); a
-            // compare-and-swap formulation is 4x cheaper for the LDS pipe but makes the
-            // wave wait twice per step, and measured no faster in this kernel (2 waves
-            // per SIMD cannot hide it), so the fire-and-forget native atomic stays
+            // DEP 0: native ds_add_f32, fire and forget; DEP 1: CasDeposit
             if (KIND == FLUVIAL) {
-              atomicAdd(&s_f0[c], r.a0 * r.s0);
-              atomicAdd(&s_f1[c], r.a1 * r.s1);
-              atomicAdd(&s_fx[c], r.a2 * r.svx);
-              atomicAdd(&s_fy[c], r.a2 * r.svy);
+              const float v0 = r.a0 * r.s0, v1 = r.a1 * r.s1, vx = r.a2 * r.svx, vy = r.a2 * r.svy;
+              if (DEP == 1) {
+                dep.p[0] = &s_f0[c], dep.p[1] = &s_f1[c], dep.p[2] = &s_fx[c], dep.p[3] = &s_fy[c];
+                dep.v[0] = v0, dep.v[1] = v1, dep.v[2] = vx, dep.v[3] = vy;
+                dep.begin();
+              } else {
+                atomicAdd(&s_f0[c], v0);
+                atomicAdd(&s_f1[c], v1);
+                atomicAdd(&s_fx[c], vx);
+                atomicAdd(&s_fy[c], vy);
+              }
             } else {
-              atomicAdd(&s_f0[c], r.a0 * r.s0);
-              atomicAdd(&s_fx[c], r.a1 * r.svx);
-              atomicAdd(&s_fy[c], r.a1 * r.svy);
+              const float v0 = r.a0 * r.s0, vx = r.a1 * r.svx, vy = r.a1 * r.svy;
+              if (DEP == 1) {
+                dep.p[0] = &s_f0[c], dep.p[1] = &s_fx[c], dep.p[2] = &s_fy[c];
+                dep.v[0] = v0, dep.v[1] = vx, dep.v[2] = vy;
+                dep.begin();
+              } else {
+                atomicAdd(&s_f0[c], v0);
+                atomicAdd(&s_fx[c], vx);
+                atomicAdd(&s_fy[c], vy);
+              }
             }
           }
           have = advance<KIND>(r, f, wh, k);
+          if (DEP == 1) dep.finish();
         }
       }
     }
   }
   {  // everything still parked goes out together (convergent: aggregate the counters)
     const uint32_t slot = wave_append(&s_out, parked);
-    const int64_t dest = parked ? tile_id(k.x0, r.px, r.py, tiles_w) : 0;
+    const int64_t dest = parked ? tile_id(k.x0, r.px, r.py, tiles_w, ts) : 0;
     (void)wave_key_append(count_next, parked, dest);
     if (parked) out[first + slot] = r;
   }
   __syncthreads();
-  for (uint32_t j = s_out + tid; j < cnt; j += kTBlock) out[first + j].iter = -1;  // unused slots
+  for (uint32_t j = s_out + tid; j < cnt; j += kBlock) out[first + j].iter = -1;  // unused slots
 
   // flush the tile's flux into the global planes: one work-group per tile per
   // round, so plain coalesced read-modify-writes suffice; loads first
@@ -450,8 +484,8 @@ __global__ void __launch_bounds__(kTBlock)
     bool ok[kPerThread];
 #pragma unroll
     for (int j = 0; j < kPerThread; ++j) {
-      const int c = tid + j * kTBlock;
-      const int lx = row0 + c / kTS, y = col0 + c % kTS;
+      const int c = tid + j * kBlock;
+      const int lx = row0 + c / TC, y = col0 + c % TC;
       ok[j] = lx < static_cast<int>(d.rows) && y < k.W;
       const int64_t l = static_cast<int64_t>(lx) * k.W + y;
       g0[j] = ok[j] ? flux0[l] : 0.0f;
@@ -461,8 +495,8 @@ __global__ void __launch_bounds__(kTBlock)
 #pragma unroll
     for (int j = 0; j < kPerThread; ++j) {
       if (!ok[j]) continue;
-      const int c = tid + j * kTBlock;
-      const int lx = row0 + c / kTS, y = col0 + c % kTS;
+      const int c = tid + j * kBlock;
+      const int lx = row0 + c / TC, y = col0 + c % TC;
       const int64_t l = static_cast<int64_t>(lx) * k.W + y;
       const float a0 = s_f0[c], ax = s_fx[c], ay = s_fy[c];
       if (a0 != 0.0f) flux0[l] = g0[j] + a0;
@@ -526,13 +560,14 @@ static int env_int(const char* name, int fallback) {
   return v > 0 ? v : fallback;
 }
 
-template <int KIND>
+template <int KIND, int TR, int TC>
 static int run_tiled(float* flux0, float* flux1, float* fluxV, soil_rng* rng, int64_t N,
                      const float* layers, const float* waterSource, const float* waterHeight,
                      const float* velocity, float* remote0, const Dom& d, Scale3 s, const Param& p,
                      hipStream_t st) {
-  const int tiles_w = static_cast<int>((d.W + kTS - 1) / kTS);
-  const int tiles_h = static_cast<int>((d.rows + kTS - 1) / kTS);
+  constexpr TileShape ts = {__builtin_ctz(TR), __builtin_ctz(TC)};
+  const int tiles_w = static_cast<int>((d.W + TC - 1) / TC);
+  const int tiles_h = static_cast<int>((d.rows + TR - 1) / TR);
   const int64_t tiles = static_cast<int64_t>(tiles_w) * tiles_h;
   auto align = [](size_t b) { return (b + 255) & ~static_cast<size_t>(255); };
   const size_t b_rec = align(sizeof(PRec) * N), b_cnt = align(sizeof(uint32_t) * (tiles + 1));
@@ -553,6 +588,7 @@ static int run_tiled(float* flux0, float* flux1, float* fluxV, soil_rng* rng, in
   // its longest walker; and the population below which the rounds stop paying
   static const int steps_per_round = env_int("SOIL_TILED_STEPS", 32);
   static const int tail = env_int("SOIL_TILED_TAIL", 200000);
+  static const int deposit = env_int("SOIL_TILED_DEP", 0);
   static const bool verbose = std::getenv("SOIL_TILED_VERBOSE") != nullptr;
 
   const int64_t lo = stencil_lo(d), hi = stencil_hi(d);
@@ -563,7 +599,7 @@ static int run_tiled(float* flux0, float* flux1, float* fluxV, soil_rng* rng, in
         s, p.exitSlope, lo, cells);
   SOIL_HIP(hipMemsetAsync(count, 0, b_cnt, st));
   k_tiled_spawn<KIND><<<blocks_for(N, 256), 256, 0, st>>>(listA, count, rng, N, p4, waterSource, d,
-                                                          s, p, tiles_w);
+                                                          s, p, tiles_w, ts);
   SOIL_LAUNCH_CHECK();
   int64_t n_src = N;  // length of listA to look at (spawn output, then survivor slots)
   const uint64_t max_rounds = p.maxage + 2;  // every live particle advances >= 1 step per round
@@ -583,9 +619,10 @@ static int run_tiled(float* flux0, float* flux1, float* fluxV, soil_rng* rng, in
     }
     SOIL_HIP(hipMemsetAsync(fill, 0, b_cnt, st));
     k_tiled_scatter<<<blocks_for(n_src, 256), 256, 0, st>>>(listB, fill, start, listA, n_src,
-                                                            static_cast<int>(d.x0), tiles_w);
+                                                            static_cast<int>(d.x0), tiles_w, ts);
     SOIL_HIP(hipMemsetAsync(count_next, 0, b_cnt, st));
-    k_tiled_round<KIND><<<static_cast<unsigned>(tiles), kTBlock, 0, st>>>(
+    auto round_kernel = deposit == 1 ? k_tiled_round<KIND, 0, TR, TC> : k_tiled_round<KIND, 1, TR, TC>;
+    round_kernel<<<static_cast<unsigned>(tiles), TR * TC / kPerThread, 0, st>>>(
         listA, count_next, listB, start, count, flux0, flux1, reinterpret_cast<float2*>(fluxV), p4,
         waterHeight, remote0, d, s, p, tiles_w, steps_per_round);
     SOIL_LAUNCH_CHECK();
@@ -597,19 +634,33 @@ static int run_tiled(float* flux0, float* flux1, float* fluxV, soil_rng* rng, in
   return SOIL_OK;
 }
 
+// tile shape: SOIL_TILED_SHAPE = 0 (64x64, 512 threads; default), 1 (128x64, 1024
+// threads), 2 (32x64, 256 threads), 3 (64x128, 1024 threads)
+template <int KIND, typename... A>
+static int run_shaped(A&&... a) {
+  static const int shape = env_int("SOIL_TILED_SHAPE", 0);
+  switch (shape) {
+    case 1: return run_tiled<KIND, 128, 64>(a...);
+    case 2: return run_tiled<KIND, 32, 64>(a...);
+    case 3: return run_tiled<KIND, 64, 128>(a...);
+    default: return run_tiled<KIND, 64, 64>(a...);
+  }
+}
+
 int launch_fluvial_tiled(float* waterFlux, float* massFlux, float* velocityFlux, soil_rng* rng,
                          int64_t N, const float* layers, const float* waterSource,
                          const float* waterHeight, const float* velocity, float* remote0,
                          const Dom& d, Scale3 s, const Param& p, hipStream_t st) {
-  return run_tiled<FLUVIAL>(waterFlux, massFlux, velocityFlux, rng, N, layers, waterSource,
-                            waterHeight, velocity, remote0, d, s, p, st);
+  return run_shaped<FLUVIAL>(waterFlux, massFlux, velocityFlux, rng, N, layers, waterSource,
+                             waterHeight, velocity, remote0, d, s, p, st);
 }
 
 int launch_debris_tiled(float* massFlux, float* velocityFlux, soil_rng* rng, int64_t N,
                         const float* layers, const float* velocity, float* remote0, const Dom& d,
                         Scale3 s, const Param& p, hipStream_t st) {
-  return run_tiled<DEBRIS>(massFlux, nullptr, velocityFlux, rng, N, layers, nullptr, nullptr,
-                           velocity, remote0, d, s, p, st);
+  return run_shaped<DEBRIS>(massFlux, static_cast<float*>(nullptr), velocityFlux, rng, N, layers,
+                            static_cast<const float*>(nullptr), static_cast<const float*>(nullptr),
+                            velocity, remote0, d, s, p, st);
 }
 
 }  // namespace soil
