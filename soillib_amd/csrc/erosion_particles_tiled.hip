@@ -97,9 +97,9 @@ __device__ __forceinline__ StepConst make_const(const Dom& d, Scale3 s, const Pa
 // The body of one loop iteration AFTER the bookkeeping at its top (oob, ++iter,
 // escape) and the deposit: erosion.cu:116-137 / :321-347.  `f` = {grad, vel} of
 // the current cell, `wh` its water height.  Returns false when the walk ends.
+// `q` is the cell's record of k_tiled_pack.
 template <int KIND>
-__device__ __forceinline__ bool advance(PRec& r, const float4 f, const float wh,
-                                        const StepConst& k) {
+__device__ __forceinline__ bool advance(PRec& r, const float4 q, const StepConst& k) {
   const float v_norm = length2(r.spx, r.spy);            // :116 / :321
   const float ux = r.spx / v_norm, uy = r.spy / v_norm;  // :117 / :322
   const float v_step = stepsize(r.px, r.py, ux, uy);     // :118 / :323
@@ -107,25 +107,25 @@ __device__ __forceinline__ bool advance(PRec& r, const float4 f, const float wh,
   const float ds = dL / v_norm;                          // :120 / :325
   if (v_norm < k.eps) return false;                      // :121-122 / :326-327
   if (KIND == FLUVIAL) {
-    const float ax = -(k.g * f.x) + k.nu * f.z + k.fx;  // :126
-    const float ay = -(k.g * f.y) + k.nu * f.w + k.fy;
+    const float ax = q.x + k.fx;  // :126
+    const float ay = q.y + k.fy;
     const float w0 = 1.0f / (1.0f + dL * (k.tau + k.nu));  // :127
     const float w1 = dL / (1.0f + dL * (k.tau + k.nu));
     r.spx = w0 * r.spx + w1 * ax;
     r.spy = w0 * r.spy + w1 * ay;
-    const float decay_v = 0.125f * k.fD / (k.eps + wh);  // :132
+    const float decay_v = q.z;  // :132
     r.a1 = r.a1 * expf_(-ds * k.kd);                     // att_m :134
     r.a0 = r.a0 * expf_(-ds * k.evap);                   // att_w :135
     r.a2 = r.a2 * expf_(-dL * decay_v);                  // att_v :136
   } else {
     const float debrisHeight = k.eps + r.a0 * r.s0;  // :331
-    const float ax = -(k.g * f.x) + k.nu * f.z;      // :332
-    const float ay = -(k.g * f.y) + k.nu * f.w;
+    const float ax = q.x;  // :332
+    const float ay = q.y;
     const float decay = k.nu + k.tau / debrisHeight;  // :333
     const float w = 1.0f / (1.0f + dL * decay);       // :334
     r.spx = w * r.spx + w * dL * ax;                  // :335
     r.spy = w * r.spy + w * dL * ay;
-    const float excessSlope = length2(f.x, f.y) - k.theta;                    // :339
+    const float excessSlope = q.z;                                            // :339
     const float excessStress = k.g * (excessSlope - k.tau_y / debrisHeight);  // :340
     const float shearRate = (excessStress < 0.0f) ? k.kdd : k.kds;            // :341
     const float decay_d = ds * shearRate * excessStress / v_norm;             // :342
@@ -154,19 +154,43 @@ __device__ __forceinline__ void park_remote(const PRec& r, float* __restrict__ r
   }
 }
 
-// ---- pre-pass: p4[cell] = {__glocal(cell), velocity[cell]} ------------------------
+// ---- pre-pass: everything a step needs from the cell it stands on ------------------
+//
+// All cell-only sub-expressions of the loop body are evaluated once per cell
+// (instead of once per visit, ~30x) with the operations and order of the
+// reference, so a step is one 16-byte gather:
+//   fluvial {a0x, a0y, decay_v, power}: a0 = -(g*grad) + nu*vel  (:77,:90,:126 before
+//            `+ force`), decay_v = 0.125*fD/(eps + waterHeight) (:132),
+//            power = pow(shear*|grad|, alpha) (:83-85, used at spawn)
+//   debris  {ax, ay, excessSlope, 0}:   a = -(g*grad) + nu*vel (:288,:298,:332),
+//            excessSlope = |grad| - critSlopeBedrock (:294,:339)
 
+template <int KIND>
 __global__ void __launch_bounds__(256)
-    k_tiled_pack(float4* __restrict__ p4, const float2* __restrict__ layers,
-                 const float2* __restrict__ velocity, Dom d, Scale3 s, float exitSlope,
-                 int64_t row_lo, int64_t cells) {
+    k_tiled_pack(float4* __restrict__ q4, const float2* __restrict__ layers,
+                 const float2* __restrict__ velocity, const float* __restrict__ waterHeight,
+                 Dom d, Scale3 s, Param param, int64_t row_lo, int64_t cells) {
   const int64_t t = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
   if (t >= cells) return;
   const int64_t lx = row_lo + t / d.W, y = t % d.W;
   const int64_t l = lx * d.W + y;
-  const float2 g = glocal(layers, d, s, d.x0 + lx, y, exitSlope);
-  const float2 v = velocity[l];
-  p4[l] = make_float4(g.x, g.y, v.x, v.y);
+  const float2 grad = glocal(layers, d, s, d.x0 + lx, y, param.exitSlope);
+  const float2 vel = velocity[l];
+  const float g = param.gravity;
+  if (KIND == FLUVIAL) {
+    const float nu = param.viscosityWater;
+    const float fD = param.frictionFactor / 8.0f;  // :70
+    const float eps = 1E-12f;
+    const float v = length2(vel.x, vel.y);                                              // :83
+    const float shear = 0.125f * fD * param.densityWater * v * v;                       // :84
+    const float power = powf_(shear * length2(grad.x, grad.y), param.fluvialExponent);  // :85
+    q4[l] = make_float4(-(g * grad.x) + nu * vel.x, -(g * grad.y) + nu * vel.y,
+                        0.125f * fD / (eps + waterHeight[l]), power);
+  } else {
+    const float nu = param.viscosityDebris;
+    q4[l] = make_float4(-(g * grad.x) + nu * vel.x, -(g * grad.y) + nu * vel.y,
+                        length2(grad.x, grad.y) - param.critSlopeBedrock, 0.0f);
+  }
 }
 
 // ---- spawn: draws, ownership, trajectory initialisation (erosion.cu:49-96 / :262-302)
@@ -190,18 +214,14 @@ __global__ void __launch_bounds__(256)
     const int64_t cx = cell_of(pos.x), cy = cell_of(pos.y);
     const int64_t ind = cx * d.W + cy;
     const int64_t l = ind - d.x0 * d.W;
-    const float g = param.gravity;
-    const float4 f = p4[l];
-    const float2 grad = make_float2(f.x, f.y), vel = make_float2(f.z, f.w);
+    const float4 q = p4[l];
     float spx, spy;
     if (KIND == FLUVIAL) {
-      const float nu = param.viscosityWater;
-      spx = -(g * grad.x) + nu * vel.x + param.force[0];  // :77
-      spy = -(g * grad.y) + nu * vel.y + param.force[1];
+      spx = q.x + param.force[0];  // :77
+      spy = q.y + param.force[1];
     } else {
-      const float nu = param.viscosityDebris;
-      spx = -(g * grad.x) + nu * vel.x;  // :288
-      spy = -(g * grad.y) + nu * vel.y;
+      spx = q.x;  // :288
+      spy = q.y;
     }
     const float den = sqrtf(length2(s.x * spx, s.y * spy));  // :78 / :289
     spx = spx / den;
@@ -215,30 +235,23 @@ __global__ void __launch_bounds__(256)
       r.iter = 0;
       r.pad[0] = r.pad[1] = 0;
       if (KIND == FLUVIAL) {
-        const float nu = param.viscosityWater;
         const float ks = param.suspensionRateFluvial / 64.0f;  // :68
-        const float fD = param.frictionFactor / 8.0f;          // :70
-        const float v = length2(vel.x, vel.y);                 // :83
-        const float shear = 0.125f * fD * param.densityWater * v * v;                       // :84
-        const float power = powf_(shear * length2(grad.x, grad.y), param.fluvialExponent);  // :85
         r.a0 = 1.0f;                                  // att_w
         r.a1 = 1.0f;                                  // att_m
         r.a2 = 1.0f;                                  // att_v
         r.s0 = Q * param.rainfall * waterSource[l];   // source_w :89
-        r.s1 = Q * ks * power;                        // source_m :88
-        r.svx = Q * (-(g * grad.x) + nu * vel.x);     // :90
-        r.svy = Q * (-(g * grad.y) + nu * vel.y);
+        r.s1 = Q * ks * q.w;                          // source_m :88
+        r.svx = Q * q.x;                              // :90
+        r.svy = Q * q.y;
       } else {
-        const float nu = param.viscosityDebris;
-        const float excessSlope0 = length2(grad.x, grad.y) - param.critSlopeBedrock;  // :294
-        const float suspend = fmaxf(0.0f, param.landslideRateDebris * excessSlope0);  // :295
+        const float suspend = fmaxf(0.0f, param.landslideRateDebris * q.z);  // :295
         r.a0 = 1.0f;                              // att_d
         r.a1 = 1.0f;                              // att_v
         r.a2 = 0.0f;
         r.s0 = Q * suspend;                       // source_d :297
         r.s1 = 0.0f;
-        r.svx = Q * (-g * grad.x + nu * vel.x);   // :298
-        r.svy = Q * (-g * grad.y + nu * vel.y);
+        r.svx = Q * q.x;                          // :298
+        r.svy = Q * q.y;
       }
       atomicAdd(&count[tile_id(static_cast<int>(d.x0), pos.x, pos.y, tiles_w, ts)], 1u);
     }
@@ -424,12 +437,11 @@ __global__ void __launch_bounds__(TR * TC / kPerThread)
           have = false;
         } else {
           --budget;
-          // the cell's fields come from the packed plane through L1/L2 (the tile's
-          // 80 KiB are touched ~4x per round); issued first, the gather's latency
+          // the cell's record comes from the packed plane through L1/L2 (the tile's
+          // 64 KiB are touched ~4x per round); issued first, the gather's latency
           // hides under the deposit and the other waves of the SIMD
           const int64_t lcell = static_cast<int64_t>(lx) * k.W + cy;
-          const float4 f = p4[lcell];
-          const float wh = (KIND == FLUVIAL) ? waterHeight[lcell] : 0.0f;
+          const float4 q = p4[lcell];
           CasDeposit<KIND == FLUVIAL ? 4 : 3> dep;
           const int c = tr * TC + tc;
           const int64_t nind = static_cast<int64_t>(cx) * k.W + cy;  // :103 / :309
@@ -461,7 +473,7 @@ __global__ void __launch_bounds__(TR * TC / kPerThread)
               }
             }
           }
-          have = advance<KIND>(r, f, wh, k);
+          have = advance<KIND>(r, q, k);
           if (DEP == 1) dep.finish();
         }
       }
@@ -535,8 +547,7 @@ __global__ void __launch_bounds__(256)
     }
     const int64_t nind = static_cast<int64_t>(cx) * k.W + cy;
     const int64_t l = nind - base;
-    const float4 f = p4[l];
-    const float wh = (KIND == FLUVIAL) ? waterHeight[l] : 0.0f;
+    const float4 q = p4[l];
     if (nind != r.ind) {
       r.ind = nind;
       if (KIND == FLUVIAL) {
@@ -550,7 +561,7 @@ __global__ void __launch_bounds__(256)
         atomicAdd(&fluxV[2 * l + 1], r.a1 * r.svy);
       }
     }
-    if (!advance<KIND>(r, f, wh, k)) break;
+    if (!advance<KIND>(r, q, k)) break;
   }
 }
 
@@ -594,9 +605,9 @@ static int run_tiled(float* flux0, float* flux1, float* fluxV, soil_rng* rng, in
   const int64_t lo = stencil_lo(d), hi = stencil_hi(d);
   const int64_t cells = (hi - lo + 1) * d.W;
   if (cells > 0)
-    k_tiled_pack<<<blocks_for(cells, 256), 256, 0, st>>>(
-        p4, reinterpret_cast<const float2*>(layers), reinterpret_cast<const float2*>(velocity), d,
-        s, p.exitSlope, lo, cells);
+    k_tiled_pack<KIND><<<blocks_for(cells, 256), 256, 0, st>>>(
+        p4, reinterpret_cast<const float2*>(layers), reinterpret_cast<const float2*>(velocity),
+        waterHeight, d, s, p, lo, cells);
   SOIL_HIP(hipMemsetAsync(count, 0, b_cnt, st));
   k_tiled_spawn<KIND><<<blocks_for(N, 256), 256, 0, st>>>(listA, count, rng, N, p4, waterSource, d,
                                                           s, p, tiles_w, ts);
