@@ -27,8 +27,10 @@
 // state is only ever parked at the top of an iteration, before `++iter` — so
 // every trajectory and every deposit is bit-identical to the direct launch
 // shape; only the order of the fp32 additions into a cell differs.
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <vector>
 
 #include "particles_common.hpp"
 
@@ -37,8 +39,9 @@ namespace soil {
 // A tile is TR rows x TC columns of cells (powers of two) and is worked on by
 // TR*TC/8 threads: the acceptance workload spawns one particle per 8 cells
 // (SURVEY 8d), so a round starts with about one particle per lane.
-constexpr int kPerThread = 8;  // cells per thread of a tile work-group
+constexpr int kPerThread = 8;  // cells per particle at spawn
 struct TileShape { int shift_r, shift_c; };  // log2(TR), log2(TC)
+constexpr uint32_t kNoTile = 0xffffffffu;     // dest[] of an empty record slot
 
 enum Kind { FLUVIAL = 0, DEBRIS = 1 };
 
@@ -197,14 +200,14 @@ __global__ void __launch_bounds__(256)
 
 template <int KIND>
 __global__ void __launch_bounds__(256)
-    k_tiled_spawn(PRec* __restrict__ recs, uint32_t* __restrict__ count,
-                  soil_rng* __restrict__ rng, int64_t N, const float4* __restrict__ p4,
+    k_tiled_spawn(PRec* __restrict__ recs, uint32_t* __restrict__ dest,
+                  uint32_t* __restrict__ count, soil_rng* __restrict__ rng, int64_t N, const float4* __restrict__ p4,
                   const float* __restrict__ waterSource, Dom d, Scale3 s, Param param,
                   int tiles_w, TileShape ts) {
   const int64_t n = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
   if (n >= N) return;
   PRec r;
-  r.iter = -1;
+  uint32_t tile = kNoTile;
   const float2 pos = spawn_position(rng, n, d);
   if (owns_spawn(d, pos.x)) {
     const float A = s.x * s.y;
@@ -253,10 +256,12 @@ __global__ void __launch_bounds__(256)
         r.svx = Q * q.x;                          // :298
         r.svy = Q * q.y;
       }
-      atomicAdd(&count[tile_id(static_cast<int>(d.x0), pos.x, pos.y, tiles_w, ts)], 1u);
+      tile = static_cast<uint32_t>(tile_id(static_cast<int>(d.x0), pos.x, pos.y, tiles_w, ts));
+      atomicAdd(&count[tile], 1u);
+      recs[n] = r;
     }
   }
-  recs[n] = r;
+  dest[n] = tile;
 }
 
 // Convergent per-key aggregation of atomicAdd(&counter[key], 1): lanes of a wave
@@ -295,20 +300,21 @@ __device__ __forceinline__ uint32_t wave_append(uint32_t* counter, bool pred) {
   return base + static_cast<uint32_t>(__popcll(mask & ((1ull << lane) - 1ull)));
 }
 
-// ---- counting sort of a record list by tile -----------------------------------------
+// ---- counting sort of the record slots by tile ---------------------------------------
+//
+// dest[i] is the tile record slot i is bound for (kNoTile: empty slot), written by
+// whoever filled the slot; only the 4-byte slot indices are sorted, the 64-byte
+// records stay where they are and are gathered by the round kernel.
 
 __global__ void __launch_bounds__(256)
-    k_tiled_scatter(PRec* __restrict__ sorted, uint32_t* __restrict__ fill,
-                    const uint32_t* __restrict__ start, const PRec* __restrict__ src,
-                    int64_t n_src, int x0, int tiles_w, TileShape ts) {
+    k_tiled_scatter(uint32_t* __restrict__ order, uint32_t* __restrict__ fill,
+                    const uint32_t* __restrict__ start, const uint32_t* __restrict__ dest,
+                    int64_t n_src) {
   const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
-  PRec r;
-  r.iter = -1;
-  if (i < n_src) r = src[i];
-  const bool valid = r.iter >= 0;
-  const int64_t tile = valid ? tile_id(x0, r.px, r.py, tiles_w, ts) : 0;
-  const uint32_t slot = wave_key_append(fill, valid, tile);
-  if (valid) sorted[start[tile] + slot] = r;
+  const uint32_t tile = i < n_src ? dest[i] : kNoTile;
+  const bool valid = tile != kNoTile;
+  const uint32_t slot = wave_key_append(fill, valid, static_cast<int64_t>(tile));
+  if (valid) order[start[tile] + slot] = static_cast<uint32_t>(i);
 }
 
 // ---- one round: advance the particles of one tile against LDS ---------------------
@@ -347,17 +353,17 @@ struct CasDeposit {
   }
 };
 
-template <int KIND, int DEP, int TR, int TC>
-__global__ void __launch_bounds__(TR * TC / kPerThread)
-    k_tiled_round(PRec* __restrict__ out, uint32_t* __restrict__ count_next,
-                  const PRec* __restrict__ in, const uint32_t* __restrict__ start,
+template <int KIND, int DEP, int TR, int TC, int NT>
+__global__ void __launch_bounds__(NT)
+    k_tiled_round(PRec* __restrict__ out, uint32_t* __restrict__ dest,
+                  uint32_t* __restrict__ count_next, const PRec* __restrict__ in,
+                  const uint32_t* __restrict__ order, const uint32_t* __restrict__ start,
                   const uint32_t* __restrict__ count, float* __restrict__ flux0,
                   float* __restrict__ flux1, float2* __restrict__ fluxV,
                   const float4* __restrict__ p4, const float* __restrict__ waterHeight,
                   float* __restrict__ remote0, Dom d, Scale3 s, Param param, int tiles_w,
-                  int steps_per_round) {
-  constexpr int kCells = TR * TC, kBlock = kCells / kPerThread;
-  constexpr TileShape ts = {__builtin_ctz(TR), __builtin_ctz(TC)};
+                  int steps_per_round, TileShape ts_next, int tiles_w_next) {
+  constexpr int kCells = TR * TC, kBlock = NT, kPer = (kCells + NT - 1) / NT;
   const int tile = blockIdx.x;
   const uint32_t cnt = count[tile];
   if (cnt == 0) return;
@@ -377,8 +383,9 @@ __global__ void __launch_bounds__(TR * TC / kPerThread)
   }
   const StepConst k = make_const<KIND>(d, s, param);
 #pragma unroll
-  for (int j = 0; j < kPerThread; ++j) {
+  for (int j = 0; j < kPer; ++j) {
     const int c = tid + j * kBlock;
+    if (kCells % NT != 0 && c >= kCells) break;
     s_f0[c] = 0.0f;
     if (KIND == FLUVIAL) s_f1[c] = 0.0f;
     s_fx[c] = 0.0f;
@@ -391,21 +398,23 @@ __global__ void __launch_bounds__(TR * TC / kPerThread)
   // loop is over: a tile starts a round with about one particle per lane, so
   // refills are the exception.
   bool have = false, drained = false, parked = false;
-  int budget = 0;  // steps this lane may still spend on its particle in this round
   PRec r;
   r.iter = -1;
   auto write_out = [&]() {
     const uint32_t slot = atomicAdd(&s_out, 1u);  // slots this tile's queue occupied
+    const uint32_t to = static_cast<uint32_t>(tile_id(k.x0, r.px, r.py, tiles_w_next, ts_next));
     out[first + slot] = r;
-    atomicAdd(&count_next[tile_id(k.x0, r.px, r.py, tiles_w, ts)], 1u);
+    dest[first + slot] = to;
+    atomicAdd(&count_next[to], 1u);
     parked = false;
   };
+  int budget = 0;  // steps this lane may still spend on its particle in this round
   for (;;) {
     if (!have && !drained) {  // take the next particle of this tile's queue
       const uint32_t i = atomicAdd(&s_next, 1u);
       if (i < cnt) {
         if (parked) write_out();
-        r = in[first + i];
+        r = in[order[first + i]];
         have = true;
         budget = steps_per_round;
       } else {
@@ -481,31 +490,34 @@ __global__ void __launch_bounds__(TR * TC / kPerThread)
   }
   {  // everything still parked goes out together (convergent: aggregate the counters)
     const uint32_t slot = wave_append(&s_out, parked);
-    const int64_t dest = parked ? tile_id(k.x0, r.px, r.py, tiles_w, ts) : 0;
-    (void)wave_key_append(count_next, parked, dest);
-    if (parked) out[first + slot] = r;
+    const int64_t dest_tile = parked ? tile_id(k.x0, r.px, r.py, tiles_w_next, ts_next) : 0;
+    (void)wave_key_append(count_next, parked, dest_tile);
+    if (parked) {
+      out[first + slot] = r;
+      dest[first + slot] = static_cast<uint32_t>(dest_tile);
+    }
   }
   __syncthreads();
-  for (uint32_t j = s_out + tid; j < cnt; j += kBlock) out[first + j].iter = -1;  // unused slots
+  for (uint32_t j = s_out + tid; j < cnt; j += kBlock) dest[first + j] = kNoTile;  // unused slots
 
   // flush the tile's flux into the global planes: one work-group per tile per
   // round, so plain coalesced read-modify-writes suffice; loads first
   {
-    float g0[kPerThread], g1[kPerThread];
-    float2 gv[kPerThread];
-    bool ok[kPerThread];
+    float g0[kPer], g1[kPer];
+    float2 gv[kPer];
+    bool ok[kPer];
 #pragma unroll
-    for (int j = 0; j < kPerThread; ++j) {
+    for (int j = 0; j < kPer; ++j) {
       const int c = tid + j * kBlock;
       const int lx = row0 + c / TC, y = col0 + c % TC;
-      ok[j] = lx < static_cast<int>(d.rows) && y < k.W;
+      ok[j] = c < kCells && lx < static_cast<int>(d.rows) && y < k.W;
       const int64_t l = static_cast<int64_t>(lx) * k.W + y;
       g0[j] = ok[j] ? flux0[l] : 0.0f;
       g1[j] = (KIND == FLUVIAL && ok[j]) ? flux1[l] : 0.0f;
       gv[j] = ok[j] ? fluxV[l] : make_float2(0.0f, 0.0f);
     }
 #pragma unroll
-    for (int j = 0; j < kPerThread; ++j) {
+    for (int j = 0; j < kPer; ++j) {
       if (!ok[j]) continue;
       const int c = tid + j * kBlock;
       const int lx = row0 + c / TC, y = col0 + c % TC;
@@ -525,14 +537,15 @@ __global__ void __launch_bounds__(TR * TC / kPerThread)
 
 template <int KIND>
 __global__ void __launch_bounds__(256)
-    k_tiled_finish(const PRec* __restrict__ recs, int64_t n, float* __restrict__ flux0,
+    k_tiled_finish(const PRec* __restrict__ recs, const uint32_t* __restrict__ dest, int64_t n,
+                   float* __restrict__ flux0,
                    float* __restrict__ flux1, float* __restrict__ fluxV,
                    const float4* __restrict__ p4, const float* __restrict__ waterHeight,
                    float* __restrict__ remote0, Dom d, Scale3 s, Param param) {
   const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
   if (i >= n) return;
+  if (dest[i] == kNoTile) return;
   PRec r = recs[i];
-  if (r.iter < 0) return;
   const StepConst k = make_const<KIND>(d, s, param);
   const int64_t base = static_cast<int64_t>(k.x0) * k.W;
   for (;;) {
@@ -571,36 +584,72 @@ static int env_int(const char* name, int fallback) {
   return v > 0 ? v : fallback;
 }
 
-template <int KIND, int TR, int TC>
+// Tile shapes a round can use: rows x columns (powers of two) and threads of the
+// work-group.  Every round re-sorts the particles by tile, so the shape may change
+// from round to round: early rounds have ~1 particle per 8 cells everywhere (big
+// tiles, few exits); later the particles sit in channels and most tiles are
+// sparse, where smaller tiles keep more work-groups resident per CU.
+struct RoundShape { int tr, tc, nt; };
+static constexpr RoundShape kShapes[] = {{64, 64, 512}, {64, 64, 768}, {32, 64, 256}, {32, 32, 128}};
+constexpr int kNumShapes = sizeof(kShapes) / sizeof(kShapes[0]);
+
+template <int KIND, int DEP, typename... A>
+static void launch_round(int shape, unsigned grid, hipStream_t st, A... a) {
+  switch (shape) {
+    case 1: k_tiled_round<KIND, DEP, 64, 64, 768><<<grid, 768, 0, st>>>(a...); break;
+    case 2: k_tiled_round<KIND, DEP, 32, 64, 256><<<grid, 256, 0, st>>>(a...); break;
+    case 3: k_tiled_round<KIND, DEP, 32, 32, 128><<<grid, 128, 0, st>>>(a...); break;
+    default: k_tiled_round<KIND, DEP, 64, 64, 512><<<grid, 512, 0, st>>>(a...); break;
+  }
+}
+
+template <int KIND>
 static int run_tiled(float* flux0, float* flux1, float* fluxV, soil_rng* rng, int64_t N,
                      const float* layers, const float* waterSource, const float* waterHeight,
                      const float* velocity, float* remote0, const Dom& d, Scale3 s, const Param& p,
                      hipStream_t st) {
-  constexpr TileShape ts = {__builtin_ctz(TR), __builtin_ctz(TC)};
-  const int tiles_w = static_cast<int>((d.W + TC - 1) / TC);
-  const int tiles_h = static_cast<int>((d.rows + TR - 1) / TR);
-  const int64_t tiles = static_cast<int64_t>(tiles_w) * tiles_h;
-  auto align = [](size_t b) { return (b + 255) & ~static_cast<size_t>(255); };
-  const size_t b_rec = align(sizeof(PRec) * N), b_cnt = align(sizeof(uint32_t) * (tiles + 1));
-  const size_t b_p4 = align(sizeof(float4) * d.rows * d.W);
-  void* base = nullptr;
-  int rc = workspace_get(2, 2 * b_rec + 4 * b_cnt + b_p4, &base);
-  if (rc != SOIL_OK) return rc;
-  char* w = static_cast<char*>(base);
-  PRec* listA = reinterpret_cast<PRec*>(w);  w += b_rec;   // spawn output / survivors
-  PRec* listB = reinterpret_cast<PRec*>(w);  w += b_rec;   // sorted by tile
-  float4* p4 = reinterpret_cast<float4*>(w);  w += b_p4;
-  uint32_t* count = reinterpret_cast<uint32_t*>(w);       w += b_cnt;
-  uint32_t* count_next = reinterpret_cast<uint32_t*>(w);  w += b_cnt;
-  uint32_t* start = reinterpret_cast<uint32_t*>(w);       w += b_cnt;
-  uint32_t* fill = reinterpret_cast<uint32_t*>(w);
-
   // steps a particle may take per round: bounds the time a work-group waits for
   // its longest walker; and the population below which the rounds stop paying
   static const int steps_per_round = env_int("SOIL_TILED_STEPS", 32);
   static const int tail = env_int("SOIL_TILED_TAIL", 200000);
   static const int deposit = env_int("SOIL_TILED_DEP", 0);
+  // measured at 8192^2 (N = cells/8): 768 threads on a 64x64 tile serve the fluvial
+  // queues (about half of them hold 513..700 particles) in one batch, 45 vs 48 ms;
+  // the debris kernel keeps 3 work-groups of 512 per CU instead, 17 vs 20 ms
+  static const int shape_early =
+      (std::getenv("SOIL_TILED_SHAPE") ? env_int("SOIL_TILED_SHAPE", 0) : (KIND == FLUVIAL ? 1 : 0)) %
+      kNumShapes;
+  static const int shape_late = env_int("SOIL_TILED_LATE", shape_early) % kNumShapes;
+  static const int switch_round = env_int("SOIL_TILED_SWITCH", 1 << 30);
   static const bool verbose = std::getenv("SOIL_TILED_VERBOSE") != nullptr;
+  auto shape_of = [&](uint64_t round) {
+    return round >= static_cast<uint64_t>(switch_round) ? shape_late : shape_early;
+  };
+  auto tiles_w_of = [&](int sh) { return static_cast<int>((d.W + kShapes[sh].tc - 1) / kShapes[sh].tc); };
+  auto tiles_of = [&](int sh) {
+    return static_cast<int64_t>(tiles_w_of(sh)) * ((d.rows + kShapes[sh].tr - 1) / kShapes[sh].tr);
+  };
+  auto ts_of = [&](int sh) {
+    return TileShape{__builtin_ctz(kShapes[sh].tr), __builtin_ctz(kShapes[sh].tc)};
+  };
+  const int64_t max_tiles = std::max(tiles_of(shape_early), tiles_of(shape_late));
+
+  auto align = [](size_t b) { return (b + 255) & ~static_cast<size_t>(255); };
+  const size_t b_rec = align(sizeof(PRec) * N), b_cnt = align(sizeof(uint32_t) * (max_tiles + 1));
+  const size_t b_p4 = align(sizeof(float4) * d.rows * d.W), b_idx = align(sizeof(uint32_t) * N);
+  void* base = nullptr;
+  int rc = workspace_get(2, 2 * b_rec + 2 * b_idx + 4 * b_cnt + b_p4, &base);
+  if (rc != SOIL_OK) return rc;
+  char* w = static_cast<char*>(base);
+  PRec* cur = reinterpret_cast<PRec*>(w);    w += b_rec;   // records of this round (any order)
+  PRec* next = reinterpret_cast<PRec*>(w);   w += b_rec;   // survivors, grouped by the tile they left
+  uint32_t* dest = reinterpret_cast<uint32_t*>(w);   w += b_idx;  // tile each slot is bound for
+  uint32_t* order = reinterpret_cast<uint32_t*>(w);  w += b_idx;  // slots sorted by tile
+  float4* p4 = reinterpret_cast<float4*>(w);  w += b_p4;
+  uint32_t* count = reinterpret_cast<uint32_t*>(w);       w += b_cnt;
+  uint32_t* count_next = reinterpret_cast<uint32_t*>(w);  w += b_cnt;
+  uint32_t* start = reinterpret_cast<uint32_t*>(w);       w += b_cnt;
+  uint32_t* fill = reinterpret_cast<uint32_t*>(w);
 
   const int64_t lo = stencil_lo(d), hi = stencil_hi(d);
   const int64_t cells = (hi - lo + 1) * d.W;
@@ -609,69 +658,85 @@ static int run_tiled(float* flux0, float* flux1, float* fluxV, soil_rng* rng, in
         p4, reinterpret_cast<const float2*>(layers), reinterpret_cast<const float2*>(velocity),
         waterHeight, d, s, p, lo, cells);
   SOIL_HIP(hipMemsetAsync(count, 0, b_cnt, st));
-  k_tiled_spawn<KIND><<<blocks_for(N, 256), 256, 0, st>>>(listA, count, rng, N, p4, waterSource, d,
-                                                          s, p, tiles_w, ts);
+  k_tiled_spawn<KIND><<<blocks_for(N, 256), 256, 0, st>>>(
+      cur, dest, count, rng, N, p4, waterSource, d, s, p, tiles_w_of(shape_of(0)), ts_of(shape_of(0)));
   SOIL_LAUNCH_CHECK();
-  int64_t n_src = N;  // length of listA to look at (spawn output, then survivor slots)
+  int64_t n_src = N;  // slots of `cur` to look at (spawn output, then survivor slots)
   const uint64_t max_rounds = p.maxage + 2;  // every live particle advances >= 1 step per round
   for (uint64_t round = 0; round < max_rounds; ++round) {
+    const int sh = shape_of(round), sh_next = shape_of(round + 1);
+    const int64_t tiles = tiles_of(sh);
+    const int tiles_w = tiles_w_of(sh);
     k_tile_scan<<<1, 1024, 0, st>>>(start, count, tiles);
     uint32_t live = 0;  // particles queued for this round = start[tiles]
     SOIL_HIP(hipMemcpyAsync(&live, start + tiles, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     SOIL_HIP(hipStreamSynchronize(st));
-    if (verbose) std::fprintf(stderr, "[tiled kind %d] round %llu: %u live\n", KIND,
-                              static_cast<unsigned long long>(round), live);
+    if (verbose) {  // queue-length statistics of the round (diagnostics only)
+      std::vector<uint32_t> h(static_cast<size_t>(tiles));
+      SOIL_HIP(hipMemcpy(h.data(), count, sizeof(uint32_t) * tiles, hipMemcpyDeviceToHost));
+      std::sort(h.begin(), h.end());
+      const int lanes = kShapes[sh].nt;
+      uint64_t batches = 0, empty = 0, sparse = 0;
+      for (uint32_t c : h) {
+        batches += (c + lanes - 1) / lanes;
+        empty += c == 0;
+        sparse += c > 0 && c < static_cast<uint32_t>(lanes) / 4;
+      }
+      std::fprintf(stderr,
+                   "[tiled kind %d] round %llu: %u live; tiles %lld empty %llu sparse(<1/4) %llu "
+                   "median %u p90 %u p99 %u max %u batches %llu\n",
+                   KIND, static_cast<unsigned long long>(round), live, static_cast<long long>(tiles),
+                   static_cast<unsigned long long>(empty), static_cast<unsigned long long>(sparse),
+                   h[h.size() / 2], h[h.size() * 9 / 10], h[h.size() * 99 / 100], h.back(),
+                   static_cast<unsigned long long>(batches));
+    }
     if (live == 0) break;
     if (static_cast<int64_t>(live) <= tail && round > 0) {
       k_tiled_finish<KIND><<<blocks_for(n_src, 256), 256, 0, st>>>(
-          listA, n_src, flux0, flux1, fluxV, p4, waterHeight, remote0, d, s, p);
+          cur, dest, n_src, flux0, flux1, fluxV, p4, waterHeight, remote0, d, s, p);
       SOIL_LAUNCH_CHECK();
       break;
     }
     SOIL_HIP(hipMemsetAsync(fill, 0, b_cnt, st));
-    k_tiled_scatter<<<blocks_for(n_src, 256), 256, 0, st>>>(listB, fill, start, listA, n_src,
-                                                            static_cast<int>(d.x0), tiles_w, ts);
+    k_tiled_scatter<<<blocks_for(n_src, 256), 256, 0, st>>>(order, fill, start, dest, n_src);
     SOIL_HIP(hipMemsetAsync(count_next, 0, b_cnt, st));
-    auto round_kernel = deposit == 1 ? k_tiled_round<KIND, 0, TR, TC> : k_tiled_round<KIND, 1, TR, TC>;
-    round_kernel<<<static_cast<unsigned>(tiles), TR * TC / kPerThread, 0, st>>>(
-        listA, count_next, listB, start, count, flux0, flux1, reinterpret_cast<float2*>(fluxV), p4,
-        waterHeight, remote0, d, s, p, tiles_w, steps_per_round);
+    if (deposit == 1)
+      launch_round<KIND, 0>(sh, static_cast<unsigned>(tiles), st, next, dest, count_next,
+                            static_cast<const PRec*>(cur), static_cast<const uint32_t*>(order),
+                            static_cast<const uint32_t*>(start),
+                            static_cast<const uint32_t*>(count), flux0, flux1,
+                            reinterpret_cast<float2*>(fluxV), static_cast<const float4*>(p4),
+                            waterHeight, remote0, d, s, p, tiles_w, steps_per_round, ts_of(sh_next),
+                            tiles_w_of(sh_next));
+    else
+      launch_round<KIND, 1>(sh, static_cast<unsigned>(tiles), st, next, dest, count_next,
+                            static_cast<const PRec*>(cur), static_cast<const uint32_t*>(order),
+                            static_cast<const uint32_t*>(start),
+                            static_cast<const uint32_t*>(count), flux0, flux1,
+                            reinterpret_cast<float2*>(fluxV), static_cast<const float4*>(p4),
+                            waterHeight, remote0, d, s, p, tiles_w, steps_per_round, ts_of(sh_next),
+                            tiles_w_of(sh_next));
     SOIL_LAUNCH_CHECK();
     n_src = live;
-    uint32_t* t = count;
-    count = count_next;
-    count_next = t;
+    std::swap(cur, next);
+    std::swap(count, count_next);
   }
   return SOIL_OK;
-}
-
-// tile shape: SOIL_TILED_SHAPE = 0 (64x64, 512 threads; default), 1 (128x64, 1024
-// threads), 2 (32x64, 256 threads), 3 (64x128, 1024 threads)
-template <int KIND, typename... A>
-static int run_shaped(A&&... a) {
-  static const int shape = env_int("SOIL_TILED_SHAPE", 0);
-  switch (shape) {
-    case 1: return run_tiled<KIND, 128, 64>(a...);
-    case 2: return run_tiled<KIND, 32, 64>(a...);
-    case 3: return run_tiled<KIND, 64, 128>(a...);
-    default: return run_tiled<KIND, 64, 64>(a...);
-  }
 }
 
 int launch_fluvial_tiled(float* waterFlux, float* massFlux, float* velocityFlux, soil_rng* rng,
                          int64_t N, const float* layers, const float* waterSource,
                          const float* waterHeight, const float* velocity, float* remote0,
                          const Dom& d, Scale3 s, const Param& p, hipStream_t st) {
-  return run_shaped<FLUVIAL>(waterFlux, massFlux, velocityFlux, rng, N, layers, waterSource,
+  return run_tiled<FLUVIAL>(waterFlux, massFlux, velocityFlux, rng, N, layers, waterSource,
                              waterHeight, velocity, remote0, d, s, p, st);
 }
 
 int launch_debris_tiled(float* massFlux, float* velocityFlux, soil_rng* rng, int64_t N,
                         const float* layers, const float* velocity, float* remote0, const Dom& d,
                         Scale3 s, const Param& p, hipStream_t st) {
-  return run_shaped<DEBRIS>(massFlux, static_cast<float*>(nullptr), velocityFlux, rng, N, layers,
-                            static_cast<const float*>(nullptr), static_cast<const float*>(nullptr),
-                            velocity, remote0, d, s, p, st);
+  return run_tiled<DEBRIS>(massFlux, nullptr, velocityFlux, rng, N, layers, nullptr, nullptr,
+                           velocity, remote0, d, s, p, st);
 }
 
 }  // namespace soil
