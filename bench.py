@@ -232,7 +232,9 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "traffic_fused_cells.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            t = json.load(open(tpath))
+            if list(t.get("grid", [])) == [S, W]:   # measured for this launch size only
+                traffic = t.get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
     out = {

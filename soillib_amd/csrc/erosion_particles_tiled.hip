@@ -2,24 +2,29 @@
 // transport (__transport_fluvial erosion.cu:29-141, __transport_debris :245-351).
 //
 // Why: with one lane per streamline and global gathers/atomics every step, the
-// phase is bound by random 64-byte HBM traffic with zero cache reuse (measured:
-// profiles/r01_first — ~1.1 TB of HBM traffic per fluvial launch at 8192^2).
-// Every step only needs data of the cell the particle stands on, and every cell
-// is visited ~30 times per launch, so the work is re-organised around cells:
+// phase is bound by fp32 atomics into L2 (measured 22.7 G atomics/s,
+// tools/microbench/l2_atomic.hip; 8.6 G of them per fluvial launch at 8192^2)
+// and by random 64-byte HBM traffic with no reuse (profiles/r01_first: ~1.1 TB
+// per fluvial launch).  Every step only needs data of the cell the particle
+// stands on, and every cell is visited ~30 times per launch, so the work is
+// re-organised around cells:
 //
-//   * a streaming pre-pass packs {__glocal gradient, velocity} of every cell
-//     into one float4 plane (evaluated once per cell instead of once per visit);
-//   * the grid is cut into 64x64-cell tiles; a tile's packed fields, its water
-//     height and its flux accumulators live in the 160 KiB LDS of one
-//     work-group (9 floats/cell = 144 KiB for fluvial);
+//   * a streaming pre-pass evaluates every cell-only sub-expression of the loop
+//     body once per cell and packs it into one float4 plane (k_tiled_pack), so a
+//     step gathers 16 bytes, through L1/L2;
+//   * the grid is cut into 64x64-cell tiles; a tile's flux accumulators (4
+//     planes fluvial / 3 debris, 64 / 48 KiB) live in the LDS of one work-group,
+//     which leaves room for 2 / 3 work-groups per CU (24 waves);
 //   * particles are kept in per-tile queues of 64-byte records.  A work-group
-//     advances the particles of its tile step by step against LDS (gather =
-//     one ds_read_b128, deposits = ds_add_f32) until they die, step onto
+//     advances the particles of its tile step by step (deposits = split-phase
+//     compare-and-swap on LDS, see CasDeposit) until they die, step onto
 //     another tile or use up the round's step budget; survivors are written
-//     back into the slots their queue occupied, counting-sorted by destination
-//     tile, and resumed in the next round;
+//     back into the slots their queue occupied together with the tile they are
+//     bound for, the 4-byte slot indices are counting-sorted by tile, and the
+//     next round resumes them;
 //   * at the end of a round the tile's flux is added to the global planes with
-//     coalesced, non-atomic read-modify-writes (one work-group per tile);
+//     non-atomic read-modify-writes of the cells that changed (one work-group
+//     per tile);
 //   * once few particles are left, one last launch walks them to the end
 //     against global memory (no more rounds for a handful of stragglers).
 //
@@ -27,6 +32,12 @@
 // state is only ever parked at the top of an iteration, before `++iter` — so
 // every trajectory and every deposit is bit-identical to the direct launch
 // shape; only the order of the fp32 additions into a cell differs.
+//
+// Measured at 8192^2, N = 8.4 M, maxage 256 (ms per launch, fluvial / debris):
+// direct 418 / 115; fields+flux in LDS with ds_add_f32 84 / 36; this file 44 / 16.
+// The round kernel issues VALU instructions on >80 % of all SIMD cycles
+// (profiles/): what is left is the instruction count of the step itself (nine
+// IEEE divisions, a square root and three exponentials per fluvial step).
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -501,34 +512,36 @@ __global__ void __launch_bounds__(NT)
   for (uint32_t j = s_out + tid; j < cnt; j += kBlock) dest[first + j] = kNoTile;  // unused slots
 
   // flush the tile's flux into the global planes: one work-group per tile per
-  // round, so plain coalesced read-modify-writes suffice; loads first
-  {
-    float g0[kPer], g1[kPer];
-    float2 gv[kPer];
-    bool ok[kPer];
+  // round, so plain read-modify-writes suffice.  Only cells that received a
+  // deposit are touched (late rounds: the particles sit in channels and most of
+  // the tile is still zero).  Two cells per thread in flight: the register
+  // budget of the stepping loop decides the occupancy, not this epilogue.
+  for (int j0 = 0; j0 < kPer; j0 += 2) {
+    float a0[2], a1[2], ax[2], ay[2], g0[2], g1[2];
+    float2 gv[2];
+    int64_t l[2];
 #pragma unroll
-    for (int j = 0; j < kPer; ++j) {
-      const int c = tid + j * kBlock;
+    for (int j = 0; j < 2; ++j) {
+      const int c = tid + (j0 + j) * kBlock;
       const int lx = row0 + c / TC, y = col0 + c % TC;
-      ok[j] = c < kCells && lx < static_cast<int>(d.rows) && y < k.W;
-      const int64_t l = static_cast<int64_t>(lx) * k.W + y;
-      g0[j] = ok[j] ? flux0[l] : 0.0f;
-      g1[j] = (KIND == FLUVIAL && ok[j]) ? flux1[l] : 0.0f;
-      gv[j] = ok[j] ? fluxV[l] : make_float2(0.0f, 0.0f);
+      const bool ok = c < kCells && lx < static_cast<int>(d.rows) && y < k.W;
+      l[j] = static_cast<int64_t>(lx) * k.W + y;
+      a0[j] = ok ? s_f0[c] : 0.0f;
+      a1[j] = (KIND == FLUVIAL && ok) ? s_f1[c] : 0.0f;
+      ax[j] = ok ? s_fx[c] : 0.0f;
+      ay[j] = ok ? s_fy[c] : 0.0f;
     }
 #pragma unroll
-    for (int j = 0; j < kPer; ++j) {
-      if (!ok[j]) continue;
-      const int c = tid + j * kBlock;
-      const int lx = row0 + c / TC, y = col0 + c % TC;
-      const int64_t l = static_cast<int64_t>(lx) * k.W + y;
-      const float a0 = s_f0[c], ax = s_fx[c], ay = s_fy[c];
-      if (a0 != 0.0f) flux0[l] = g0[j] + a0;
-      if (KIND == FLUVIAL) {
-        const float a1 = s_f1[c];
-        if (a1 != 0.0f) flux1[l] = g1[j] + a1;
-      }
-      if (ax != 0.0f || ay != 0.0f) fluxV[l] = make_float2(gv[j].x + ax, gv[j].y + ay);
+    for (int j = 0; j < 2; ++j) {
+      g0[j] = (a0[j] != 0.0f) ? flux0[l[j]] : 0.0f;
+      g1[j] = (KIND == FLUVIAL && a1[j] != 0.0f) ? flux1[l[j]] : 0.0f;
+      gv[j] = (ax[j] != 0.0f || ay[j] != 0.0f) ? fluxV[l[j]] : make_float2(0.0f, 0.0f);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      if (a0[j] != 0.0f) flux0[l[j]] = g0[j] + a0[j];
+      if (KIND == FLUVIAL && a1[j] != 0.0f) flux1[l[j]] = g1[j] + a1[j];
+      if (ax[j] != 0.0f || ay[j] != 0.0f) fluxV[l[j]] = make_float2(gv[j].x + ax[j], gv[j].y + ay[j]);
     }
   }
 }
