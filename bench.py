@@ -203,6 +203,7 @@ def main():
         runner.step()
     runner.barrier()
     runner.sync()
+    soil.particle_steps(reset=True)
     phase = [0.0, 0.0, 0.0]
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -217,6 +218,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if world > 1:
         elapsed = runner.max_over_ranks(elapsed)
+    psteps_rank = soil.particle_steps(reset=True)   # this rank's particle steps in the timed region
 
     if world > 1 or os.environ.get("SOIL_BENCH_FORCE_SLAB") == "1":
         runner.shutdown()
@@ -252,6 +254,8 @@ def main():
             "grid": [H_global, W], "particles": cells // args.particles_div, "maxage": 256,
             "parallelism": "row-slabs x%d" % world if world > 1 else "single GPU",
         },
+        "particle_steps_per_step": psteps_rank * world // K,
+        "gparticle_steps_per_s": psteps_rank * world / elapsed / 1e9,
         "phases_ms": {"particles_fluvial": phase[0] / K, "particles_debris": phase[1] / K,
                       "cells_fused": phase[2] / K},
         "cell_phase_mcells_per_s": cells_rank / t_cells / 1e6 * world,

@@ -296,8 +296,8 @@ int soil_particles_debris_slab(float* massFlux, float* velocityFlux, float* albe
                                const soil_param* param, void* stream);
 /* Launch shape of the particle kernels: 0 = auto, 1 = direct (the reference's:
  * thread n = particle n, 5-point stencil gathers), 2 = staged (packed field
- * plane + tile-ordered particles), 3 = tiled (per-tile particle queues advanced
- * against LDS-resident field and flux tiles; no colour planes).  Auto picks
+ * plane + tile-ordered particles), 3 = tiled (per-tile particle queues, one
+ * gather of pre-digested cell terms per step, flux tiles in LDS; no colour planes).  Auto picks
  * tiled for N >= 32768 without albedo, staged for N >= 1024, else direct.  All
  * shapes produce the same trajectories and deposits; only the order of the
  * fp32 additions into a cell differs.  For ablation and tests. */
@@ -306,6 +306,12 @@ int soil_set_particle_mode(int mode);
  * leave it: ceil(sqrt(2) * maxage) + 2 (one __stepsize step moves a particle
  * by at most sqrt(2) cells, erosion_map.cu:61-76). */
 int64_t soil_ghost_rows(const soil_param* param);
+/* Particle steps (loop iterations of erosion.cu:100 / :306 that pass the loop
+ * head) executed by all particle launches on the current device since the last
+ * reset; synchronises `stream`.  The reference has no counterpart: it is the
+ * numerator of the Mparticle-steps/s that SURVEY.md 8d asks to report, and an
+ * exact integer the parity tests compare with the oracle's count. */
+int soil_particle_steps(uint64_t* total, int reset, void* stream);
 
 /* ------------------------------------------------------------- flow graphs */
 

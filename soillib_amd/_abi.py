@@ -101,6 +101,7 @@ SIGNATURES = {
                                    [C.POINTER(Domain), F3, C.POINTER(Param), vp]),
     "soil_set_particle_mode": (cint, [cint]),
     "soil_ghost_rows": (i64, [C.POINTER(Param)]),
+    "soil_particle_steps": (cint, [C.POINTER(u64), cint, vp]),
     "soil_direction": (cint, [vp, vp, i64, i64, cint, vp]),
     "soil_steepest": (cint, [vp, vp, i64, i64, cint, vp]),
     "soil_random_weighted": (cint, [vp, vp, i64, i64, cint, u64, u64, f32, vp]),

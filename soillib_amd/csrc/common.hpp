@@ -47,6 +47,11 @@ int require_device();
 int workspace_get(int slot, size_t bytes, void** out);
 int workspace_release_all();
 
+// Device counter of particle steps (iterations that pass the loop head and its
+// slab check, i.e. what the oracle counts), accumulated by every particle launch
+// on this device; read and reset through soil_particle_steps().
+int step_counter(unsigned long long** out);
+
 inline hipStream_t as_stream(void* s) { return static_cast<hipStream_t>(s); }
 inline unsigned blocks_for(int64_t n, int threads) {
   return static_cast<unsigned>((n + threads - 1) / threads);

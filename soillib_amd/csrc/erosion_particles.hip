@@ -72,6 +72,7 @@ struct FluvialPlanes {
   const float* __restrict__ waterHeight;
   const float* __restrict__ albedoSource;
   float* __restrict__ remote0;
+  unsigned long long* __restrict__ steps;  // step_counter() of the device
 };
 
 // __transport_fluvial, erosion.cu:49-139, from the spawn position on
@@ -123,6 +124,7 @@ __device__ __forceinline__ void trace_fluvial(const Fields& F, const FluvialPlan
   float att_w = 1.0f, att_m = 1.0f, att_v = 1.0f;  // :94-96
   const float lenL = length2(Lx, Ly);
   uint64_t iter = 0;
+  uint32_t nsteps = 0;
   while (!oob(d, px, py) && ++iter < param.maxage) {  // :100
     const int64_t cx = cell_of(px), cy = cell_of(py);
     if (slab_escape(d, cx)) {
@@ -136,6 +138,7 @@ __device__ __forceinline__ void trace_fluvial(const Fields& F, const FluvialPlan
       }
       break;
     }
+    ++nsteps;
     const int64_t nind = cx * W + cy;  // :103
     if (nind != ind) {                 // :104-113
       ind = nind;
@@ -173,6 +176,7 @@ __device__ __forceinline__ void trace_fluvial(const Fields& F, const FluvialPlan
     px += v_step * ux;                                             // :137
     py += v_step * uy;
   }
+  atomicAdd(P.steps, static_cast<unsigned long long>(nsteps));  // one atomic per wave
 }
 
 struct DebrisPlanes {
@@ -181,6 +185,7 @@ struct DebrisPlanes {
   float* __restrict__ albedoFlux;
   const float* __restrict__ albedoSource;
   float* __restrict__ remote0;
+  unsigned long long* __restrict__ steps;  // step_counter() of the device
 };
 
 // __transport_debris, erosion.cu:262-349, from the spawn position on
@@ -229,6 +234,7 @@ __device__ __forceinline__ void trace_debris(const Fields& F, const DebrisPlanes
   float att_d = 1.0f, att_v = 1.0f;  // :301-302
   const float lenL = length2(Lx, Ly);
   uint64_t iter = 0;
+  uint32_t nsteps = 0;
   while (!oob(d, px, py) && ++iter < param.maxage) {  // :306
     const int64_t cx = cell_of(px), cy = cell_of(py);
     if (slab_escape(d, cx)) {
@@ -239,6 +245,7 @@ __device__ __forceinline__ void trace_debris(const Fields& F, const DebrisPlanes
       }
       break;
     }
+    ++nsteps;
     const int64_t nind = cx * W + cy;  // :309
     if (nind != ind) {                 // :310-318
       ind = nind;
@@ -277,6 +284,7 @@ __device__ __forceinline__ void trace_debris(const Fields& F, const DebrisPlanes
     px += v_step * ux;                                                    // :347
     py += v_step * uy;
   }
+  atomicAdd(P.steps, static_cast<unsigned long long>(nsteps));
 }
 
 // ---- direct mode: thread n = particle n ---------------------------------------
@@ -473,8 +481,10 @@ static int launch_particles_fluvial(float* waterFlux, float* massFlux, float* ve
   if (use_tiled(N, albedoFlux))
     return launch_fluvial_tiled(waterFlux, massFlux, velocityFlux, rng, N, layers, waterSource,
                                 waterHeight, velocity, remote0, d, s, p, st);
-  const FluvialPlanes P{waterFlux,   massFlux,     velocityFlux, albedoFlux,
-                        waterSource, waterHeight, albedoSource, remote0};
+  unsigned long long* steps = nullptr;
+  if (int rc = step_counter(&steps); rc != SOIL_OK) return rc;
+  const FluvialPlanes P{waterFlux,   massFlux,    velocityFlux, albedoFlux, waterSource,
+                        waterHeight, albedoSource, remote0,      steps};
   if (use_staged(N)) {
     Staged sg;
     int rc = stage(&sg, rng, N, layers, velocity, d, s, p, st);
@@ -499,7 +509,9 @@ static int launch_particles_debris(float* massFlux, float* velocityFlux, float* 
   if (use_tiled(N, albedoFlux))
     return launch_debris_tiled(massFlux, velocityFlux, rng, N, layers, velocity, remote0, d, s, p,
                                st);
-  const DebrisPlanes P{massFlux, velocityFlux, albedoFlux, albedoSource, remote0};
+  unsigned long long* steps = nullptr;
+  if (int rc = step_counter(&steps); rc != SOIL_OK) return rc;
+  const DebrisPlanes P{massFlux, velocityFlux, albedoFlux, albedoSource, remote0, steps};
   if (use_staged(N)) {
     Staged sg;
     int rc = stage(&sg, rng, N, layers, velocity, d, s, p, st);
@@ -617,6 +629,19 @@ int soil_particles_debris_slab(float* massFlux, float* velocityFlux, float* albe
   return launch_particles_debris(massFlux, velocityFlux, albedoFlux, rng, N, layers, velocity,
                                  albedoSource, remote0, d, s3p(scale), *param,
                                  as_stream(stream));
+}
+
+int soil_particle_steps(uint64_t* total, int reset, void* stream) {
+  SOIL_REQUIRE(total != nullptr, "soil_particle_steps: null output");
+  unsigned long long* counter = nullptr;
+  if (int rc = step_counter(&counter); rc != SOIL_OK) return rc;
+  unsigned long long v = 0;
+  hipStream_t st = as_stream(stream);
+  SOIL_HIP(hipMemcpyAsync(&v, counter, sizeof(v), hipMemcpyDeviceToHost, st));
+  if (reset) SOIL_HIP(hipMemsetAsync(counter, 0, sizeof(v), st));
+  SOIL_HIP(hipStreamSynchronize(st));
+  *total = v;
+  return SOIL_OK;
 }
 
 }  // extern "C"

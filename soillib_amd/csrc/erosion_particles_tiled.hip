@@ -372,8 +372,9 @@ __global__ void __launch_bounds__(NT)
                   const uint32_t* __restrict__ count, float* __restrict__ flux0,
                   float* __restrict__ flux1, float2* __restrict__ fluxV,
                   const float4* __restrict__ p4, const float* __restrict__ waterHeight,
-                  float* __restrict__ remote0, Dom d, Scale3 s, Param param, int tiles_w,
-                  int steps_per_round, TileShape ts_next, int tiles_w_next) {
+                  float* __restrict__ remote0, unsigned long long* __restrict__ steps, Dom d,
+                  Scale3 s, Param param, int tiles_w, int steps_per_round, TileShape ts_next,
+                  int tiles_w_next) {
   constexpr int kCells = TR * TC, kBlock = NT, kPer = (kCells + NT - 1) / NT;
   const int tile = blockIdx.x;
   const uint32_t cnt = count[tile];
@@ -386,11 +387,12 @@ __global__ void __launch_bounds__(NT)
   __shared__ float s_f0[kCells];                        // fluvial water | debris mass
   __shared__ float s_f1[KIND == FLUVIAL ? kCells : 1];  // fluvial mass
   __shared__ float s_fx[kCells], s_fy[kCells];          // velocity flux
-  __shared__ uint32_t s_next, s_out;
+  __shared__ uint32_t s_next, s_out, s_steps;
   const int tid = threadIdx.x;
   if (tid == 0) {
     s_next = 0;
     s_out = 0;
+    s_steps = 0;
   }
   const StepConst k = make_const<KIND>(d, s, param);
 #pragma unroll
@@ -420,6 +422,7 @@ __global__ void __launch_bounds__(NT)
     parked = false;
   };
   int budget = 0;  // steps this lane may still spend on its particle in this round
+  uint32_t nsteps = 0;
   for (;;) {
     if (!have && !drained) {  // take the next particle of this tile's queue
       const uint32_t i = atomicAdd(&s_next, 1u);
@@ -457,6 +460,7 @@ __global__ void __launch_bounds__(NT)
           have = false;
         } else {
           --budget;
+          ++nsteps;
           // the cell's record comes from the packed plane through L1/L2 (the tile's
           // 64 KiB are touched ~4x per round); issued first, the gather's latency
           // hides under the deposit and the other waves of the SIMD
@@ -508,7 +512,9 @@ __global__ void __launch_bounds__(NT)
       dest[first + slot] = static_cast<uint32_t>(dest_tile);
     }
   }
+  atomicAdd(&s_steps, nsteps);
   __syncthreads();
+  if (tid == 0) atomicAdd(steps, static_cast<unsigned long long>(s_steps));
   for (uint32_t j = s_out + tid; j < cnt; j += kBlock) dest[first + j] = kNoTile;  // unused slots
 
   // flush the tile's flux into the global planes: one work-group per tile per
@@ -554,11 +560,13 @@ __global__ void __launch_bounds__(256)
                    float* __restrict__ flux0,
                    float* __restrict__ flux1, float* __restrict__ fluxV,
                    const float4* __restrict__ p4, const float* __restrict__ waterHeight,
-                   float* __restrict__ remote0, Dom d, Scale3 s, Param param) {
+                   float* __restrict__ remote0, unsigned long long* __restrict__ steps, Dom d,
+                   Scale3 s, Param param) {
   const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
   if (i >= n) return;
   if (dest[i] == kNoTile) return;
   PRec r = recs[i];
+  uint32_t nsteps = 0;
   const StepConst k = make_const<KIND>(d, s, param);
   const int64_t base = static_cast<int64_t>(k.x0) * k.W;
   for (;;) {
@@ -571,6 +579,7 @@ __global__ void __launch_bounds__(256)
       park_remote<KIND>(r, remote0);
       break;
     }
+    ++nsteps;
     const int64_t nind = static_cast<int64_t>(cx) * k.W + cy;
     const int64_t l = nind - base;
     const float4 q = p4[l];
@@ -589,6 +598,7 @@ __global__ void __launch_bounds__(256)
     }
     if (!advance<KIND>(r, q, k)) break;
   }
+  atomicAdd(steps, static_cast<unsigned long long>(nsteps));  // one atomic per wave
 }
 
 static int env_int(const char* name, int fallback) {
@@ -664,6 +674,10 @@ static int run_tiled(float* flux0, float* flux1, float* fluxV, soil_rng* rng, in
   uint32_t* start = reinterpret_cast<uint32_t*>(w);       w += b_cnt;
   uint32_t* fill = reinterpret_cast<uint32_t*>(w);
 
+  unsigned long long* steps = nullptr;
+  rc = step_counter(&steps);
+  if (rc != SOIL_OK) return rc;
+
   const int64_t lo = stencil_lo(d), hi = stencil_hi(d);
   const int64_t cells = (hi - lo + 1) * d.W;
   if (cells > 0)
@@ -706,7 +720,7 @@ static int run_tiled(float* flux0, float* flux1, float* fluxV, soil_rng* rng, in
     if (live == 0) break;
     if (static_cast<int64_t>(live) <= tail && round > 0) {
       k_tiled_finish<KIND><<<blocks_for(n_src, 256), 256, 0, st>>>(
-          cur, dest, n_src, flux0, flux1, fluxV, p4, waterHeight, remote0, d, s, p);
+          cur, dest, n_src, flux0, flux1, fluxV, p4, waterHeight, remote0, steps, d, s, p);
       SOIL_LAUNCH_CHECK();
       break;
     }
@@ -719,7 +733,8 @@ static int run_tiled(float* flux0, float* flux1, float* fluxV, soil_rng* rng, in
                             static_cast<const uint32_t*>(start),
                             static_cast<const uint32_t*>(count), flux0, flux1,
                             reinterpret_cast<float2*>(fluxV), static_cast<const float4*>(p4),
-                            waterHeight, remote0, d, s, p, tiles_w, steps_per_round, ts_of(sh_next),
+                            waterHeight, remote0, steps, d, s, p, tiles_w, steps_per_round,
+                            ts_of(sh_next),
                             tiles_w_of(sh_next));
     else
       launch_round<KIND, 1>(sh, static_cast<unsigned>(tiles), st, next, dest, count_next,
@@ -727,7 +742,8 @@ static int run_tiled(float* flux0, float* flux1, float* fluxV, soil_rng* rng, in
                             static_cast<const uint32_t*>(start),
                             static_cast<const uint32_t*>(count), flux0, flux1,
                             reinterpret_cast<float2*>(fluxV), static_cast<const float4*>(p4),
-                            waterHeight, remote0, d, s, p, tiles_w, steps_per_round, ts_of(sh_next),
+                            waterHeight, remote0, steps, d, s, p, tiles_w, steps_per_round,
+                            ts_of(sh_next),
                             tiles_w_of(sh_next));
     SOIL_LAUNCH_CHECK();
     n_src = live;

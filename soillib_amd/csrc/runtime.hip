@@ -81,6 +81,21 @@ int workspace_get(int slot, size_t bytes, void** out) {
   return SOIL_OK;
 }
 
+static std::map<int, unsigned long long*> g_step_counter;  // device -> counter
+
+int step_counter(unsigned long long** out) {
+  int dev = 0;
+  SOIL_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(g_ws_mutex);
+  unsigned long long*& c = g_step_counter[dev];
+  if (!c) {
+    SOIL_HIP(hipMalloc(&c, sizeof(unsigned long long)));
+    SOIL_HIP(hipMemset(c, 0, sizeof(unsigned long long)));
+  }
+  *out = c;
+  return SOIL_OK;
+}
+
 int workspace_release_all() {
   int dev = 0;
   SOIL_HIP(hipGetDevice(&dev));

@@ -262,6 +262,14 @@ def mass_creep(delta, layers, scale, param):
           param._ref(), _abi.stream())
 
 
+def particle_steps(reset=True):
+    """Particle steps executed on the current GPU since the last reset (soil_hip.h:
+    soil_particle_steps) — not in the reference; the numerator of Mparticle-steps/s."""
+    n = C.c_uint64(0)
+    _call("soil_particle_steps", C.byref(n), 1 if reset else 0, _abi.stream())
+    return n.value
+
+
 def layer_merge(height, layers):
     """model.cpp:343-351 -> soil::layer_merge (erosion.cu:747-757)."""
     _call("soil_layer_merge", _f(height, "height"), _f(layers, "layers"), height.elem(),

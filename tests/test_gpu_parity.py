@@ -293,8 +293,10 @@ def test_transport_fluvial_parity(hip, oracle, particle_mode, H, W, N, which):
     g = dict(wh=to_gpu(wh0), wf=to_gpu(z1), m=to_gpu(z1), mf=to_gpu(z1), v=to_gpu(vel0),
              vf=to_gpu(z2), af=to_gpu(z3))
     grng = rng_to_gpu(oracle.rng_seed(N, 5, 100))
+    soil.particle_steps(reset=True)
     soil.transport_fluvial(to_gpu(layers), to_gpu(rain), g["wh"], g["wf"], g["m"], g["mf"], g["v"],
                            g["vf"], None, g["af"], to_gpu(asrc), grng, scale, pp)
+    assert soil.particle_steps(reset=True) == steps     # same walks, step for step
     assert (to_np(grng)["offset"] == orng["offset"]).all()
     for k in ("wf", "mf", "vf"):
         _flux_close(to_np(g[k]), o[k], "fluvial flux " + k)
@@ -324,8 +326,10 @@ def test_transport_debris_parity(hip, oracle, particle_mode, H, W, N):
     assert steps > N and o["mf"].max() > 0
     g = dict(v=to_gpu(vel0), vf=to_gpu(z2), m=to_gpu(z1), mf=to_gpu(z1))
     grng = rng_to_gpu(oracle.rng_seed(N, 6, 0))
+    soil.particle_steps(reset=True)
     soil.transport_debris(to_gpu(layers), g["v"], g["vf"], g["m"], g["mf"], None, None, None, grng,
                           scale, pp)
+    assert soil.particle_steps(reset=True) == steps
     for k in ("mf", "vf"):
         _flux_close(to_np(g[k]), o[k], "debris flux " + k)
     for k in ("m", "v"):
