@@ -14,6 +14,7 @@
 
 #include <array>
 #include <cstdint>
+#include <limits>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -234,5 +235,143 @@ inline F noise(const silt::shape shape, noise_param_t param) {  // generated str
   check(soil_noise(out.data(), shape[0], shape[1], &param, nullptr));
   return out;
 }
+
+// ---- io/tiff.hpp:20-241, io/geotiff.hpp:63-318 -------------------------------------------------
+// Host-side raster IO.  The samples live in a std::vector (the reference keeps a CPU
+// silt::tensor): `f32` unless the file holds 64-bit samples (tiff.hpp:116-124), in
+// scanline order; shape() is (width, height) as in the reference.
+namespace io {
+
+struct tiff {
+  tiff() = default;
+  explicit tiff(const char* filename) { read(filename); }
+  tiff(const std::vector<float>& data, uint32_t width, uint32_t height)
+      : f32(data), _width(width), _height(height), _bits(32) {}
+  tiff(const std::vector<double>& data, uint32_t width, uint32_t height)
+      : f64(data), _width(width), _height(height), _bits(64) {}
+
+  bool peek(const char* filename) {
+    check_io(soil_tiff_peek(filename, &info));
+    _width = info.width, _height = info.height, _bits = info.bits;
+    meta_loaded = true;
+    return true;
+  }
+  bool read(const char* filename) {
+    if (!meta_loaded) peek(filename);
+    const size_t n = static_cast<size_t>(_width) * _height;
+    if (_bits == 64) {
+      f64.assign(n, 0.0);
+      check_io(soil_tiff_read(filename, f64.data(), n * sizeof(double)));
+    } else {
+      f32.assign(n, 0.0f);
+      check_io(soil_tiff_read(filename, f32.data(), n * sizeof(float)));
+    }
+    return true;
+  }
+  bool write(const char* filename) { return write_tags(filename, nullptr); }
+
+  uint32_t bits() const { return _bits; }
+  uint32_t width() const { return _width; }
+  uint32_t height() const { return _height; }
+  silt::shape shape() const { return silt::shape(_width, _height); }
+
+  std::vector<float> f32;
+  std::vector<double> f64;
+
+ protected:
+  static void check_io(int rc) {
+    if (rc == SOIL_ERR_IO) throw std::runtime_error(soil_last_error());  // silt::error::missing_file
+    silt::check(rc);
+  }
+  bool write_tags(const char* filename, const soil_geotiff_tags* geo) {
+    const void* data = _bits == 64 ? static_cast<const void*>(f64.data()) : f32.data();
+    check_io(soil_tiff_write(filename, data, _width, _height, _bits, geo));
+    return true;
+  }
+  bool meta_loaded = false;
+  soil_tiff_info info{};
+  uint32_t _width = 0, _height = 0, _bits = 0;
+};
+
+struct geotiff : tiff {
+  struct meta_t {  // geotiff.hpp:83-101
+    std::string filename;
+    size_t width = 0, height = 0, bits = 0;
+    std::string gdal_nodata, gdal_metadata, geoasciiparams;
+    std::vector<double> scale = {1.0, 1.0, 1.0};
+    std::vector<double> coords = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    std::vector<double> params;
+    std::vector<short> keydir;
+  };
+
+  geotiff() = default;
+  explicit geotiff(const char* filename) { read(filename); }
+  geotiff(const std::vector<float>& data, uint32_t width, uint32_t height) : tiff(data, width, height) {
+    _meta.coords[3] = width;  // geotiff.hpp:72-73
+    _meta.coords[4] = height;
+  }
+
+  bool peek(const char* filename) {  // geotiff.hpp:131-173
+    tiff::peek(filename);
+    _meta.filename = filename;
+    _meta.width = _width, _meta.height = _height, _meta.bits = _bits;
+    auto text = [&](int tag, uint32_t n, std::string& out) {
+      if (!n) return;
+      std::vector<char> buf(n + 1, 0);
+      uint64_t got = 0;
+      check_io(soil_tiff_tag(filename, tag, buf.data(), n, &got));
+      out = std::string(buf.data());
+    };
+    auto reals = [&](int tag, uint32_t n, std::vector<double>& out) {
+      if (!n) return;
+      out.assign(n, 0.0);
+      uint64_t got = 0;
+      check_io(soil_tiff_tag(filename, tag, out.data(), n * sizeof(double), &got));
+    };
+    text(SOIL_TIFFTAG_GDAL_NODATA, info.n_nodata, _meta.gdal_nodata);
+    text(SOIL_TIFFTAG_GDAL_METADATA, info.n_metadata, _meta.gdal_metadata);
+    text(SOIL_TIFFTAG_GEOASCIIPARAMS, info.n_ascii, _meta.geoasciiparams);
+    reals(SOIL_TIFFTAG_GEOPIXELSCALE, info.n_scale, _meta.scale);
+    if (_meta.scale.size() > 2 && _meta.scale[2] == 0.0) _meta.scale[2] = 1.0;  // :160-161
+    reals(SOIL_TIFFTAG_GEOTIEPOINTS, info.n_tiepoints, _meta.coords);
+    reals(SOIL_TIFFTAG_GEODOUBLEPARAMS, info.n_params, _meta.params);
+    if (info.n_keydir) {
+      _meta.keydir.assign(info.n_keydir, 0);
+      uint64_t got = 0;
+      check_io(soil_tiff_tag(filename, SOIL_TIFFTAG_GEOKEYDIRECTORY, _meta.keydir.data(),
+                             info.n_keydir * sizeof(short), &got));
+    }
+    return true;
+  }
+  bool read(const char* filename) {  // geotiff.hpp:175-182, NoData -> NaN :228-263
+    peek(filename);
+    tiff::read(filename);
+    if (!_meta.gdal_nodata.empty()) {
+      if (_bits == 64) {
+        const double nodata = std::stod(_meta.gdal_nodata);
+        for (double& v : f64) if (v == nodata) v = std::numeric_limits<double>::quiet_NaN();
+      } else {
+        const float nodata = std::stof(_meta.gdal_nodata);
+        for (float& v : f32) if (v == nodata) v = std::numeric_limits<float>::quiet_NaN();
+      }
+    }
+    return true;
+  }
+  bool write(const char* filename) {  // geotiff.hpp:183-226
+    soil_geotiff_tags g{};
+    g.scale = _meta.scale.data(), g.n_scale = static_cast<uint32_t>(_meta.scale.size());
+    g.tiepoints = _meta.coords.data(), g.n_tiepoints = static_cast<uint32_t>(_meta.coords.size());
+    g.params = _meta.params.data(), g.n_params = static_cast<uint32_t>(_meta.params.size());
+    g.keydir = _meta.keydir.data(), g.n_keydir = static_cast<uint32_t>(_meta.keydir.size());
+    g.ascii = _meta.geoasciiparams.empty() ? nullptr : _meta.geoasciiparams.c_str();
+    g.metadata = _meta.gdal_metadata.empty() ? nullptr : _meta.gdal_metadata.c_str();
+    g.nodata = _meta.gdal_nodata.empty() ? nullptr : _meta.gdal_nodata.c_str();
+    return write_tags(filename, &g);
+  }
+  silt::vec2 scale() const { return {static_cast<float>(_meta.scale[0]), static_cast<float>(_meta.scale[1])}; }
+  meta_t _meta;
+};
+
+}  // namespace io
 
 }  // namespace soil

@@ -49,7 +49,8 @@ typedef enum soil_status {
   SOIL_ERR_INVALID_ARGUMENT = -1, /* std::invalid_argument in the reference (graph.cu:88) */
   SOIL_ERR_NO_DEVICE = -2,        /* no HIP device / runtime failure at init            */
   SOIL_ERR_HIP = -3,              /* a HIP runtime call failed (message has the detail) */
-  SOIL_ERR_OUT_OF_MEMORY = -4
+  SOIL_ERR_OUT_OF_MEMORY = -4,
+  SOIL_ERR_IO = -5 /* silt::error::missing_file / an unreadable or unsupported file (tiff.hpp:73) */
 } soil_status;
 
 /* graph.hpp:11-14  enum edge_t { D4 = 0, D8 = 1 } */
@@ -396,6 +397,61 @@ int soil_noise_host(float* out_host, int64_t H, int64_t W, const soil_noise_para
 /* Rows [x0, x0+rows) of the same heightmap (the slab a rank owns). */
 int soil_noise_window(float* out, int64_t rows, int64_t W, int64_t x0, const soil_noise_param* p,
                       void* stream);
+
+/* ------------------------------------------------------- TIFF / GeoTIFF IO */
+/* Host-side file IO of the callers either side of the path:
+ * soil::io::tiff (io/tiff.hpp:20-241) and soil::io::geotiff (io/geotiff.hpp:63-318),
+ * bound in python/source/io.cpp:20-100.  The reference delegates the format to
+ * libtiff (third party, not in its tree); this is a codec of its own for
+ * single-band rasters: classic + BigTIFF, either byte order, strips or tiles,
+ * compression none / LZW / Deflate / PackBits, predictors 1-3.  No GPU needed. */
+#define SOIL_TIFFTAG_GEOPIXELSCALE 33550   /* geotiff.hpp:13-21 */
+#define SOIL_TIFFTAG_GEOTIEPOINTS 33922
+#define SOIL_TIFFTAG_GEOKEYDIRECTORY 34735
+#define SOIL_TIFFTAG_GEODOUBLEPARAMS 34736
+#define SOIL_TIFFTAG_GEOASCIIPARAMS 34737
+#define SOIL_TIFFTAG_GDAL_METADATA 42112
+#define SOIL_TIFFTAG_GDAL_NODATA 42113
+
+typedef struct soil_tiff_info { /* what tiff::peek / geotiff::peek learn (tiff.hpp:69-99) */
+  uint32_t width, height;       /* ImageWidth, ImageLength                          */
+  uint32_t bits;                /* BitsPerSample                                    */
+  uint32_t sample_format;       /* 1 unsigned, 2 signed, 3 IEEE float               */
+  uint32_t samples;             /* SamplesPerPixel                                  */
+  uint32_t tiled, tile_width, tile_height;
+  uint32_t compression, predictor;
+  /* element counts of the GeoTIFF / GDAL tags present (0 = absent), for soil_tiff_tag */
+  uint32_t n_scale, n_tiepoints, n_params, n_keydir, n_ascii, n_metadata, n_nodata;
+} soil_tiff_info;
+
+typedef struct soil_geotiff_tags { /* geotiff::meta_t as written by geotiff::write (:199-213) */
+  const double* scale;     uint32_t n_scale;      /* GeoPixelScale   */
+  const double* tiepoints; uint32_t n_tiepoints;  /* GeoTiePoints    */
+  const double* params;    uint32_t n_params;     /* GeoDoubleParams */
+  const int16_t* keydir;   uint32_t n_keydir;     /* GeoKeyDirectory */
+  const char* ascii;       /* GeoAsciiParams, NUL-terminated or NULL */
+  const char* metadata;    /* GDAL_METADATA                          */
+  const char* nodata;      /* GDAL_NODATA                            */
+} soil_geotiff_tags;
+
+/* tiff::peek + geotiff::peek: SOIL_ERR_IO when the file is missing (the
+ * reference throws silt::error::missing_file) or is not a TIFF. */
+int soil_tiff_peek(const char* filename, soil_tiff_info* info);
+/* Payload of one tag: doubles (8 B each), shorts (2 B) or the raw bytes of an
+ * ASCII tag including its NUL.  *written_bytes = 0 when the tag is absent. */
+int soil_tiff_tag(const char* filename, int tag, void* dst, uint64_t capacity_bytes,
+                  uint64_t* written_bytes);
+/* tiff::read (tiff.hpp:102-213): width*height samples in scanline order into
+ * `dst`: float64 when the file holds 64-bit samples, float32 otherwise
+ * (tiff.hpp:116-124).  Integer and half-float samples are converted to
+ * float32 (the reference leaves the 16-bit case unfilled). */
+int soil_tiff_read(const char* filename, void* dst, uint64_t dst_bytes);
+/* tiff::write / geotiff::write (tiff.hpp:215-241, geotiff.hpp:183-226):
+ * uncompressed little-endian IEEE-float strips, ROWSPERSTRIP = width (what
+ * TIFFDefaultStripSize(tif, width) returns); `geo` may be NULL.  Images beyond
+ * 4 GiB are written as BigTIFF (libtiff would fail). */
+int soil_tiff_write(const char* filename, const void* data, uint32_t width, uint32_t height,
+                    uint32_t bits, const soil_geotiff_tags* geo);
 
 #ifdef __cplusplus
 } /* extern "C" */

@@ -3,7 +3,8 @@
 
 Live API: soillib_amd.soil (mirror of python/source/model.cpp).  Legacy API used
 by example/erosion_gpu.py (map_t, data_t, erode, multiply, legacy param names,
-normal): soillib_amd.legacy.  Helpers (`soil.util`): soillib_amd.util.
+normal): soillib_amd.legacy.  IO (tiff, geotiff): soillib_amd.io.  Helpers (`soil.util`):
+soillib_amd.util.
 """
 import silt  # noqa: F401
 
@@ -14,5 +15,7 @@ from soillib_amd.soil import (accumulate, accumulate_decay, albedo_discharge, al
                               noise, noise_t, normal, ns, random_weighted, s, slope,
                               solve_uniform, steepest, timer, transport_debris, transport_fluvial,
                               us)
+from soillib_amd.soil import particle_steps  # noqa: F401
+from soillib_amd.io import geotiff, geotiff_meta, tiff  # noqa: F401  (python/source/io.cpp:20-100)
 from soillib_amd.legacy import (clamp, data_t, erode, map_t, multiply, param_t)  # noqa: F401
 from soillib_amd import util  # noqa: F401

@@ -102,6 +102,10 @@ SIGNATURES = {
     "soil_set_particle_mode": (cint, [cint]),
     "soil_ghost_rows": (i64, [C.POINTER(Param)]),
     "soil_particle_steps": (cint, [C.POINTER(u64), cint, vp]),
+    "soil_tiff_peek": (cint, [C.c_char_p, vp]),
+    "soil_tiff_tag": (cint, [C.c_char_p, cint, vp, u64, C.POINTER(u64)]),
+    "soil_tiff_read": (cint, [C.c_char_p, vp, u64]),
+    "soil_tiff_write": (cint, [C.c_char_p, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp]),
     "soil_direction": (cint, [vp, vp, i64, i64, cint, vp]),
     "soil_steepest": (cint, [vp, vp, i64, i64, cint, vp]),
     "soil_random_weighted": (cint, [vp, vp, i64, i64, cint, u64, u64, f32, vp]),
@@ -157,6 +161,10 @@ def lib():
             fn.restype = res
             fn.argtypes = args
     return _lib
+
+
+def last_error():
+    return lib().soil_last_error().decode("utf-8", "replace")
 
 
 class SoilError(RuntimeError):

@@ -18,7 +18,7 @@ OBJDIR = os.path.join(HERE, "build")
 LIB = os.path.join(LIBDIR, "libsoil_hip.so")
 
 SOURCES = ["runtime.hip", "erosion_cells.hip", "erosion_particles.hip", "erosion_particles_tiled.hip", "graph.hip",
-           "stencil.hip", "path.hip", "noise.hip"]
+           "stencil.hip", "path.hip", "noise.hip", "io_tiff.hip"]
 
 # -ffp-contract=off / no fast-math: the numerical contract
 # needs every fp32 operation evaluated as written.  -munsafe-fp-atomics selects
@@ -71,7 +71,7 @@ def build(force=False, verbose=False):
 
     with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
         objs = list(ex.map(compile_one, SOURCES))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-lz"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))

@@ -31,6 +31,11 @@ int require_device();
     if (!(cond)) return ::soil::fail(SOIL_ERR_INVALID_ARGUMENT, msg);      \
   } while (0)
 
+#define SOIL_REQUIRE_IO(cond, msg)                            \
+  do {                                                        \
+    if (!(cond)) return ::soil::fail(SOIL_ERR_IO, msg);       \
+  } while (0)
+
 #define SOIL_DEVICE()                                  \
   do {                                                 \
     int soil_rc_ = ::soil::require_device();           \

@@ -8,15 +8,30 @@ from . import silt
 from . import soil as _soil
 
 
-def relief_shade(height, normal, light=(-1.0, 2.0, 1.0)):
-    """Lambertian hill-shade of a height map with its normal map (util.py:75-100)."""
-    light = np.asarray(light, np.float64)
+def iter_tiff(path, max_files=None):
+    """Yields (file name, full path) of one file or of every file in a directory
+    (util.py:8-30)."""
+    import os
+    path = os.fsencode(path)
+    if not os.path.exists(path):
+        raise RuntimeError("path does not exist")
+    if os.path.isfile(path):
+        yield os.path.basename(path).decode("utf-8"), path.decode("utf-8")
+    elif os.path.isdir(path):
+        for k, file in enumerate(os.listdir(path)):
+            if max_files is not None and k > max_files:
+                break
+            yield file.decode("utf-8"), os.path.join(path, file).decode("utf-8")
+    else:
+        raise RuntimeError("path must be file or directory")
+
+
+def relief_shade(height, normal):
+    """Diffuse shade of a normal map under the light (-1, 2, 1) (util.py:32-52).  The
+    height only enters the reference through terms whose weight is 0 there."""
+    light = np.array([-1.0, 2.0, 1.0])
     light = light / np.linalg.norm(light)
-    diffuse = np.clip(np.sum(light * normal, axis=-1), 0.0, 1.0)
-    h = np.asarray(height, np.float64)
-    span = np.nanmax(h) - np.nanmin(h)
-    flat = (h - np.nanmin(h)) / span if span > 0 else np.zeros_like(h)
-    return 0.25 + 0.75 * diffuse * (0.5 + 0.5 * flat)
+    return np.sum(light * np.asarray(normal), axis=-1)
 
 
 def show_relief(tensor, scale=(1.0, 1.0, 1.0), show=False):
