@@ -398,6 +398,14 @@ int soil_noise_host(float* out_host, int64_t H, int64_t W, const soil_noise_para
 int soil_noise_window(float* out, int64_t rows, int64_t W, int64_t x0, const soil_noise_param* p,
                       void* stream);
 
+/* ------------------------------------------------------ multiscale driver */
+/* soil.resize(dst, src, newres, oldres) of example/erosion_gpu_multiscale.py:104-141
+ * (SURVEY.md 8f row 4).  The reference snapshot has no definition of it; this
+ * one is the reference's bilinear sampler (sample.hpp:154-186) at corner-aligned
+ * positions, for planes of D = 1..3 interleaved channels.  Parity unpinned. */
+int soil_resize(float* dst, const float* src, int64_t Hn, int64_t Wn, int64_t Ho, int64_t Wo, int D,
+                void* stream);
+
 /* ------------------------------------------------------- TIFF / GeoTIFF IO */
 /* Host-side file IO of the callers either side of the path:
  * soil::io::tiff (io/tiff.hpp:20-241) and soil::io::geotiff (io/geotiff.hpp:63-318),

@@ -348,6 +348,17 @@ def negslope(t, scale):
     return out
 
 
+def resize(src, newres):
+    """soil.resize (multiscale driver): (Ho, Wo[, D]) -> (Hn, Wn[, D])."""
+    Ho, Wo = src.shape[:2]
+    D = 1 if src.ndim == 2 else src.shape[2]
+    Hn, Wn = newres
+    out = np.empty((Hn, Wn) + src.shape[2:], np.float32)
+    lib().orc_resize(_f(out), _f(_chk(src)), C.c_int64(Hn), C.c_int64(Wn), C.c_int64(Ho),
+                     C.c_int64(Wo), C.c_int(D))
+    return out
+
+
 def laplacian(t, scale):
     H, W, D = t.shape
     out = np.empty((H, W, D), np.float32)

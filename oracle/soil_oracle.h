@@ -125,6 +125,8 @@ void orc_gaussian_blur(float* tensor, float* scratch, int64_t H, int64_t W, int 
 void orc_normal(float* out, const float* in, int64_t H, int64_t W, const float scale[3]);
 
 /* path-integral solver */
+void orc_resize(float* dst, const float* src, int64_t Hn, int64_t Wn, int64_t Ho, int64_t Wo,
+                int D);
 void orc_solve_uniform(float* flux, const float* flow, const float* source, const float* decay,
                        orc_rng* rng, int64_t N, int64_t H, int64_t W, int K,
                        const float scale[2], uint64_t count);

@@ -10,6 +10,9 @@ meaning is reconstructed from the script and from the commented code
     soil.param_t()             legacy attribute names mapped onto the live ones (§8a)
     soil.erode(model, data, track, param, steps)                                (:142)
     soil.multiply(tensor, scalar) / soil.clamp(tensor, lo, hi)
+and, for example/erosion_gpu_multiscale.py:
+    soil.index(res), soil.buffer(dtype, elem, host) (`buf[:] = v`), soil.data_t(elem),
+    soil.resize(dst, src, newres, oldres)
 
 `erode` runs soillib_amd.erosion.ErosionModel on the caller's tensors: `data.*`
 are the transported fields, `track.*` the flux accumulators.
@@ -69,21 +72,60 @@ class map_t:
 
 
 class data_t:
-    """model.cpp:103-140: transported quantities (or their flux accumulators)."""
+    """model.cpp:103-140: transported quantities (or their flux accumulators).
+    `data_t(shape)` leaves the planes to the caller (erosion_gpu.py:59-71);
+    `data_t(elem)` allocates them on the GPU (erosion_gpu_multiscale.py:60-67)."""
 
     def __init__(self, shape):
-        self.shape = shape if isinstance(shape, silt.shape) else silt.shape(*shape)
         self.discharge = None
         self.momentum = None
         self.mass = None
         self.debris = None
         self.debris_momentum = None
+        if isinstance(shape, int):
+            self.shape = silt.shape(shape)
+            for name, dims in (("discharge", (shape,)), ("mass", (shape,)), ("debris", (shape,)),
+                               ("momentum", (shape, 2)), ("debris_momentum", (shape, 2))):
+                t = silt.tensor(silt.float32, silt.shape(*dims), silt.gpu)
+                silt.set(t, 0.0)
+                setattr(self, name, t)
+        else:
+            self.shape = shape if isinstance(shape, silt.shape) else silt.shape(*shape)
+
+
+def index(res):
+    """soil.index(res): the grid extent — a silt.shape today."""
+    return silt.shape(*[int(v) for v in res])
+
+
+def buffer(dtype, elem, host=silt.cpu):
+    """soil.buffer(dtype, elem, host): a flat tensor; `buf[:] = v` fills it."""
+    return silt.tensor(dtype, silt.shape(int(elem)), host)
+
+
+def resize(dst, src, newres, oldres):
+    """soil.resize(dst, src, newres, oldres) (erosion_gpu_multiscale.py:112-138): bilinear
+    resampling of a plane of 1..3 interleaved channels on the GPU (soil_hip.h: soil_resize)."""
+    Hn, Wn = int(newres[0]), int(newres[1])
+    Ho, Wo = int(oldres[0]), int(oldres[1])
+    for t in (dst, src):
+        if t.host is not silt.gpu or t.type is not silt.float32:
+            raise _abi.SoilError("resize: float32 silt.gpu tensors only")
+    D = src.elem() // (Ho * Wo)
+    if D * Ho * Wo != src.elem() or D * Hn * Wn != dst.elem():
+        raise ValueError("resize: tensor sizes do not match the resolutions")
+    _abi.check(_abi.lib().soil_resize(dst.c_ptr, src.c_ptr, Hn, Wn, Ho, Wo, D, _abi.stream()))
+    return dst
 
 
 def _engine(model, data, track, param):
     H, W = model.shape[0], model.shape[1]
     eng = model._engine
     if eng is None or eng.N != param.samples:
+        for key in ("height", "sediment", "uplift", "rainfall"):
+            t = getattr(model, key)
+            if t is not None and t.elem() != H * W:
+                raise ValueError("erode: model.%s does not hold %d x %d cells" % (key, H, W))
         # planes the caller owns are aliased, not copied
         names = {
             "uplift": model.uplift, "rainfall": model.rainfall,

@@ -233,6 +233,26 @@ class tensor:
     def __repr__(self):
         return "silt.tensor(%s, %s, %s)" % (self._dtype.name, tuple(self._shape), self._host.name)
 
+    def __setitem__(self, key, value):
+        """`t[:] = scalar` or `t[:] = [a, b]` (one value per channel of the trailing axis):
+        the fill idiom of the legacy buffers (example/erosion_gpu_multiscale.py:45,63-67)."""
+        if key != slice(None):
+            raise TypeError("silt.tensor supports only t[:] = value")
+        if np.isscalar(value):
+            set(self, value)
+            return
+        v = np.asarray(value, self._dtype.np_dtype).reshape(-1)
+        dims = tuple(self._shape)
+        if dims[-1] != v.size:
+            raise ValueError("t[:] = %r needs a trailing axis of %d" % (value, v.size))
+        host = np.ascontiguousarray(np.broadcast_to(v, dims))
+        if self._host is cpu:
+            self._np[...] = host
+        elif host.nbytes:
+            _abi.check(_abi.lib().soil_memcpy_h2d(self.c_ptr, host.ctypes.data_as(C.c_void_p),
+                                                  host.nbytes, _abi.stream()))
+            _abi.check(_abi.lib().soil_stream_synchronize(_abi.stream()))
+
     # -- movement -------------------------------------------------------------
     def numpy(self):
         if self._host is not cpu:

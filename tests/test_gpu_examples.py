@@ -7,6 +7,7 @@ GPU box, so their API usage is re-enacted here statement for statement).
   example/dem_multiflow.py  random_weighted + accumulate loop, host-side averaging
   example/dem_process.py    direction / random_weighted / accumulate_decay
   example/tiff_normal.py    soil.normal on a CPU tensor
+  example/erosion_gpu_multiscale.py   legacy index / buffer / data_t(elem) / resize / clamp
 """
 import numpy as np
 import pytest
@@ -147,3 +148,74 @@ def test_dem_process_and_tiff_normal_sequences(hip, oracle):
     normal = soil.normal(tensor.cpu(), [1.0, 1.0, 1.0]).numpy()
     normal = 0.5 + 0.5 * normal
     assert normal.shape == (H, W, 3) and normal.min() >= 0 and normal.max() <= 1
+
+
+def test_erosion_gpu_multiscale_script_sequence(hip, oracle):
+    import soillib as soil
+    simres = np.array([32, 32])                           # erosion_gpu_multiscale.py:28-34
+    wscale = np.array([20.0, 20.0, 4.0])
+    nscale = np.array([20.0, 20.0])
+    pscale = [wscale[0] / simres[0], wscale[1] / simres[1], wscale[2]]
+    noise_param = soil.noise_t()                          # :36-38
+    noise_param.ext = simres * nscale / wscale[0:2]
+    noise_param.seed = 3
+    index = soil.index(simres)                            # :40-42
+    height = soil.noise(index, noise_param)
+    soil.multiply(height, 1.0)
+    sediment = soil.buffer(soil.float32, index.elem(), soil.gpu)   # :44-45
+    sediment[:] = 0.0
+    model = soil.map_t(index, pscale)                     # :49-59
+    model.height = height.gpu()
+    model.sediment = sediment.gpu()
+    model.rainfall = soil.buffer(soil.float32, index.elem(), soil.gpu)
+    soil.set(model.rainfall, 1.0)
+    uplift = soil.noise(index, noise_param)
+    soil.clamp(uplift, 0.0, 1.0)
+    assert uplift.numpy().min() >= 0.0 and uplift.numpy().max() <= 1.0
+    model.uplift = uplift.gpu()
+    data = soil.data_t(index.elem())                      # :60-67
+    track = soil.data_t(index.elem())
+    data.discharge[:] = 0.0
+    data.momentum[:] = [0.0, 0.0]
+    data.mass[:] = 0.0
+    data.debris[:] = 0.0
+    data.debris_momentum[:] = [0.0, 0.0]
+    param = soil.param_t()                                # :71-97 (abridged: same names)
+    param.timeStep = 10.0
+    param.samples = 2048
+    param.maxage = 64
+    param.uplift = 0.01
+    param.suspensionRate = 0.0000008
+    param.critSlope = 0.57
+    timer = soil.timer()
+
+    def scaleup(model, data, track, oldres, simres):      # :102-141
+        index = soil.index(simres)
+        pscale = [wscale[0] / simres[0], wscale[1] / simres[1], wscale[2]]
+        planes = {}
+        for name in ("height", "sediment", "rainfall", "uplift"):
+            planes[name] = soil.buffer(soil.float32, index.elem(), soil.gpu)
+            soil.resize(planes[name], getattr(model, name), simres, oldres)
+        model = soil.map_t(index, pscale)
+        for name, t in planes.items():
+            setattr(model, name, t)
+        newdata = soil.data_t(index.elem())
+        newtrack = soil.data_t(index.elem())
+        for name in ("mass", "discharge", "momentum", "debris_momentum", "debris"):
+            soil.resize(getattr(newdata, name), getattr(data, name), simres, oldres)
+        return model, newtrack, newdata, index, simres, pscale
+
+    h_before = None
+    for nextres, steps in (([32, 32], 3), ([64, 64], 2), ([100, 100], 2)):   # :143-160
+        old_h = model.height.cpu().numpy().reshape(simres[0], simres[1])
+        model, data, track, index, simres, pscale = scaleup(model, data, track, simres, nextres)
+        up = model.height.cpu().numpy().reshape(nextres)
+        np.testing.assert_array_equal(up, oracle.resize(old_h, tuple(nextres)))
+        for _ in range(steps):
+            with timer:
+                soil.erode(model, data, track, param, 1)
+        h_after = model.height.cpu().numpy()
+        assert h_after.size == nextres[0] * nextres[1] and np.isfinite(h_after).all()
+        assert np.abs(h_after.reshape(nextres) - up).max() > 0          # it eroded at this scale
+        h_before = h_after
+    assert h_before is not None and timer.count >= 0

@@ -551,3 +551,27 @@ def test_silt_gpu_ops(hip):
     with pytest.raises(_abi.SoilError, match="mismatch_host"):
         from soillib_amd import soil
         soil.steepest(silt.tensor.from_numpy(np.zeros((4, 4), np.float32)), 0)
+
+
+@pytest.mark.parametrize("old,new,D", [((16, 16), (32, 32), 1), ((24, 40), (61, 45), 2),
+                                       ((33, 20), (33, 20), 1), ((40, 40), (17, 23), 3),
+                                       ((5, 7), (1, 1), 1), ((1, 9), (4, 30), 2)])
+def test_resize_bit_exact(hip, oracle, old, new, D):
+    """soil.resize of the multiscale driver (soil_hip.h: soil_resize; parity unpinned —
+    the reference snapshot has no definition, the oracle restates this build's)."""
+    from soillib_amd import legacy, silt
+    r = np.random.default_rng(31)
+    src = r.standard_normal(old + ((D,) if D > 1 else ())).astype(np.float32)
+    want = oracle.resize(src, new)
+    dst = silt.tensor(silt.float32, silt.shape(*(new + ((D,) if D > 1 else ()))), silt.gpu)
+    legacy.resize(dst, to_gpu(src), new, old)
+    assert_bit_equal(to_np(dst), want, "resize")
+    if old == new:
+        assert_bit_equal(to_np(dst), src, "resize to the same resolution is the identity")
+    const = np.full(old + ((D,) if D > 1 else ()), 3.25, np.float32)
+    legacy.resize(dst, to_gpu(const), new, old)
+    assert (to_np(dst) == 3.25).all()                 # weights sum to 1 exactly
+    corners = to_np(legacy.resize(dst, to_gpu(src), new, old))
+    if new[0] > 1 and new[1] > 1:
+        assert_bit_equal(corners[0, 0], src[0, 0], "corner-aligned")
+        assert_bit_equal(corners[-1, -1], src[-1, -1], "corner-aligned")
