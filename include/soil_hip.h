@@ -338,6 +338,15 @@ int soil_slope(float* slope, const float* tensor, const int32_t* flow, int64_t H
  * stream before returning, like the reference (graph.cu:564). */
 int soil_accumulate(float* out, const int32_t* graph, const float* source, const float* decay,
                     int64_t H, int64_t W, int edge, void* stream);
+/* The realisation loop of example/dem_multiflow.py:43-49 as one call, without the
+ * per-realisation trip through host memory: for k = k_first, k_first+k_stride, ... < k_end
+ *   sum += double(float(accumulate(random_weighted(height, edge, seed, k, T), source) / K))
+ * `sum` (H*W doubles) is accumulated into — zero it first.  A rank of an N-GPU run
+ * passes k_first = rank, k_stride = N and all-reduces `sum` afterwards: accumulation
+ * does not shard (pointer jumps span the grid), the realisations do. */
+int soil_multiflow(double* sum, const float* height, const float* source, int64_t H, int64_t W,
+                   int edge, uint64_t seed, uint64_t k_first, uint64_t k_stride, uint64_t k_end,
+                   uint64_t K, float T, void* stream);
 /* Frees the cached accumulate workspace of the current device. */
 int soil_workspace_release(void);
 

@@ -246,6 +246,16 @@ static int accumulate_impl(float* out, const int32_t* graph, const float* source
   return SOIL_OK;
 }
 
+// sum += double(float(acc / K)): the term of example/dem_multiflow.py:49
+// (`multiflow += accumulation.cpu().numpy() / float(K)`, a float32 quotient
+// added into a float64 array), kept on the device
+__global__ void __launch_bounds__(kGBlock)
+    k_mean_add(double* __restrict__ sum, const float* __restrict__ acc, float Kf, int64_t elem) {
+  const int64_t n = static_cast<int64_t>(blockIdx.x) * kGBlock + threadIdx.x;
+  if (n >= elem) return;
+  sum[n] += static_cast<double>(acc[n] / Kf);
+}
+
 }  // namespace soil
 
 using namespace soil;
@@ -319,6 +329,29 @@ int soil_accumulate(float* out, const int32_t* graph, const float* source, const
     case SOIL_D8: return accumulate_impl<8>(out, graph, source, decay, H, W, as_stream(stream));
     default: return fail(SOIL_ERR_INVALID_ARGUMENT, "invalid edge enumerator");  // graph.cu:573
   }
+}
+
+int soil_multiflow(double* sum, const float* height, const float* source, int64_t H, int64_t W,
+                   int edge, uint64_t seed, uint64_t k_first, uint64_t k_stride, uint64_t k_end,
+                   uint64_t K, float T, void* stream) {
+  SOIL_DEVICE();
+  SOIL_REQUIRE(sum && height && source, "multiflow: null tensor");
+  SOIL_REQUIRE(k_stride > 0 && K > 0, "multiflow: stride and realisation count must be positive");
+  const int64_t elem = H * W;
+  auto align = [](size_t b) { return (b + 255) & ~static_cast<size_t>(255); };
+  void* base = nullptr;
+  if (int rc = workspace_get(3, align(sizeof(int32_t) * elem) + sizeof(float) * elem, &base); rc != SOIL_OK)
+    return rc;
+  int32_t* graph = static_cast<int32_t*>(base);
+  float* acc = reinterpret_cast<float*>(static_cast<char*>(base) + align(sizeof(int32_t) * elem));
+  hipStream_t st = as_stream(stream);
+  for (uint64_t k = k_first; k < k_end; k += k_stride) {
+    if (int rc = soil_random_weighted(graph, height, H, W, edge, seed, k, T, stream); rc != SOIL_OK) return rc;
+    if (int rc = soil_accumulate(acc, graph, source, nullptr, H, W, edge, stream); rc != SOIL_OK) return rc;
+    k_mean_add<<<blocks_for(elem, kGBlock), kGBlock, 0, st>>>(sum, acc, static_cast<float>(K), elem);
+    SOIL_LAUNCH_CHECK();
+  }
+  return SOIL_OK;
 }
 
 int soil_workspace_release(void) {

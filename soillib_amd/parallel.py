@@ -338,3 +338,34 @@ class SlabRunner:
                          device=getattr(self.ops, "device", "cpu"))
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
+
+
+# ---- flow accumulation: replicas, realisations sharded ------------------------------
+
+def multiflow(height, source, K, T, edge=1, seed=0, comm=None, rank=None, world=None,
+              local_sum=None):
+    """Stochastic multiple-flow accumulation (example/dem_multiflow.py:43-49) over all
+    ranks.  `accumulate` does not shard — its pointer jumps span the whole grid
+     — so every rank holds the full DEM and computes the realisations
+    k = rank, rank + world, ... < K; one all-reduce(sum) of the float64 mean plane
+    (128 MiB at 4096^2) combines them.
+
+    `height`, `source`: silt.gpu float32 tensors (H, W), the same on every rank.
+    Returns a torch float64 tensor (H, W) holding the mean on every rank.
+    `local_sum(first, stride) -> torch tensor` replaces the HIP back-end in the
+    CPU (gloo) tests."""
+    if comm is None:
+        import torch.distributed as comm
+    if world is None:
+        live = comm.is_available() and comm.is_initialized()
+        rank, world = (comm.get_rank(), comm.get_world_size()) if live else (0, 1)
+    if local_sum is None:
+        from . import soil
+
+        def local_sum(first, stride):
+            out = soil.multiflow(height, source, K, T, edge, seed, first=first, stride=stride)
+            return out.view_torch()
+    total = local_sum(rank, world)
+    if world > 1:
+        comm.all_reduce(total, op=comm.ReduceOp.SUM)
+    return total

@@ -142,6 +142,21 @@ def accumulate_decay(graph, field, decay, edge_):
     return out
 
 
+def multiflow(height, source, K, T, edge_=None, seed=0, first=0, stride=1, out=None):
+    """Mean of `accumulate(random_weighted(height, edge, seed, k, T), source)` over the
+    realisations k = first, first+stride, ... < K, each term divided by K in float32 and
+    summed in float64 — the loop of example/dem_multiflow.py:43-49 kept on the GPU
+    (soil_hip.h: soil_multiflow).  Returns (or adds into `out`) a float64 GPU tensor."""
+    H, W = _hw(height)
+    if out is None:
+        out = silt.tensor(silt.float64, silt.shape(H, W), silt.gpu)
+        _call("soil_set_f32", out.c_ptr, 0.0, 2 * H * W, _abi.stream())   # all-zero bits = 0.0
+    e = d8 if edge_ is None else edge_
+    _call("soil_multiflow", out.c_ptr, _f(height, "height"), _f(source, "source"), H, W, int(e),
+          int(seed), int(first), int(stride), int(K), int(K), float(T), _abi.stream())
+    return out
+
+
 def gaussian_blur(tensor, sigma):
     """model.cpp:189-191 -> soil::gaussian_blur (filter.cu:72-91): blurs IN PLACE
     and returns its input handle (filter.cu:90)."""

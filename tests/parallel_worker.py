@@ -101,7 +101,30 @@ class OracleOps:
         pass
 
 
+def multiflow_main():
+    """parallel.multiflow with the oracle as back-end: realisations sharded over ranks."""
+    out_dir, H, W, K = sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
+    torch.distributed.init_process_group("gloo")
+    rank = torch.distributed.get_rank()
+    dem = o.noise(H, W, seed=1.0, ext=(float(H), float(W))) * 100.0
+    rain = np.ones((H, W), np.float32)
+
+    def local_sum(first, stride):
+        total = np.zeros((H, W), np.float64)
+        for k in range(first, K, stride):
+            acc = o.accumulate(o.random_weighted(dem, 1, 0, k, 10.0), rain, 1)
+            total += (acc / np.float32(K)).astype(np.float64)
+        return torch.from_numpy(total)
+
+    mean = parallel.multiflow(None, None, K, 10.0, local_sum=local_sum)
+    np.save(os.path.join(out_dir, "multiflow_rank%d.npy" % rank), mean.numpy())
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
 def main():
+    if sys.argv[1] == "multiflow":
+        return multiflow_main()
     out_dir, S, W, steps, maxage = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), \
         int(sys.argv[4]), int(sys.argv[5])
     param = script_param(o.default_param())

@@ -118,6 +118,12 @@ def test_dem_multiflow_script_sequence(hip, oracle):
             multiflow += accumulation.cpu().numpy() / float(K)
     assert t.count > 0
     assert multiflow.min() >= 1.0 - 1e-6           # every cell holds at least its own rain
+    # the same loop kept on the GPU (soil_hip.h: soil_multiflow), whole and in two shards
+    mean = soil.multiflow(tensor, rain, K, T, soil.d8, seed=0)
+    np.testing.assert_allclose(mean.cpu().numpy(), multiflow, rtol=1e-13, atol=0)
+    halves = soil.multiflow(tensor, rain, K, T, soil.d8, seed=0, first=0, stride=2)
+    soil.multiflow(tensor, rain, K, T, soil.d8, seed=0, first=1, stride=2, out=halves)
+    np.testing.assert_allclose(halves.cpu().numpy(), multiflow, rtol=1e-13, atol=0)
     # total drained area is conserved in every realisation: outlets sum to H*W
     flow0 = soil.random_weighted(tensor, soil.d8, 0, 0, T)
     acc0 = soil.accumulate(flow0, rain, soil.d8).cpu().numpy()

@@ -101,3 +101,31 @@ def test_slab_layout_partitions_rows():
             assert x0 == max(0, r * S - G) and x0 + rows == min(world * S, (r + 1) * S + G)
             covered.extend(range(x0 + r0, x0 + r1))
         assert covered == list(range(world * S))
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_multiflow_realisations_sharded_over_ranks(oracle, tmp_path, world):
+    """accumulation does not shard, its realisations do — every rank
+    ends with the mean over all K realisations of dem_multiflow.py:43-49."""
+    H, W, K = 40, 56, 7
+    port = _free_port()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen(
+            [sys.executable, os.path.join(ROOT, "tests", "parallel_worker.py"), "multiflow",
+             str(tmp_path), str(H), str(W), str(K)], env=env, stdout=subprocess.PIPE,
+            stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    for p, out in zip(procs, outs):
+        assert p.returncode == 0, out
+    dem = oracle.noise(H, W, seed=1.0, ext=(float(H), float(W))) * 100.0
+    rain = np.ones((H, W), np.float32)
+    want = np.zeros((H, W), np.float64)
+    for k in range(K):                       # the script's serial loop
+        want += oracle.accumulate(oracle.random_weighted(dem, 1, 0, k, 10.0), rain, 1) / float(K)
+    for rank in range(world):
+        got = np.load(os.path.join(str(tmp_path), "multiflow_rank%d.npy" % rank))
+        np.testing.assert_allclose(got, want, rtol=1e-13, atol=0)
+    assert want.min() >= 1.0 - 1e-6

@@ -1,18 +1,26 @@
 #!/usr/bin/env python
-"""Tuning aid / BASELINE config 3: D8 stochastic-MFD accumulation on a 4096^2 DEM
-(example/dem_multiflow.py:43-49): random_weighted + accumulate per realisation."""
+"""BASELINE config 3: D8 stochastic multiple-flow accumulation on a 4096^2 DEM
+(example/dem_multiflow.py:43-49): K realisations of random_weighted + accumulate,
+averaged on the device (soil_multiflow).  `--gpus N` under torch.distributed.run
+shards the realisations over ranks (soillib_amd.parallel.multiflow)."""
 import argparse
 import os
 import sys
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from soillib_amd import _abi, silt, soil  # noqa: E402
+from soillib_amd import _abi, parallel, silt, soil  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--size", type=int, default=4096)
-ap.add_argument("--k", type=int, default=8)
+ap.add_argument("--k", type=int, default=32)
 args = ap.parse_args()
+world = int(os.environ.get("WORLD_SIZE", "1"))
+rank = int(os.environ.get("RANK", "0"))
+if world > 1:
+    import torch
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    torch.distributed.init_process_group("nccl")
 lib = _abi.lib()
 S = args.size
 npar = soil.noise_t()
@@ -22,16 +30,16 @@ h = soil.noise(silt.shape(S, S), npar, host=silt.gpu)
 silt.multiply(h, 100.0)
 rain = silt.tensor(silt.float32, silt.shape(S, S), silt.gpu)
 silt.set(rain, 1.0)
-flow = soil.random_weighted(h, soil.d8, 0, 0, 10.0)
-acc = soil.accumulate(flow, rain, soil.d8)          # warm-up (allocates the workspace)
+parallel.multiflow(h, rain, world, 10.0)            # warm-up (allocates the workspaces)
 _abi.check(lib.soil_device_synchronize())
 t0 = time.perf_counter()
-for k in range(args.k):
-    flow = soil.random_weighted(h, soil.d8, 0, k, 10.0)
-    acc = soil.accumulate(flow, rain, soil.d8)
+mean = parallel.multiflow(h, rain, args.k, 10.0)
 _abi.check(lib.soil_device_synchronize())
-dt = (time.perf_counter() - t0) / args.k
-a = acc.cpu().numpy()
-f = flow.cpu().numpy()
-print("MFD accumulate %dx%d D8: %.2f ms per realisation = %.0f Mcells/s; outlets sum %.0f (cells %d)" % (
-    S, S, dt * 1e3, S * S / dt / 1e6, a[f < 0].sum(), S * S))
+dt = time.perf_counter() - t0
+if rank == 0:
+    m = mean.cpu().numpy()
+    print("MFD accumulate %dx%d D8, K=%d on %d GPU(s): %.2f ms per realisation = %.0f Mcells/s "
+          "(whole job); mean upstream area min %.3f max %.0f" % (
+              S, S, args.k, world, dt / args.k * 1e3, S * S * args.k / dt / 1e6, m.min(), m.max()))
+if world > 1:
+    torch.distributed.destroy_process_group()
