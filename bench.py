@@ -219,6 +219,13 @@ def main():
     if world > 1:
         elapsed = runner.max_over_ranks(elapsed)
     psteps_rank = soil.particle_steps(reset=True)   # this rank's particle steps in the timed region
+    final = None
+    if world == 1 and os.environ.get("SOIL_BENCH_FORCE_SLAB") != "1":
+        # sanity of the evolved terrain (outside the timed region): no NaN/inf may appear
+        import numpy as np
+        hh = model.height.cpu().numpy()
+        final = {"height_min": float(np.nanmin(hh)), "height_max": float(np.nanmax(hh)),
+                 "nonfinite_cells": int((~np.isfinite(hh)).sum())}
 
     if world > 1 or os.environ.get("SOIL_BENCH_FORCE_SLAB") == "1":
         runner.shutdown()
@@ -240,7 +247,7 @@ def main():
         except Exception:
             traffic = None
     out = {
-        "metric": "Mcells/s on 8192^2 hydraulic-erosion step",
+        "metric": "Mcells/s on %d^2 hydraulic-erosion step" % S,   # BASELINE.json's at the default size
         "value": cells / (elapsed / K) / 1e6,
         "unit": "Mcells/s",
         "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": ms_step,
@@ -254,6 +261,7 @@ def main():
             "grid": [H_global, W], "particles": cells // args.particles_div, "maxage": 256,
             "parallelism": "row-slabs x%d" % world if world > 1 else "single GPU",
         },
+        "final_state": final,
         "particle_steps_per_step": psteps_rank * world // K,
         "gparticle_steps_per_s": psteps_rank * world / elapsed / 1e9,
         "phases_ms": {"particles_fluvial": phase[0] / K, "particles_debris": phase[1] / K,

@@ -634,7 +634,11 @@ static int run_tiled(float* flux0, float* flux1, float* fluxV, soil_rng* rng, in
   // steps a particle may take per round: bounds the time a work-group waits for
   // its longest walker; and the population below which the rounds stop paying
   static const int steps_per_round = env_int("SOIL_TILED_STEPS", 32);
-  static const int tail = env_int("SOIL_TILED_TAIL", 200000);
+  // the finishing launch pays ~4 L2 atomics per step (22.7 G/s), a round a fixed
+  // cost that grows with the number of tiles: N/40 within [4096, 200000] is where
+  // they cross for 512^2 .. 8192^2 grids with N = cells/8
+  static const int tail_env = env_int("SOIL_TILED_TAIL", 0);
+  const int64_t tail = tail_env > 0 ? tail_env : std::min<int64_t>(200000, std::max<int64_t>(4096, N / 40));
   static const int deposit = env_int("SOIL_TILED_DEP", 0);
   // measured at 8192^2 (N = cells/8): 768 threads on a 64x64 tile serve the fluvial
   // queues (about half of them hold 513..700 particles) in one batch, 45 vs 48 ms;
@@ -690,6 +694,19 @@ static int run_tiled(float* flux0, float* flux1, float* fluxV, soil_rng* rng, in
   SOIL_LAUNCH_CHECK();
   int64_t n_src = N;  // slots of `cur` to look at (spawn output, then survivor slots)
   const uint64_t max_rounds = p.maxage + 2;  // every live particle advances >= 1 step per round
+  // A round is worth its fixed cost while it advances particles faster than the
+  // finishing launch would (4 L2 atomics per step at 22.7 G/s = 5.7 G steps/s).
+  // Particles that zig-zag along a tile edge get a handful of steps per round; on
+  // small grids they are most of what is left after maxage/steps_per_round rounds.
+  // The rate of the round just done (device step counter / HIP event time) decides.
+  static thread_local hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  if (!ev0) {
+    SOIL_HIP(hipEventCreate(&ev0));
+    SOIL_HIP(hipEventCreate(&ev1));
+  }
+  static const double finish_rate = env_int("SOIL_TILED_FINISH_MRATE", 4000) * 1e6;  // steps/s
+  unsigned long long steps_before = 0, steps_now = 0;
+  bool timed = false;
   for (uint64_t round = 0; round < max_rounds; ++round) {
     const int sh = shape_of(round), sh_next = shape_of(round + 1);
     const int64_t tiles = tiles_of(sh);
@@ -697,7 +714,15 @@ static int run_tiled(float* flux0, float* flux1, float* fluxV, soil_rng* rng, in
     k_tile_scan<<<1, 1024, 0, st>>>(start, count, tiles);
     uint32_t live = 0;  // particles queued for this round = start[tiles]
     SOIL_HIP(hipMemcpyAsync(&live, start + tiles, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    SOIL_HIP(hipMemcpyAsync(&steps_now, steps, sizeof(steps_now), hipMemcpyDeviceToHost, st));
     SOIL_HIP(hipStreamSynchronize(st));
+    double rate = 1e30;  // steps per second of the round just done
+    if (timed) {
+      float ms = 0.0f;
+      SOIL_HIP(hipEventElapsedTime(&ms, ev0, ev1));
+      if (ms > 0.0f) rate = static_cast<double>(steps_now - steps_before) / (ms * 1e-3);
+    }
+    steps_before = steps_now;
     if (verbose) {  // queue-length statistics of the round (diagnostics only)
       std::vector<uint32_t> h(static_cast<size_t>(tiles));
       SOIL_HIP(hipMemcpy(h.data(), count, sizeof(uint32_t) * tiles, hipMemcpyDeviceToHost));
@@ -718,12 +743,14 @@ static int run_tiled(float* flux0, float* flux1, float* fluxV, soil_rng* rng, in
                    static_cast<unsigned long long>(batches));
     }
     if (live == 0) break;
-    if (static_cast<int64_t>(live) <= tail && round > 0) {
+    if (verbose && timed) std::fprintf(stderr, "[tiled kind %d]   last round: %.2f G steps/s\n", KIND, rate * 1e-9);
+    if (round > 0 && (static_cast<int64_t>(live) <= tail || rate < finish_rate)) {
       k_tiled_finish<KIND><<<blocks_for(n_src, 256), 256, 0, st>>>(
           cur, dest, n_src, flux0, flux1, fluxV, p4, waterHeight, remote0, steps, d, s, p);
       SOIL_LAUNCH_CHECK();
       break;
     }
+    SOIL_HIP(hipEventRecord(ev0, st));
     SOIL_HIP(hipMemsetAsync(fill, 0, b_cnt, st));
     k_tiled_scatter<<<blocks_for(n_src, 256), 256, 0, st>>>(order, fill, start, dest, n_src);
     SOIL_HIP(hipMemsetAsync(count_next, 0, b_cnt, st));
@@ -746,6 +773,8 @@ static int run_tiled(float* flux0, float* flux1, float* fluxV, soil_rng* rng, in
                             ts_of(sh_next),
                             tiles_w_of(sh_next));
     SOIL_LAUNCH_CHECK();
+    SOIL_HIP(hipEventRecord(ev1, st));
+    timed = true;
     n_src = live;
     std::swap(cur, next);
     std::swap(count, count_next);
