@@ -16,7 +16,7 @@ from soillib_amd.soil import (accumulate, accumulate_decay, albedo_discharge, al
                               solve_uniform, steepest, timer, transport_debris, transport_fluvial,
                               us)
 from soillib_amd.soil import particle_steps  # noqa: F401
-from soillib_amd.io import geotiff, geotiff_meta, tiff  # noqa: F401  (python/source/io.cpp:20-100)
+from soillib_amd.io import geotiff, geotiff_meta, mesh, tiff  # noqa: F401  (python/source/io.cpp:20-110)
 from soillib_amd.legacy import (buffer, clamp, data_t, erode, index, map_t, multiply, param_t,  # noqa: F401
                                 resize)
 from soillib_amd.silt import cpu, float32, float64, gpu, int32, set, shape, tensor  # noqa: F401,A004  (legacy: soil.float32, soil.gpu, soil.set, ...)

@@ -271,3 +271,73 @@ class geotiff(tiff):
 
     def map(self, p):                   # geotiff.hpp:112
         return self.min + self.scale * np.asarray(p, np.float32)
+
+
+class mesh:
+    """io/mesh.hpp:33-213 — terrain triangle mesh of a height tensor with binary / ASCII
+    PLY export (the reference's binding is commented out, io.cpp:104-110; used by
+    example/tiff_mesh.py:15-17).  One vertex per non-NaN cell, p = (x, y, value) * scale
+    (:62-77); two triangles per 2x2 block whose four cells are all non-NaN (:80-114)."""
+
+    def __init__(self, tensor=None, scale=(1.0, 1.0, 1.0)):
+        self.vertices = np.zeros((0, 3), np.float32)
+        self.faces = np.zeros((0, 3), np.uint32)
+        flt = np.finfo(np.float32)
+        self.min = np.full(3, flt.max, np.float32)      # :42-43: max starts at FLT_MIN (> 0),
+        self.max = np.full(3, flt.tiny, np.float32)     # as numeric_limits<float>::min() is
+        if tensor is not None:
+            self._triangulate(tensor, scale)
+            if len(self.vertices):
+                self.min = np.minimum(self.min, self.vertices.min(axis=0))
+                self.max = np.maximum(self.max, self.vertices.max(axis=0))
+
+    def _triangulate(self, tensor, scale):
+        host = tensor.cpu() if tensor.host is silt.gpu else tensor
+        a = host.numpy()
+        H, W = a.shape[0], a.shape[1]
+        a = a.reshape(H, W)
+        ok = ~np.isnan(a)
+        ids = np.full(H * W, -1, np.int64)
+        ids[ok.reshape(-1)] = np.arange(int(ok.sum()))
+        ids = ids.reshape(H, W)
+        x, y = np.nonzero(ok)                           # flat (row-major) order, :63-77
+        s = np.asarray(scale, np.float32)
+        self.vertices = (np.stack([x, y, a[ok]], axis=1).astype(np.float32) * s).astype(np.float32)
+        quad = ok[:-1, :-1] & ok[:-1, 1:] & ok[1:, :-1] & ok[1:, 1:]
+        i00, i01 = ids[:-1, :-1][quad], ids[:-1, 1:][quad]
+        i10, i11 = ids[1:, :-1][quad], ids[1:, 1:][quad]
+        f0 = np.stack([i01, i00, i10], axis=1)          # :108-109
+        f1 = np.stack([i01, i10, i11], axis=1)
+        self.faces = np.stack([f0, f1], axis=1).reshape(-1, 3).astype(np.uint32)
+
+    def center(self):                                   # :117-122
+        self.vertices = self.vertices - np.float32(0.5) * (self.max + self.min)
+
+    def write(self, filename):                          # :134-168: ASCII, positions normalised
+        with open(filename, "w") as out:
+            out.write("ply\nformat ascii 1.0\ncomment Created in soillib\n")
+            out.write("element vertex %d\nproperty float x\nproperty float y\nproperty float z\n"
+                      % len(self.vertices))
+            out.write("element face %d\nproperty list uchar uint vertex_indices\nend_header\n"
+                      % len(self.faces))
+            with np.errstate(divide="ignore", invalid="ignore"):
+                vm = (self.vertices - self.min) / (self.max - self.min)
+            for v in vm:
+                out.write("%g %g %g\n" % (v[0], v[1], v[2]))
+            for f in self.faces:
+                out.write("3 %d %d %d\n" % (f[0], f[1], f[2]))
+        return True
+
+    def write_binary(self, filename):                   # :170-207
+        with open(filename, "wb") as out:
+            out.write(b"ply\nformat binary_little_endian 1.0\n")
+            out.write(b"element vertex %d\nproperty float x\nproperty float y\nproperty float z\n"
+                      % len(self.vertices))
+            out.write(b"element face %d\nproperty list uchar uint vertex_indices\nend_header\n"
+                      % len(self.faces))
+            out.write(np.ascontiguousarray(self.vertices, "<f4").tobytes())
+            rec = np.zeros(len(self.faces), np.dtype([("n", "u1"), ("v", "<u4", 3)]))
+            rec["n"] = 3
+            rec["v"] = self.faces
+            out.write(rec.tobytes())
+        return True

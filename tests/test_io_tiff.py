@@ -257,3 +257,30 @@ def test_config1_geotiff_to_cpu_normal(soil, oracle, tmp_path):
         np.testing.assert_array_equal(normal, want)
         relief = soil.util.relief_shade(image.tensor.numpy(), normal)
         assert relief.shape == (H, W) and np.isfinite(relief).all()
+
+
+def test_mesh_ply_export(soil, tmp_path):
+    """io/mesh.hpp via example/tiff_mesh.py:15-17: vertices skip NaN cells, quads touching one drop out."""
+    import silt
+    h = np.arange(12, dtype=np.float32).reshape(3, 4)
+    h[1, 2] = np.nan
+    m = soil.mesh(silt.tensor.from_numpy(h), [2.0, 3.0, 0.5])
+    assert m.vertices.shape == (11, 3) and m.faces.shape == (4, 3)        # 6 quads, 4 touch the NaN... 2 left
+    np.testing.assert_array_equal(m.vertices[5], np.array([1 * 2.0, 1 * 3.0, 5 * 0.5], np.float32))
+    np.testing.assert_array_equal(m.faces[0], [1, 0, 4])                   # (i01, i00, i10), mesh.hpp:108
+    np.testing.assert_array_equal(m.faces[1], [1, 4, 5])                   # (i01, i10, i11)
+    lo, hi = m.min.copy(), m.max.copy()
+    m.center()
+    np.testing.assert_allclose(m.vertices.min(axis=0) + m.vertices.max(axis=0), 0, atol=1e-6)
+    path = tmp_path / "mesh.ply"
+    assert m.write_binary(str(path))
+    raw = path.read_bytes()
+    head, body = raw.split(b"end_header\n", 1)
+    assert b"format binary_little_endian 1.0" in head and b"element vertex 11" in head
+    assert b"element face 4" in head and len(body) == 11 * 12 + 4 * 13
+    v = np.frombuffer(body[:11 * 12], "<f4").reshape(11, 3)
+    np.testing.assert_array_equal(v, m.vertices)
+    assert m.write(str(tmp_path / "mesh_ascii.ply"))
+    lines = (tmp_path / "mesh_ascii.ply").read_text().splitlines()
+    assert lines[0] == "ply" and lines[1] == "format ascii 1.0" and lines[-1].startswith("3 ")
+    assert (hi > lo).all()
