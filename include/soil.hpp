@@ -183,6 +183,12 @@ inline F accumulate_decay(const silt::tensor_t<int> graph, const F source, const
                         graph.shape()[1], edge, nullptr));
   return out;
 }
+inline F fill_depressions(const F height, const edge_t edge) {  // build-defined
+  F out(height.shape(), silt::GPU);
+  check(soil_fill_depressions(out.data(), height.data(), height.shape()[0], height.shape()[1], edge,
+                              nullptr));
+  return out;
+}
 inline F slope(const F tensor, const silt::tensor_t<int> flow, const silt::vec2 scale) {
   F out(tensor.shape(), silt::GPU);
   check(soil_slope(out.data(), tensor.data(), flow.data(), tensor.shape()[0], tensor.shape()[1],

@@ -347,6 +347,14 @@ int soil_accumulate(float* out, const int32_t* graph, const float* source, const
 int soil_multiflow(double* sum, const float* height, const float* source, int64_t H, int64_t W,
                    int edge, uint64_t seed, uint64_t k_first, uint64_t k_stride, uint64_t k_end,
                    uint64_t K, float T, void* stream);
+/* Depression filling before flow routing (BASELINE config 3).  The reference has
+ * none — example/dem_condition.py:35-41 calls the third-party pysheds — so this is
+ * build-defined, parity unpinned: out(c) = the lowest level at which
+ * cell c can drain to an outlet (a step off the grid or onto a NaN cell) along `edge`
+ * connectivity, i.e. the priority-flood surface; NaN cells stay NaN.  Exact in fp32
+ * (only min/max), iterative tile relaxation in LDS; synchronises the stream. */
+int soil_fill_depressions(float* out, const float* height, int64_t H, int64_t W, int edge,
+                          void* stream);
 /* Frees the cached accumulate workspace of the current device. */
 int soil_workspace_release(void);
 

@@ -348,6 +348,16 @@ def negslope(t, scale):
     return out
 
 
+def fill_depressions(height, edge):
+    """Priority-flood depression filling (build-defined)."""
+    H, W = height.shape
+    out = np.empty((H, W), np.float32)
+    rc = lib().orc_fill_depressions(_f(out), _f(_chk(height)), C.c_int64(H), C.c_int64(W),
+                                    C.c_int(edge))
+    assert rc == 0
+    return out
+
+
 def resize(src, newres):
     """soil.resize (multiscale driver): (Ho, Wo[, D]) -> (Hn, Wn[, D])."""
     Ho, Wo = src.shape[:2]

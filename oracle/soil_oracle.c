@@ -1193,3 +1193,84 @@ void orc_solve_uniform(float* flux, const float* flow, const float* source, cons
       flux[K * n + c] = (source[K * n + c] * A + flux[K * n + c] / (float)count) / norm; /* :168 */
   }
 }
+
+/* --------------------------------------------------- depression filling (F5) */
+
+/* The reference has none (its example calls pysheds, example/dem_condition.py:35-41);
+ * BASELINE config 3 asks for a pit-filled DEM, so the build defines one — parity
+ * unpinned.  This oracle is Barnes, Lehman & Mulla (2014) priority-flood: cells next
+ * to an outlet (off-grid or NaN) enter a min-heap with w = z; popping the lowest cell
+ * c gives every unvisited neighbour n the level w(n) = max(z(n), w(c)).  The result is
+ * w(c) = min over paths to an outlet of the highest z on the path. */
+typedef struct { float w; int64_t n; } orc_heap_item;
+
+static void orc_heap_push(orc_heap_item* h, int64_t* size, orc_heap_item it) {
+  int64_t i = (*size)++;
+  while (i > 0) {
+    const int64_t p = (i - 1) / 2;
+    if (h[p].w <= it.w) break;
+    h[i] = h[p];
+    i = p;
+  }
+  h[i] = it;
+}
+static orc_heap_item orc_heap_pop(orc_heap_item* h, int64_t* size) {
+  const orc_heap_item top = h[0];
+  const orc_heap_item last = h[--(*size)];
+  int64_t i = 0;
+  for (;;) {
+    int64_t c = 2 * i + 1;
+    if (c >= *size) break;
+    if (c + 1 < *size && h[c + 1].w < h[c].w) ++c;
+    if (last.w <= h[c].w) break;
+    h[i] = h[c];
+    i = c;
+  }
+  if (*size > 0) h[i] = last;
+  return top;
+}
+
+int orc_fill_depressions(float* out, const float* height, int64_t H, int64_t W, int edge) {
+  static const int dx[8] = {-1, 0, 0, 1, -1, -1, 1, 1}, dy[8] = {0, -1, 1, 0, -1, 1, -1, 1};
+  const int K = edge == 1 ? 8 : 4;
+  const int64_t elem = H * W;
+  orc_heap_item* heap = (orc_heap_item*)malloc(sizeof(orc_heap_item) * (size_t)elem);
+  unsigned char* seen = (unsigned char*)calloc((size_t)elem, 1);
+  if (!heap || !seen) { free(heap); free(seen); return -1; }
+  int64_t size = 0;
+  for (int64_t n = 0; n < elem; ++n) {
+    const int64_t x = n / W, y = n % W;
+    const float z = height[n];
+    out[n] = z;
+    if (z != z) { seen[n] = 1; continue; } /* NoData: stays NaN, drains its neighbours */
+    int outlet = 0;
+    for (int k = 0; k < K; ++k) {
+      const int64_t nx = x + dx[k], ny = y + dy[k];
+      if (nx < 0 || ny < 0 || nx >= H || ny >= W) outlet = 1;
+      else if (height[nx * W + ny] != height[nx * W + ny]) outlet = 1;
+    }
+    if (outlet) {
+      seen[n] = 1;
+      const orc_heap_item it = {z, n};
+      orc_heap_push(heap, &size, it);
+    }
+  }
+  while (size > 0) {
+    const orc_heap_item c = orc_heap_pop(heap, &size);
+    const int64_t x = c.n / W, y = c.n % W;
+    for (int k = 0; k < K; ++k) {
+      const int64_t nx = x + dx[k], ny = y + dy[k];
+      if (nx < 0 || ny < 0 || nx >= H || ny >= W) continue;
+      const int64_t n = nx * W + ny;
+      if (seen[n]) continue;
+      seen[n] = 1;
+      const float w = fmaxf(height[n], c.w);
+      out[n] = w;
+      const orc_heap_item it = {w, n};
+      orc_heap_push(heap, &size, it);
+    }
+  }
+  free(heap);
+  free(seen);
+  return 0;
+}

@@ -125,6 +125,7 @@ void orc_gaussian_blur(float* tensor, float* scratch, int64_t H, int64_t W, int 
 void orc_normal(float* out, const float* in, int64_t H, int64_t W, const float scale[3]);
 
 /* path-integral solver */
+int orc_fill_depressions(float* out, const float* height, int64_t H, int64_t W, int edge);
 void orc_resize(float* dst, const float* src, int64_t Hn, int64_t Wn, int64_t Ho, int64_t Wo,
                 int D);
 void orc_solve_uniform(float* flux, const float* flow, const float* source, const float* decay,

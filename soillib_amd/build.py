@@ -18,7 +18,7 @@ OBJDIR = os.path.join(HERE, "build")
 LIB = os.path.join(LIBDIR, "libsoil_hip.so")
 
 SOURCES = ["runtime.hip", "erosion_cells.hip", "erosion_particles.hip", "erosion_particles_tiled.hip", "graph.hip",
-           "stencil.hip", "path.hip", "noise.hip", "io_tiff.hip"]
+           "stencil.hip", "path.hip", "noise.hip", "io_tiff.hip", "conditioning.hip"]
 
 # -ffp-contract=off / no fast-math: the numerical contract
 # needs every fp32 operation evaluated as written.  -munsafe-fp-atomics selects

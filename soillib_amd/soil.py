@@ -142,6 +142,16 @@ def accumulate_decay(graph, field, decay, edge_):
     return out
 
 
+def fill_depressions(height, edge_=None):
+    """Priority-flood surface of a DEM (soil_hip.h: soil_fill_depressions) — the
+    conditioning step the reference leaves to pysheds (example/dem_condition.py:35-41)."""
+    H, W = _hw(height)
+    out = silt.tensor(silt.float32, silt.shape(H, W), silt.gpu)
+    _call("soil_fill_depressions", out.c_ptr, _f(height, "height"), H, W,
+          int(d8 if edge_ is None else edge_), _abi.stream())
+    return out
+
+
 def multiflow(height, source, K, T, edge_=None, seed=0, first=0, stride=1, out=None):
     """Mean of `accumulate(random_weighted(height, edge, seed, k, T), source)` over the
     realisations k = first, first+stride, ... < K, each term divided by K in float32 and

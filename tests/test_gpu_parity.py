@@ -575,3 +575,37 @@ def test_resize_bit_exact(hip, oracle, old, new, D):
     if new[0] > 1 and new[1] > 1:
         assert_bit_equal(corners[0, 0], src[0, 0], "corner-aligned")
         assert_bit_equal(corners[-1, -1], src[-1, -1], "corner-aligned")
+
+
+@pytest.mark.parametrize("H,W", [(64, 64), (97, 130), (200, 31), (1, 9), (300, 300)])
+@pytest.mark.parametrize("edge", [0, 1])
+def test_fill_depressions_bit_exact(hip, oracle, H, W, edge):
+    """soil_fill_depressions vs the priority-flood oracle (build-defined):
+    only min/max are involved, so the fixed point is exact whatever the update order."""
+    from soillib_amd import soil
+    r = np.random.default_rng(H * 7 + W + edge)
+    dem = oracle.noise(H, W, seed=2.0, ext=(float(H), float(W))) * 50.0
+    dem += (r.standard_normal((H, W)) * 2.0).astype(np.float32)        # plenty of pits
+    if H > 8 and W > 8:
+        dem[H // 3:H // 3 + 3, W // 2:W // 2 + 4] = np.nan                 # a NoData hole drains
+        dem[H // 2, W // 4] = -1000.0                                     # a deep pit fills up
+    want = oracle.fill_depressions(dem, edge)
+    got = to_np(soil.fill_depressions(to_gpu(dem), edge))
+    assert_bit_equal(got, want, "fill_depressions")
+    ok = ~np.isnan(dem)
+    assert (got[ok] >= dem[ok]).all() and np.isnan(got[~ok]).all()
+    again = to_np(soil.fill_depressions(to_gpu(got), edge))
+    assert_bit_equal(again, got, "filling is idempotent")
+    if H > 8 and W > 8:
+        assert got[H // 2, W // 4] > -1000.0
+        # no cell is strictly below all of its neighbours any more (outlets aside)
+        flow = to_np(soil.steepest(to_gpu(np.nan_to_num(got, nan=-1e9)), edge))
+        inner = np.zeros((H, W), bool)
+        inner[1:-1, 1:-1] = True
+        pits = (flow < 0) & inner & ok
+        # cells left without a receiver sit on flats (equal neighbours), never in a hole
+        for x, y in zip(*np.nonzero(pits)):
+            nb = got[x - 1:x + 2, y - 1:y + 2].copy()
+            if edge == 0:
+                nb[::2, ::2] = np.nan                      # D4: the diagonals are no neighbours
+            assert np.nanmin(nb) >= got[x, y]
