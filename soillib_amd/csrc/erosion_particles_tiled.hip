@@ -437,70 +437,72 @@ __global__ void __launch_bounds__(NT)
     }
     if (!__any(have)) break;
 
+    // top of the reference loop: while(!__oob(pos) && ++iter < maxage)  (:100 / :306),
+    // then the slab check.  The outcome is worked out as flags first, so that the
+    // particle state is only written inside the one `if (step)` region below (a
+    // chain of nested branches costs a register copy of the record per level).
+    bool step = false;
+    int lx = 0, cy = 0, c = 0, cx = 0;
     if (have) {
-      // top of the reference loop: while(!__oob(pos) && ++iter < maxage)  (:100 / :306)
-      if (r.px < 0 || r.py < 0 || r.px >= k.Hf || r.py >= k.Wf) {  // __oob, erosion_map.cu:29-40
-        have = false;
-      } else {
-        const int cx = cell32(r.px), cy = cell32(r.py);
-        const int lx = cx - k.x0;
-        const bool esc = lx < k.lo || lx > k.hi;  // slab_escape
-        const int tr = lx - row0, tc = cy - col0;
-        const bool inside =
-            esc || (static_cast<unsigned>(tr) < TR && static_cast<unsigned>(tc) < TC);
-        if (!inside || budget == 0) {
-          // the particle stands on another tile, or its round budget is used
-          // up: park it (state untouched) and resume next round
-          parked = true;
-          have = false;
-        } else if (static_cast<uint32_t>(++r.iter) >= k.maxage) {
-          have = false;
-        } else if (esc) {
-          park_remote<KIND>(r, remote0);
-          have = false;
-        } else {
-          --budget;
-          ++nsteps;
-          // the cell's record comes from the packed plane through L1/L2 (the tile's
-          // 64 KiB are touched ~4x per round); issued first, the gather's latency
-          // hides under the deposit and the other waves of the SIMD
-          const int64_t lcell = static_cast<int64_t>(lx) * k.W + cy;
-          const float4 q = p4[lcell];
-          CasDeposit<KIND == FLUVIAL ? 4 : 3> dep;
-          const int c = tr * TC + tc;
-          const int64_t nind = static_cast<int64_t>(cx) * k.W + cy;  // :103 / :309
-          if (nind != r.ind) {                                       // :104-113 / :310-318
-            r.ind = nind;
-            // DEP 0: native ds_add_f32, fire and forget; DEP 1: CasDeposit
-            if (KIND == FLUVIAL) {
-              const float v0 = r.a0 * r.s0, v1 = r.a1 * r.s1, vx = r.a2 * r.svx, vy = r.a2 * r.svy;
-              if (DEP == 1) {
-                dep.p[0] = &s_f0[c], dep.p[1] = &s_f1[c], dep.p[2] = &s_fx[c], dep.p[3] = &s_fy[c];
-                dep.v[0] = v0, dep.v[1] = v1, dep.v[2] = vx, dep.v[3] = vy;
-                dep.begin();
-              } else {
-                atomicAdd(&s_f0[c], v0);
-                atomicAdd(&s_f1[c], v1);
-                atomicAdd(&s_fx[c], vx);
-                atomicAdd(&s_fy[c], vy);
-              }
-            } else {
-              const float v0 = r.a0 * r.s0, vx = r.a1 * r.svx, vy = r.a1 * r.svy;
-              if (DEP == 1) {
-                dep.p[0] = &s_f0[c], dep.p[1] = &s_fx[c], dep.p[2] = &s_fy[c];
-                dep.v[0] = v0, dep.v[1] = vx, dep.v[2] = vy;
-                dep.begin();
-              } else {
-                atomicAdd(&s_f0[c], v0);
-                atomicAdd(&s_fx[c], vx);
-                atomicAdd(&s_fy[c], vy);
-              }
-            }
+      const bool oob = r.px < 0 || r.py < 0 || r.px >= k.Hf || r.py >= k.Wf;  // erosion_map.cu:29-40
+      cx = cell32(r.px);
+      cy = cell32(r.py);
+      lx = cx - k.x0;
+      const bool esc = lx < k.lo || lx > k.hi;  // slab_escape
+      const int tr = lx - row0, tc = cy - col0;
+      c = tr * TC + tc;
+      const bool inside =
+          esc || (static_cast<unsigned>(tr) < TR && static_cast<unsigned>(tc) < TC);
+      // the particle stands on another tile, or its round budget is used up:
+      // park it (state untouched) and resume next round
+      const bool park = !oob && (!inside || budget == 0);
+      const bool aged = static_cast<uint32_t>(r.iter + 1) >= k.maxage;
+      step = !oob && !park && !aged && !esc;
+      if (!oob && !park && !aged && esc) park_remote<KIND>(r, remote0);
+      parked = parked || park;
+      have = step;
+    }
+    if (step) {
+      ++r.iter;
+      --budget;
+      ++nsteps;
+      // the cell's record comes from the packed plane through L1/L2 (the tile's
+      // 64 KiB are touched ~4x per round); issued first, the gather's latency
+      // hides under the deposit and the other waves of the SIMD
+      const int64_t lcell = static_cast<int64_t>(lx) * k.W + cy;
+      const float4 q = p4[lcell];
+      CasDeposit<KIND == FLUVIAL ? 4 : 3> dep;
+      const int64_t nind = static_cast<int64_t>(cx) * k.W + cy;  // :103 / :309
+      if (nind != r.ind) {                                       // :104-113 / :310-318
+        r.ind = nind;
+        // DEP 0: native ds_add_f32, fire and forget; DEP 1: CasDeposit
+        if (KIND == FLUVIAL) {
+          const float v0 = r.a0 * r.s0, v1 = r.a1 * r.s1, vx = r.a2 * r.svx, vy = r.a2 * r.svy;
+          if (DEP == 1) {
+            dep.p[0] = &s_f0[c], dep.p[1] = &s_f1[c], dep.p[2] = &s_fx[c], dep.p[3] = &s_fy[c];
+            dep.v[0] = v0, dep.v[1] = v1, dep.v[2] = vx, dep.v[3] = vy;
+            dep.begin();
+          } else {
+            atomicAdd(&s_f0[c], v0);
+            atomicAdd(&s_f1[c], v1);
+            atomicAdd(&s_fx[c], vx);
+            atomicAdd(&s_fy[c], vy);
           }
-          have = advance<KIND>(r, q, k);
-          if (DEP == 1) dep.finish();
+        } else {
+          const float v0 = r.a0 * r.s0, vx = r.a1 * r.svx, vy = r.a1 * r.svy;
+          if (DEP == 1) {
+            dep.p[0] = &s_f0[c], dep.p[1] = &s_fx[c], dep.p[2] = &s_fy[c];
+            dep.v[0] = v0, dep.v[1] = vx, dep.v[2] = vy;
+            dep.begin();
+          } else {
+            atomicAdd(&s_f0[c], v0);
+            atomicAdd(&s_fx[c], vx);
+            atomicAdd(&s_fy[c], vy);
+          }
         }
       }
+      have = advance<KIND>(r, q, k);
+      if (DEP == 1) dep.finish();
     }
   }
   {  // everything still parked goes out together (convergent: aggregate the counters)
