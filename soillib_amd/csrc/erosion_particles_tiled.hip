@@ -328,6 +328,35 @@ __global__ void __launch_bounds__(256)
   if (valid) order[start[tile] + slot] = static_cast<uint32_t>(i);
 }
 
+// ---- heaviest tiles first -------------------------------------------------------------
+//
+// Once the particles sit in channels a few tiles hold ten times the average queue.
+// Work-groups are dispatched in blockIdx order, so the round kernel looks its tile up
+// in a list sorted by queue length (256 buckets of 16 particles, longest first): the
+// long queues start at once and the short ones fill in behind them, instead of a
+// long queue starting last and the rest of the chip idling until it is done.
+__global__ void __launch_bounds__(1024)
+    k_tile_order(uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ count,
+                 int64_t tiles) {
+  __shared__ uint32_t hist[256], base[256];
+  const int tid = threadIdx.x;
+  if (tid < 256) hist[tid] = 0;
+  __syncthreads();
+  auto bucket = [](uint32_t c) { return 255u - (c >> 4 > 255u ? 255u : c >> 4); };
+  for (int64_t i = tid; i < tiles; i += 1024) atomicAdd(&hist[bucket(count[i])], 1u);
+  __syncthreads();
+  if (tid == 0) {
+    uint32_t run = 0;
+    for (int b = 0; b < 256; ++b) {
+      base[b] = run;
+      run += hist[b];
+    }
+  }
+  __syncthreads();
+  for (int64_t i = tid; i < tiles; i += 1024)
+    tile_order[atomicAdd(&base[bucket(count[i])], 1u)] = static_cast<uint32_t>(i);
+}
+
 // ---- one round: advance the particles of one tile against LDS ---------------------
 
 // Float adds on LDS words by compare-and-swap, split in two halves so that the
@@ -368,7 +397,8 @@ template <int KIND, int DEP, int TR, int TC, int NT>
 __global__ void __launch_bounds__(NT)
     k_tiled_round(PRec* __restrict__ out, uint32_t* __restrict__ dest,
                   uint32_t* __restrict__ count_next, const PRec* __restrict__ in,
-                  const uint32_t* __restrict__ order, const uint32_t* __restrict__ start,
+                  const uint32_t* __restrict__ order, const uint32_t* __restrict__ tile_order,
+                  const uint32_t* __restrict__ start,
                   const uint32_t* __restrict__ count, float* __restrict__ flux0,
                   float* __restrict__ flux1, float2* __restrict__ fluxV,
                   const float4* __restrict__ p4, const float* __restrict__ waterHeight,
@@ -376,7 +406,7 @@ __global__ void __launch_bounds__(NT)
                   Scale3 s, Param param, int tiles_w, int steps_per_round, TileShape ts_next,
                   int tiles_w_next) {
   constexpr int kCells = TR * TC, kBlock = NT, kPer = (kCells + NT - 1) / NT;
-  const int tile = blockIdx.x;
+  const int tile = static_cast<int>(tile_order[blockIdx.x]);
   const uint32_t cnt = count[tile];
   if (cnt == 0) return;
   const uint32_t first = start[tile];
@@ -667,7 +697,7 @@ static int run_tiled(float* flux0, float* flux1, float* fluxV, soil_rng* rng, in
   const size_t b_rec = align(sizeof(PRec) * N), b_cnt = align(sizeof(uint32_t) * (max_tiles + 1));
   const size_t b_p4 = align(sizeof(float4) * d.rows * d.W), b_idx = align(sizeof(uint32_t) * N);
   void* base = nullptr;
-  int rc = workspace_get(2, 2 * b_rec + 2 * b_idx + 4 * b_cnt + b_p4, &base);
+  int rc = workspace_get(2, 2 * b_rec + 2 * b_idx + 5 * b_cnt + b_p4, &base);
   if (rc != SOIL_OK) return rc;
   char* w = static_cast<char*>(base);
   PRec* cur = reinterpret_cast<PRec*>(w);    w += b_rec;   // records of this round (any order)
@@ -678,6 +708,7 @@ static int run_tiled(float* flux0, float* flux1, float* fluxV, soil_rng* rng, in
   uint32_t* count = reinterpret_cast<uint32_t*>(w);       w += b_cnt;
   uint32_t* count_next = reinterpret_cast<uint32_t*>(w);  w += b_cnt;
   uint32_t* start = reinterpret_cast<uint32_t*>(w);       w += b_cnt;
+  uint32_t* tile_order = reinterpret_cast<uint32_t*>(w);  w += b_cnt;
   uint32_t* fill = reinterpret_cast<uint32_t*>(w);
 
   unsigned long long* steps = nullptr;
@@ -714,6 +745,7 @@ static int run_tiled(float* flux0, float* flux1, float* fluxV, soil_rng* rng, in
     const int64_t tiles = tiles_of(sh);
     const int tiles_w = tiles_w_of(sh);
     k_tile_scan<<<1, 1024, 0, st>>>(start, count, tiles);
+    k_tile_order<<<1, 1024, 0, st>>>(tile_order, count, tiles);
     uint32_t live = 0;  // particles queued for this round = start[tiles]
     SOIL_HIP(hipMemcpyAsync(&live, start + tiles, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     SOIL_HIP(hipMemcpyAsync(&steps_now, steps, sizeof(steps_now), hipMemcpyDeviceToHost, st));
@@ -759,6 +791,7 @@ static int run_tiled(float* flux0, float* flux1, float* fluxV, soil_rng* rng, in
     if (deposit == 1)
       launch_round<KIND, 0>(sh, static_cast<unsigned>(tiles), st, next, dest, count_next,
                             static_cast<const PRec*>(cur), static_cast<const uint32_t*>(order),
+                            static_cast<const uint32_t*>(tile_order),
                             static_cast<const uint32_t*>(start),
                             static_cast<const uint32_t*>(count), flux0, flux1,
                             reinterpret_cast<float2*>(fluxV), static_cast<const float4*>(p4),
@@ -768,6 +801,7 @@ static int run_tiled(float* flux0, float* flux1, float* fluxV, soil_rng* rng, in
     else
       launch_round<KIND, 1>(sh, static_cast<unsigned>(tiles), st, next, dest, count_next,
                             static_cast<const PRec*>(cur), static_cast<const uint32_t*>(order),
+                            static_cast<const uint32_t*>(tile_order),
                             static_cast<const uint32_t*>(start),
                             static_cast<const uint32_t*>(count), flux0, flux1,
                             reinterpret_cast<float2*>(fluxV), static_cast<const float4*>(p4),
