@@ -74,6 +74,32 @@ __device__ __forceinline__ int64_t tile_id(int x0, float px, float py, int tiles
   return static_cast<int64_t>(lx >> ts.shift_r) * tiles_w + (cy >> ts.shift_c);
 }
 
+// A tile's queue is kept in kNB sections by how long a walker is expected to stay:
+// the steps until it leaves the tile along its present direction (about one cell
+// per step) or runs out of life, against the round's step budget K — >= K, >= K/2,
+// >= K/4, less.  Lanes of a wave take consecutive queue entries, so walkers that
+// stop early share waves and those waves retire early, instead of every wave
+// carrying a few idle lanes to the end of the round.  Only an ordering hint: any
+// section is a valid place for any particle.
+constexpr int kNB = 4;
+
+__device__ __forceinline__ uint32_t queue_key(int x0, float px, float py, float spx, float spy,
+                                              uint32_t life, int tiles_w, TileShape ts, int K) {
+  const int lx = cell32(px) - x0, cy = cell32(py);
+  const int trow = lx >> ts.shift_r, tcol = cy >> ts.shift_c;
+  const float x_lo = static_cast<float>((trow << ts.shift_r) + x0), y_lo = static_cast<float>(tcol << ts.shift_c);
+  const float x_hi = x_lo + static_cast<float>(1 << ts.shift_r), y_hi = y_lo + static_cast<float>(1 << ts.shift_c);
+  const float inv = __builtin_amdgcn_rsqf(spx * spx + spy * spy);
+  const float ux = spx * inv, uy = spy * inv;
+  const float big = 1.0e9f;
+  const float tx = ux > 0.0f ? (x_hi - px) / ux : (ux < 0.0f ? (x_lo - px) / ux : big);
+  const float ty = uy > 0.0f ? (y_hi - py) / uy : (uy < 0.0f ? (y_lo - py) / uy : big);
+  const float t = fminf(fminf(tx, ty), static_cast<float>(life));
+  const float k = static_cast<float>(K);
+  const uint32_t section = t >= k ? 0u : (t >= 0.5f * k ? 1u : (t >= 0.25f * k ? 2u : 3u));
+  return static_cast<uint32_t>(trow * tiles_w + tcol) * kNB + section;
+}
+
 // per-launch constants of the step (erosion.cu:63-72 / :276-283), hoisted
 struct StepConst {
   float Hf, Wf, eps, g, lenL, nu, tau, kd, fD, evap, theta, kdd, kds, tau_y, fx, fy;
@@ -214,7 +240,7 @@ __global__ void __launch_bounds__(256)
     k_tiled_spawn(PRec* __restrict__ recs, uint32_t* __restrict__ dest,
                   uint32_t* __restrict__ count, soil_rng* __restrict__ rng, int64_t N, const float4* __restrict__ p4,
                   const float* __restrict__ waterSource, Dom d, Scale3 s, Param param,
-                  int tiles_w, TileShape ts) {
+                  int tiles_w, TileShape ts, int steps_per_round) {
   const int64_t n = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
   if (n >= N) return;
   PRec r;
@@ -267,7 +293,9 @@ __global__ void __launch_bounds__(256)
         r.svx = Q * q.x;                          // :298
         r.svy = Q * q.y;
       }
-      tile = static_cast<uint32_t>(tile_id(static_cast<int>(d.x0), pos.x, pos.y, tiles_w, ts));
+      tile = queue_key(static_cast<int>(d.x0), pos.x, pos.y, spx, spy,
+                       param.maxage > 0x7fffffffull ? 0x7fffffffu : static_cast<uint32_t>(param.maxage),
+                       tiles_w, ts, steps_per_round);
       atomicAdd(&count[tile], 1u);
       recs[n] = r;
     }
@@ -328,6 +356,38 @@ __global__ void __launch_bounds__(256)
   if (valid) order[start[tile] + slot] = static_cast<uint32_t>(i);
 }
 
+// ---- queue offsets: exclusive scan of the kNB section counts of every tile ----------------
+// (one work-group; a thread owns a run of whole tiles and moves them as uint4)
+static_assert(kNB == 4, "k_queue_scan moves the sections of a tile as one uint4");
+__global__ void __launch_bounds__(1024)
+    k_queue_scan(uint32_t* __restrict__ start, const uint4* __restrict__ count4, int64_t tiles) {
+  __shared__ uint32_t part[1024];
+  const int tid = threadIdx.x;
+  const int64_t chunk = (tiles + 1023) / 1024;
+  const int64_t b = tid * chunk, e = (b + chunk < tiles) ? b + chunk : tiles;
+  uint32_t sum = 0;
+  for (int64_t i = b; i < e; ++i) {
+    const uint4 c = count4[i];
+    sum += c.x + c.y + c.z + c.w;
+  }
+  part[tid] = sum;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
+    const uint32_t v = (tid >= off) ? part[tid - off] : 0u;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  uint32_t run = part[tid] - sum;
+  uint4* out = reinterpret_cast<uint4*>(start);
+  for (int64_t i = b; i < e; ++i) {
+    const uint4 c = count4[i];
+    out[i] = make_uint4(run, run + c.x, run + c.x + c.y, run + c.x + c.y + c.z);
+    run += c.x + c.y + c.z + c.w;
+  }
+  if (tid == 1023) start[tiles * kNB] = part[1023];  // particles queued in total
+}
+
 // ---- heaviest tiles first -------------------------------------------------------------
 //
 // Once the particles sit in channels a few tiles hold ten times the average queue.
@@ -336,14 +396,15 @@ __global__ void __launch_bounds__(256)
 // long queues start at once and the short ones fill in behind them, instead of a
 // long queue starting last and the rest of the chip idling until it is done.
 __global__ void __launch_bounds__(1024)
-    k_tile_order(uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ count,
+    k_tile_order(uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ start,
                  int64_t tiles) {
   __shared__ uint32_t hist[256], base[256];
   const int tid = threadIdx.x;
   if (tid < 256) hist[tid] = 0;
   __syncthreads();
   auto bucket = [](uint32_t c) { return 255u - (c >> 4 > 255u ? 255u : c >> 4); };
-  for (int64_t i = tid; i < tiles; i += 1024) atomicAdd(&hist[bucket(count[i])], 1u);
+  auto queued = [&](int64_t t) { return start[(t + 1) * kNB] - start[t * kNB]; };
+  for (int64_t i = tid; i < tiles; i += 1024) atomicAdd(&hist[bucket(queued(i))], 1u);
   __syncthreads();
   if (tid == 0) {
     uint32_t run = 0;
@@ -354,7 +415,7 @@ __global__ void __launch_bounds__(1024)
   }
   __syncthreads();
   for (int64_t i = tid; i < tiles; i += 1024)
-    tile_order[atomicAdd(&base[bucket(count[i])], 1u)] = static_cast<uint32_t>(i);
+    tile_order[atomicAdd(&base[bucket(queued(i))], 1u)] = static_cast<uint32_t>(i);
 }
 
 // ---- one round: advance the particles of one tile against LDS ---------------------
@@ -398,8 +459,7 @@ __global__ void __launch_bounds__(NT)
     k_tiled_round(PRec* __restrict__ out, uint32_t* __restrict__ dest,
                   uint32_t* __restrict__ count_next, const PRec* __restrict__ in,
                   const uint32_t* __restrict__ order, const uint32_t* __restrict__ tile_order,
-                  const uint32_t* __restrict__ start,
-                  const uint32_t* __restrict__ count, float* __restrict__ flux0,
+                  const uint32_t* __restrict__ start, float* __restrict__ flux0,
                   float* __restrict__ flux1, float2* __restrict__ fluxV,
                   const float4* __restrict__ p4, const float* __restrict__ waterHeight,
                   float* __restrict__ remote0, unsigned long long* __restrict__ steps, Dom d,
@@ -407,9 +467,9 @@ __global__ void __launch_bounds__(NT)
                   int tiles_w_next) {
   constexpr int kCells = TR * TC, kBlock = NT, kPer = (kCells + NT - 1) / NT;
   const int tile = static_cast<int>(tile_order[blockIdx.x]);
-  const uint32_t cnt = count[tile];
+  const uint32_t first = start[tile * kNB];
+  const uint32_t cnt = start[(tile + 1) * kNB] - first;
   if (cnt == 0) return;
-  const uint32_t first = start[tile];
   const int row0 = (tile / tiles_w) * TR, col0 = (tile % tiles_w) * TC;  // local row, column
 
   // flux accumulators as separate planes: lane addresses c map to 32 distinct
@@ -445,7 +505,8 @@ __global__ void __launch_bounds__(NT)
   r.iter = -1;
   auto write_out = [&]() {
     const uint32_t slot = atomicAdd(&s_out, 1u);  // slots this tile's queue occupied
-    const uint32_t to = static_cast<uint32_t>(tile_id(k.x0, r.px, r.py, tiles_w_next, ts_next));
+    const uint32_t to = queue_key(k.x0, r.px, r.py, r.spx, r.spy, k.maxage - static_cast<uint32_t>(r.iter),
+                                  tiles_w_next, ts_next, steps_per_round);
     out[first + slot] = r;
     dest[first + slot] = to;
     atomicAdd(&count_next[to], 1u);
@@ -537,7 +598,10 @@ __global__ void __launch_bounds__(NT)
   }
   {  // everything still parked goes out together (convergent: aggregate the counters)
     const uint32_t slot = wave_append(&s_out, parked);
-    const int64_t dest_tile = parked ? tile_id(k.x0, r.px, r.py, tiles_w_next, ts_next) : 0;
+    const int64_t dest_tile =
+        parked ? queue_key(k.x0, r.px, r.py, r.spx, r.spy, k.maxage - static_cast<uint32_t>(r.iter),
+                           tiles_w_next, ts_next, steps_per_round)
+               : 0;
     (void)wave_key_append(count_next, parked, dest_tile);
     if (parked) {
       out[first + slot] = r;
@@ -694,7 +758,7 @@ static int run_tiled(float* flux0, float* flux1, float* fluxV, soil_rng* rng, in
   const int64_t max_tiles = std::max(tiles_of(shape_early), tiles_of(shape_late));
 
   auto align = [](size_t b) { return (b + 255) & ~static_cast<size_t>(255); };
-  const size_t b_rec = align(sizeof(PRec) * N), b_cnt = align(sizeof(uint32_t) * (max_tiles + 1));
+  const size_t b_rec = align(sizeof(PRec) * N), b_cnt = align(sizeof(uint32_t) * (max_tiles * kNB + 1));
   const size_t b_p4 = align(sizeof(float4) * d.rows * d.W), b_idx = align(sizeof(uint32_t) * N);
   void* base = nullptr;
   int rc = workspace_get(2, 2 * b_rec + 2 * b_idx + 5 * b_cnt + b_p4, &base);
@@ -723,7 +787,8 @@ static int run_tiled(float* flux0, float* flux1, float* fluxV, soil_rng* rng, in
         waterHeight, d, s, p, lo, cells);
   SOIL_HIP(hipMemsetAsync(count, 0, b_cnt, st));
   k_tiled_spawn<KIND><<<blocks_for(N, 256), 256, 0, st>>>(
-      cur, dest, count, rng, N, p4, waterSource, d, s, p, tiles_w_of(shape_of(0)), ts_of(shape_of(0)));
+      cur, dest, count, rng, N, p4, waterSource, d, s, p, tiles_w_of(shape_of(0)), ts_of(shape_of(0)),
+      steps_per_round);
   SOIL_LAUNCH_CHECK();
   int64_t n_src = N;  // slots of `cur` to look at (spawn output, then survivor slots)
   const uint64_t max_rounds = p.maxage + 2;  // every live particle advances >= 1 step per round
@@ -744,10 +809,10 @@ static int run_tiled(float* flux0, float* flux1, float* fluxV, soil_rng* rng, in
     const int sh = shape_of(round), sh_next = shape_of(round + 1);
     const int64_t tiles = tiles_of(sh);
     const int tiles_w = tiles_w_of(sh);
-    k_tile_scan<<<1, 1024, 0, st>>>(start, count, tiles);
-    k_tile_order<<<1, 1024, 0, st>>>(tile_order, count, tiles);
+    k_queue_scan<<<1, 1024, 0, st>>>(start, reinterpret_cast<const uint4*>(count), tiles);
+    k_tile_order<<<1, 1024, 0, st>>>(tile_order, start, tiles);
     uint32_t live = 0;  // particles queued for this round = start[tiles]
-    SOIL_HIP(hipMemcpyAsync(&live, start + tiles, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    SOIL_HIP(hipMemcpyAsync(&live, start + tiles * kNB, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     SOIL_HIP(hipMemcpyAsync(&steps_now, steps, sizeof(steps_now), hipMemcpyDeviceToHost, st));
     SOIL_HIP(hipStreamSynchronize(st));
     double rate = 1e30;  // steps per second of the round just done
@@ -758,8 +823,9 @@ static int run_tiled(float* flux0, float* flux1, float* fluxV, soil_rng* rng, in
     }
     steps_before = steps_now;
     if (verbose) {  // queue-length statistics of the round (diagnostics only)
-      std::vector<uint32_t> h(static_cast<size_t>(tiles));
-      SOIL_HIP(hipMemcpy(h.data(), count, sizeof(uint32_t) * tiles, hipMemcpyDeviceToHost));
+      std::vector<uint32_t> pre(static_cast<size_t>(tiles * kNB + 1)), h(static_cast<size_t>(tiles));
+      SOIL_HIP(hipMemcpy(pre.data(), start, sizeof(uint32_t) * pre.size(), hipMemcpyDeviceToHost));
+      for (int64_t t = 0; t < tiles; ++t) h[t] = pre[(t + 1) * kNB] - pre[t * kNB];
       std::sort(h.begin(), h.end());
       const int lanes = kShapes[sh].nt;
       uint64_t batches = 0, empty = 0, sparse = 0;
@@ -792,8 +858,7 @@ static int run_tiled(float* flux0, float* flux1, float* fluxV, soil_rng* rng, in
       launch_round<KIND, 0>(sh, static_cast<unsigned>(tiles), st, next, dest, count_next,
                             static_cast<const PRec*>(cur), static_cast<const uint32_t*>(order),
                             static_cast<const uint32_t*>(tile_order),
-                            static_cast<const uint32_t*>(start),
-                            static_cast<const uint32_t*>(count), flux0, flux1,
+                            static_cast<const uint32_t*>(start), flux0, flux1,
                             reinterpret_cast<float2*>(fluxV), static_cast<const float4*>(p4),
                             waterHeight, remote0, steps, d, s, p, tiles_w, steps_per_round,
                             ts_of(sh_next),
@@ -802,8 +867,7 @@ static int run_tiled(float* flux0, float* flux1, float* fluxV, soil_rng* rng, in
       launch_round<KIND, 1>(sh, static_cast<unsigned>(tiles), st, next, dest, count_next,
                             static_cast<const PRec*>(cur), static_cast<const uint32_t*>(order),
                             static_cast<const uint32_t*>(tile_order),
-                            static_cast<const uint32_t*>(start),
-                            static_cast<const uint32_t*>(count), flux0, flux1,
+                            static_cast<const uint32_t*>(start), flux0, flux1,
                             reinterpret_cast<float2*>(fluxV), static_cast<const float4*>(p4),
                             waterHeight, remote0, steps, d, s, p, tiles_w, steps_per_round,
                             ts_of(sh_next),
