@@ -140,6 +140,9 @@ def main():
     ap.add_argument("--particles-div", type=int, default=8, help="N = cells / this")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-size", type=int, default=1024)
+    ap.add_argument("--overlap-particles", action="store_true",
+                    help="issue the fluvial and debris launches overlapped on two streams "
+                         "(soil_particles_pair_slab) instead of back to back")
     ap.add_argument("--particle-mode", type=int, default=0,
                     help="0 auto, 1 direct (reference launch shape), 2 staged — ablation")
     args = ap.parse_args()
@@ -159,6 +162,8 @@ def main():
     _abi.check(lib.soil_set_particle_mode(args.particle_mode))
 
     S = args.size
+    if args.overlap_particles:
+        os.environ["SOIL_STEP_PAIR"] = "1"       # the slab runner reads it too
     param = script_param(soil)
     if world > 1 or os.environ.get("SOIL_BENCH_FORCE_SLAB") == "1":
         from soillib_amd import parallel
@@ -182,9 +187,13 @@ def main():
             def step(self_inner, ev=None):
                 model.seed_step()
                 if ev: ev.record(0)
-                model.particles_fluvial()
-                if ev: ev.record(1)
-                model.particles_debris()
+                if serial:
+                    model.particles_fluvial()
+                    if ev: ev.record(1)
+                    model.particles_debris()
+                else:                     # both launches overlapped on two streams
+                    model.particles_pair()
+                    if ev: ev.record(1)
                 if ev: ev.record(2)
                 model.cells_fused()
                 if ev: ev.record(3)
@@ -199,6 +208,7 @@ def main():
         runner = _Single()
 
     ev = Events(_abi, 4)
+    serial = not (args.overlap_particles or os.environ.get("SOIL_STEP_PAIR") == "1")
     for _ in range(args.warmup):
         runner.step()
     runner.barrier()
@@ -264,7 +274,8 @@ def main():
         "final_state": final,
         "particle_steps_per_step": psteps_rank * world // K,
         "gparticle_steps_per_s": psteps_rank * world / elapsed / 1e9,
-        "phases_ms": {"particles_fluvial": phase[0] / K, "particles_debris": phase[1] / K,
+        "phases_ms": ({"particles_fluvial": phase[0] / K, "particles_debris": phase[1] / K}
+                      if serial else {"particles_fluvial+debris_overlapped": (phase[0] + phase[1]) / K}) | {
                       "cells_fused": phase[2] / K},
         "cell_phase_mcells_per_s": cells_rank / t_cells / 1e6 * world,
         "roofline": {"bound": "hbm", "kernel": "k_erode_cells_fused", "achieved": achieved,

@@ -295,6 +295,18 @@ int soil_particles_debris_slab(float* massFlux, float* velocityFlux, float* albe
                                const float* velocity, const float* albedoSource, float* remote0,
                                const soil_domain* dom, const float scale[3],
                                const soil_param* param, void* stream);
+/* Both particle launches of one step (the two calls above) issued together so that
+ * they overlap: the debris launch fills the SIMD slots the fluvial launch leaves idle
+ * in its sparse late rounds (two internal streams forked from and joined into
+ * `stream`).  The reference runs them back to back on ONE rng tensor, each launch
+ * consuming two draws per particle; give the debris launch its own tensor seeded two
+ * draws further — soil_rng_seed(rng_debris, N, seed, offset + 2) — and every
+ * trajectory is the same as in the sequential order.  Planes as in
+ * soil_erode_cells_fused (the cell-phase outputs are not touched). */
+int soil_particles_pair_slab(const soil_erosion_planes* planes, soil_rng* rng_fluvial,
+                             soil_rng* rng_debris, int64_t N, float* remote0,
+                             const soil_domain* dom, const float scale[3], const soil_param* param,
+                             void* stream);
 /* Launch shape of the particle kernels: 0 = auto, 1 = direct (the reference's:
  * thread n = particle n, 5-point stencil gathers), 2 = staged (packed field
  * plane + tile-ordered particles), 3 = tiled (per-tile particle queues, one

@@ -99,6 +99,8 @@ SIGNATURES = {
                                     [C.POINTER(Domain), F3, C.POINTER(Param), vp]),
     "soil_particles_debris_slab": (cint, [vp] * 4 + [i64] + [vp] * 4 +
                                    [C.POINTER(Domain), F3, C.POINTER(Param), vp]),
+    "soil_particles_pair_slab": (cint, [C.POINTER(ErosionPlanes), vp, vp, i64, vp,
+                                        C.POINTER(Domain), F3, C.POINTER(Param), vp]),
     "soil_set_particle_mode": (cint, [cint]),
     "soil_ghost_rows": (i64, [C.POINTER(Param)]),
     "soil_particle_steps": (cint, [C.POINTER(u64), cint, vp]),

@@ -631,6 +631,34 @@ int soil_particles_debris_slab(float* massFlux, float* velocityFlux, float* albe
                                  as_stream(stream));
 }
 
+int soil_particles_pair_slab(const soil_erosion_planes* planes, soil_rng* rng_fluvial,
+                             soil_rng* rng_debris, int64_t N, float* remote0,
+                             const soil_domain* dom, const float scale[3], const soil_param* param,
+                             void* stream) {
+  SOIL_DEVICE();
+  SOIL_REQUIRE(planes && dom && scale && param, "particles_pair_slab: null argument");
+  const soil_erosion_planes& P = *planes;
+  SOIL_REQUIRE(P.layers && P.rainfall && P.waterHeight && P.waterFlux && P.massFlux && P.velocity &&
+                   P.velocityFlux && P.debrisFlux && P.debrisVelocity && P.debrisVelocityFlux,
+               "particles_pair_slab: null plane");
+  SOIL_REQUIRE(N >= 0 && (N == 0 || (rng_fluvial && rng_debris && rng_fluvial != rng_debris)),
+               "particles_pair_slab: needs two distinct rng tensors");
+  const Dom d = to_dom(dom);
+  int rc = check_domain(d);
+  if (rc != SOIL_OK) return rc;
+  if (N <= 0) return SOIL_OK;
+  const Scale3 s = s3p(scale);
+  hipStream_t st = as_stream(stream);
+  if (use_tiled(N, nullptr))
+    return launch_pair_tiled(P, rng_fluvial, rng_debris, N, remote0, d, s, *param, st);
+  rc = launch_particles_fluvial(P.waterFlux, P.massFlux, P.velocityFlux, nullptr, rng_fluvial, N,
+                                P.layers, P.rainfall, P.waterHeight, P.velocity, nullptr, remote0, d,
+                                s, *param, st);
+  if (rc != SOIL_OK) return rc;
+  return launch_particles_debris(P.debrisFlux, P.debrisVelocityFlux, nullptr, rng_debris, N, P.layers,
+                                 P.debrisVelocity, nullptr, remote0, d, s, *param, st);
+}
+
 int soil_particle_steps(uint64_t* total, int reset, void* stream) {
   SOIL_REQUIRE(total != nullptr, "soil_particle_steps: null output");
   unsigned long long* counter = nullptr;

@@ -703,6 +703,10 @@ static int env_int(const char* name, int fallback) {
   return v > 0 ? v : fallback;
 }
 
+__global__ void k_fold_steps(unsigned long long* total, const unsigned long long* part) {
+  atomicAdd(total, *part);
+}
+
 // Tile shapes a round can use: rows x columns (powers of two) and threads of the
 // work-group.  Every round re-sorts the particles by tile, so the shape may change
 // from round to round: early rounds have ~1 particle per 8 cells everywhere (big
@@ -722,99 +726,168 @@ static void launch_round(int shape, unsigned grid, hipStream_t st, A... a) {
   }
 }
 
+// One tiled launch as a resumable object: begin() queues the pre-pass, the spawn and
+// the first queue scan; every advance() waits for the scan of the round that is about
+// to start (its queue length and the step counter travel to pinned host memory),
+// decides between another round and the finishing launch, and queues that work plus
+// the next scan.  Between two advance() calls the stream stays busy, so two runs on
+// two streams (fluvial and debris of one step, run_pair below) overlap: while the
+// host waits for one, the other's kernels fill the SIMD slots the first leaves idle
+// in its sparse late rounds.
+struct TiledHostWord {  // pinned; written by the device-to-host copies of a scan
+  uint32_t live;
+  uint32_t pad;
+  unsigned long long steps;
+};
+
 template <int KIND>
-static int run_tiled(float* flux0, float* flux1, float* fluxV, soil_rng* rng, int64_t N,
-                     const float* layers, const float* waterSource, const float* waterHeight,
-                     const float* velocity, float* remote0, const Dom& d, Scale3 s, const Param& p,
-                     hipStream_t st) {
-  // steps a particle may take per round: bounds the time a work-group waits for
-  // its longest walker; and the population below which the rounds stop paying
-  static const int steps_per_round = env_int("SOIL_TILED_STEPS", 32);
-  // the finishing launch pays ~4 L2 atomics per step (22.7 G/s), a round a fixed
-  // cost that grows with the number of tiles: N/40 within [4096, 200000] is where
-  // they cross for 512^2 .. 8192^2 grids with N = cells/8
-  static const int tail_env = env_int("SOIL_TILED_TAIL", 0);
-  const int64_t tail = tail_env > 0 ? tail_env : std::min<int64_t>(200000, std::max<int64_t>(4096, N / 40));
-  static const int deposit = env_int("SOIL_TILED_DEP", 0);
-  // measured at 8192^2 (N = cells/8): 768 threads on a 64x64 tile serve the fluvial
-  // queues (about half of them hold 513..700 particles) in one batch, 45 vs 48 ms;
-  // the debris kernel keeps 3 work-groups of 512 per CU instead, 17 vs 20 ms
-  static const int shape_early =
-      (std::getenv("SOIL_TILED_SHAPE") ? env_int("SOIL_TILED_SHAPE", 0) : (KIND == FLUVIAL ? 1 : 0)) %
-      kNumShapes;
-  static const int shape_late = env_int("SOIL_TILED_LATE", shape_early) % kNumShapes;
-  static const int switch_round = env_int("SOIL_TILED_SWITCH", 1 << 30);
-  static const bool verbose = std::getenv("SOIL_TILED_VERBOSE") != nullptr;
-  auto shape_of = [&](uint64_t round) {
-    return round >= static_cast<uint64_t>(switch_round) ? shape_late : shape_early;
-  };
-  auto tiles_w_of = [&](int sh) { return static_cast<int>((d.W + kShapes[sh].tc - 1) / kShapes[sh].tc); };
-  auto tiles_of = [&](int sh) {
+struct TiledRun {
+  // arguments
+  float *flux0, *flux1, *fluxV;
+  soil_rng* rng;
+  int64_t N;
+  const float *layers, *waterSource, *waterHeight, *velocity;
+  float* remote0;
+  Dom d;
+  Scale3 s;
+  Param p;
+  hipStream_t st;
+  // tuning (see the comments at their definitions in setup())
+  int steps_per_round = 32, deposit = 0, shape_early = 0, shape_late = 0, switch_round = 1 << 30;
+  int64_t tail = 0;
+  double finish_rate = 4.0e9;
+  bool verbose = false;
+  // workspace
+  PRec *cur = nullptr, *next = nullptr;
+  uint32_t *dest = nullptr, *order = nullptr, *count = nullptr, *count_next = nullptr,
+           *start = nullptr, *tile_order = nullptr, *fill = nullptr;
+  float4* p4 = nullptr;
+  unsigned long long *steps_global = nullptr, *steps_run = nullptr;
+  size_t b_cnt = 0;
+  TiledHostWord* host = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // progress
+  uint64_t round = 0;
+  int64_t n_src = 0;
+  unsigned long long steps_before = 0;
+  bool timed = false, done = false;
+
+  int shape_of(uint64_t r) const { return r >= static_cast<uint64_t>(switch_round) ? shape_late : shape_early; }
+  int tiles_w_of(int sh) const { return static_cast<int>((d.W + kShapes[sh].tc - 1) / kShapes[sh].tc); }
+  int64_t tiles_of(int sh) const {
     return static_cast<int64_t>(tiles_w_of(sh)) * ((d.rows + kShapes[sh].tr - 1) / kShapes[sh].tr);
-  };
-  auto ts_of = [&](int sh) {
-    return TileShape{__builtin_ctz(kShapes[sh].tr), __builtin_ctz(kShapes[sh].tc)};
-  };
-  const int64_t max_tiles = std::max(tiles_of(shape_early), tiles_of(shape_late));
-
-  auto align = [](size_t b) { return (b + 255) & ~static_cast<size_t>(255); };
-  const size_t b_rec = align(sizeof(PRec) * N), b_cnt = align(sizeof(uint32_t) * (max_tiles * kNB + 1));
-  const size_t b_p4 = align(sizeof(float4) * d.rows * d.W), b_idx = align(sizeof(uint32_t) * N);
-  void* base = nullptr;
-  int rc = workspace_get(2, 2 * b_rec + 2 * b_idx + 5 * b_cnt + b_p4, &base);
-  if (rc != SOIL_OK) return rc;
-  char* w = static_cast<char*>(base);
-  PRec* cur = reinterpret_cast<PRec*>(w);    w += b_rec;   // records of this round (any order)
-  PRec* next = reinterpret_cast<PRec*>(w);   w += b_rec;   // survivors, grouped by the tile they left
-  uint32_t* dest = reinterpret_cast<uint32_t*>(w);   w += b_idx;  // tile each slot is bound for
-  uint32_t* order = reinterpret_cast<uint32_t*>(w);  w += b_idx;  // slots sorted by tile
-  float4* p4 = reinterpret_cast<float4*>(w);  w += b_p4;
-  uint32_t* count = reinterpret_cast<uint32_t*>(w);       w += b_cnt;
-  uint32_t* count_next = reinterpret_cast<uint32_t*>(w);  w += b_cnt;
-  uint32_t* start = reinterpret_cast<uint32_t*>(w);       w += b_cnt;
-  uint32_t* tile_order = reinterpret_cast<uint32_t*>(w);  w += b_cnt;
-  uint32_t* fill = reinterpret_cast<uint32_t*>(w);
-
-  unsigned long long* steps = nullptr;
-  rc = step_counter(&steps);
-  if (rc != SOIL_OK) return rc;
-
-  const int64_t lo = stencil_lo(d), hi = stencil_hi(d);
-  const int64_t cells = (hi - lo + 1) * d.W;
-  if (cells > 0)
-    k_tiled_pack<KIND><<<blocks_for(cells, 256), 256, 0, st>>>(
-        p4, reinterpret_cast<const float2*>(layers), reinterpret_cast<const float2*>(velocity),
-        waterHeight, d, s, p, lo, cells);
-  SOIL_HIP(hipMemsetAsync(count, 0, b_cnt, st));
-  k_tiled_spawn<KIND><<<blocks_for(N, 256), 256, 0, st>>>(
-      cur, dest, count, rng, N, p4, waterSource, d, s, p, tiles_w_of(shape_of(0)), ts_of(shape_of(0)),
-      steps_per_round);
-  SOIL_LAUNCH_CHECK();
-  int64_t n_src = N;  // slots of `cur` to look at (spawn output, then survivor slots)
-  const uint64_t max_rounds = p.maxage + 2;  // every live particle advances >= 1 step per round
-  // A round is worth its fixed cost while it advances particles faster than the
-  // finishing launch would (4 L2 atomics per step at 22.7 G/s = 5.7 G steps/s).
-  // Particles that zig-zag along a tile edge get a handful of steps per round; on
-  // small grids they are most of what is left after maxage/steps_per_round rounds.
-  // The rate of the round just done (device step counter / HIP event time) decides.
-  static thread_local hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  if (!ev0) {
-    SOIL_HIP(hipEventCreate(&ev0));
-    SOIL_HIP(hipEventCreate(&ev1));
   }
-  static const double finish_rate = env_int("SOIL_TILED_FINISH_MRATE", 4000) * 1e6;  // steps/s
-  unsigned long long steps_before = 0, steps_now = 0;
-  bool timed = false;
-  for (uint64_t round = 0; round < max_rounds; ++round) {
+  static TileShape ts_of(int sh) {
+    return TileShape{__builtin_ctz(kShapes[sh].tr), __builtin_ctz(kShapes[sh].tc)};
+  }
+
+  int setup() {
+    // steps a particle may take per round: bounds the time a work-group waits for
+    // its longest walker
+    steps_per_round = env_int("SOIL_TILED_STEPS", 32);
+    // the finishing launch pays ~4 L2 atomics per step (22.7 G/s), a round a fixed
+    // cost that grows with the number of tiles: N/40 within [4096, 200000] is where
+    // they cross for 512^2 .. 8192^2 grids with N = cells/8
+    const int tail_env = env_int("SOIL_TILED_TAIL", 0);
+    tail = tail_env > 0 ? tail_env : std::min<int64_t>(200000, std::max<int64_t>(4096, N / 40));
+    deposit = env_int("SOIL_TILED_DEP", 0);
+    // measured at 8192^2 (N = cells/8): 768 threads on a 64x64 tile serve the fluvial
+    // queues (about half of them hold 513..700 particles) in one batch, 45 vs 48 ms;
+    // the debris kernel keeps 3 work-groups of 512 per CU instead, 17 vs 20 ms
+    shape_early = (std::getenv("SOIL_TILED_SHAPE") ? env_int("SOIL_TILED_SHAPE", 0)
+                                                   : (KIND == FLUVIAL ? 1 : 0)) % kNumShapes;
+    shape_late = env_int("SOIL_TILED_LATE", shape_early) % kNumShapes;
+    switch_round = env_int("SOIL_TILED_SWITCH", 1 << 30);
+    // A round is worth its fixed cost while it advances particles faster than the
+    // finishing launch would (4 L2 atomics per step at 22.7 G/s = 5.7 G steps/s).
+    // Particles that zig-zag along a tile edge get a handful of steps per round; on
+    // small grids they are most of what is left after maxage/steps_per_round rounds.
+    // The rate of the round just done (step counter / HIP event time) decides.
+    finish_rate = env_int("SOIL_TILED_FINISH_MRATE", 4000) * 1e6;
+    verbose = std::getenv("SOIL_TILED_VERBOSE") != nullptr;
+
+    const int64_t max_tiles = std::max(tiles_of(shape_early), tiles_of(shape_late));
+    auto align = [](size_t b) { return (b + 255) & ~static_cast<size_t>(255); };
+    const size_t b_rec = align(sizeof(PRec) * N);
+    const size_t b_p4 = align(sizeof(float4) * d.rows * d.W), b_idx = align(sizeof(uint32_t) * N);
+    b_cnt = align(sizeof(uint32_t) * (max_tiles * kNB + 1));
+    void* base = nullptr;
+    // one workspace per kind: the two launches of a step may be in flight together
+    int rc = workspace_get(KIND == FLUVIAL ? 2 : 5, 2 * b_rec + 2 * b_idx + 5 * b_cnt + b_p4 + 256, &base);
+    if (rc != SOIL_OK) return rc;
+    char* w = static_cast<char*>(base);
+    cur = reinterpret_cast<PRec*>(w);    w += b_rec;   // records of this round (any order)
+    next = reinterpret_cast<PRec*>(w);   w += b_rec;   // survivors, grouped by the tile they left
+    dest = reinterpret_cast<uint32_t*>(w);   w += b_idx;  // queue section each slot is bound for
+    order = reinterpret_cast<uint32_t*>(w);  w += b_idx;  // slots sorted by queue section
+    p4 = reinterpret_cast<float4*>(w);  w += b_p4;
+    count = reinterpret_cast<uint32_t*>(w);       w += b_cnt;
+    count_next = reinterpret_cast<uint32_t*>(w);  w += b_cnt;
+    start = reinterpret_cast<uint32_t*>(w);       w += b_cnt;
+    tile_order = reinterpret_cast<uint32_t*>(w);  w += b_cnt;
+    fill = reinterpret_cast<uint32_t*>(w);        w += b_cnt;
+    steps_run = reinterpret_cast<unsigned long long*>(w);
+    rc = step_counter(&steps_global);
+    if (rc != SOIL_OK) return rc;
+    // pinned word + events, one set per (thread, kind)
+    static thread_local TiledHostWord* t_host = nullptr;
+    static thread_local hipEvent_t t_ev0 = nullptr, t_ev1 = nullptr;
+    if (!t_host) {
+      SOIL_HIP(hipHostMalloc(reinterpret_cast<void**>(&t_host), sizeof(TiledHostWord)));
+      SOIL_HIP(hipEventCreate(&t_ev0));
+      SOIL_HIP(hipEventCreate(&t_ev1));
+    }
+    host = t_host;
+    ev0 = t_ev0;
+    ev1 = t_ev1;
+    return SOIL_OK;
+  }
+
+  // scan of the queues the next round starts from + what the host needs to decide
+  int queue_scan() {
+    const int64_t tiles = tiles_of(shape_of(round));
+    k_queue_scan<<<1, 1024, 0, st>>>(start, reinterpret_cast<const uint4*>(count), tiles);
+    k_tile_order<<<1, 1024, 0, st>>>(tile_order, start, tiles);
+    SOIL_LAUNCH_CHECK();
+    SOIL_HIP(hipMemcpyAsync(&host->live, start + tiles * kNB, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    SOIL_HIP(hipMemcpyAsync(&host->steps, steps_run, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    return SOIL_OK;
+  }
+
+  int begin() {
+    if (int rc = setup(); rc != SOIL_OK) return rc;
+    const int64_t lo = stencil_lo(d), hi = stencil_hi(d);
+    const int64_t cells = (hi - lo + 1) * d.W;
+    if (cells > 0)
+      k_tiled_pack<KIND><<<blocks_for(cells, 256), 256, 0, st>>>(
+          p4, reinterpret_cast<const float2*>(layers), reinterpret_cast<const float2*>(velocity),
+          waterHeight, d, s, p, lo, cells);
+    SOIL_HIP(hipMemsetAsync(count, 0, b_cnt, st));
+    SOIL_HIP(hipMemsetAsync(steps_run, 0, sizeof(unsigned long long), st));
+    k_tiled_spawn<KIND><<<blocks_for(N, 256), 256, 0, st>>>(
+        cur, dest, count, rng, N, p4, waterSource, d, s, p, tiles_w_of(shape_of(0)),
+        ts_of(shape_of(0)), steps_per_round);
+    SOIL_LAUNCH_CHECK();
+    n_src = N;  // slots of `cur` to look at (spawn output, then survivor slots)
+    round = 0;
+    return queue_scan();
+  }
+
+  int finish_steps() {  // fold this launch's steps into the device-wide counter
+    k_fold_steps<<<1, 1, 0, st>>>(steps_global, steps_run);
+    SOIL_LAUNCH_CHECK();
+    done = true;
+    return SOIL_OK;
+  }
+
+  int advance() {
+    if (done) return SOIL_OK;
+    SOIL_HIP(hipStreamSynchronize(st));
+    const uint32_t live = host->live;  // particles queued for this round
+    const unsigned long long steps_now = host->steps;
     const int sh = shape_of(round), sh_next = shape_of(round + 1);
     const int64_t tiles = tiles_of(sh);
     const int tiles_w = tiles_w_of(sh);
-    k_queue_scan<<<1, 1024, 0, st>>>(start, reinterpret_cast<const uint4*>(count), tiles);
-    k_tile_order<<<1, 1024, 0, st>>>(tile_order, start, tiles);
-    uint32_t live = 0;  // particles queued for this round = start[tiles]
-    SOIL_HIP(hipMemcpyAsync(&live, start + tiles * kNB, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    SOIL_HIP(hipMemcpyAsync(&steps_now, steps, sizeof(steps_now), hipMemcpyDeviceToHost, st));
-    SOIL_HIP(hipStreamSynchronize(st));
     double rate = 1e30;  // steps per second of the round just done
     if (timed) {
       float ms = 0.0f;
@@ -836,19 +909,19 @@ static int run_tiled(float* flux0, float* flux1, float* fluxV, soil_rng* rng, in
       }
       std::fprintf(stderr,
                    "[tiled kind %d] round %llu: %u live; tiles %lld empty %llu sparse(<1/4) %llu "
-                   "median %u p90 %u p99 %u max %u batches %llu\n",
+                   "median %u p90 %u p99 %u max %u batches %llu; last round %.2f G steps/s\n",
                    KIND, static_cast<unsigned long long>(round), live, static_cast<long long>(tiles),
                    static_cast<unsigned long long>(empty), static_cast<unsigned long long>(sparse),
                    h[h.size() / 2], h[h.size() * 9 / 10], h[h.size() * 99 / 100], h.back(),
-                   static_cast<unsigned long long>(batches));
+                   static_cast<unsigned long long>(batches), timed ? rate * 1e-9 : 0.0);
     }
-    if (live == 0) break;
-    if (verbose && timed) std::fprintf(stderr, "[tiled kind %d]   last round: %.2f G steps/s\n", KIND, rate * 1e-9);
+    // every live particle advances >= 1 step per round: maxage + 2 rounds always suffice
+    if (live == 0 || round >= p.maxage + 2) return finish_steps();
     if (round > 0 && (static_cast<int64_t>(live) <= tail || rate < finish_rate)) {
       k_tiled_finish<KIND><<<blocks_for(n_src, 256), 256, 0, st>>>(
-          cur, dest, n_src, flux0, flux1, fluxV, p4, waterHeight, remote0, steps, d, s, p);
+          cur, dest, n_src, flux0, flux1, fluxV, p4, waterHeight, remote0, steps_run, d, s, p);
       SOIL_LAUNCH_CHECK();
-      break;
+      return finish_steps();
     }
     SOIL_HIP(hipEventRecord(ev0, st));
     SOIL_HIP(hipMemsetAsync(fill, 0, b_cnt, st));
@@ -860,25 +933,95 @@ static int run_tiled(float* flux0, float* flux1, float* fluxV, soil_rng* rng, in
                             static_cast<const uint32_t*>(tile_order),
                             static_cast<const uint32_t*>(start), flux0, flux1,
                             reinterpret_cast<float2*>(fluxV), static_cast<const float4*>(p4),
-                            waterHeight, remote0, steps, d, s, p, tiles_w, steps_per_round,
-                            ts_of(sh_next),
-                            tiles_w_of(sh_next));
+                            waterHeight, remote0, steps_run, d, s, p, tiles_w, steps_per_round,
+                            ts_of(sh_next), tiles_w_of(sh_next));
     else
       launch_round<KIND, 1>(sh, static_cast<unsigned>(tiles), st, next, dest, count_next,
                             static_cast<const PRec*>(cur), static_cast<const uint32_t*>(order),
                             static_cast<const uint32_t*>(tile_order),
                             static_cast<const uint32_t*>(start), flux0, flux1,
                             reinterpret_cast<float2*>(fluxV), static_cast<const float4*>(p4),
-                            waterHeight, remote0, steps, d, s, p, tiles_w, steps_per_round,
-                            ts_of(sh_next),
-                            tiles_w_of(sh_next));
+                            waterHeight, remote0, steps_run, d, s, p, tiles_w, steps_per_round,
+                            ts_of(sh_next), tiles_w_of(sh_next));
     SOIL_LAUNCH_CHECK();
     SOIL_HIP(hipEventRecord(ev1, st));
     timed = true;
     n_src = live;
     std::swap(cur, next);
     std::swap(count, count_next);
+    ++round;
+    return queue_scan();
   }
+};
+
+template <int KIND>
+static TiledRun<KIND> make_run(float* flux0, float* flux1, float* fluxV, soil_rng* rng, int64_t N,
+                               const float* layers, const float* waterSource,
+                               const float* waterHeight, const float* velocity, float* remote0,
+                               const Dom& d, Scale3 s, const Param& p, hipStream_t st) {
+  TiledRun<KIND> r;
+  r.flux0 = flux0, r.flux1 = flux1, r.fluxV = fluxV, r.rng = rng, r.N = N;
+  r.layers = layers, r.waterSource = waterSource, r.waterHeight = waterHeight, r.velocity = velocity;
+  r.remote0 = remote0, r.d = d, r.s = s, r.p = p, r.st = st;
+  return r;
+}
+
+template <int KIND>
+static int run_tiled(float* flux0, float* flux1, float* fluxV, soil_rng* rng, int64_t N,
+                     const float* layers, const float* waterSource, const float* waterHeight,
+                     const float* velocity, float* remote0, const Dom& d, Scale3 s, const Param& p,
+                     hipStream_t st) {
+  TiledRun<KIND> r = make_run<KIND>(flux0, flux1, fluxV, rng, N, layers, waterSource, waterHeight,
+                                    velocity, remote0, d, s, p, st);
+  if (int rc = r.begin(); rc != SOIL_OK) return rc;
+  while (!r.done)
+    if (int rc = r.advance(); rc != SOIL_OK) return rc;
+  return SOIL_OK;
+}
+
+// Both launches of a step, overlapped: two internal streams forked from `st` and joined
+// back into it; the host alternates between the two runs' decisions.
+int launch_pair_tiled(const soil_erosion_planes& P, soil_rng* rng_fluvial, soil_rng* rng_debris, int64_t N,
+                      float* remote0, const Dom& d, Scale3 s, const Param& p, hipStream_t st) {
+  static thread_local hipStream_t sA = nullptr, sB = nullptr;
+  static thread_local hipEvent_t fork = nullptr, joinA = nullptr, joinB = nullptr;
+  if (!sA) {
+    SOIL_HIP(hipStreamCreateWithFlags(&sA, hipStreamNonBlocking));
+    SOIL_HIP(hipStreamCreateWithFlags(&sB, hipStreamNonBlocking));
+    SOIL_HIP(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
+    SOIL_HIP(hipEventCreateWithFlags(&joinA, hipEventDisableTiming));
+    SOIL_HIP(hipEventCreateWithFlags(&joinB, hipEventDisableTiming));
+  }
+  SOIL_HIP(hipEventRecord(fork, st));
+  SOIL_HIP(hipStreamWaitEvent(sA, fork, 0));
+  SOIL_HIP(hipStreamWaitEvent(sB, fork, 0));
+  TiledRun<FLUVIAL> A = make_run<FLUVIAL>(P.waterFlux, P.massFlux, P.velocityFlux, rng_fluvial, N,
+                                          P.layers, P.rainfall, P.waterHeight, P.velocity, remote0,
+                                          d, s, p, sA);
+  TiledRun<DEBRIS> B = make_run<DEBRIS>(P.debrisFlux, nullptr, P.debrisVelocityFlux, rng_debris, N,
+                                        P.layers, nullptr, nullptr, P.debrisVelocity, remote0, d, s,
+                                        p, sB);
+  // The early rounds of either launch keep the VALUs >90 % busy on their own, so the
+  // debris launch is held back until the fluvial one has done its maxage/K full rounds
+  // and thins out: its kernels then fill the slots the sparse late rounds leave idle.
+  static const int delay_env = env_int("SOIL_PAIR_DELAY", 0);
+  if (int rc = A.begin(); rc != SOIL_OK) return rc;
+  const uint64_t delay = delay_env > 0 ? static_cast<uint64_t>(delay_env)
+                                       : (p.maxage + A.steps_per_round - 1) / A.steps_per_round;
+  bool b_started = false;
+  while (!A.done || !B.done) {
+    if (!b_started && (A.done || A.round >= delay)) {
+      if (int rc = B.begin(); rc != SOIL_OK) return rc;
+      b_started = true;
+    }
+    if (int rc = A.advance(); rc != SOIL_OK) return rc;
+    if (b_started)
+      if (int rc = B.advance(); rc != SOIL_OK) return rc;
+  }
+  SOIL_HIP(hipEventRecord(joinA, sA));
+  SOIL_HIP(hipEventRecord(joinB, sB));
+  SOIL_HIP(hipStreamWaitEvent(st, joinA, 0));
+  SOIL_HIP(hipStreamWaitEvent(st, joinB, 0));
   return SOIL_OK;
 }
 

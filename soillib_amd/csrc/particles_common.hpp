@@ -55,5 +55,9 @@ int launch_fluvial_tiled(float* waterFlux, float* massFlux, float* velocityFlux,
 int launch_debris_tiled(float* massFlux, float* velocityFlux, soil_rng* rng, int64_t N,
                         const float* layers, const float* velocity, float* remote0, const Dom& d,
                         Scale3 s, const Param& p, hipStream_t st);
+// both launches of a step overlapped on two internal streams forked from / joined into `st`
+int launch_pair_tiled(const soil_erosion_planes& P, soil_rng* rng_fluvial, soil_rng* rng_debris,
+                      int64_t N, float* remote0, const Dom& d, Scale3 s, const Param& p,
+                      hipStream_t st);
 
 }  // namespace soil

@@ -16,6 +16,7 @@ ops (one launch each) and exists so that tests can show both are bit-identical.
 The model may be a row slab of a larger grid (see soillib_amd.parallel).
 """
 import ctypes as C
+import os
 
 from . import _abi, silt
 
@@ -50,6 +51,7 @@ class ErosionModel:
         for name in self.PLANES_2:
             setattr(self, name, alloc(silt.float32, (r, w, 2)))
         self.rng = alloc(silt.rng, (self.N,))
+        self.rng_debris = alloc(silt.rng, (self.N,))   # the fluvial launch's state two draws on
         for name in ("layers", "layers_next") + self.PLANES_1 + self.PLANES_2:
             silt.set(getattr(self, name), 0.0)
         silt.seed(self.rng, self.seed, 0)
@@ -71,6 +73,16 @@ class ErosionModel:
     # -- the three phases ------------------------------------------------------
     def seed_step(self):
         silt.seed(self.rng, self.seed, self.step_index * self.N)
+
+    def particles_pair(self):
+        """Both particle launches of the step, overlapped (soil_particles_pair_slab).  The
+        debris launch draws from its own tensor, seeded where the fluvial launch leaves
+        the shared one in the sequential order (two draws per particle further)."""
+        silt.seed(self.rng_debris, self.seed, self.step_index * self.N + 2)
+        planes = self._planes()
+        _abi.check(_abi.lib().soil_particles_pair_slab(
+            C.byref(planes), self.rng.c_ptr, self.rng_debris.c_ptr, self.N, None,
+            C.byref(self.dom), self._scale(), self.param._ref(), _abi.stream()))
 
     def particles_fluvial(self):
         L = _abi.lib()
@@ -101,10 +113,15 @@ class ErosionModel:
 
     # -- whole steps -----------------------------------------------------------
     def step(self):
-        """One erosion step: 2 particle launches + 1 fused cell launch."""
+        """One erosion step: 2 particle launches + 1 fused cell launch.  SOIL_STEP_PAIR=1
+        issues the two launches overlapped on two streams (particles_pair; measured gain at
+        8192^2: 1 %, both launches are VALU-bound on their own — DESIGN.md §3.2)."""
         self.seed_step()
-        self.particles_fluvial()
-        self.particles_debris()
+        if os.environ.get("SOIL_STEP_PAIR") == "1":
+            self.particles_pair()
+        else:
+            self.particles_fluvial()
+            self.particles_debris()
         self.cells_fused()
         self.swap_layers()
         self.step_index += 1

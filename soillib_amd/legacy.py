@@ -152,6 +152,7 @@ def _engine(model, data, track, param):
         for key, t in names.items():
             setattr(eng, key, t)
         eng.rng = silt.tensor(silt.rng, silt.shape(eng.N), silt.gpu)
+        eng.rng_debris = silt.tensor(silt.rng, silt.shape(eng.N), silt.gpu)
         model._engine = eng
     eng.param = param
     return eng

@@ -122,6 +122,15 @@ class HipOps:
             self._p(P["layers"]), self._p(P["debrisVelocity"]), None, self._p(remote0),
             C.byref(dom), self.abi.vec(scale, 3), param._ref(), self._stream()))
 
+    def particles_pair(self, P, rng, rng_debris, N, dom, scale, param, remote0):
+        """Both launches overlapped (soil_particles_pair_slab)."""
+        planes = self.abi.ErosionPlanes()
+        for name in self.abi._PLANES:
+            setattr(planes, name, P[name].data_ptr())
+        self.abi.check(self.lib.soil_particles_pair_slab(
+            C.byref(planes), self._p(rng), self._p(rng_debris), N, self._p(remote0), C.byref(dom),
+            self.abi.vec(scale, 3), param._ref(), self._stream()))
+
     def add_cell0(self, P, remote0):
         """Global cell (0,0) += the all-reduced deposits of the other ranks' NaN walkers."""
         for plane, lo, n in (("waterFlux", 0, 1), ("massFlux", 1, 1), ("velocityFlux", 2, 2),
@@ -194,6 +203,8 @@ class SlabRunner:
         self.P = {name: ops.alloc((self.rows, self.W, ch) if ch > 1 else (self.rows, self.W))
                   for name, ch in PLANE_CHANNELS.items()}
         self.rng = ops.alloc((self.N,), "rng")
+        self.rng_debris = ops.alloc((self.N,), "rng") if hasattr(ops, "particles_pair") else None
+        self.serial_particles = os.environ.get("SOIL_STEP_PAIR") != "1"   # overlap is opt-in
         self.remote0 = ops.alloc((8,))
         self.up = self.rank - 1 if self.rank > 0 else None
         self.down = self.rank + 1 if self.rank < self.world - 1 else None
@@ -289,9 +300,19 @@ class SlabRunner:
         ops.seed(self.rng, self.seed, self.step_index * self.N)
         ops.zero(self.remote0)
         if ev: ev.record(0)
-        ops.particles_fluvial(P, self.rng, self.N, self.dom, self.scale, self.param, self.remote0)
-        if ev: ev.record(1)
-        ops.particles_debris(P, self.rng, self.N, self.dom, self.scale, self.param, self.remote0)
+        if hasattr(ops, "particles_pair") and not self.serial_particles:
+            # the debris launch draws from a tensor of its own, seeded where the fluvial
+            # launch leaves the shared one in the sequential order
+            ops.seed(self.rng_debris, self.seed, self.step_index * self.N + 2)
+            ops.particles_pair(P, self.rng, self.rng_debris, self.N, self.dom, self.scale,
+                               self.param, self.remote0)
+            if ev: ev.record(1)
+        else:
+            ops.particles_fluvial(P, self.rng, self.N, self.dom, self.scale, self.param,
+                                  self.remote0)
+            if ev: ev.record(1)
+            ops.particles_debris(P, self.rng, self.N, self.dom, self.scale, self.param,
+                                 self.remote0)
         if ev: ev.record(2)
         if self.world == 1:
             ops.cells(P, self.dom, self.r0, self.r1, self.scale, self.param)

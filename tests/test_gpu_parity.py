@@ -609,3 +609,47 @@ def test_fill_depressions_bit_exact(hip, oracle, H, W, edge):
             if edge == 0:
                 nb[::2, ::2] = np.nan                      # D4: the diagonals are no neighbours
             assert np.nanmin(nb) >= got[x, y]
+
+
+@pytest.mark.parametrize("S,maxage", [(512, 96), (96, 64)])
+def test_particle_pair_equals_sequential_launches(hip, S, maxage):
+    """soil_particles_pair_slab (both launches overlapped on two streams, the debris launch
+    on an rng tensor seeded two draws further) walks the same trajectories as the
+    reference's order — fluvial, then debris on the same rng tensor."""
+    from soillib_amd import silt, soil
+    from soillib_amd.erosion import ErosionModel
+    param = script_param(soil.param_t())
+    param.maxage = maxage
+    param.critSlopeBedrock = 0.05
+    param.yieldStress = 0.001
+    m = ErosionModel(S, S, (20.0 / S, 20.0 / S, 4.0), param, S * S // 8, seed=3)
+    p = soil.noise_t()
+    p.seed = 3.0
+    p.ext = [S, S]
+    bed = soil.noise(silt.shape(S, S), p, host=silt.gpu)
+    zero = silt.tensor(silt.float32, silt.shape(S, S), silt.gpu)
+    silt.set(zero, 0.0)
+    from soillib_amd import _abi
+    _abi.check(hip.soil_layers_from_planes(m.layers.c_ptr, bed.c_ptr, zero.c_ptr, S * S, None))
+    silt.set(m.rainfall, 1.0)
+    m.step()
+    m.step()
+    flux = ("waterFlux", "massFlux", "velocityFlux", "debrisFlux", "debrisVelocityFlux")
+    out = {}
+    for how in ("sequential", "pair"):
+        for k in flux:
+            silt.set(getattr(m, k), 0.0)
+        m.seed_step()
+        soil.particle_steps(reset=True)
+        if how == "pair":
+            m.particles_pair()
+        else:
+            m.particles_fluvial()
+            m.particles_debris()
+        steps = soil.particle_steps(reset=True)
+        out[how] = (steps, {k: to_np(getattr(m, k)).copy() for k in flux},
+                    to_np(m.rng_debris if how == "pair" else m.rng)["offset"].copy())
+    assert out["pair"][0] == out["sequential"][0] > 0
+    assert (out["pair"][2] == out["sequential"][2]).all()      # both end four draws further
+    for k in flux:
+        _flux_close(out["pair"][1][k], out["sequential"][1][k], "pair vs sequential " + k)
