@@ -106,6 +106,10 @@ __global__ void __launch_bounds__(kGBlock)
 
 // ---- accumulate --------------------------------------------------------------
 
+// donor / decay slot k of cell n lives at [k * elem + n] (the reference interleaves the
+// K slots of a cell, graph.cu:448-520): neighbouring threads then touch neighbouring
+// words, and a cell with one pending donor moves 4 bytes per array instead of a
+// 32-byte sector
 struct Acc {  // acc_t, graph.cu:422-427
   int32_t* donor;
   int32_t* count;
@@ -126,7 +130,7 @@ __global__ void __launch_bounds__(kGBlock)
     const int64_t nx = x + kShiftX[k], ny = y + kShiftY[k];
     if (nx < 0 || ny < 0 || nx >= H || ny >= W) continue;  // :340-341
     const int64_t nind = nx * W + ny;
-    if (nind == next) donor[K * nind + k] = static_cast<int32_t>(n);  // :344-345
+    if (nind == next) donor[k * (H * W) + nind] = static_cast<int32_t>(n);  // :344-345
   }
 }
 
@@ -143,65 +147,87 @@ __global__ void __launch_bounds__(kGBlock)
   int32_t dn[K];
 #pragma unroll
   for (int k = 0; k < K; ++k) {
-    const int32_t dd = donor[K * n + k];
+    const int32_t dd = donor[k * elem + n];
     if (dd >= 0) dn[c++] = dd;
   }
   count[n] = c;
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     const bool live = k < c;
-    donor[K * n + k] = live ? dn[k] : -1;
+    donor[k * elem + n] = live ? dn[k] : -1;
     if (live) {
       const float D = TENSOR_DECAY ? decayIn[dn[k]] : 1.0f;
-      decay[K * n + k] = (k < 4) ? D : powf_(D, 1.414f);
+      decay[k * elem + n] = (k < 4) ? D : powf_(D, 1.414f);
     }
   }
 }
 
-// __rake_compress, graph.cu:429-522: one synchronous round, in -> out
+// __rake_compress, graph.cu:429-522: one synchronous round, in -> out.
+//
+// The arithmetic and its order are the reference's; two things keep finished work
+// out of HBM.  (1) `count` carries one more state: > 0 donors pending, 0 final but
+// the other buffer still holds the stale cell, -1 final in both buffers — such a
+// cell costs one 4-byte read per round instead of 16 bytes read + written (on a
+// 4096^2 DEM most cells are final after a few of the 26 rounds).  (2) A round whose
+// predecessor left every cell at -1 has nothing to do and returns at once
+// (`flags`: [round % 3] = "work left", set by the previous round).
 template <int K>
 __global__ void __launch_bounds__(kGBlock)
-    k_rake_compress(Acc out, const Acc in, int64_t elem) {
+    k_rake_compress(Acc out, const Acc in, int64_t elem, int* __restrict__ flags, int round) {
+  if (flags[round % 3] == 0) return;
+  if (blockIdx.x == 0 && threadIdx.x == 0) flags[(round + 2) % 3] = 0;
   const int64_t n = static_cast<int64_t>(blockIdx.x) * kGBlock + threadIdx.x;
-  if (n >= elem) return;
-  float value = in.value[n];  // :440
-  int count = in.count[n];    // :441
-  int32_t donors[K];
-  float decays[K];
+  bool pending = false;
+  if (n < elem) {
+    int count = in.count[n];  // :441
+    if (count >= 0) {
+      float value = in.value[n];  // :440
+      int32_t donors[K];
+      float decays[K];
 #pragma unroll
-  for (int k = 0; k < K; ++k) {  // :448-468
-    if (k < count) {
-      donors[k] = in.donor[K * n + k];
-      decays[k] = in.decay[K * n + k];
-    }
-  }
-  for (int k = 0; k < count; ++k) {  // :471
-    const int32_t donor = donors[k];
-    const float decay = decays[k];
-    const int dcount = in.count[donor];  // :476
-    if (dcount == 0) {                   // :479-487
-      value += decay * in.value[donor];
-      donors[k] = donors[count - 1];
-      decays[k] = decays[count - 1];
-      donors[count - 1] = -1;
-      decays[count - 1] = 0.0f;
-      count -= 1;
-      k -= 1;
-    } else if (dcount == 1) {  // :490-494
-      value += decay * in.value[donor];
-      donors[k] = in.donor[static_cast<int64_t>(K) * donor];
-      decays[k] = decay * in.decay[static_cast<int64_t>(K) * donor];
-    }
-  }
-  out.value[n] = value;  // :498
-  out.count[n] = count;  // :499
+      for (int k = 0; k < K; ++k) {  // :448-468
+        if (k < count) {
+          donors[k] = in.donor[k * elem + n];
+          decays[k] = in.decay[k * elem + n];
+        }
+      }
+      const bool was_final = count == 0;
+      for (int k = 0; k < count; ++k) {  // :471
+        const int32_t donor = donors[k];
+        const float decay = decays[k];
+        const int dcount = in.count[donor];  // :476
+        if (dcount <= 0) {                   // :479-487
+          value += decay * in.value[donor];
+          donors[k] = donors[count - 1];
+          decays[k] = decays[count - 1];
+          donors[count - 1] = -1;
+          decays[count - 1] = 0.0f;
+          count -= 1;
+          k -= 1;
+        } else if (dcount == 1) {  // :490-494
+          value += decay * in.value[donor];
+          donors[k] = in.donor[donor];  // slot 0 of the donor
+          decays[k] = decay * in.decay[donor];
+        }
+      }
+      out.value[n] = value;  // :498
+      if (was_final) {       // both buffers hold the final value from here on
+        out.count[n] = -1;
+        in.count[n] = -1;
+      } else {
+        out.count[n] = count;  // :499
+        pending = true;        // still has donors, or became final only in `out`
 #pragma unroll
-  for (int k = 0; k < K; ++k) {  // :500-520
-    if (k < count) {
-      out.donor[K * n + k] = donors[k];
-      out.decay[K * n + k] = decays[k];
+        for (int k = 0; k < K; ++k) {  // :500-520
+          if (k < count) {
+            out.donor[k * elem + n] = donors[k];
+            out.decay[k * elem + n] = decays[k];
+          }
+        }
+      }
     }
   }
+  if (__any(pending) && (threadIdx.x & 63) == 0) flags[(round + 1) % 3] = 1;
 }
 
 template <int K>
@@ -211,7 +237,7 @@ static int accumulate_impl(float* out, const int32_t* graph, const float* source
   auto align = [](size_t b) { return (b + 255) & ~static_cast<size_t>(255); };
   const size_t b1 = align(sizeof(float) * elem), bK = align(sizeof(float) * elem * K);
   void* base = nullptr;
-  int rc = workspace_get(0, 4 * b1 + 4 * bK, &base);
+  int rc = workspace_get(0, 4 * b1 + 4 * bK + 256, &base);
   if (rc != SOIL_OK) return rc;
   char* p = static_cast<char*>(base);
   Acc A, B;
@@ -222,7 +248,8 @@ static int accumulate_impl(float* out, const int32_t* graph, const float* source
   A.donor = reinterpret_cast<int32_t*>(p); p += bK;
   A.decay = reinterpret_cast<float*>(p);   p += bK;
   B.donor = reinterpret_cast<int32_t*>(p); p += bK;
-  B.decay = reinterpret_cast<float*>(p);
+  B.decay = reinterpret_cast<float*>(p);   p += bK;
+  int* flags = reinterpret_cast<int*>(p);
 
   const unsigned nb = blocks_for(elem, kGBlock);
   SOIL_HIP(hipMemsetAsync(A.donor, 0xff, sizeof(int32_t) * elem * K, st));  // silt::set(donor,-1) :552
@@ -236,9 +263,11 @@ static int accumulate_impl(float* out, const int32_t* graph, const float* source
 
   const int64_t iter =
       static_cast<int64_t>(std::ceil(std::log2(static_cast<float>(elem)) / 2.0f));  // :559
+  const int first_flags[3] = {1, 0, 0};
+  SOIL_HIP(hipMemcpyAsync(flags, first_flags, sizeof(first_flags), hipMemcpyHostToDevice, st));
   for (int64_t i = 0; i <= iter; ++i) {                                             // :560-563
-    k_rake_compress<K><<<nb, kGBlock, 0, st>>>(B, A, elem);
-    k_rake_compress<K><<<nb, kGBlock, 0, st>>>(A, B, elem);
+    k_rake_compress<K><<<nb, kGBlock, 0, st>>>(B, A, elem, flags, static_cast<int>(2 * i));
+    k_rake_compress<K><<<nb, kGBlock, 0, st>>>(A, B, elem, flags, static_cast<int>(2 * i + 1));
   }
   SOIL_LAUNCH_CHECK();
   SOIL_HIP(hipMemcpyAsync(out, A.value, sizeof(float) * elem, hipMemcpyDeviceToDevice, st));
