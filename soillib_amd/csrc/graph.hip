@@ -117,45 +117,39 @@ struct Acc {  // acc_t, graph.cu:422-427
   float* decay;
 };
 
-// __donor, graph.cu:321-348: one writer per (receiver, k) slot, race-free
-template <int K>
-__global__ void __launch_bounds__(kGBlock)
-    k_donor(int32_t* __restrict__ donor, const int32_t* __restrict__ graph, int64_t H, int64_t W) {
-  const int64_t n = static_cast<int64_t>(blockIdx.x) * kGBlock + threadIdx.x;
-  if (n >= H * W) return;
-  const int64_t x = n / W, y = n % W;
-  const int64_t next = graph[n];  // :333
-#pragma unroll
-  for (int k = 0; k < K; ++k) {
-    const int64_t nx = x + kShiftX[k], ny = y + kShiftY[k];
-    if (nx < 0 || ny < 0 || nx >= H || ny >= W) continue;  // :340-341
-    const int64_t nind = nx * W + ny;
-    if (nind == next) donor[k * (H * W) + nind] = static_cast<int32_t>(n);  // :344-345
-  }
-}
-
-// __count (graph.cu:350-380) fused with my_decay (:382-420): compact the donor
-// slots, count them and assign the per-edge decay (diagonal exponent by
-// COMPACTED slot index k >= 4).
+// __donor (graph.cu:321-348) + __count (:350-380) + my_decay (:382-420) in one pass
+// from the receiver's side.  The reference lets every donor n write itself into
+// slot k of its receiver, k = the direction with n + shift[k] == receiver, then
+// compacts the K slots in that order and assigns the per-edge decay (diagonal
+// exponent by COMPACTED slot index k >= 4).  Here cell n
+// asks its K neighbours n - shift[k] whether they drain into it: same slots, same
+// order, no -1 fill of the K*elem slot array, no scatter, and value = source rides
+// along.
 template <int K, bool TENSOR_DECAY>
 __global__ void __launch_bounds__(kGBlock)
-    k_count_decay(int32_t* __restrict__ count, int32_t* __restrict__ donor,
-                  float* __restrict__ decay, const float* __restrict__ decayIn, int64_t elem) {
+    k_donors(int32_t* __restrict__ count, int32_t* __restrict__ donor, float* __restrict__ decay,
+             float* __restrict__ value, const int32_t* __restrict__ graph,
+             const float* __restrict__ source, const float* __restrict__ decayIn, int64_t H,
+             int64_t W) {
   const int64_t n = static_cast<int64_t>(blockIdx.x) * kGBlock + threadIdx.x;
+  const int64_t elem = H * W;
   if (n >= elem) return;
+  const int64_t x = n / W, y = n % W;
   int c = 0;
   int32_t dn[K];
 #pragma unroll
   for (int k = 0; k < K; ++k) {
-    const int32_t dd = donor[k * elem + n];
-    if (dd >= 0) dn[c++] = dd;
+    const int64_t dx = x - kShiftX[k], dy = y - kShiftY[k];  // the cell whose k-th neighbour is n
+    if (dx < 0 || dy < 0 || dx >= H || dy >= W) continue;
+    const int64_t d = dx * W + dy;
+    if (graph[d] == n) dn[c++] = static_cast<int32_t>(d);  // :333-345
   }
   count[n] = c;
+  value[n] = source[n];  // silt::set(value, source), :553
 #pragma unroll
   for (int k = 0; k < K; ++k) {
-    const bool live = k < c;
-    donor[k * elem + n] = live ? dn[k] : -1;
-    if (live) {
+    if (k < c) {
+      donor[k * elem + n] = dn[k];
       const float D = TENSOR_DECAY ? decayIn[dn[k]] : 1.0f;
       decay[k * elem + n] = (k < 4) ? D : powf_(D, 1.414f);
     }
@@ -237,12 +231,12 @@ static int accumulate_impl(float* out, const int32_t* graph, const float* source
   auto align = [](size_t b) { return (b + 255) & ~static_cast<size_t>(255); };
   const size_t b1 = align(sizeof(float) * elem), bK = align(sizeof(float) * elem * K);
   void* base = nullptr;
-  int rc = workspace_get(0, 4 * b1 + 4 * bK + 256, &base);
+  int rc = workspace_get(0, 3 * b1 + 4 * bK + 256, &base);
   if (rc != SOIL_OK) return rc;
   char* p = static_cast<char*>(base);
   Acc A, B;
   A.count = reinterpret_cast<int32_t*>(p); p += b1;
-  A.value = reinterpret_cast<float*>(p);   p += b1;
+  A.value = out;  // the even rounds write here: the result needs no copy
   B.count = reinterpret_cast<int32_t*>(p); p += b1;
   B.value = reinterpret_cast<float*>(p);   p += b1;
   A.donor = reinterpret_cast<int32_t*>(p); p += bK;
@@ -252,13 +246,12 @@ static int accumulate_impl(float* out, const int32_t* graph, const float* source
   int* flags = reinterpret_cast<int*>(p);
 
   const unsigned nb = blocks_for(elem, kGBlock);
-  SOIL_HIP(hipMemsetAsync(A.donor, 0xff, sizeof(int32_t) * elem * K, st));  // silt::set(donor,-1) :552
-  SOIL_HIP(hipMemcpyAsync(A.value, source, sizeof(float) * elem, hipMemcpyDeviceToDevice, st));  // :553
-  k_donor<K><<<nb, kGBlock, 0, st>>>(A.donor, graph, H, W);  // :554
-  if (decayIn)
-    k_count_decay<K, true><<<nb, kGBlock, 0, st>>>(A.count, A.donor, A.decay, decayIn, elem);  // :555-556
+  if (decayIn)  // :552-556
+    k_donors<K, true><<<nb, kGBlock, 0, st>>>(A.count, A.donor, A.decay, A.value, graph, source,
+                                              decayIn, H, W);
   else
-    k_count_decay<K, false><<<nb, kGBlock, 0, st>>>(A.count, A.donor, A.decay, nullptr, elem);
+    k_donors<K, false><<<nb, kGBlock, 0, st>>>(A.count, A.donor, A.decay, A.value, graph, source,
+                                               nullptr, H, W);
   SOIL_LAUNCH_CHECK();
 
   const int64_t iter =
@@ -270,7 +263,6 @@ static int accumulate_impl(float* out, const int32_t* graph, const float* source
     k_rake_compress<K><<<nb, kGBlock, 0, st>>>(A, B, elem, flags, static_cast<int>(2 * i + 1));
   }
   SOIL_LAUNCH_CHECK();
-  SOIL_HIP(hipMemcpyAsync(out, A.value, sizeof(float) * elem, hipMemcpyDeviceToDevice, st));
   SOIL_HIP(hipStreamSynchronize(st));  // cudaDeviceSynchronize, graph.cu:564
   return SOIL_OK;
 }
