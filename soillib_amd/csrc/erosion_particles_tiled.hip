@@ -237,7 +237,7 @@ __global__ void __launch_bounds__(256)
 
 template <int KIND>
 __global__ void __launch_bounds__(256)
-    k_tiled_spawn(PRec* __restrict__ recs, uint32_t* __restrict__ dest,
+    k_tiled_spawn(PRec* __restrict__ recs, uint32_t* __restrict__ dest, uint32_t* __restrict__ rank,
                   uint32_t* __restrict__ count, soil_rng* __restrict__ rng, int64_t N, const float4* __restrict__ p4,
                   const float* __restrict__ waterSource, Dom d, Scale3 s, Param param,
                   int tiles_w, TileShape ts, int steps_per_round) {
@@ -296,7 +296,7 @@ __global__ void __launch_bounds__(256)
       tile = queue_key(static_cast<int>(d.x0), pos.x, pos.y, spx, spy,
                        param.maxage > 0x7fffffffull ? 0x7fffffffu : static_cast<uint32_t>(param.maxage),
                        tiles_w, ts, steps_per_round);
-      atomicAdd(&count[tile], 1u);
+      rank[n] = atomicAdd(&count[tile], 1u);  // its place in that queue section
       recs[n] = r;
     }
   }
@@ -339,30 +339,52 @@ __device__ __forceinline__ uint32_t wave_append(uint32_t* counter, bool pred) {
   return base + static_cast<uint32_t>(__popcll(mask & ((1ull << lane) - 1ull)));
 }
 
-// ---- counting sort of the record slots by tile ---------------------------------------
+// ---- counting sort of the record slots by queue section ---------------------------------
 //
-// dest[i] is the tile record slot i is bound for (kNoTile: empty slot), written by
-// whoever filled the slot; only the 4-byte slot indices are sorted, the 64-byte
-// records stay where they are and are gathered by the round kernel.
+// dest[i] is the queue section record slot i is bound for (kNoTile: empty slot) and
+// rank[i] its place in that section — the value the atomic that counted it returned —
+// both written by whoever filled the slot.  Only the 4-byte slot indices are moved;
+// the 64-byte records stay where they are and are gathered by the round kernel.
 
 __global__ void __launch_bounds__(256)
-    k_tiled_scatter(uint32_t* __restrict__ order, uint32_t* __restrict__ fill,
-                    const uint32_t* __restrict__ start, const uint32_t* __restrict__ dest,
+    k_tiled_scatter(uint32_t* __restrict__ order, const uint32_t* __restrict__ start,
+                    const uint32_t* __restrict__ dest, const uint32_t* __restrict__ rank,
                     int64_t n_src) {
   const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
-  const uint32_t tile = i < n_src ? dest[i] : kNoTile;
-  const bool valid = tile != kNoTile;
-  const uint32_t slot = wave_key_append(fill, valid, static_cast<int64_t>(tile));
-  if (valid) order[start[tile] + slot] = static_cast<uint32_t>(i);
+  if (i >= n_src) return;
+  const uint32_t key = dest[i];
+  if (key != kNoTile) order[start[key] + rank[i]] = static_cast<uint32_t>(i);
 }
 
-// ---- queue offsets: exclusive scan of the kNB section counts of every tile ----------------
-// (one work-group; a thread owns a run of whole tiles and moves them as uint4)
-static_assert(kNB == 4, "k_queue_scan moves the sections of a tile as one uint4");
+// ---- between two rounds: queue offsets, dispatch order, word for the host -----------------
+//
+// One work-group does the three small jobs a round needs done first:
+//  * exclusive scan of the kNB section counts of every tile (a thread owns a run of
+//    whole tiles and moves them as uint4);
+//  * heaviest tiles first: once the particles sit in channels a few tiles hold ten
+//    times the average queue.  Work-groups are dispatched in blockIdx order, so the
+//    round kernel looks its tile up in a list sorted by queue length (256 buckets of
+//    16 particles, longest first): the long queues start at once and the short ones
+//    fill in behind them, instead of a long queue starting last and the rest of the
+//    chip idling until it is done;
+//  * the queue total and the launch's step counter go straight into pinned host
+//    memory (a device-to-host copy is a 23 us blit kernel each on this stack).
+static_assert(kNB == 4, "k_queue_prepare moves the sections of a tile as one uint4");
+
+struct TiledHostWord {  // pinned, device-mapped
+  uint32_t live;
+  uint32_t pad;
+  unsigned long long steps;
+};
+
 __global__ void __launch_bounds__(1024)
-    k_queue_scan(uint32_t* __restrict__ start, const uint4* __restrict__ count4, int64_t tiles) {
+    k_queue_prepare(uint32_t* __restrict__ start, uint32_t* __restrict__ tile_order,
+                    const uint4* __restrict__ count4, int64_t tiles,
+                    const unsigned long long* __restrict__ steps_run, TiledHostWord* host) {
   __shared__ uint32_t part[1024];
+  __shared__ uint32_t hist[256], base[256];
   const int tid = threadIdx.x;
+  if (tid < 256) hist[tid] = 0;
   const int64_t chunk = (tiles + 1023) / 1024;
   const int64_t b = tid * chunk, e = (b + chunk < tiles) ? b + chunk : tiles;
   uint32_t sum = 0;
@@ -378,44 +400,34 @@ __global__ void __launch_bounds__(1024)
     part[tid] += v;
     __syncthreads();
   }
+  auto bucket = [](uint32_t c) { return 255u - (c >> 4 > 255u ? 255u : c >> 4); };
   uint32_t run = part[tid] - sum;
   uint4* out = reinterpret_cast<uint4*>(start);
   for (int64_t i = b; i < e; ++i) {
     const uint4 c = count4[i];
+    const uint32_t total = c.x + c.y + c.z + c.w;
     out[i] = make_uint4(run, run + c.x, run + c.x + c.y, run + c.x + c.y + c.z);
-    run += c.x + c.y + c.z + c.w;
+    run += total;
+    atomicAdd(&hist[bucket(total)], 1u);
   }
-  if (tid == 1023) start[tiles * kNB] = part[1023];  // particles queued in total
-}
-
-// ---- heaviest tiles first -------------------------------------------------------------
-//
-// Once the particles sit in channels a few tiles hold ten times the average queue.
-// Work-groups are dispatched in blockIdx order, so the round kernel looks its tile up
-// in a list sorted by queue length (256 buckets of 16 particles, longest first): the
-// long queues start at once and the short ones fill in behind them, instead of a
-// long queue starting last and the rest of the chip idling until it is done.
-__global__ void __launch_bounds__(1024)
-    k_tile_order(uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ start,
-                 int64_t tiles) {
-  __shared__ uint32_t hist[256], base[256];
-  const int tid = threadIdx.x;
-  if (tid < 256) hist[tid] = 0;
-  __syncthreads();
-  auto bucket = [](uint32_t c) { return 255u - (c >> 4 > 255u ? 255u : c >> 4); };
-  auto queued = [&](int64_t t) { return start[(t + 1) * kNB] - start[t * kNB]; };
-  for (int64_t i = tid; i < tiles; i += 1024) atomicAdd(&hist[bucket(queued(i))], 1u);
+  if (tid == 1023) {
+    start[tiles * kNB] = part[1023];  // particles queued in total
+    host->live = part[1023];
+    host->steps = *steps_run;
+  }
   __syncthreads();
   if (tid == 0) {
-    uint32_t run = 0;
-    for (int b = 0; b < 256; ++b) {
-      base[b] = run;
-      run += hist[b];
+    uint32_t r = 0;
+    for (int k = 0; k < 256; ++k) {
+      base[k] = r;
+      r += hist[k];
     }
   }
   __syncthreads();
-  for (int64_t i = tid; i < tiles; i += 1024)
-    tile_order[atomicAdd(&base[bucket(queued(i))], 1u)] = static_cast<uint32_t>(i);
+  for (int64_t i = b; i < e; ++i) {
+    const uint4 c = count4[i];
+    tile_order[atomicAdd(&base[bucket(c.x + c.y + c.z + c.w)], 1u)] = static_cast<uint32_t>(i);
+  }
 }
 
 // ---- one round: advance the particles of one tile against LDS ---------------------
@@ -456,7 +468,7 @@ struct CasDeposit {
 
 template <int KIND, int DEP, int TR, int TC, int NT>
 __global__ void __launch_bounds__(NT)
-    k_tiled_round(PRec* __restrict__ out, uint32_t* __restrict__ dest,
+    k_tiled_round(PRec* __restrict__ out, uint32_t* __restrict__ dest, uint32_t* __restrict__ rank,
                   uint32_t* __restrict__ count_next, const PRec* __restrict__ in,
                   const uint32_t* __restrict__ order, const uint32_t* __restrict__ tile_order,
                   const uint32_t* __restrict__ start, float* __restrict__ flux0,
@@ -509,7 +521,7 @@ __global__ void __launch_bounds__(NT)
                                   tiles_w_next, ts_next, steps_per_round);
     out[first + slot] = r;
     dest[first + slot] = to;
-    atomicAdd(&count_next[to], 1u);
+    rank[first + slot] = atomicAdd(&count_next[to], 1u);
     parked = false;
   };
   int budget = 0;  // steps this lane may still spend on its particle in this round
@@ -602,10 +614,11 @@ __global__ void __launch_bounds__(NT)
         parked ? queue_key(k.x0, r.px, r.py, r.spx, r.spy, k.maxage - static_cast<uint32_t>(r.iter),
                            tiles_w_next, ts_next, steps_per_round)
                : 0;
-    (void)wave_key_append(count_next, parked, dest_tile);
+    const uint32_t place = wave_key_append(count_next, parked, dest_tile);
     if (parked) {
       out[first + slot] = r;
       dest[first + slot] = static_cast<uint32_t>(dest_tile);
+      rank[first + slot] = place;
     }
   }
   atomicAdd(&s_steps, nsteps);
@@ -734,12 +747,6 @@ static void launch_round(int shape, unsigned grid, hipStream_t st, A... a) {
 // two streams (fluvial and debris of one step, run_pair below) overlap: while the
 // host waits for one, the other's kernels fill the SIMD slots the first leaves idle
 // in its sparse late rounds.
-struct TiledHostWord {  // pinned; written by the device-to-host copies of a scan
-  uint32_t live;
-  uint32_t pad;
-  unsigned long long steps;
-};
-
 template <int KIND>
 struct TiledRun {
   // arguments
@@ -759,12 +766,12 @@ struct TiledRun {
   bool verbose = false;
   // workspace
   PRec *cur = nullptr, *next = nullptr;
-  uint32_t *dest = nullptr, *order = nullptr, *count = nullptr, *count_next = nullptr,
-           *start = nullptr, *tile_order = nullptr, *fill = nullptr;
+  uint32_t *dest = nullptr, *rank = nullptr, *order = nullptr, *count = nullptr,
+           *count_next = nullptr, *start = nullptr, *tile_order = nullptr;
   float4* p4 = nullptr;
   unsigned long long *steps_global = nullptr, *steps_run = nullptr;
   size_t b_cnt = 0;
-  TiledHostWord* host = nullptr;
+  TiledHostWord *host = nullptr, *host_dev = nullptr;  // the same pinned word, host / device view
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   // progress
   uint64_t round = 0;
@@ -813,31 +820,33 @@ struct TiledRun {
     b_cnt = align(sizeof(uint32_t) * (max_tiles * kNB + 1));
     void* base = nullptr;
     // one workspace per kind: the two launches of a step may be in flight together
-    int rc = workspace_get(KIND == FLUVIAL ? 2 : 5, 2 * b_rec + 2 * b_idx + 5 * b_cnt + b_p4 + 256, &base);
+    int rc = workspace_get(KIND == FLUVIAL ? 2 : 5, 2 * b_rec + 3 * b_idx + 4 * b_cnt + b_p4 + 256, &base);
     if (rc != SOIL_OK) return rc;
     char* w = static_cast<char*>(base);
     cur = reinterpret_cast<PRec*>(w);    w += b_rec;   // records of this round (any order)
     next = reinterpret_cast<PRec*>(w);   w += b_rec;   // survivors, grouped by the tile they left
     dest = reinterpret_cast<uint32_t*>(w);   w += b_idx;  // queue section each slot is bound for
+    rank = reinterpret_cast<uint32_t*>(w);   w += b_idx;  // ... and its place in that section
     order = reinterpret_cast<uint32_t*>(w);  w += b_idx;  // slots sorted by queue section
     p4 = reinterpret_cast<float4*>(w);  w += b_p4;
     count = reinterpret_cast<uint32_t*>(w);       w += b_cnt;
     count_next = reinterpret_cast<uint32_t*>(w);  w += b_cnt;
     start = reinterpret_cast<uint32_t*>(w);       w += b_cnt;
     tile_order = reinterpret_cast<uint32_t*>(w);  w += b_cnt;
-    fill = reinterpret_cast<uint32_t*>(w);        w += b_cnt;
     steps_run = reinterpret_cast<unsigned long long*>(w);
     rc = step_counter(&steps_global);
     if (rc != SOIL_OK) return rc;
     // pinned word + events, one set per (thread, kind)
-    static thread_local TiledHostWord* t_host = nullptr;
+    static thread_local TiledHostWord *t_host = nullptr, *t_host_dev = nullptr;
     static thread_local hipEvent_t t_ev0 = nullptr, t_ev1 = nullptr;
     if (!t_host) {
-      SOIL_HIP(hipHostMalloc(reinterpret_cast<void**>(&t_host), sizeof(TiledHostWord)));
+      SOIL_HIP(hipHostMalloc(reinterpret_cast<void**>(&t_host), sizeof(TiledHostWord), hipHostMallocMapped));
+      SOIL_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&t_host_dev), t_host, 0));
       SOIL_HIP(hipEventCreate(&t_ev0));
       SOIL_HIP(hipEventCreate(&t_ev1));
     }
     host = t_host;
+    host_dev = t_host_dev;
     ev0 = t_ev0;
     ev1 = t_ev1;
     return SOIL_OK;
@@ -846,11 +855,9 @@ struct TiledRun {
   // scan of the queues the next round starts from + what the host needs to decide
   int queue_scan() {
     const int64_t tiles = tiles_of(shape_of(round));
-    k_queue_scan<<<1, 1024, 0, st>>>(start, reinterpret_cast<const uint4*>(count), tiles);
-    k_tile_order<<<1, 1024, 0, st>>>(tile_order, start, tiles);
+    k_queue_prepare<<<1, 1024, 0, st>>>(start, tile_order, reinterpret_cast<const uint4*>(count), tiles,
+                                        steps_run, host_dev);
     SOIL_LAUNCH_CHECK();
-    SOIL_HIP(hipMemcpyAsync(&host->live, start + tiles * kNB, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    SOIL_HIP(hipMemcpyAsync(&host->steps, steps_run, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     return SOIL_OK;
   }
 
@@ -865,7 +872,7 @@ struct TiledRun {
     SOIL_HIP(hipMemsetAsync(count, 0, b_cnt, st));
     SOIL_HIP(hipMemsetAsync(steps_run, 0, sizeof(unsigned long long), st));
     k_tiled_spawn<KIND><<<blocks_for(N, 256), 256, 0, st>>>(
-        cur, dest, count, rng, N, p4, waterSource, d, s, p, tiles_w_of(shape_of(0)),
+        cur, dest, rank, count, rng, N, p4, waterSource, d, s, p, tiles_w_of(shape_of(0)),
         ts_of(shape_of(0)), steps_per_round);
     SOIL_LAUNCH_CHECK();
     n_src = N;  // slots of `cur` to look at (spawn output, then survivor slots)
@@ -924,11 +931,10 @@ struct TiledRun {
       return finish_steps();
     }
     SOIL_HIP(hipEventRecord(ev0, st));
-    SOIL_HIP(hipMemsetAsync(fill, 0, b_cnt, st));
-    k_tiled_scatter<<<blocks_for(n_src, 256), 256, 0, st>>>(order, fill, start, dest, n_src);
+    k_tiled_scatter<<<blocks_for(n_src, 256), 256, 0, st>>>(order, start, dest, rank, n_src);
     SOIL_HIP(hipMemsetAsync(count_next, 0, b_cnt, st));
     if (deposit == 1)
-      launch_round<KIND, 0>(sh, static_cast<unsigned>(tiles), st, next, dest, count_next,
+      launch_round<KIND, 0>(sh, static_cast<unsigned>(tiles), st, next, dest, rank, count_next,
                             static_cast<const PRec*>(cur), static_cast<const uint32_t*>(order),
                             static_cast<const uint32_t*>(tile_order),
                             static_cast<const uint32_t*>(start), flux0, flux1,
@@ -936,7 +942,7 @@ struct TiledRun {
                             waterHeight, remote0, steps_run, d, s, p, tiles_w, steps_per_round,
                             ts_of(sh_next), tiles_w_of(sh_next));
     else
-      launch_round<KIND, 1>(sh, static_cast<unsigned>(tiles), st, next, dest, count_next,
+      launch_round<KIND, 1>(sh, static_cast<unsigned>(tiles), st, next, dest, rank, count_next,
                             static_cast<const PRec*>(cur), static_cast<const uint32_t*>(order),
                             static_cast<const uint32_t*>(tile_order),
                             static_cast<const uint32_t*>(start), flux0, flux1,
