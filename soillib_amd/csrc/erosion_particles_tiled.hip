@@ -377,46 +377,69 @@ struct TiledHostWord {  // pinned, device-mapped
   unsigned long long steps;
 };
 
+constexpr int kPanel = 16384;  // tiles per LDS panel of k_queue_prepare
+
 __global__ void __launch_bounds__(1024)
     k_queue_prepare(uint32_t* __restrict__ start, uint32_t* __restrict__ tile_order,
                     const uint4* __restrict__ count4, int64_t tiles,
                     const unsigned long long* __restrict__ steps_run, TiledHostWord* host) {
+  // Global traffic is coalesced (thread t takes tiles t, t + 1024, ...); the scan wants
+  // each thread on a run of consecutive tiles, so the per-tile totals go through LDS.
+  __shared__ uint32_t tot[kPanel];
   __shared__ uint32_t part[1024];
   __shared__ uint32_t hist[256], base[256];
+  __shared__ uint32_t carry;
   const int tid = threadIdx.x;
-  if (tid < 256) hist[tid] = 0;
-  const int64_t chunk = (tiles + 1023) / 1024;
-  const int64_t b = tid * chunk, e = (b + chunk < tiles) ? b + chunk : tiles;
-  uint32_t sum = 0;
-  for (int64_t i = b; i < e; ++i) {
-    const uint4 c = count4[i];
-    sum += c.x + c.y + c.z + c.w;
-  }
-  part[tid] = sum;
-  __syncthreads();
-  for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
-    const uint32_t v = (tid >= off) ? part[tid - off] : 0u;
-    __syncthreads();
-    part[tid] += v;
-    __syncthreads();
-  }
+  constexpr int kRun = kPanel / 1024;  // consecutive tiles per thread within a panel
   auto bucket = [](uint32_t c) { return 255u - (c >> 4 > 255u ? 255u : c >> 4); };
-  uint32_t run = part[tid] - sum;
-  uint4* out = reinterpret_cast<uint4*>(start);
-  for (int64_t i = b; i < e; ++i) {
-    const uint4 c = count4[i];
-    const uint32_t total = c.x + c.y + c.z + c.w;
-    out[i] = make_uint4(run, run + c.x, run + c.x + c.y, run + c.x + c.y + c.z);
-    run += total;
-    atomicAdd(&hist[bucket(total)], 1u);
-  }
-  if (tid == 1023) {
-    start[tiles * kNB] = part[1023];  // particles queued in total
-    host->live = part[1023];
-    host->steps = *steps_run;
-  }
+  if (tid < 256) hist[tid] = 0;
+  if (tid == 0) carry = 0;
   __syncthreads();
+  uint4* out = reinterpret_cast<uint4*>(start);
+  for (int64_t p0 = 0; p0 < tiles; p0 += kPanel) {
+    const int n = static_cast<int>(tiles - p0 < kPanel ? tiles - p0 : kPanel);
+    for (int i = tid; i < kPanel; i += 1024) {
+      uint32_t t = 0;
+      if (i < n) {
+        const uint4 c = count4[p0 + i];
+        t = c.x + c.y + c.z + c.w;
+        atomicAdd(&hist[bucket(t)], 1u);
+      }
+      tot[i] = t;
+    }
+    __syncthreads();
+    uint32_t sum = 0;
+#pragma unroll
+    for (int j = 0; j < kRun; ++j) sum += tot[tid * kRun + j];
+    part[tid] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
+      const uint32_t v = (tid >= off) ? part[tid - off] : 0u;
+      __syncthreads();
+      part[tid] += v;
+      __syncthreads();
+    }
+    uint32_t run = carry + part[tid] - sum;
+#pragma unroll
+    for (int j = 0; j < kRun; ++j) {  // tot[] becomes the exclusive prefix
+      const uint32_t t = tot[tid * kRun + j];
+      tot[tid * kRun + j] = run;
+      run += t;
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) {
+      const uint4 c = count4[p0 + i];
+      const uint32_t r = tot[i];
+      out[p0 + i] = make_uint4(r, r + c.x, r + c.x + c.y, r + c.x + c.y + c.z);
+    }
+    __syncthreads();
+    if (tid == 1023) carry += part[1023];
+    __syncthreads();
+  }
   if (tid == 0) {
+    start[tiles * kNB] = carry;  // particles queued in total
+    host->live = carry;
+    host->steps = *steps_run;
     uint32_t r = 0;
     for (int k = 0; k < 256; ++k) {
       base[k] = r;
@@ -424,7 +447,7 @@ __global__ void __launch_bounds__(1024)
     }
   }
   __syncthreads();
-  for (int64_t i = b; i < e; ++i) {
+  for (int64_t i = tid; i < tiles; i += 1024) {
     const uint4 c = count4[i];
     tile_order[atomicAdd(&base[bucket(c.x + c.y + c.z + c.w)], 1u)] = static_cast<uint32_t>(i);
   }
