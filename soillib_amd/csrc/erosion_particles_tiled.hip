@@ -372,16 +372,19 @@ __global__ void __launch_bounds__(256)
 static_assert(kNB == 4, "k_queue_prepare moves the sections of a tile as one uint4");
 
 struct TiledHostWord {  // pinned, device-mapped
-  uint32_t live;
-  uint32_t pad;
+  uint32_t live;    // particles queued for the round
+  uint32_t blocks;  // work-groups the round needs (entries of the block list)
   unsigned long long steps;
+  uint32_t chunk;   // particles of a tile's queue one work-group takes at most
+  uint32_t pad;
 };
 
 constexpr int kPanel = 16384;  // tiles per LDS panel of k_queue_prepare
 
 __global__ void __launch_bounds__(1024)
     k_queue_prepare(uint32_t* __restrict__ start, uint32_t* __restrict__ tile_order,
-                    const uint4* __restrict__ count4, int64_t tiles,
+                    uint2* __restrict__ block_list, const uint4* __restrict__ count4,
+                    int64_t tiles, int lanes, int slots,
                     const unsigned long long* __restrict__ steps_run, TiledHostWord* host) {
   // Global traffic is coalesced (thread t takes tiles t, t + 1024, ...); the scan wants
   // each thread on a run of consecutive tiles, so the per-tile totals go through LDS.
@@ -451,6 +454,69 @@ __global__ void __launch_bounds__(1024)
     const uint4 c = count4[i];
     tile_order[atomicAdd(&base[bucket(c.x + c.y + c.z + c.w)], 1u)] = static_cast<uint32_t>(i);
   }
+  __syncthreads();
+  // The block list: walking the tiles longest queue first, every non-empty tile gets a
+  // work-group.  A work-group serves its queue in batches of `lanes` particles, so a
+  // round takes at least (batches of the longest queue) x (time of a batch), while the
+  // chip as a whole needs (all batches / resident work-groups) batch times: a queue
+  // longer than that share is cut into chunks of that many batches, each with a
+  // work-group of its own (they share the tile, keep flux accumulators of their own
+  // and add them to the global planes atomically).  On an 8192^2 grid the share is
+  // ~40 batches and nothing is cut; on 1024^2 .. 2048^2 it is 1-3 and the handful
+  // of channel tiles would otherwise be the critical path of the whole round.
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  {
+    uint32_t batches = 0;
+    for (int64_t i = tid; i < tiles; i += 1024) {
+      const uint4 c = count4[i];
+      batches += (c.x + c.y + c.z + c.w + lanes - 1) / lanes;
+    }
+    atomicAdd(&carry, batches);
+    __syncthreads();
+    if (tid == 0) {
+      const uint32_t share = (carry + slots - 1) / slots;
+      hist[0] = (share > 0 ? share : 1u) * static_cast<uint32_t>(lanes);  // chunk capacity
+      host->chunk = hist[0];
+      carry = 0;
+    }
+    __syncthreads();
+  }
+  const uint32_t chunk_cap = hist[0];
+  auto groups = [&](int64_t pos) {
+    const uint32_t t = tile_order[pos];
+    const uint32_t c = start[(t + 1) * kNB] - start[t * kNB];
+    return (c + chunk_cap - 1) / chunk_cap;
+  };
+  for (int64_t p0 = 0; p0 < tiles; p0 += kPanel) {
+    const int n = static_cast<int>(tiles - p0 < kPanel ? tiles - p0 : kPanel);
+    for (int i = tid; i < kPanel; i += 1024) tot[i] = i < n ? groups(p0 + i) : 0u;
+    __syncthreads();
+    uint32_t sum = 0;
+#pragma unroll
+    for (int j = 0; j < kRun; ++j) sum += tot[tid * kRun + j];
+    part[tid] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+      const uint32_t v = (tid >= off) ? part[tid - off] : 0u;
+      __syncthreads();
+      part[tid] += v;
+      __syncthreads();
+    }
+    uint32_t run = carry + part[tid] - sum;
+#pragma unroll
+    for (int j = 0; j < kRun; ++j) {
+      const int i = tid * kRun + j;
+      const uint32_t g = tot[i];
+      if (i < n)
+        for (uint32_t q = 0; q < g; ++q) block_list[run + q] = make_uint2(tile_order[p0 + i], q);
+      run += g;
+    }
+    __syncthreads();
+    if (tid == 1023) carry += part[1023];
+    __syncthreads();
+  }
+  if (tid == 0) host->blocks = carry;
 }
 
 // ---- one round: advance the particles of one tile against LDS ---------------------
@@ -493,18 +559,23 @@ template <int KIND, int DEP, int TR, int TC, int NT>
 __global__ void __launch_bounds__(NT)
     k_tiled_round(PRec* __restrict__ out, uint32_t* __restrict__ dest, uint32_t* __restrict__ rank,
                   uint32_t* __restrict__ count_next, const PRec* __restrict__ in,
-                  const uint32_t* __restrict__ order, const uint32_t* __restrict__ tile_order,
+                  const uint32_t* __restrict__ order, const uint2* __restrict__ block_list,
                   const uint32_t* __restrict__ start, float* __restrict__ flux0,
                   float* __restrict__ flux1, float2* __restrict__ fluxV,
                   const float4* __restrict__ p4, const float* __restrict__ waterHeight,
                   float* __restrict__ remote0, unsigned long long* __restrict__ steps, Dom d,
                   Scale3 s, Param param, int tiles_w, int steps_per_round, TileShape ts_next,
-                  int tiles_w_next) {
+                  int tiles_w_next, uint32_t chunk_cap) {
   constexpr int kCells = TR * TC, kBlock = NT, kPer = (kCells + NT - 1) / NT;
-  const int tile = static_cast<int>(tile_order[blockIdx.x]);
-  const uint32_t first = start[tile * kNB];
-  const uint32_t cnt = start[(tile + 1) * kNB] - first;
-  if (cnt == 0) return;
+  // this work-group's share of its tile's queue (k_queue_prepare's block list)
+  const uint2 job = block_list[blockIdx.x];
+  const int tile = static_cast<int>(job.x);
+  const uint32_t q_first = start[tile * kNB], q_cnt = start[(tile + 1) * kNB] - q_first;
+  const uint32_t groups = (q_cnt + chunk_cap - 1) / chunk_cap, per = (q_cnt + groups - 1) / groups;
+  const uint32_t first = q_first + job.y * per;
+  if (job.y * per >= q_cnt) return;
+  const uint32_t cnt = (q_cnt - job.y * per < per) ? q_cnt - job.y * per : per;
+  const bool shared_tile = groups > 1;  // other work-groups deposit into the same cells
   const int row0 = (tile / tiles_w) * TR, col0 = (tile % tiles_w) * TC;  // local row, column
 
   // flux accumulators as separate planes: lane addresses c map to 32 distinct
@@ -649,8 +720,8 @@ __global__ void __launch_bounds__(NT)
   if (tid == 0) atomicAdd(steps, static_cast<unsigned long long>(s_steps));
   for (uint32_t j = s_out + tid; j < cnt; j += kBlock) dest[first + j] = kNoTile;  // unused slots
 
-  // flush the tile's flux into the global planes: one work-group per tile per
-  // round, so plain read-modify-writes suffice.  Only cells that received a
+  // flush the tile's flux into the global planes: with one work-group per tile per
+  // round plain read-modify-writes suffice; the groups of a split tile add atomically.  Only cells that received a
   // deposit are touched (late rounds: the particles sit in channels and most of
   // the tile is still zero).  Two cells per thread in flight: the register
   // budget of the stepping loop decides the occupancy, not this epilogue.
@@ -668,6 +739,16 @@ __global__ void __launch_bounds__(NT)
       a1[j] = (KIND == FLUVIAL && ok) ? s_f1[c] : 0.0f;
       ax[j] = ok ? s_fx[c] : 0.0f;
       ay[j] = ok ? s_fy[c] : 0.0f;
+    }
+    if (shared_tile) {  // uniform per work-group
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if (a0[j] != 0.0f) atomicAdd(&flux0[l[j]], a0[j]);
+        if (KIND == FLUVIAL && a1[j] != 0.0f) atomicAdd(&flux1[l[j]], a1[j]);
+        if (ax[j] != 0.0f) atomicAdd(&fluxV[l[j]].x, ax[j]);
+        if (ay[j] != 0.0f) atomicAdd(&fluxV[l[j]].y, ay[j]);
+      }
+      continue;
     }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -791,6 +872,7 @@ struct TiledRun {
   PRec *cur = nullptr, *next = nullptr;
   uint32_t *dest = nullptr, *rank = nullptr, *order = nullptr, *count = nullptr,
            *count_next = nullptr, *start = nullptr, *tile_order = nullptr;
+  uint2* block_list = nullptr;  // (tile, group) of every work-group of the round
   float4* p4 = nullptr;
   unsigned long long *steps_global = nullptr, *steps_run = nullptr;
   size_t b_cnt = 0;
@@ -801,6 +883,7 @@ struct TiledRun {
   int64_t n_src = 0;
   unsigned long long steps_before = 0;
   bool timed = false, done = false;
+  int resident_groups = 512;  // work-groups of a round kernel the chip holds at once
 
   int shape_of(uint64_t r) const { return r >= static_cast<uint64_t>(switch_round) ? shape_late : shape_early; }
   int tiles_w_of(int sh) const { return static_cast<int>((d.W + kShapes[sh].tc - 1) / kShapes[sh].tc); }
@@ -835,6 +918,12 @@ struct TiledRun {
     // The rate of the round just done (step counter / HIP event time) decides.
     finish_rate = env_int("SOIL_TILED_FINISH_MRATE", 4000) * 1e6;
     verbose = std::getenv("SOIL_TILED_VERBOSE") != nullptr;
+    {  // LDS decides: 64 KiB (fluvial) / 48 KiB (debris) of accumulators per 64x64 tile
+      int dev = 0, cus = 256;
+      SOIL_HIP(hipGetDevice(&dev));
+      SOIL_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+      resident_groups = env_int("SOIL_TILED_SLOTS", cus * (KIND == FLUVIAL ? 2 : 3));
+    }
 
     const int64_t max_tiles = std::max(tiles_of(shape_early), tiles_of(shape_late));
     auto align = [](size_t b) { return (b + 255) & ~static_cast<size_t>(255); };
@@ -843,7 +932,8 @@ struct TiledRun {
     b_cnt = align(sizeof(uint32_t) * (max_tiles * kNB + 1));
     void* base = nullptr;
     // one workspace per kind: the two launches of a step may be in flight together
-    int rc = workspace_get(KIND == FLUVIAL ? 2 : 5, 2 * b_rec + 3 * b_idx + 4 * b_cnt + b_p4 + 256, &base);
+    const size_t b_blk = align(sizeof(uint2) * (max_tiles + N / 128 + 1));
+    int rc = workspace_get(KIND == FLUVIAL ? 2 : 5, 2 * b_rec + 3 * b_idx + 4 * b_cnt + b_blk + b_p4 + 256, &base);
     if (rc != SOIL_OK) return rc;
     char* w = static_cast<char*>(base);
     cur = reinterpret_cast<PRec*>(w);    w += b_rec;   // records of this round (any order)
@@ -856,6 +946,7 @@ struct TiledRun {
     count_next = reinterpret_cast<uint32_t*>(w);  w += b_cnt;
     start = reinterpret_cast<uint32_t*>(w);       w += b_cnt;
     tile_order = reinterpret_cast<uint32_t*>(w);  w += b_cnt;
+    block_list = reinterpret_cast<uint2*>(w);     w += b_blk;
     steps_run = reinterpret_cast<unsigned long long*>(w);
     rc = step_counter(&steps_global);
     if (rc != SOIL_OK) return rc;
@@ -878,8 +969,10 @@ struct TiledRun {
   // scan of the queues the next round starts from + what the host needs to decide
   int queue_scan() {
     const int64_t tiles = tiles_of(shape_of(round));
-    k_queue_prepare<<<1, 1024, 0, st>>>(start, tile_order, reinterpret_cast<const uint4*>(count), tiles,
-                                        steps_run, host_dev);
+    k_queue_prepare<<<1, 1024, 0, st>>>(start, tile_order, block_list,
+                                        reinterpret_cast<const uint4*>(count), tiles,
+                                        kShapes[shape_of(round)].nt, resident_groups, steps_run,
+                                        host_dev);
     SOIL_LAUNCH_CHECK();
     return SOIL_OK;
   }
@@ -914,6 +1007,8 @@ struct TiledRun {
     if (done) return SOIL_OK;
     SOIL_HIP(hipStreamSynchronize(st));
     const uint32_t live = host->live;  // particles queued for this round
+    const unsigned blocks = host->blocks;
+    const uint32_t chunk_cap = host->chunk;
     const unsigned long long steps_now = host->steps;
     const int sh = shape_of(round), sh_next = shape_of(round + 1);
     const int64_t tiles = tiles_of(sh);
@@ -957,21 +1052,21 @@ struct TiledRun {
     k_tiled_scatter<<<blocks_for(n_src, 256), 256, 0, st>>>(order, start, dest, rank, n_src);
     SOIL_HIP(hipMemsetAsync(count_next, 0, b_cnt, st));
     if (deposit == 1)
-      launch_round<KIND, 0>(sh, static_cast<unsigned>(tiles), st, next, dest, rank, count_next,
+      launch_round<KIND, 0>(sh, blocks, st, next, dest, rank, count_next,
                             static_cast<const PRec*>(cur), static_cast<const uint32_t*>(order),
-                            static_cast<const uint32_t*>(tile_order),
+                            static_cast<const uint2*>(block_list),
                             static_cast<const uint32_t*>(start), flux0, flux1,
                             reinterpret_cast<float2*>(fluxV), static_cast<const float4*>(p4),
                             waterHeight, remote0, steps_run, d, s, p, tiles_w, steps_per_round,
-                            ts_of(sh_next), tiles_w_of(sh_next));
+                            ts_of(sh_next), tiles_w_of(sh_next), chunk_cap);
     else
-      launch_round<KIND, 1>(sh, static_cast<unsigned>(tiles), st, next, dest, rank, count_next,
+      launch_round<KIND, 1>(sh, blocks, st, next, dest, rank, count_next,
                             static_cast<const PRec*>(cur), static_cast<const uint32_t*>(order),
-                            static_cast<const uint32_t*>(tile_order),
+                            static_cast<const uint2*>(block_list),
                             static_cast<const uint32_t*>(start), flux0, flux1,
                             reinterpret_cast<float2*>(fluxV), static_cast<const float4*>(p4),
                             waterHeight, remote0, steps_run, d, s, p, tiles_w, steps_per_round,
-                            ts_of(sh_next), tiles_w_of(sh_next));
+                            ts_of(sh_next), tiles_w_of(sh_next), chunk_cap);
     SOIL_LAUNCH_CHECK();
     SOIL_HIP(hipEventRecord(ev1, st));
     timed = true;
