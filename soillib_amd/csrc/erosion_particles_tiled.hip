@@ -50,7 +50,6 @@ namespace soil {
 // A tile is TR rows x TC columns of cells (powers of two) and is worked on by
 // TR*TC/8 threads: the acceptance workload spawns one particle per 8 cells
 // (SURVEY 8d), so a round starts with about one particle per lane.
-constexpr int kPerThread = 8;  // cells per particle at spawn
 struct TileShape { int shift_r, shift_c; };  // log2(TR), log2(TC)
 constexpr uint32_t kNoTile = 0xffffffffu;     // dest[] of an empty record slot
 
@@ -562,9 +561,9 @@ __global__ void __launch_bounds__(NT)
                   const uint32_t* __restrict__ order, const uint2* __restrict__ block_list,
                   const uint32_t* __restrict__ start, float* __restrict__ flux0,
                   float* __restrict__ flux1, float2* __restrict__ fluxV,
-                  const float4* __restrict__ p4, const float* __restrict__ waterHeight,
-                  float* __restrict__ remote0, unsigned long long* __restrict__ steps, Dom d,
-                  Scale3 s, Param param, int tiles_w, int steps_per_round, TileShape ts_next,
+                  const float4* __restrict__ p4, float* __restrict__ remote0,
+                  unsigned long long* __restrict__ steps, Dom d, Scale3 s, Param param,
+                  int tiles_w, int steps_per_round, TileShape ts_next,
                   int tiles_w_next, uint32_t chunk_cap) {
   constexpr int kCells = TR * TC, kBlock = NT, kPer = (kCells + NT - 1) / NT;
   // this work-group's share of its tile's queue (k_queue_prepare's block list)
@@ -772,9 +771,8 @@ __global__ void __launch_bounds__(256)
     k_tiled_finish(const PRec* __restrict__ recs, const uint32_t* __restrict__ dest, int64_t n,
                    float* __restrict__ flux0,
                    float* __restrict__ flux1, float* __restrict__ fluxV,
-                   const float4* __restrict__ p4, const float* __restrict__ waterHeight,
-                   float* __restrict__ remote0, unsigned long long* __restrict__ steps, Dom d,
-                   Scale3 s, Param param) {
+                   const float4* __restrict__ p4, float* __restrict__ remote0,
+                   unsigned long long* __restrict__ steps, Dom d, Scale3 s, Param param) {
   const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
   if (i >= n) return;
   if (dest[i] == kNoTile) return;
@@ -1044,7 +1042,7 @@ struct TiledRun {
     if (live == 0 || round >= p.maxage + 2) return finish_steps();
     if (round > 0 && (static_cast<int64_t>(live) <= tail || rate < finish_rate)) {
       k_tiled_finish<KIND><<<blocks_for(n_src, 256), 256, 0, st>>>(
-          cur, dest, n_src, flux0, flux1, fluxV, p4, waterHeight, remote0, steps_run, d, s, p);
+          cur, dest, n_src, flux0, flux1, fluxV, p4, remote0, steps_run, d, s, p);
       SOIL_LAUNCH_CHECK();
       return finish_steps();
     }
@@ -1057,7 +1055,7 @@ struct TiledRun {
                             static_cast<const uint2*>(block_list),
                             static_cast<const uint32_t*>(start), flux0, flux1,
                             reinterpret_cast<float2*>(fluxV), static_cast<const float4*>(p4),
-                            waterHeight, remote0, steps_run, d, s, p, tiles_w, steps_per_round,
+                            remote0, steps_run, d, s, p, tiles_w, steps_per_round,
                             ts_of(sh_next), tiles_w_of(sh_next), chunk_cap);
     else
       launch_round<KIND, 1>(sh, blocks, st, next, dest, rank, count_next,
@@ -1065,7 +1063,7 @@ struct TiledRun {
                             static_cast<const uint2*>(block_list),
                             static_cast<const uint32_t*>(start), flux0, flux1,
                             reinterpret_cast<float2*>(fluxV), static_cast<const float4*>(p4),
-                            waterHeight, remote0, steps_run, d, s, p, tiles_w, steps_per_round,
+                            remote0, steps_run, d, s, p, tiles_w, steps_per_round,
                             ts_of(sh_next), tiles_w_of(sh_next), chunk_cap);
     SOIL_LAUNCH_CHECK();
     SOIL_HIP(hipEventRecord(ev1, st));
