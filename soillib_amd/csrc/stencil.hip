@@ -96,26 +96,74 @@ struct BlurWeights {
   float w[33];
 };
 
-template <bool XDIR>
+// __blur<T>, filter.cu:24-70: 33 taps along one axis, index clamped to the edge,
+// accumulated in the order k = -16..16 (:35-54).  Two launch shapes, both on the
+// plane seen as an (H, W*C) matrix of floats:
+//
+//  * along axis 0 (rows): a thread owns one float column of a 32-row band, reads the
+//    64 rows it needs (coalesced across the wave) into registers and produces its 32
+//    outputs from them — no LDS, 33 taps from registers;
+//  * along axis 1 (the contiguous one): a work-group stages a 1024-float row segment
+//    plus its 16-cell aprons in LDS (clamped per cell, channels interleaved), every
+//    thread then produces 4 outputs 256 floats apart (coalesced stores) from 33
+//    conflict-free LDS reads each.
+//
+// The one-thread-per-output form it replaces issued 33 global loads per output
+// (1.4-1.6 ms per pass at 8192^2, 4.5 % of the HBM roofline).
+constexpr int kBlurBand = 32;  // output rows per thread of the axis-0 pass
+
 __global__ void __launch_bounds__(kSBlock)
-    k_blur(float* __restrict__ out, const float* __restrict__ in, int64_t H, int64_t W, int C,
-           BlurWeights bw) {
-  const int64_t t = static_cast<int64_t>(blockIdx.x) * kSBlock + threadIdx.x;
-  if (t >= H * W * C) return;
-  const int64_t n = t / C;
-  const int c = static_cast<int>(t % C);
-  const int64_t x = n / W, y = n % W;
-  float val = 0.0f;  // :35
+    k_blur_rows(float* __restrict__ out, const float* __restrict__ in, int64_t H, int64_t WC,
+                BlurWeights bw) {
+  const int64_t col = static_cast<int64_t>(blockIdx.x) * kSBlock + threadIdx.x;
+  const int64_t x0 = static_cast<int64_t>(blockIdx.y) * kBlurBand;
+  if (col >= WC) return;
+  float v[kBlurBand + 32];
 #pragma unroll
-  for (int k = -16; k <= 16; ++k) {  // :37
-    int64_t nx = x + (XDIR ? k : 0), ny = y + (XDIR ? 0 : k);  // :39
-    if (nx < 0) nx = 0;                                         // :40-43
-    if (ny < 0) ny = 0;
-    if (nx > H - 1) nx = H - 1;
-    if (ny > W - 1) ny = W - 1;
-    val += in[C * (nx * W + ny) + c] * bw.w[k + 16];  // :49-50
+  for (int r = 0; r < kBlurBand + 32; ++r) {
+    int64_t x = x0 + r - 16;  // :39-43
+    if (x < 0) x = 0;
+    if (x > H - 1) x = H - 1;
+    v[r] = in[x * WC + col];
   }
-  out[t] = val;  // :54
+#pragma unroll
+  for (int r = 0; r < kBlurBand; ++r) {
+    if (x0 + r >= H) break;
+    float val = 0.0f;  // :35
+#pragma unroll
+    for (int k = 0; k < 33; ++k) val += v[r + k] * bw.w[k];  // :49-50
+    out[(x0 + r) * WC + col] = val;                           // :54
+  }
+}
+
+template <int C>
+__global__ void __launch_bounds__(kSBlock)
+    k_blur_cols(float* __restrict__ out, const float* __restrict__ in, int64_t W, BlurWeights bw) {
+  constexpr int kSeg = 4 * kSBlock;  // output floats per work-group
+  __shared__ float seg[kSeg + 32 * C];
+  const int64_t WC = W * C;
+  const int64_t row = blockIdx.x;
+  const int64_t f0 = static_cast<int64_t>(blockIdx.y) * kSeg;  // first output float of the segment
+  const float* src = in + row * WC;
+  // LDS float i holds row float f0 - 16*C + i, its cell clamped into the row (:39-43)
+  for (int i = threadIdx.x; i < kSeg + 32 * C; i += kSBlock) {
+    const int64_t f = f0 - 16 * C + i;
+    const int64_t c = ((f % C) + C) % C;
+    int64_t y = (f - c) / C;
+    if (y < 0) y = 0;
+    if (y > W - 1) y = W - 1;
+    seg[i] = src[y * C + c];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int i = threadIdx.x + j * kSBlock;
+    if (f0 + i >= WC) break;
+    float val = 0.0f;  // :35
+#pragma unroll
+    for (int k = 0; k < 33; ++k) val += seg[i + k * C] * bw.w[k];  // :49-50
+    out[row * WC + f0 + i] = val;                                   // :54
+  }
 }
 
 // lerp5 gradient along one axis: the build's definition of silt's lerp5_t::grad
@@ -271,9 +319,15 @@ int soil_gaussian_blur(float* tensor, float* scratch, int64_t H, int64_t W, int 
     const float Z = sqrtf(2.0f * 3.14159265f) * sigma;                                // filter.cu:47
     bw.w[k + 16] = expf_(-0.5f * (static_cast<float>(k) / sigma) * (static_cast<float>(k) / sigma)) / Z;  // :48
   }
-  const unsigned nb = blocks_for(H * W * C, kSBlock);
-  k_blur<true><<<nb, kSBlock, 0, as_stream(stream)>>>(scratch, tensor, H, W, C, bw);   // :81 / :86
-  k_blur<false><<<nb, kSBlock, 0, as_stream(stream)>>>(tensor, scratch, H, W, C, bw);  // :82 / :87
+  const int64_t WC = W * C;
+  hipStream_t st = as_stream(stream);
+  const dim3 grid_rows(blocks_for(WC, kSBlock), static_cast<unsigned>((H + kBlurBand - 1) / kBlurBand));
+  SOIL_REQUIRE(grid_rows.y <= 65535u && WC <= 65535 * 4 * static_cast<int64_t>(kSBlock),
+               "gaussian_blur: grid too large for one launch");
+  k_blur_rows<<<grid_rows, kSBlock, 0, st>>>(scratch, tensor, H, WC, bw);  // :81 / :86
+  const dim3 grid_cols(static_cast<unsigned>(H), blocks_for(WC, 4 * kSBlock));
+  if (C == 1) k_blur_cols<1><<<grid_cols, kSBlock, 0, st>>>(tensor, scratch, W, bw);  // :82 / :87
+  else k_blur_cols<2><<<grid_cols, kSBlock, 0, st>>>(tensor, scratch, W, bw);
   SOIL_LAUNCH_CHECK();
   return SOIL_OK;
 }
