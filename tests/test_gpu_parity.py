@@ -501,6 +501,18 @@ def test_stencils_bit_exact(hip, oracle, H, W):
     assert_bit_equal(to_np(soil.normal(gh, s3)), oracle.normal(h, s3), "normal (gpu)")
 
 
+@pytest.mark.parametrize("H,W", [(70, 1500), (33, 1025), (300, 7)])
+def test_gaussian_blur_across_tile_seams(hip, oracle, H, W):
+    """Grids wider than one 1024-float LDS segment and taller than one 32-row band."""
+    from soillib_amd import soil
+    r = np.random.default_rng(H + W)
+    for D in (1, 2):
+        t = r.standard_normal((H, W, D)).astype(np.float32)
+        gt = to_gpu(t)
+        soil.gaussian_blur(gt, 2.5)
+        assert_bit_equal(to_np(gt), oracle.gaussian_blur(t, 2.5), "gaussian_blur C=%d" % D)
+
+
 def test_solve_uniform_parity(hip, oracle):
     from soillib_amd import soil
     H, W, N = 48, 40, 6000
