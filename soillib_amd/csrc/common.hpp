@@ -57,6 +57,21 @@ int workspace_release_all();
 // on this device; read and reset through soil_particle_steps().
 int step_counter(unsigned long long** out);
 
+// Launch shape of the per-cell kernels: threads along the contiguous axis, and a
+// work-group walks a band of kRowBand consecutive rows (SOIL_ROW_LOOP).  A 64-bit
+// n / W, n % W per cell costs more than most of these kernels' arithmetic, and with
+// consecutive rows in one work-group the rows x-1, x of a 3x3 stencil come out of
+// that CU's L1 instead of being fetched again by a work-group on another XCD.
+constexpr int kRowBand = 16;
+inline dim3 grid_rows(int64_t H, int64_t W, int threads) {
+  return dim3(static_cast<unsigned>((W + threads - 1) / threads),
+              static_cast<unsigned>((H + kRowBand - 1) / kRowBand));
+}
+#define SOIL_ROW_LOOP(x, H)                                                        \
+  for (int64_t x = static_cast<int64_t>(blockIdx.y) * ::soil::kRowBand,            \
+               x##_end = (x + ::soil::kRowBand < (H)) ? x + ::soil::kRowBand : (H); \
+       x < x##_end; ++x)
+
 inline hipStream_t as_stream(void* s) { return static_cast<hipStream_t>(s); }
 inline unsigned blocks_for(int64_t n, int threads) {
   return static_cast<unsigned>((n + threads - 1) / threads);

@@ -18,6 +18,12 @@ constexpr int kGBlock = 256;
 __device__ __constant__ int kShiftX[8] = {-1, 0, 0, 1, -1, -1, 1, 1};
 __device__ __constant__ int kShiftY[8] = {0, -1, 1, 0, -1, 1, -1, 1};
 
+// the same tables as compile-time constants for fully unrolled loops; __length(shift)
+// (graph.cu:23-25) is sqrtf(1) or sqrtf(2), correctly rounded
+constexpr int kDX[8] = {-1, 0, 0, 1, -1, -1, 1, 1};
+constexpr int kDY[8] = {0, -1, 1, 0, -1, 1, -1, 1};
+constexpr float kShiftLen[8] = {1.0f, 1.0f, 1.0f, 1.0f, kSqrt2, kSqrt2, kSqrt2, kSqrt2};
+
 __device__ __forceinline__ float shift_len(int k) {  // __length(shift), graph.cu:23-25
   const float dx = static_cast<float>(kShiftX[k]), dy = static_cast<float>(kShiftY[k]);
   return sqrtf(dx * dx + dy * dy);
@@ -27,24 +33,26 @@ __device__ __forceinline__ float shift_len(int k) {  // __length(shift), graph.c
 template <int K, bool STORE_K>
 __global__ void __launch_bounds__(kGBlock)
     k_steepest(int32_t* __restrict__ out, const float* __restrict__ height, int64_t H, int64_t W) {
-  const int64_t n = static_cast<int64_t>(blockIdx.x) * kGBlock + threadIdx.x;
-  if (n >= H * W) return;
-  const int64_t x = n / W, y = n % W;
-  const float hlocal = height[n];  // :40
-  float smax = 0.0f;               // :42
-  int32_t next = -1;               // :43
+  const int64_t y = static_cast<int64_t>(blockIdx.x) * kGBlock + threadIdx.x;
+  if (y >= W) return;
+  SOIL_ROW_LOOP(x, H) {
+    const int64_t n = x * W + y;
+    const float hlocal = height[n];  // :40
+    float smax = 0.0f;               // :42
+    int32_t next = -1;               // :43
 #pragma unroll
-  for (int k = 0; k < K; ++k) {  // :46
-    const int64_t nx = x + kShiftX[k], ny = y + kShiftY[k];
-    if (nx < 0 || ny < 0 || nx >= H || ny >= W) continue;  // :51-52
-    const int64_t nind = nx * W + ny;
-    const float scur = (hlocal - height[nind]) / shift_len(k);  // :56
-    if (scur > smax) {                                          // :57-60
-      smax = scur;
-      next = STORE_K ? static_cast<int32_t>(k) : static_cast<int32_t>(nind);
+    for (int k = 0; k < K; ++k) {  // :46
+      const int64_t nx = x + kDX[k], ny = y + kDY[k];
+      if (nx < 0 || ny < 0 || nx >= H || ny >= W) continue;  // :51-52
+      const int64_t nind = nx * W + ny;
+      const float scur = (hlocal - height[nind]) / kShiftLen[k];  // :56
+      if (scur > smax) {                                          // :57-60
+        smax = scur;
+        next = STORE_K ? static_cast<int32_t>(k) : static_cast<int32_t>(nind);
+      }
     }
+    out[n] = next;  // :68
   }
-  out[n] = next;  // :68
 }
 
 // __seed (graph.cu:97-101) + __random_weighted (:103-173): the per-cell
@@ -54,35 +62,37 @@ template <int K>
 __global__ void __launch_bounds__(kGBlock)
     k_random_weighted(int32_t* __restrict__ graph, const float* __restrict__ height, int64_t H,
                       int64_t W, uint64_t seed, uint64_t offset, float T) {
-  const int64_t n = static_cast<int64_t>(blockIdx.x) * kGBlock + threadIdx.x;
-  if (n >= H * W) return;
-  const int64_t x = n / W, y = n % W;
-  const float hlocal = height[n];  // :118
-  float CDF[K];                    // :126
-  float Z = 0.0f;                  // :127
+  const int64_t y = static_cast<int64_t>(blockIdx.x) * kGBlock + threadIdx.x;
+  if (y >= W) return;
+  SOIL_ROW_LOOP(x, H) {
+    const int64_t n = x * W + y;
+    const float hlocal = height[n];  // :118
+    float CDF[K];                    // :126
+    float Z = 0.0f;                  // :127
 #pragma unroll
-  for (int k = 0; k < K; ++k) {  // :129-143
-    CDF[k] = 0.0f;
-    const int64_t nx = x + kShiftX[k], ny = y + kShiftY[k];
-    if (nx < 0 || ny < 0 || nx >= H || ny >= W) continue;
-    const float dE = (hlocal - height[nx * W + ny]) / shift_len(k);  // :138
-    const float P = (dE <= 0.0f) ? 0.0f : expf_(dE / T);             // :139
-    CDF[k] = Z + P;                                                  // :140
-    Z += P;                                                          // :141
-  }
-  int32_t next = -1;                                                            // :149
-  const float uniform = rng_uniform_at(seed, static_cast<uint64_t>(n), offset);  // :100, :150
-  bool found = false;
-#pragma unroll
-  for (int k = 0; k < K; ++k) {  // :151-165
-    const int64_t nx = x + kShiftX[k], ny = y + kShiftY[k];
-    if (nx < 0 || ny < 0 || nx >= H || ny >= W) continue;
-    if (!found && uniform < (CDF[k] / Z)) {  // :160 (Z == 0 -> NaN -> false)
-      next = static_cast<int32_t>(nx * W + ny);
-      found = true;
+    for (int k = 0; k < K; ++k) {  // :129-143
+      CDF[k] = 0.0f;
+      const int64_t nx = x + kDX[k], ny = y + kDY[k];
+      if (nx < 0 || ny < 0 || nx >= H || ny >= W) continue;
+      const float dE = (hlocal - height[nx * W + ny]) / kShiftLen[k];  // :138
+      const float P = (dE <= 0.0f) ? 0.0f : expf_(dE / T);             // :139
+      CDF[k] = Z + P;                                                  // :140
+      Z += P;                                                          // :141
     }
+    int32_t next = -1;                                                            // :149
+    const float uniform = rng_uniform_at(seed, static_cast<uint64_t>(n), offset);  // :100, :150
+    bool found = false;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {  // :151-165
+      const int64_t nx = x + kDX[k], ny = y + kDY[k];
+      if (nx < 0 || ny < 0 || nx >= H || ny >= W) continue;
+      if (!found && uniform < (CDF[k] / Z)) {  // :160 (Z == 0 -> NaN -> false)
+        next = static_cast<int32_t>(nx * W + ny);
+        found = true;
+      }
+    }
+    graph[n] = next;  // :171
   }
-  graph[n] = next;  // :171
 }
 
 // __slope, graph.cu:270-295
@@ -131,27 +141,29 @@ __global__ void __launch_bounds__(kGBlock)
              float* __restrict__ value, const int32_t* __restrict__ graph,
              const float* __restrict__ source, const float* __restrict__ decayIn, int64_t H,
              int64_t W) {
-  const int64_t n = static_cast<int64_t>(blockIdx.x) * kGBlock + threadIdx.x;
+  const int64_t y = static_cast<int64_t>(blockIdx.x) * kGBlock + threadIdx.x;
   const int64_t elem = H * W;
-  if (n >= elem) return;
-  const int64_t x = n / W, y = n % W;
-  int c = 0;
-  int32_t dn[K];
+  if (y >= W) return;
+  SOIL_ROW_LOOP(x, H) {
+    const int64_t n = x * W + y;
+    int c = 0;
+    int32_t dn[K];
 #pragma unroll
-  for (int k = 0; k < K; ++k) {
-    const int64_t dx = x - kShiftX[k], dy = y - kShiftY[k];  // the cell whose k-th neighbour is n
-    if (dx < 0 || dy < 0 || dx >= H || dy >= W) continue;
-    const int64_t d = dx * W + dy;
-    if (graph[d] == n) dn[c++] = static_cast<int32_t>(d);  // :333-345
-  }
-  count[n] = c;
-  value[n] = source[n];  // silt::set(value, source), :553
+    for (int k = 0; k < K; ++k) {
+      const int64_t dx = x - kDX[k], dy = y - kDY[k];  // the cell whose k-th neighbour is n
+      if (dx < 0 || dy < 0 || dx >= H || dy >= W) continue;
+      const int64_t d = dx * W + dy;
+      if (graph[d] == n) dn[c++] = static_cast<int32_t>(d);  // :333-345
+    }
+    count[n] = c;
+    value[n] = source[n];  // silt::set(value, source), :553
 #pragma unroll
-  for (int k = 0; k < K; ++k) {
-    if (k < c) {
-      donor[k * elem + n] = dn[k];
-      const float D = TENSOR_DECAY ? decayIn[dn[k]] : 1.0f;
-      decay[k * elem + n] = (k < 4) ? D : powf_(D, 1.414f);
+    for (int k = 0; k < K; ++k) {
+      if (k < c) {
+        donor[k * elem + n] = dn[k];
+        const float D = TENSOR_DECAY ? decayIn[dn[k]] : 1.0f;
+        decay[k * elem + n] = (k < 4) ? D : powf_(D, 1.414f);
+      }
     }
   }
 }
@@ -247,10 +259,10 @@ static int accumulate_impl(float* out, const int32_t* graph, const float* source
 
   const unsigned nb = blocks_for(elem, kGBlock);
   if (decayIn)  // :552-556
-    k_donors<K, true><<<nb, kGBlock, 0, st>>>(A.count, A.donor, A.decay, A.value, graph, source,
+    k_donors<K, true><<<grid_rows(H, W, kGBlock), kGBlock, 0, st>>>(A.count, A.donor, A.decay, A.value, graph, source,
                                               decayIn, H, W);
   else
-    k_donors<K, false><<<nb, kGBlock, 0, st>>>(A.count, A.donor, A.decay, A.value, graph, source,
+    k_donors<K, false><<<grid_rows(H, W, kGBlock), kGBlock, 0, st>>>(A.count, A.donor, A.decay, A.value, graph, source,
                                                nullptr, H, W);
   SOIL_LAUNCH_CHECK();
 
@@ -290,8 +302,8 @@ int soil_direction(int32_t* direction, const float* height, int64_t H, int64_t W
   SOIL_REQUIRE(H > 0 && W > 0, "direction: empty grid");
   const unsigned nb = blocks_for(H * W, kGBlock);
   switch (edge) {
-    case SOIL_D4: k_steepest<4, true><<<nb, kGBlock, 0, as_stream(stream)>>>(direction, height, H, W); break;
-    case SOIL_D8: k_steepest<8, true><<<nb, kGBlock, 0, as_stream(stream)>>>(direction, height, H, W); break;
+    case SOIL_D4: k_steepest<4, true><<<grid_rows(H, W, kGBlock), kGBlock, 0, as_stream(stream)>>>(direction, height, H, W); break;
+    case SOIL_D8: k_steepest<8, true><<<grid_rows(H, W, kGBlock), kGBlock, 0, as_stream(stream)>>>(direction, height, H, W); break;
     default: return fail(SOIL_ERR_INVALID_ARGUMENT, "invalid edge enumerator");  // graph.cu:262
   }
   SOIL_LAUNCH_CHECK();
@@ -305,8 +317,8 @@ int soil_steepest(int32_t* graph, const float* height, int64_t H, int64_t W, int
   SOIL_REQUIRE(H > 0 && W > 0 && H * W <= INT32_MAX, "steepest: grid must have 1..2^31-1 cells");
   const unsigned nb = blocks_for(H * W, kGBlock);
   switch (edge) {
-    case SOIL_D4: k_steepest<4, false><<<nb, kGBlock, 0, as_stream(stream)>>>(graph, height, H, W); break;
-    case SOIL_D8: k_steepest<8, false><<<nb, kGBlock, 0, as_stream(stream)>>>(graph, height, H, W); break;
+    case SOIL_D4: k_steepest<4, false><<<grid_rows(H, W, kGBlock), kGBlock, 0, as_stream(stream)>>>(graph, height, H, W); break;
+    case SOIL_D8: k_steepest<8, false><<<grid_rows(H, W, kGBlock), kGBlock, 0, as_stream(stream)>>>(graph, height, H, W); break;
     default: return fail(SOIL_ERR_INVALID_ARGUMENT, "invalid edge enumerator");  // graph.cu:88
   }
   SOIL_LAUNCH_CHECK();
@@ -321,8 +333,8 @@ int soil_random_weighted(int32_t* graph, const float* height, int64_t H, int64_t
                "random_weighted: grid must have 1..2^31-1 cells");
   const unsigned nb = blocks_for(H * W, kGBlock);
   switch (edge) {
-    case SOIL_D4: k_random_weighted<4><<<nb, kGBlock, 0, as_stream(stream)>>>(graph, height, H, W, seed, offset, T); break;
-    case SOIL_D8: k_random_weighted<8><<<nb, kGBlock, 0, as_stream(stream)>>>(graph, height, H, W, seed, offset, T); break;
+    case SOIL_D4: k_random_weighted<4><<<grid_rows(H, W, kGBlock), kGBlock, 0, as_stream(stream)>>>(graph, height, H, W, seed, offset, T); break;
+    case SOIL_D8: k_random_weighted<8><<<grid_rows(H, W, kGBlock), kGBlock, 0, as_stream(stream)>>>(graph, height, H, W, seed, offset, T); break;
     default: return fail(SOIL_ERR_INVALID_ARGUMENT, "invalid edge enumerator");  // graph.cu:192
   }
   SOIL_LAUNCH_CHECK();

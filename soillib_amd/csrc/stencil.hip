@@ -10,57 +10,61 @@ constexpr int kSBlock = 256;
 __global__ void __launch_bounds__(kSBlock)
     k_gradient(float2* __restrict__ out, const float* __restrict__ in, int64_t H, int64_t W,
                Scale2 s) {
-  const int64_t n = static_cast<int64_t>(blockIdx.x) * kSBlock + threadIdx.x;
-  if (n >= H * W) return;
-  const int64_t x = n / W, y = n % W;
+  const int64_t y = static_cast<int64_t>(blockIdx.x) * kSBlock + threadIdx.x;
+  if (y >= W) return;
   const float nan = __builtin_nanf("");
-  const float h = in[n];
-  const float hn0 = (x - 1 < 0) ? nan : in[n - W];  // :35-38
-  const float hp0 = (x + 1 >= H) ? nan : in[n + W];
-  const float h0n = (y - 1 < 0) ? nan : in[n - 1];
-  const float h0p = (y + 1 >= W) ? nan : in[n + 1];
-  const float gxn = (h - hn0) / s.x;    // :46
-  const float gyn = (h - h0n) / s.y;    // :50
-  const float gxp = (hp0 - h) / s.x;    // :54
-  const float gyp = (h0p - h) / s.y;    // :58
-  float gx = 0.5f * (hp0 - hn0) / s.x;  // :62
-  float gy = 0.5f * (h0p - h0n) / s.y;  // :63
-  if (gx != gx) gx = gxn;               // :65-67
-  if (gx != gx) gx = gxp;
-  if (gx != gx) gx = 0.0f;
-  if (gy != gy) gy = gyn;  // :69-71
-  if (gy != gy) gy = gyp;
-  if (gy != gy) gy = 0.0f;
-  out[n] = make_float2(gx, gy);  // :84-85
+  SOIL_ROW_LOOP(x, H) {
+    const int64_t n = x * W + y;
+    const float h = in[n];
+    const float hn0 = (x - 1 < 0) ? nan : in[n - W];  // :35-38
+    const float hp0 = (x + 1 >= H) ? nan : in[n + W];
+    const float h0n = (y - 1 < 0) ? nan : in[n - 1];
+    const float h0p = (y + 1 >= W) ? nan : in[n + 1];
+    const float gxn = (h - hn0) / s.x;    // :46
+    const float gyn = (h - h0n) / s.y;    // :50
+    const float gxp = (hp0 - h) / s.x;    // :54
+    const float gyp = (h0p - h) / s.y;    // :58
+    float gx = 0.5f * (hp0 - hn0) / s.x;  // :62
+    float gy = 0.5f * (h0p - h0n) / s.y;  // :63
+    if (gx != gx) gx = gxn;               // :65-67
+    if (gx != gx) gx = gxp;
+    if (gx != gx) gx = 0.0f;
+    if (gy != gy) gy = gyn;  // :69-71
+    if (gy != gy) gy = gyp;
+    if (gy != gy) gy = 0.0f;
+    out[n] = make_float2(gx, gy);  // :84-85
+  }
 }
 
 // __negslope, grad.cu:101-131
 __global__ void __launch_bounds__(kSBlock)
     k_negslope(float* __restrict__ out, const float* __restrict__ in, int64_t H, int64_t W,
                Scale2 s) {
-  const int64_t n = static_cast<int64_t>(blockIdx.x) * kSBlock + threadIdx.x;
-  if (n >= H * W) return;
-  const int64_t x = n / W, y = n % W;
-  const float h = in[n];
-  float gx = 0.0f;  // :120-122, glm::max(a, b) = (a < b) ? b : a
-  if (x - 1 >= 0) {
-    const float c = (h - in[n - W]) / s.x;
-    gx = (gx < c) ? c : gx;
+  const int64_t y = static_cast<int64_t>(blockIdx.x) * kSBlock + threadIdx.x;
+  if (y >= W) return;
+  SOIL_ROW_LOOP(x, H) {
+    const int64_t n = x * W + y;
+    const float h = in[n];
+    float gx = 0.0f;  // :120-122, glm::max(a, b) = (a < b) ? b : a
+    if (x - 1 >= 0) {
+      const float c = (h - in[n - W]) / s.x;
+      gx = (gx < c) ? c : gx;
+    }
+    if (x + 1 < H) {
+      const float c = (h - in[n + W]) / s.x;
+      gx = (gx < c) ? c : gx;
+    }
+    float gy = 0.0f;  // :124-126
+    if (y - 1 >= 0) {
+      const float c = (h - in[n - 1]) / s.y;
+      gy = (gy < c) ? c : gy;
+    }
+    if (y + 1 < W) {
+      const float c = (h - in[n + 1]) / s.y;
+      gy = (gy < c) ? c : gy;
+    }
+    out[n] = sqrtf(gx * gx + gy * gy);  // :129
   }
-  if (x + 1 < H) {
-    const float c = (h - in[n + W]) / s.x;
-    gx = (gx < c) ? c : gx;
-  }
-  float gy = 0.0f;  // :124-126
-  if (y - 1 >= 0) {
-    const float c = (h - in[n - 1]) / s.y;
-    gy = (gy < c) ? c : gy;
-  }
-  if (y + 1 < W) {
-    const float c = (h - in[n + 1]) / s.y;
-    gy = (gy < c) ? c : gy;
-  }
-  out[n] = sqrtf(gx * gx + gy * gy);  // :129
 }
 
 // __laplacian<D>, grad.cu:147-183 — one thread per (cell, channel)
@@ -68,25 +72,27 @@ template <int D>
 __global__ void __launch_bounds__(kSBlock)
     k_laplacian(float* __restrict__ out, const float* __restrict__ in, int64_t H, int64_t W,
                 Scale2 s) {
-  const int64_t t = static_cast<int64_t>(blockIdx.x) * kSBlock + threadIdx.x;
-  if (t >= H * W * D) return;
-  const int64_t n = t / D;
-  const int c = static_cast<int>(t % D);
-  const int64_t x = n / W, y = n % W;
-  auto at = [&](int dx, int dy) -> float {  // clamp-to-self, :166-173
-    const int64_t nx = x + dx, ny = y + dy;
-    if (nx < 0 || nx >= H || ny < 0 || ny >= W) return in[D * n + c];
-    return in[D * (nx * W + ny) + c];
-  };
-  const float v00 = in[D * n + c];
-  const float vn0 = at(-1, 0), vp0 = at(1, 0), v0n = at(0, -1), v0p = at(0, 1);
-  const float vnn = at(-1, -1), vpp = at(1, 1), vpn = at(1, -1), vnp = at(-1, 1);
+  const int64_t f = static_cast<int64_t>(blockIdx.x) * kSBlock + threadIdx.x;  // float of the row
+  if (f >= W * D) return;
+  const int64_t y = f / D;
+  const int c = static_cast<int>(f % D);
   const float hx = (1.0f / s.x / s.x);  // :175
   const float hy = (1.0f / s.y / s.y);  // :176
-  const float LH = (vn0 - v00) * hx + (vp0 - v00) * hx + (v0n - v00) * hy + (v0p - v00) * hy;  // :178
-  const float LD = 0.5f * (vnn - v00) * hx + 0.5f * (vpp - v00) * hx + 0.5f * (vpn - v00) * hy +
-                   0.5f * (vnp - v00) * hy;   // :179
-  out[D * n + c] = 0.5f * LH + 0.5f * LD;    // :181
+  SOIL_ROW_LOOP(x, H) {
+    const int64_t n = x * W + y;
+    auto at = [&](int dx, int dy) -> float {  // clamp-to-self, :166-173
+      const int64_t nx = x + dx, ny = y + dy;
+      if (nx < 0 || nx >= H || ny < 0 || ny >= W) return in[D * n + c];
+      return in[D * (nx * W + ny) + c];
+    };
+    const float v00 = in[D * n + c];
+    const float vn0 = at(-1, 0), vp0 = at(1, 0), v0n = at(0, -1), v0p = at(0, 1);
+    const float vnn = at(-1, -1), vpp = at(1, 1), vpn = at(1, -1), vnp = at(-1, 1);
+    const float LH = (vn0 - v00) * hx + (vp0 - v00) * hx + (v0n - v00) * hy + (v0p - v00) * hy;  // :178
+    const float LD = 0.5f * (vnn - v00) * hx + 0.5f * (vpp - v00) * hx + 0.5f * (vpn - v00) * hy +
+                     0.5f * (vnp - v00) * hy;   // :179
+    out[D * n + c] = 0.5f * LH + 0.5f * LD;    // :181
+  }
 }
 
 // __gaussian_blur / __blur, filter.cu:24-70.  The 33 tap weights depend on
@@ -186,8 +192,9 @@ SOIL_HD float lerp5_axis(const float* in, int64_t n, int64_t stride, int64_t i, 
 }
 
 // soil::op::normal, normal.hpp:29-35, for one cell
-SOIL_HD void normal_cell(float* out, const float* in, int64_t n, int64_t H, int64_t W, Scale3 s) {
-  const int64_t x = n / W, y = n % W;
+SOIL_HD void normal_cell(float* out, const float* in, int64_t x, int64_t y, int64_t H, int64_t W,
+                         Scale3 s) {
+  const int64_t n = x * W + y;
   const float gx = lerp5_axis(in, n, W, x, H) * s.z / s.x;  // :31-32
   const float gy = lerp5_axis(in, n, 1, y, W) * s.z / s.y;
   const float vx = -gx, vy = -gy, vz = 1.0f;  // :33
@@ -200,9 +207,9 @@ SOIL_HD void normal_cell(float* out, const float* in, int64_t n, int64_t H, int6
 __global__ void __launch_bounds__(kSBlock)
     k_normal(float* __restrict__ out, const float* __restrict__ in, int64_t H, int64_t W,
              Scale3 s) {
-  const int64_t n = static_cast<int64_t>(blockIdx.x) * kSBlock + threadIdx.x;
-  if (n >= H * W) return;
-  normal_cell(out, in, n, H, W, s);
+  const int64_t y = static_cast<int64_t>(blockIdx.x) * kSBlock + threadIdx.x;
+  if (y >= W) return;
+  SOIL_ROW_LOOP(x, H) normal_cell(out, in, x, y, H, W, s);
 }
 
 // soil.resize of the multiscale driver (example/erosion_gpu_multiscale.py:104-141).
@@ -274,7 +281,7 @@ int soil_gradient(float* out, const float* in, int64_t H, int64_t W, const float
   SOIL_DEVICE();
   SOIL_REQUIRE(out && in && scale, "gradient: null argument");
   SOIL_REQUIRE(H > 0 && W > 0, "gradient: empty grid");
-  k_gradient<<<blocks_for(H * W, kSBlock), kSBlock, 0, as_stream(stream)>>>(
+  k_gradient<<<grid_rows(H, W, kSBlock), kSBlock, 0, as_stream(stream)>>>(
       reinterpret_cast<float2*>(out), in, H, W, Scale2{scale[0], scale[1]});
   SOIL_LAUNCH_CHECK();
   return SOIL_OK;
@@ -285,7 +292,7 @@ int soil_negslope(float* out, const float* in, int64_t H, int64_t W, const float
   SOIL_DEVICE();
   SOIL_REQUIRE(out && in && scale, "negslope: null argument");
   SOIL_REQUIRE(H > 0 && W > 0, "negslope: empty grid");
-  k_negslope<<<blocks_for(H * W, kSBlock), kSBlock, 0, as_stream(stream)>>>(
+  k_negslope<<<grid_rows(H, W, kSBlock), kSBlock, 0, as_stream(stream)>>>(
       out, in, H, W, Scale2{scale[0], scale[1]});
   SOIL_LAUNCH_CHECK();
   return SOIL_OK;
@@ -297,11 +304,10 @@ int soil_laplacian(float* out, const float* in, int64_t H, int64_t W, int D, con
   SOIL_REQUIRE(out && in && scale, "laplacian: null argument");
   SOIL_REQUIRE(H > 0 && W > 0, "laplacian: empty grid");
   const Scale2 s{scale[0], scale[1]};
-  const unsigned nb = blocks_for(H * W * D, kSBlock);
   if (D == 1)  // grad.cu:196-198
-    k_laplacian<1><<<nb, kSBlock, 0, as_stream(stream)>>>(out, in, H, W, s);
+    k_laplacian<1><<<grid_rows(H, W, kSBlock), kSBlock, 0, as_stream(stream)>>>(out, in, H, W, s);
   else if (D == 2)  // grad.cu:200-202
-    k_laplacian<2><<<nb, kSBlock, 0, as_stream(stream)>>>(out, in, H, W, s);
+    k_laplacian<2><<<grid_rows(H, 2 * W, kSBlock), kSBlock, 0, as_stream(stream)>>>(out, in, H, W, s);
   else
     return fail(SOIL_ERR_INVALID_ARGUMENT, "laplacian: channel count must be 1 or 2");
   SOIL_LAUNCH_CHECK();
@@ -337,7 +343,7 @@ int soil_normal(float* out, const float* in, int64_t H, int64_t W, const float s
   SOIL_DEVICE();
   SOIL_REQUIRE(out && in && scale, "normal: null argument");
   SOIL_REQUIRE(H > 0 && W > 0, "normal: empty grid");
-  k_normal<<<blocks_for(H * W, kSBlock), kSBlock, 0, as_stream(stream)>>>(
+  k_normal<<<grid_rows(H, W, kSBlock), kSBlock, 0, as_stream(stream)>>>(
       out, in, H, W, Scale3{scale[0], scale[1], scale[2]});
   SOIL_LAUNCH_CHECK();
   return SOIL_OK;
@@ -347,7 +353,8 @@ int soil_normal_host(float* out, const float* in, int64_t H, int64_t W, const fl
   SOIL_REQUIRE(out && in && scale, "normal_host: null argument");
   SOIL_REQUIRE(H > 0 && W > 0, "normal_host: empty grid");
   const Scale3 s{scale[0], scale[1], scale[2]};
-  for (int64_t n = 0; n < H * W; ++n) normal_cell(out, in, n, H, W, s);  // normal.hpp:29-35
+  for (int64_t x = 0; x < H; ++x)
+    for (int64_t y = 0; y < W; ++y) normal_cell(out, in, x, y, H, W, s);  // normal.hpp:29-35
   return SOIL_OK;
 }
 
