@@ -15,6 +15,7 @@ GPU tensors live in HBM (hipMalloc through the C ABI) or alias external device
 memory (e.g. a torch tensor) through `tensor.from_device`.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -121,18 +122,51 @@ builtins_int = _builtins.int
 
 # ----------------------------------------------------------------- tensor
 
+# Freed device blocks are kept for reuse (exact size match) instead of going back to
+# the driver: the operator API returns a new tensor per call (as the reference's does),
+# and a hipMalloc + hipFree pair costs ~0.25 ms — hipFree also synchronises the device —
+# which is more than most per-cell kernels take at 8192^2.  Reuse is stream-ordered: every
+# launch of this package goes to the one current stream (_abi.set_stream).
+_POOL = {}                      # nbytes -> [device pointers]
+_POOL_STATE = {"bytes": 0,
+               "limit": builtins_int(os.environ.get("SOIL_POOL_BYTES", str(16 << 30)))}
+
+
+def empty_cache():
+    """Hand the cached device blocks back to the driver."""
+    for ptrs in _POOL.values():
+        for ptr in ptrs:
+            _abi.lib().soil_free(C.c_void_p(ptr))
+    _POOL.clear()
+    _POOL_STATE["bytes"] = 0
+
+
 class _DeviceBlock:
-    """Owns one hipMalloc'd block; freed when the last tensor handle dies."""
+    """Owns one hipMalloc'd block; recycled when the last tensor handle dies."""
 
     def __init__(self, nbytes):
-        p = C.c_void_p()
-        _abi.check(_abi.lib().soil_malloc(C.byref(p), nbytes))
-        self.ptr = p.value or 0
+        cached = _POOL.get(nbytes)
+        if cached:
+            self.ptr = cached.pop()
+            _POOL_STATE["bytes"] -= nbytes
+        else:
+            p = C.c_void_p()
+            rc = _abi.lib().soil_malloc(C.byref(p), nbytes)
+            if rc != 0 and _POOL_STATE["bytes"]:      # out of memory: drop the cache, try again
+                empty_cache()
+                rc = _abi.lib().soil_malloc(C.byref(p), nbytes)
+            _abi.check(rc)
+            self.ptr = p.value or 0
         self.nbytes = nbytes
 
     def __del__(self):
         try:
-            if self.ptr:
+            if not self.ptr:
+                return
+            if self.nbytes and _POOL_STATE["bytes"] + self.nbytes <= _POOL_STATE["limit"]:
+                _POOL.setdefault(self.nbytes, []).append(self.ptr)
+                _POOL_STATE["bytes"] += self.nbytes
+            else:
                 _abi.lib().soil_free(C.c_void_p(self.ptr))
         except Exception:
             pass
