@@ -19,14 +19,20 @@
 //     advances the particles of its tile step by step (deposits = split-phase
 //     compare-and-swap on LDS, see CasDeposit) until they die, step onto
 //     another tile or use up the round's step budget; survivors are written
-//     back into the slots their queue occupied together with the tile they are
-//     bound for, the 4-byte slot indices are counting-sorted by tile, and the
-//     next round resumes them;
+//     back into the slots their queue occupied together with the queue section
+//     they are bound for (tile x expected residence time, queue_key) and their
+//     rank in it, the 4-byte slot indices are sorted by section without atomics,
+//     and the next round resumes them;
+//   * between two rounds k_queue_prepare scans the section counts, orders the
+//     tiles longest queue first, lists the work-groups of the round (none for an
+//     empty tile, several for a queue longer than the chip's share) and hands the
+//     host the queue total and the step counter through pinned memory;
 //   * at the end of a round the tile's flux is added to the global planes with
-//     non-atomic read-modify-writes of the cells that changed (one work-group
-//     per tile);
-//   * once few particles are left, one last launch walks them to the end
-//     against global memory (no more rounds for a handful of stragglers).
+//     non-atomic read-modify-writes of the cells that changed (atomic adds when
+//     several work-groups share the tile);
+//   * once rounds advance particles more slowly than the finishing launch would
+//     (measured rate of the last round), one last launch walks what is left to
+//     the end against global memory.
 //
 // A particle executes exactly the instruction sequence of the reference loop —
 // state is only ever parked at the top of an iteration, before `++iter` — so
@@ -34,7 +40,7 @@
 // shape; only the order of the fp32 additions into a cell differs.
 //
 // Measured at 8192^2, N = 8.4 M, maxage 256 (ms per launch, fluvial / debris):
-// direct 418 / 115; fields+flux in LDS with ds_add_f32 84 / 36; this file 44 / 16.
+// direct 418 / 115; fields+flux in LDS with ds_add_f32 84 / 36; this file 40 / 15.
 // The round kernel issues VALU instructions on >80 % of all SIMD cycles
 // (profiles/): what is left is the instruction count of the step itself (nine
 // IEEE divisions, a square root and three exponentials per fluvial step).
@@ -47,9 +53,8 @@
 
 namespace soil {
 
-// A tile is TR rows x TC columns of cells (powers of two) and is worked on by
-// TR*TC/8 threads: the acceptance workload spawns one particle per 8 cells
-// (SURVEY 8d), so a round starts with about one particle per lane.
+// A tile is TR rows x TC columns of cells (powers of two).  The acceptance workload
+// spawns one particle per 8 cells: a 64x64 tile starts with ~512 of them.
 struct TileShape { int shift_r, shift_c; };  // log2(TR), log2(TC)
 constexpr uint32_t kNoTile = 0xffffffffu;     // dest[] of an empty record slot
 
