@@ -528,7 +528,7 @@ __global__ void __launch_bounds__(1024)
 // Float adds on LDS words by compare-and-swap, split in two halves so that the
 // swaps' round trip hides under the step arithmetic: begin() reads the old words
 // and issues one swap per plane, finish() (after the step) looks at the results
-// and only a lane that lost a race retries.  ds_add_f32 needs no such care but
+// and a lane that lost a race falls back to the native atomic.  ds_add_f32 needs no such care but
 // occupies the LDS pipe ~170 cycles per wave instruction on gfx950 (2.6 per lane;
 // tools/microbench/lds_atomic.hip), a ds_cmpst ~6.
 template <int NP>
@@ -549,12 +549,13 @@ struct CasDeposit {
   }
   __device__ __forceinline__ void finish() {
     if (!pending) return;
+    // a lane that lost its race (another walker hit the same cell in between — common
+    // once the particles share channels) hands the add to the native atomic instead of
+    // retrying: nothing was written by the failed swap, ds_add_f32 needs no answer, and
+    // a k-way collision costs k lane-slots of the LDS pipe instead of k round trips
 #pragma unroll
     for (int j = 0; j < NP; ++j)
-      while (g[j] != o[j]) {
-        o[j] = g[j];
-        g[j] = swap(p[j], o[j], v[j]);
-      }
+      if (g[j] != o[j]) atomicAdd(p[j], v[j]);
     pending = false;
   }
 };
