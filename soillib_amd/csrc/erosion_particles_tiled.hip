@@ -395,14 +395,16 @@ __global__ void __launch_bounds__(1024)
   __shared__ uint32_t tot[kPanel];
   __shared__ uint32_t part[1024];
   __shared__ uint32_t hist[256], base[256];
-  __shared__ uint32_t carry;
+  __shared__ uint32_t carry, s_batches, s_longest, s_cap;
   const int tid = threadIdx.x;
   constexpr int kRun = kPanel / 1024;  // consecutive tiles per thread within a panel
-  auto bucket = [](uint32_t c) { return 255u - (c >> 4 > 255u ? 255u : c >> 4); };
+  // bucket 255: empty tiles; 254..0: 1-15, 16-31, ... particles (longest first)
+  auto bucket = [](uint32_t c) { return c == 0 ? 255u : 254u - (c >> 4 > 254u ? 254u : c >> 4); };
   if (tid < 256) hist[tid] = 0;
-  if (tid == 0) carry = 0;
+  if (tid == 0) carry = s_batches = s_longest = 0;
   __syncthreads();
   uint4* out = reinterpret_cast<uint4*>(start);
+  uint32_t my_batches = 0, my_longest = 0;
   for (int64_t p0 = 0; p0 < tiles; p0 += kPanel) {
     const int n = static_cast<int>(tiles - p0 < kPanel ? tiles - p0 : kPanel);
     for (int i = tid; i < kPanel; i += 1024) {
@@ -411,6 +413,8 @@ __global__ void __launch_bounds__(1024)
         const uint4 c = count4[p0 + i];
         t = c.x + c.y + c.z + c.w;
         atomicAdd(&hist[bucket(t)], 1u);
+        my_batches += (t + lanes - 1) / lanes;
+        my_longest = t > my_longest ? t : my_longest;
       }
       tot[i] = t;
     }
@@ -443,21 +447,8 @@ __global__ void __launch_bounds__(1024)
     if (tid == 1023) carry += part[1023];
     __syncthreads();
   }
-  if (tid == 0) {
-    start[tiles * kNB] = carry;  // particles queued in total
-    host->live = carry;
-    host->steps = *steps_run;
-    uint32_t r = 0;
-    for (int k = 0; k < 256; ++k) {
-      base[k] = r;
-      r += hist[k];
-    }
-  }
-  __syncthreads();
-  for (int64_t i = tid; i < tiles; i += 1024) {
-    const uint4 c = count4[i];
-    tile_order[atomicAdd(&base[bucket(c.x + c.y + c.z + c.w)], 1u)] = static_cast<uint32_t>(i);
-  }
+  atomicAdd(&s_batches, my_batches);
+  atomicMax(&s_longest, my_longest);
   __syncthreads();
   // The block list: walking the tiles longest queue first, every non-empty tile gets a
   // work-group.  A work-group serves its queue in batches of `lanes` particles, so a
@@ -468,25 +459,35 @@ __global__ void __launch_bounds__(1024)
   // and add them to the global planes atomically).  On an 8192^2 grid the share is
   // ~40 batches and nothing is cut; on 1024^2 .. 2048^2 it is 1-3 and the handful
   // of channel tiles would otherwise be the critical path of the whole round.
-  if (tid == 0) carry = 0;
-  __syncthreads();
-  {
-    uint32_t batches = 0;
-    for (int64_t i = tid; i < tiles; i += 1024) {
-      const uint4 c = count4[i];
-      batches += (c.x + c.y + c.z + c.w + lanes - 1) / lanes;
+  if (tid == 0) {
+    start[tiles * kNB] = carry;  // particles queued in total
+    host->live = carry;
+    host->steps = *steps_run;
+    const uint32_t share = (s_batches + slots - 1) / slots;
+    s_cap = (share > 0 ? share : 1u) * static_cast<uint32_t>(lanes);  // chunk capacity
+    host->chunk = s_cap;
+    uint32_t r = 0;
+    for (int k = 0; k < 256; ++k) {
+      base[k] = r;
+      r += hist[k];
     }
-    atomicAdd(&carry, batches);
-    __syncthreads();
-    if (tid == 0) {
-      const uint32_t share = (carry + slots - 1) / slots;
-      hist[0] = (share > 0 ? share : 1u) * static_cast<uint32_t>(lanes);  // chunk capacity
-      host->chunk = hist[0];
-      carry = 0;
-    }
-    __syncthreads();
+    carry = 0;
   }
-  const uint32_t chunk_cap = hist[0];
+  __syncthreads();
+  const uint32_t chunk_cap = s_cap;
+  const bool cut = s_longest > chunk_cap;  // some queue needs more than one work-group
+  for (int64_t i = tid; i < tiles; i += 1024) {
+    const uint4 c = count4[i];
+    const uint32_t t = c.x + c.y + c.z + c.w;
+    const uint32_t pos = atomicAdd(&base[bucket(t)], 1u);
+    tile_order[pos] = static_cast<uint32_t>(i);
+    if (!cut && t > 0) block_list[pos] = make_uint2(static_cast<uint32_t>(i), 0u);
+  }
+  if (!cut) {  // the common case on large grids: one work-group per non-empty tile
+    if (tid == 0) host->blocks = static_cast<uint32_t>(tiles) - hist[255];
+    return;
+  }
+  __syncthreads();
   auto groups = [&](int64_t pos) {
     const uint32_t t = tile_order[pos];
     const uint32_t c = start[(t + 1) * kNB] - start[t * kNB];
