@@ -665,3 +665,47 @@ def test_particle_pair_equals_sequential_launches(hip, S, maxage):
     assert (out["pair"][2] == out["sequential"][2]).all()      # both end four draws further
     for k in flux:
         _flux_close(out["pair"][1][k], out["sequential"][1][k], "pair vs sequential " + k)
+
+
+@pytest.mark.parametrize("maxage", [0, 1, 2, 33])
+@pytest.mark.parametrize("N", [0, 1, 63, 5000])
+def test_transport_edge_cases(hip, oracle, particle_mode, maxage, N):
+    """Degenerate launches: no particles, one particle, lifetimes of 0 / 1 / 2 steps and one
+    step past a round's budget — every launch shape against the oracle (fluvial and debris)."""
+    from soillib_amd import soil
+    H, W = 70, 90
+    op = script_param(oracle.default_param())
+    op.maxage = maxage
+    op.critSlopeBedrock = 0.05
+    op.yieldStress = 0.001
+    pp = product_param(op)
+    scale = (20.0 / H, 20.0 / W, 4.0)
+    r = np.random.default_rng(5)
+    layers = terrain(oracle, H, W, sediment=0.01)
+    rain = np.ones((H, W), np.float32)
+    wh0 = (r.random((H, W)) * 0.1).astype(np.float32)
+    vel0 = (r.standard_normal((H, W, 2))).astype(np.float32)
+    z1, z2 = np.zeros((H, W), np.float32), np.zeros((H, W, 2), np.float32)
+    o = dict(wf=z1.copy(), mf=z1.copy(), vf=z2.copy(), df=z1.copy(), dvf=z2.copy())
+    orng = oracle.rng_seed(max(N, 1), 9, 40)[:N]
+    steps = 0
+    if N:
+        steps += oracle.particles_fluvial(o["wf"], o["mf"], o["vf"], None, orng, layers, rain, wh0,
+                                          vel0, None, scale, op)
+        steps += oracle.particles_debris(o["df"], o["dvf"], None, orng, layers, vel0, None, scale, op)
+    import ctypes as C
+    from soillib_amd import _abi
+    g = {k: to_gpu(v) for k, v in dict(wf=z1, mf=z1, vf=z2, df=z1, dvf=z2).items()}
+    grng = rng_to_gpu(oracle.rng_seed(max(N, 1), 9, 40))
+    lay, gr, gw, gv = to_gpu(layers), to_gpu(rain), to_gpu(wh0), to_gpu(vel0)
+    dom = _abi.Domain(H, W, 0, H, 0, H)
+    soil.particle_steps(reset=True)
+    _abi.check(hip.soil_particles_fluvial_slab(
+        g["wf"].c_ptr, g["mf"].c_ptr, g["vf"].c_ptr, None, grng.c_ptr if N else None, N, lay.c_ptr,
+        gr.c_ptr, gw.c_ptr, gv.c_ptr, None, None, C.byref(dom), _abi.vec(scale, 3), pp._ref(), None))
+    _abi.check(hip.soil_particles_debris_slab(
+        g["df"].c_ptr, g["dvf"].c_ptr, None, grng.c_ptr if N else None, N, lay.c_ptr, gv.c_ptr,
+        None, None, C.byref(dom), _abi.vec(scale, 3), pp._ref(), None))
+    assert soil.particle_steps(reset=True) == steps
+    for k in ("wf", "mf", "vf", "df", "dvf"):
+        _flux_close(to_np(g[k]), o[k], "edge case flux " + k)
