@@ -829,21 +829,19 @@ __global__ void k_fold_steps(unsigned long long* total, const unsigned long long
   atomicAdd(total, *part);
 }
 
-// Tile shapes a round can use: rows x columns (powers of two) and threads of the
-// work-group.  Every round re-sorts the particles by tile, so the shape may change
-// from round to round: early rounds have ~1 particle per 8 cells everywhere (big
-// tiles, few exits); later the particles sit in channels and most tiles are
-// sparse, where smaller tiles keep more work-groups resident per CU.
+// Work-group shapes a round can use: tile rows x columns (powers of two) and threads.
+// Every round re-sorts the particles by tile, so the shape may change from round to
+// round (SOIL_TILED_LATE / SOIL_TILED_SWITCH).  Smaller tiles (32x64, 32x32) were
+// measured too: more exits per step and no better occupancy — 64x64 it is; what is
+// left to choose is how many lanes serve a tile.
 struct RoundShape { int tr, tc, nt; };
-static constexpr RoundShape kShapes[] = {{64, 64, 512}, {64, 64, 768}, {32, 64, 256}, {32, 32, 128}};
+static constexpr RoundShape kShapes[] = {{64, 64, 512}, {64, 64, 768}};
 constexpr int kNumShapes = sizeof(kShapes) / sizeof(kShapes[0]);
 
 template <int KIND, int DEP, typename... A>
 static void launch_round(int shape, unsigned grid, hipStream_t st, A... a) {
   switch (shape) {
     case 1: k_tiled_round<KIND, DEP, 64, 64, 768><<<grid, 768, 0, st>>>(a...); break;
-    case 2: k_tiled_round<KIND, DEP, 32, 64, 256><<<grid, 256, 0, st>>>(a...); break;
-    case 3: k_tiled_round<KIND, DEP, 32, 32, 128><<<grid, 128, 0, st>>>(a...); break;
     default: k_tiled_round<KIND, DEP, 64, 64, 512><<<grid, 512, 0, st>>>(a...); break;
   }
 }
