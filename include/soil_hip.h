@@ -430,8 +430,9 @@ int soil_noise_window(float* out, int64_t rows, int64_t W, int64_t x0, const soi
 /* ------------------------------------------------------ multiscale driver */
 /* soil.resize(dst, src, newres, oldres) of example/erosion_gpu_multiscale.py:104-141
  * (SURVEY.md 8f row 4).  The reference snapshot has no definition of it; this
- * one is the reference's bilinear sampler (sample.hpp:154-186) at corner-aligned
- * positions, for planes of D = 1..3 interleaved channels.  Parity unpinned. */
+ * one is bilinear resampling at corner-aligned positions (equal resolutions give
+ * the identity, corners are kept), for planes of D = 1..3 interleaved channels.
+ * Parity unpinned. */
 int soil_resize(float* dst, const float* src, int64_t Hn, int64_t Wn, int64_t Ho, int64_t Wo, int D,
                 void* stream);
 

@@ -1117,8 +1117,10 @@ static void orc_bilinear(const float* flow, int64_t H, int64_t W, float px, floa
 }
 
 /* soil.resize of example/erosion_gpu_multiscale.py:104-141: no definition exists in
- * the reference snapshot (parity unpinned); defined as the bilinear sampler above
- * (sample.hpp:154-186) at corner-aligned positions i*(Ho-1)/(Hn-1). */
+ * the reference snapshot (parity unpinned); defined as bilinear resampling at
+ * corner-aligned positions i*(Ho-1)/(Hn-1) with the weights written as in the
+ * reference's sampler, (1 - t)*a + t*b (sample.hpp:48-60), interpolating in every
+ * cell including the last one of each axis (where that sampler stops, :172-173). */
 static float orc_resize_pos(int64_t i, int64_t n_new, int64_t n_old) {
   if (n_new <= 1) return 0.0f;
   const float step = (float)(n_old - 1) / (float)(n_new - 1);
@@ -1128,12 +1130,14 @@ void orc_resize(float* dst, const float* src, int64_t Hn, int64_t Wn, int64_t Ho
                 int D) {
   for (int64_t n = 0; n < Hn * Wn; ++n) {
     const float px = orc_resize_pos(n / Wn, Hn, Ho), py = orc_resize_pos(n % Wn, Wn, Wo);
-    const int64_t ix = (int64_t)px, iy = (int64_t)py;
-    float wx = px - floorf(px), wy = py - floorf(py);
-    int64_t i00 = ix * Wo + iy, i01 = ix * Wo + (iy + 1);
-    int64_t i10 = (ix + 1) * Wo + iy, i11 = (ix + 1) * Wo + (iy + 1);
-    if (px + 1 > (float)Ho - 1) { wx = 0; i10 = 0; i11 = 0; } /* :172 */
-    if (py + 1 > (float)Wo - 1) { wy = 0; i01 = 0; i11 = 0; } /* :173 */
+    int64_t ix = (int64_t)px, iy = (int64_t)py;
+    if (ix > Ho - 2) ix = Ho - 2;
+    if (ix < 0) ix = 0;
+    if (iy > Wo - 2) iy = Wo - 2;
+    if (iy < 0) iy = 0;
+    const int64_t jx = (Ho > 1) ? ix + 1 : ix, jy = (Wo > 1) ? iy + 1 : iy;
+    const float wx = px - (float)ix, wy = py - (float)iy;
+    const int64_t i00 = ix * Wo + iy, i01 = ix * Wo + jy, i10 = jx * Wo + iy, i11 = jx * Wo + jy;
     for (int c = 0; c < D; ++c) {
       const float l0 = (1.0f + -1.0f * wy) * src[D * i00 + c] + (0.0f + 1.0f * wy) * src[D * i01 + c];
       const float l1 = (1.0f + -1.0f * wy) * src[D * i10 + c] + (0.0f + 1.0f * wy) * src[D * i11 + c];

@@ -213,11 +213,13 @@ __global__ void __launch_bounds__(kSBlock)
 }
 
 // soil.resize of the multiscale driver (example/erosion_gpu_multiscale.py:104-141).
-// The reference snapshot holds no definition of it, so it is
-// defined here with the reference's own bilinear sampler (sample.hpp:154-186,
-// as in path.hip) evaluated at corner-aligned positions: new cell (i, j) samples
-// the old grid at (i*(Ho-1)/(Hn-1), j*(Wo-1)/(Wn-1)), which stays inside
-// [0,Ho-1]x[0,Wo-1] where that sampler is defined.
+// The reference snapshot holds no definition of it; defined here as
+// bilinear resampling at corner-aligned positions: new cell (i, j) samples the old
+// grid at (i*(Ho-1)/(Hn-1), j*(Wo-1)/(Wn-1)), with the weights written as in the
+// reference's sampler, (1 - t)*a + t*b (sample.hpp:48-60) — exact at t = 0 and 1, so
+// equal resolutions give the identity and the corners are kept.  (That sampler itself
+// stops interpolating in the last cell of each axis, sample.hpp:172-173; a resize
+// must not.)
 __device__ __forceinline__ float resize_pos(int64_t i, int64_t n_new, int64_t n_old) {
   if (n_new <= 1) return 0.0f;
   const float step = static_cast<float>(n_old - 1) / static_cast<float>(n_new - 1);
@@ -228,30 +230,31 @@ template <int D>
 __global__ void __launch_bounds__(kSBlock)
     k_resize(float* __restrict__ dst, const float* __restrict__ src, int64_t Hn, int64_t Wn,
              int64_t Ho, int64_t Wo) {
-  const int64_t n = static_cast<int64_t>(blockIdx.x) * kSBlock + threadIdx.x;
-  if (n >= Hn * Wn) return;
-  const float px = resize_pos(n / Wn, Hn, Ho), py = resize_pos(n % Wn, Wn, Wo);
-  const int64_t ix = static_cast<int64_t>(px), iy = static_cast<int64_t>(py);
-  float wx = px - floorf(px), wy = py - floorf(py);
-  int64_t i00 = ix * Wo + iy, i01 = ix * Wo + (iy + 1);
-  int64_t i10 = (ix + 1) * Wo + iy, i11 = (ix + 1) * Wo + (iy + 1);
-  if (px + 1 > static_cast<float>(Ho) - 1) {  // sample.hpp:172
-    wx = 0;
-    i10 = 0;
-    i11 = 0;
-  }
-  if (py + 1 > static_cast<float>(Wo) - 1) {  // :173
-    wy = 0;
-    i01 = 0;
-    i11 = 0;
-  }
+  const int64_t y = static_cast<int64_t>(blockIdx.x) * kSBlock + threadIdx.x;
+  if (y >= Wn) return;
+  const float py = resize_pos(y, Wn, Wo);
+  int64_t iy = static_cast<int64_t>(py);
+  if (iy > Wo - 2) iy = Wo - 2;
+  if (iy < 0) iy = 0;  // Wo == 1
+  const int64_t jy = (Wo > 1) ? iy + 1 : iy;
+  const float wy = py - static_cast<float>(iy);
   const float ay = 1.0f + -1.0f * wy, by = 0.0f + 1.0f * wy;
-  const float ax = 1.0f + -1.0f * wx, bx = 0.0f + 1.0f * wx;
+  SOIL_ROW_LOOP(x, Hn) {
+    const float px = resize_pos(x, Hn, Ho);
+    int64_t ix = static_cast<int64_t>(px);
+    if (ix > Ho - 2) ix = Ho - 2;
+    if (ix < 0) ix = 0;
+    const int64_t jx = (Ho > 1) ? ix + 1 : ix;
+    const float wx = px - static_cast<float>(ix);
+    const float ax = 1.0f + -1.0f * wx, bx = 0.0f + 1.0f * wx;
+    const int64_t i00 = ix * Wo + iy, i01 = ix * Wo + jy, i10 = jx * Wo + iy, i11 = jx * Wo + jy;
+    const int64_t n = x * Wn + y;
 #pragma unroll
-  for (int c = 0; c < D; ++c) {
-    const float l0 = ay * src[D * i00 + c] + by * src[D * i01 + c];
-    const float l1 = ay * src[D * i10 + c] + by * src[D * i11 + c];
-    dst[D * n + c] = ax * l0 + bx * l1;
+    for (int c = 0; c < D; ++c) {
+      const float l0 = ay * src[D * i00 + c] + by * src[D * i01 + c];
+      const float l1 = ay * src[D * i10 + c] + by * src[D * i11 + c];
+      dst[D * n + c] = ax * l0 + bx * l1;
+    }
   }
 }
 
@@ -267,7 +270,7 @@ int soil_resize(float* dst, const float* src, int64_t Hn, int64_t Wn, int64_t Ho
   SOIL_REQUIRE(dst && src, "resize: null argument");
   SOIL_REQUIRE(Hn > 0 && Wn > 0 && Ho > 0 && Wo > 0, "resize: empty grid");
   SOIL_REQUIRE(D >= 1 && D <= 3, "resize: 1, 2 or 3 channels");
-  const unsigned grid = blocks_for(Hn * Wn, kSBlock);
+  const dim3 grid = grid_rows(Hn, Wn, kSBlock);
   hipStream_t st = as_stream(stream);
   if (D == 1) k_resize<1><<<grid, kSBlock, 0, st>>>(dst, src, Hn, Wn, Ho, Wo);
   else if (D == 2) k_resize<2><<<grid, kSBlock, 0, st>>>(dst, src, Hn, Wn, Ho, Wo);

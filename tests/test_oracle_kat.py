@@ -372,3 +372,57 @@ def test_slab_particles_partition_exactly(oracle):
     # row 0 has to drop its own, so that one cell is compared for NaN-ness only
     assert np.isnan(full[0, 0])
     np.testing.assert_allclose(parts.ravel()[1:], full.ravel()[1:], rtol=1e-5, atol=1e-9)
+
+
+# ------------------------------------------------ build-defined operators (no reference definition)
+
+def test_fill_depressions_known_answers(oracle):
+    """Priority-flood surface: a bowl fills to its lowest rim, a NaN cell drains its
+    neighbours like the grid border does, ramps and already drained terrain are untouched."""
+    bowl = np.full((7, 7), 10.0, np.float32)
+    bowl[1:-1, 1:-1] = 5.0
+    bowl[3, 3] = 1.0
+    bowl[0, 3] = 7.0                                   # the lowest point of the rim
+    for edge in (0, 1):
+        w = oracle.fill_depressions(bowl, edge)
+        assert (w[1:-1, 1:-1] == 7.0).all() and w[0, 3] == 7.0 and w[0, 0] == 10.0
+    # D8 reaches a diagonal gap in the rim that D4 cannot use
+    gap = np.full((5, 5), 9.0, np.float32)
+    gap[1:-1, 1:-1] = 2.0
+    gap[0, 0] = 3.0
+    assert oracle.fill_depressions(gap, 1)[2, 2] == 3.0
+    assert oracle.fill_depressions(gap, 0)[2, 2] == 9.0
+    hole = bowl.copy()
+    hole[3, 4] = np.nan                                # NoData inside the bowl: an outlet
+    w = oracle.fill_depressions(hole, 1)
+    assert np.isnan(w[3, 4]) and w[3, 3] == 1.0 and w[2, 2] == 5.0
+    ramp = np.add.outer(np.arange(6, dtype=np.float32), np.arange(9, dtype=np.float32))
+    np.testing.assert_array_equal(oracle.fill_depressions(ramp, 1), ramp)
+    r = np.random.default_rng(0)
+    rough = r.standard_normal((40, 30)).astype(np.float32)
+    w = oracle.fill_depressions(rough, 1)
+    np.testing.assert_array_equal(oracle.fill_depressions(w, 1), w)          # idempotent
+    assert (w >= rough).all()
+
+
+def test_resize_known_answers(oracle):
+    """Bilinear resampling at corner-aligned positions: identity at equal size, corners kept,
+    a linear ramp stays linear, constants stay constant, channels are independent."""
+    r = np.random.default_rng(1)
+    src = r.standard_normal((9, 13)).astype(np.float32)
+    np.testing.assert_array_equal(oracle.resize(src, (9, 13)), src)
+    up = oracle.resize(src, (17, 25))                  # every other sample is an original one
+    np.testing.assert_array_equal(up[::2, ::2], src)
+    np.testing.assert_allclose(up[1::2, ::2], 0.5 * (src[:-1] + src[1:]), rtol=1e-6, atol=1e-7)
+    for corner in ((0, 0), (0, -1), (-1, 0), (-1, -1)):
+        assert up[corner] == src[corner]
+    ramp = np.add.outer(2.0 * np.arange(5, dtype=np.float32), np.arange(8, dtype=np.float32))
+    big = oracle.resize(ramp, (33, 50))
+    want = np.add.outer(np.linspace(0, 8, 33), np.linspace(0, 7, 50))
+    np.testing.assert_allclose(big, want, rtol=1e-5, atol=1e-5)
+    assert (oracle.resize(np.full((4, 6), 2.5, np.float32), (11, 3)) == 2.5).all()
+    two = r.standard_normal((6, 7, 2)).astype(np.float32)
+    got = oracle.resize(two, (10, 12))
+    for c in range(2):
+        np.testing.assert_array_equal(got[..., c], oracle.resize(np.ascontiguousarray(two[..., c]), (10, 12)))
+    assert oracle.resize(src, (1, 1))[0, 0] == src[0, 0]
