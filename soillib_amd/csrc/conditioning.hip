@@ -16,6 +16,8 @@
 // the update order: the kernel relaxes 64x64 tiles in LDS until they stop
 // changing (chaotic Gauss-Seidel inside a tile, Jacobi across tiles per launch)
 // and the host repeats launches until no tile changed.
+#include <utility>
+
 #include "common.hpp"
 
 namespace soil {
@@ -28,10 +30,23 @@ constexpr int kFPer = kFT * kFT / kFBlock;
 template <int K>
 __global__ void __launch_bounds__(kFBlock)
     k_fill_relax(float* __restrict__ w, const float* __restrict__ z, int64_t H, int64_t W,
-                 int tiles_w, int inner_max, int* __restrict__ changed) {
+                 int tiles_w, int tiles_h, int inner_max, int* __restrict__ changed,
+                 const unsigned char* __restrict__ dirty_prev,
+                 unsigned char* __restrict__ dirty_next) {
   __shared__ float sw[kFH * kFH];
   __shared__ int s_flag, s_any;
   const int tid = threadIdx.x;
+  {  // a tile can only move if it or one of its 8 neighbours moved in the previous launch
+    const int tx = blockIdx.x / tiles_w, ty = blockIdx.x % tiles_w;
+    bool live = false;
+    for (int dx = -1; dx <= 1; ++dx)
+      for (int dy = -1; dy <= 1; ++dy) {
+        const int nx = tx + dx, ny = ty + dy;
+        if (nx >= 0 && ny >= 0 && nx < tiles_h && ny < tiles_w)
+          live = live || dirty_prev[nx * tiles_w + ny] != 0;
+      }
+    if (!live) return;
+  }
   const int64_t row0 = static_cast<int64_t>(blockIdx.x / tiles_w) * kFT;
   const int64_t col0 = static_cast<int64_t>(blockIdx.x % tiles_w) * kFT;
   const float ninf = -__builtin_inff();
@@ -91,7 +106,10 @@ __global__ void __launch_bounds__(kFBlock)
       const int64_t x = row0 + c / kFT, y = col0 + c % kFT;
       w[x * W + y] = sw[(c / kFT + 1) * kFH + (c % kFT + 1)];
     }
-    if (tid == 0) *changed = 1;
+    if (tid == 0) {
+      *changed = 1;
+      dirty_next[blockIdx.x] = 1;
+    }
   }
 }
 
@@ -122,9 +140,13 @@ template <int K>
 static int fill_impl(float* out, const float* height, int64_t H, int64_t W, hipStream_t st) {
   const int tiles_w = static_cast<int>((W + kFT - 1) / kFT);
   const int tiles_h = static_cast<int>((H + kFT - 1) / kFT);
+  const size_t ntiles = static_cast<size_t>(tiles_w) * tiles_h, b_dirty = (ntiles + 255) & ~size_t{255};
   void* base = nullptr;
-  if (int rc = workspace_get(4, 256, &base); rc != SOIL_OK) return rc;
+  if (int rc = workspace_get(4, 256 + 2 * b_dirty, &base); rc != SOIL_OK) return rc;
   int* changed = static_cast<int*>(base);
+  unsigned char* dirty_prev = static_cast<unsigned char*>(base) + 256;
+  unsigned char* dirty_next = dirty_prev + b_dirty;
+  SOIL_HIP(hipMemsetAsync(dirty_prev, 1, ntiles, st));  // first launch: every tile
   k_fill_init<K><<<blocks_for(H * W, kFBlock), kFBlock, 0, st>>>(out, height, H, W);
   SOIL_LAUNCH_CHECK();
   // a launch moves information at least one tile further; H*W launches is a bound
@@ -132,8 +154,10 @@ static int fill_impl(float* out, const float* height, int64_t H, int64_t W, hipS
   const int64_t max_launches = 4 * (static_cast<int64_t>(tiles_w) + tiles_h) * kFT + 16;
   for (int64_t launch = 0; launch < max_launches; ++launch) {
     SOIL_HIP(hipMemsetAsync(changed, 0, sizeof(int), st));
-    k_fill_relax<K><<<static_cast<unsigned>(tiles_w * tiles_h), kFBlock, 0, st>>>(
-        out, height, H, W, tiles_w, 4 * kFT, changed);
+    SOIL_HIP(hipMemsetAsync(dirty_next, 0, ntiles, st));
+    k_fill_relax<K><<<static_cast<unsigned>(ntiles), kFBlock, 0, st>>>(
+        out, height, H, W, tiles_w, tiles_h, 4 * kFT, changed, dirty_prev, dirty_next);
+    std::swap(dirty_prev, dirty_next);
     SOIL_LAUNCH_CHECK();
     int flag = 0;
     SOIL_HIP(hipMemcpyAsync(&flag, changed, sizeof(int), hipMemcpyDeviceToHost, st));
