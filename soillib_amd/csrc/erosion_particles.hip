@@ -420,10 +420,10 @@ static bool use_staged(int64_t N) {
   if (g_particle_mode == 2) return true;
   return N >= 1024;
 }
-// the tiled shape keeps 9 floats per cell in LDS and has no room for the three
-// albedo accumulators, so colour transport stays on the staged shape
-static bool use_tiled(int64_t N, const void* albedoFlux) {
-  if (albedoFlux) return false;
+// the tiled shape keeps the last cell index in 32 bits (and the slot indices of its
+// queues): grids and launches beyond 2^31 stay on the staged shape
+static bool use_tiled(int64_t N, const Dom& d) {
+  if (d.H * d.W > 0x7fffffffll || N > 0x7fffffffll) return false;
   if (g_particle_mode == 3) return true;
   return g_particle_mode == 0 && N >= 32768;
 }
@@ -478,9 +478,10 @@ static int launch_particles_fluvial(float* waterFlux, float* massFlux, float* ve
                                     const float* albedoSource, float* remote0, const Dom& d,
                                     Scale3 s, const Param& p, hipStream_t st) {
   if (N <= 0) return SOIL_OK;
-  if (use_tiled(N, albedoFlux))
-    return launch_fluvial_tiled(waterFlux, massFlux, velocityFlux, rng, N, layers, waterSource,
-                                waterHeight, velocity, remote0, d, s, p, st);
+  if (use_tiled(N, d))
+    return launch_fluvial_tiled(waterFlux, massFlux, velocityFlux, albedoFlux, rng, N, layers,
+                                waterSource, waterHeight, velocity, albedoSource, remote0, d, s, p,
+                                st);
   unsigned long long* steps = nullptr;
   if (int rc = step_counter(&steps); rc != SOIL_OK) return rc;
   const FluvialPlanes P{waterFlux,   massFlux,    velocityFlux, albedoFlux, waterSource,
@@ -506,9 +507,9 @@ static int launch_particles_debris(float* massFlux, float* velocityFlux, float* 
                                    float* remote0, const Dom& d, Scale3 s, const Param& p,
                                    hipStream_t st) {
   if (N <= 0) return SOIL_OK;
-  if (use_tiled(N, albedoFlux))
-    return launch_debris_tiled(massFlux, velocityFlux, rng, N, layers, velocity, remote0, d, s, p,
-                               st);
+  if (use_tiled(N, d))
+    return launch_debris_tiled(massFlux, velocityFlux, albedoFlux, rng, N, layers, velocity,
+                               albedoSource, remote0, d, s, p, st);
   unsigned long long* steps = nullptr;
   if (int rc = step_counter(&steps); rc != SOIL_OK) return rc;
   const DebrisPlanes P{massFlux, velocityFlux, albedoFlux, albedoSource, remote0, steps};
@@ -649,7 +650,7 @@ int soil_particles_pair_slab(const soil_erosion_planes* planes, soil_rng* rng_fl
   if (N <= 0) return SOIL_OK;
   const Scale3 s = s3p(scale);
   hipStream_t st = as_stream(stream);
-  if (use_tiled(N, nullptr))
+  if (use_tiled(N, d))
     return launch_pair_tiled(P, rng_fluvial, rng_debris, N, remote0, d, s, *param, st);
   rc = launch_particles_fluvial(P.waterFlux, P.massFlux, P.velocityFlux, nullptr, rng_fluvial, N,
                                 P.layers, P.rainfall, P.waterHeight, P.velocity, nullptr, remote0, d,

@@ -64,9 +64,9 @@ struct alignas(16) PRec {  // parked particle, 64 bytes
   float px, py, spx, spy;
   float a0, a1, a2, s0;  // fluvial: att_w att_m att_v source_w | debris: att_d att_v - source_d
   float s1, svx, svy;    // fluvial: source_m, source_v        | debris: -, source_v
-  int32_t iter;          // < 0: empty slot
-  int64_t ind;           // global flat index of the last cell deposited into (erosion.cu:60,105)
-  int32_t pad[2];
+  int32_t iter;
+  uint32_t ind;          // global flat index of the last cell deposited into (erosion.cu:60,105)
+  float sa[3];           // colour source = source_m | source_d times albedoSource[spawn cell] (:91 / :299)
 };
 static_assert(sizeof(PRec) == 64, "PRec must be one 64-byte line");
 
@@ -243,7 +243,8 @@ template <int KIND>
 __global__ void __launch_bounds__(256)
     k_tiled_spawn(PRec* __restrict__ recs, uint32_t* __restrict__ dest, uint32_t* __restrict__ rank,
                   uint32_t* __restrict__ count, soil_rng* __restrict__ rng, int64_t N, const float4* __restrict__ p4,
-                  const float* __restrict__ waterSource, Dom d, Scale3 s, Param param,
+                  const float* __restrict__ waterSource, const float* __restrict__ albedoSource,
+                  Dom d, Scale3 s, Param param,
                   int tiles_w, TileShape ts, int steps_per_round) {
   const int64_t n = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
   if (n >= N) return;
@@ -275,9 +276,8 @@ __global__ void __launch_bounds__(256)
       r.py = pos.y;
       r.spx = spx;
       r.spy = spy;
-      r.ind = ind;
+      r.ind = static_cast<uint32_t>(ind);
       r.iter = 0;
-      r.pad[0] = r.pad[1] = 0;
       if (KIND == FLUVIAL) {
         const float ks = param.suspensionRateFluvial / 64.0f;  // :68
         r.a0 = 1.0f;                                  // att_w
@@ -297,6 +297,10 @@ __global__ void __launch_bounds__(256)
         r.svx = Q * q.x;                          // :298
         r.svy = Q * q.y;
       }
+      const float source_mass = (KIND == FLUVIAL) ? r.s1 : r.s0;
+#pragma unroll
+      for (int c = 0; c < 3; ++c)  // :91 / :299
+        r.sa[c] = albedoSource ? source_mass * albedoSource[3 * l + c] : 0.0f;
       tile = queue_key(static_cast<int>(d.x0), pos.x, pos.y, spx, spy,
                        param.maxage > 0x7fffffffull ? 0x7fffffffu : static_cast<uint32_t>(param.maxage),
                        tiles_w, ts, steps_per_round);
@@ -561,16 +565,16 @@ struct CasDeposit {
   }
 };
 
-template <int KIND, int DEP, int TR, int TC, int NT>
+template <int KIND, int DEP, int TR, int TC, int NT, bool ALB>
 __global__ void __launch_bounds__(NT)
     k_tiled_round(PRec* __restrict__ out, uint32_t* __restrict__ dest, uint32_t* __restrict__ rank,
                   uint32_t* __restrict__ count_next, const PRec* __restrict__ in,
                   const uint32_t* __restrict__ order, const uint2* __restrict__ block_list,
                   const uint32_t* __restrict__ start, float* __restrict__ flux0,
                   float* __restrict__ flux1, float2* __restrict__ fluxV,
-                  const float4* __restrict__ p4, float* __restrict__ remote0,
-                  unsigned long long* __restrict__ steps, Dom d, Scale3 s, Param param,
-                  int tiles_w, int steps_per_round, TileShape ts_next,
+                  float* __restrict__ fluxA, const float4* __restrict__ p4,
+                  float* __restrict__ remote0, unsigned long long* __restrict__ steps, Dom d,
+                  Scale3 s, Param param, int tiles_w, int steps_per_round, TileShape ts_next,
                   int tiles_w_next, uint32_t chunk_cap) {
   constexpr int kCells = TR * TC, kBlock = NT, kPer = (kCells + NT - 1) / NT;
   // this work-group's share of its tile's queue (k_queue_prepare's block list)
@@ -589,6 +593,7 @@ __global__ void __launch_bounds__(NT)
   __shared__ float s_f0[kCells];                        // fluvial water | debris mass
   __shared__ float s_f1[KIND == FLUVIAL ? kCells : 1];  // fluvial mass
   __shared__ float s_fx[kCells], s_fy[kCells];          // velocity flux
+  __shared__ float s_c0[ALB ? kCells : 1], s_c1[ALB ? kCells : 1], s_c2[ALB ? kCells : 1];  // colour
   __shared__ uint32_t s_next, s_out, s_steps;
   const int tid = threadIdx.x;
   if (tid == 0) {
@@ -605,6 +610,7 @@ __global__ void __launch_bounds__(NT)
     if (KIND == FLUVIAL) s_f1[c] = 0.0f;
     s_fx[c] = 0.0f;
     s_fy[c] = 0.0f;
+    if (ALB) s_c0[c] = s_c1[c] = s_c2[c] = 0.0f;
   }
   __syncthreads();
 
@@ -674,35 +680,36 @@ __global__ void __launch_bounds__(NT)
       // hides under the deposit and the other waves of the SIMD
       const int64_t lcell = static_cast<int64_t>(lx) * k.W + cy;
       const float4 q = p4[lcell];
-      CasDeposit<KIND == FLUVIAL ? 4 : 3> dep;
+      constexpr int kFluxPlanes = (KIND == FLUVIAL) ? 4 : 3;
+      CasDeposit<kFluxPlanes + (ALB ? 3 : 0)> dep;
       const int64_t nind = static_cast<int64_t>(cx) * k.W + cy;  // :103 / :309
-      if (nind != r.ind) {                                       // :104-113 / :310-318
-        r.ind = nind;
+      if (static_cast<uint32_t>(nind) != r.ind) {                // :104-113 / :310-318
+        r.ind = static_cast<uint32_t>(nind);
         // DEP 0: native ds_add_f32, fire and forget; DEP 1: CasDeposit
+        float v[kFluxPlanes + 3];
+        float* p[kFluxPlanes + 3];
         if (KIND == FLUVIAL) {
-          const float v0 = r.a0 * r.s0, v1 = r.a1 * r.s1, vx = r.a2 * r.svx, vy = r.a2 * r.svy;
-          if (DEP == 1) {
-            dep.p[0] = &s_f0[c], dep.p[1] = &s_f1[c], dep.p[2] = &s_fx[c], dep.p[3] = &s_fy[c];
-            dep.v[0] = v0, dep.v[1] = v1, dep.v[2] = vx, dep.v[3] = vy;
-            dep.begin();
-          } else {
-            atomicAdd(&s_f0[c], v0);
-            atomicAdd(&s_f1[c], v1);
-            atomicAdd(&s_fx[c], vx);
-            atomicAdd(&s_fy[c], vy);
-          }
+          v[0] = r.a0 * r.s0, v[1] = r.a1 * r.s1, v[2] = r.a2 * r.svx, v[3] = r.a2 * r.svy;
+          p[0] = &s_f0[c], p[1] = &s_f1[c], p[2] = &s_fx[c], p[3] = &s_fy[c];
         } else {
-          const float v0 = r.a0 * r.s0, vx = r.a1 * r.svx, vy = r.a1 * r.svy;
+          v[0] = r.a0 * r.s0, v[1] = r.a1 * r.svx, v[2] = r.a1 * r.svy;
+          p[0] = &s_f0[c], p[1] = &s_fx[c], p[2] = &s_fy[c];
+        }
+        if (ALB) {  // colour rides on the mass attenuation, :110-112 / :315-317
+          const float att = (KIND == FLUVIAL) ? r.a1 : r.a0;
+          v[kFluxPlanes] = att * r.sa[0], v[kFluxPlanes + 1] = att * r.sa[1], v[kFluxPlanes + 2] = att * r.sa[2];
+          p[kFluxPlanes] = &s_c0[c], p[kFluxPlanes + 1] = &s_c1[c], p[kFluxPlanes + 2] = &s_c2[c];
+        }
+#pragma unroll
+        for (int j = 0; j < kFluxPlanes + (ALB ? 3 : 0); ++j) {
           if (DEP == 1) {
-            dep.p[0] = &s_f0[c], dep.p[1] = &s_fx[c], dep.p[2] = &s_fy[c];
-            dep.v[0] = v0, dep.v[1] = vx, dep.v[2] = vy;
-            dep.begin();
+            dep.p[j] = p[j];
+            dep.v[j] = v[j];
           } else {
-            atomicAdd(&s_f0[c], v0);
-            atomicAdd(&s_fx[c], vx);
-            atomicAdd(&s_fy[c], vy);
+            atomicAdd(p[j], v[j]);
           }
         }
+        if (DEP == 1) dep.begin();
       }
       have = advance<KIND>(r, q, k);
       if (DEP == 1) dep.finish();
@@ -769,6 +776,24 @@ __global__ void __launch_bounds__(NT)
       if (ax[j] != 0.0f || ay[j] != 0.0f) fluxV[l[j]] = make_float2(gv[j].x + ax[j], gv[j].y + ay[j]);
     }
   }
+  if (ALB) {  // the three colour planes, AoS (vec3) in global memory
+    for (int cc = tid; cc < kCells; cc += kBlock) {
+      const int lx = row0 + cc / TC, y = col0 + cc % TC;
+      if (lx >= static_cast<int>(d.rows) || y >= k.W) continue;
+      const int64_t l3 = 3 * (static_cast<int64_t>(lx) * k.W + y);
+      const float c0 = s_c0[cc], c1 = s_c1[cc], c2 = s_c2[cc];
+      if (c0 == 0.0f && c1 == 0.0f && c2 == 0.0f) continue;
+      if (shared_tile) {
+        atomicAdd(&fluxA[l3], c0);
+        atomicAdd(&fluxA[l3 + 1], c1);
+        atomicAdd(&fluxA[l3 + 2], c2);
+      } else {
+        fluxA[l3] += c0;
+        fluxA[l3 + 1] += c1;
+        fluxA[l3 + 2] += c2;
+      }
+    }
+  }
 }
 
 // ---- the last launch: walk the remaining particles to the end against HBM ----------
@@ -777,7 +802,7 @@ template <int KIND>
 __global__ void __launch_bounds__(256)
     k_tiled_finish(const PRec* __restrict__ recs, const uint32_t* __restrict__ dest, int64_t n,
                    float* __restrict__ flux0,
-                   float* __restrict__ flux1, float* __restrict__ fluxV,
+                   float* __restrict__ flux1, float* __restrict__ fluxV, float* __restrict__ fluxA,
                    const float4* __restrict__ p4, float* __restrict__ remote0,
                    unsigned long long* __restrict__ steps, Dom d, Scale3 s, Param param) {
   const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
@@ -801,8 +826,8 @@ __global__ void __launch_bounds__(256)
     const int64_t nind = static_cast<int64_t>(cx) * k.W + cy;
     const int64_t l = nind - base;
     const float4 q = p4[l];
-    if (nind != r.ind) {
-      r.ind = nind;
+    if (static_cast<uint32_t>(nind) != r.ind) {
+      r.ind = static_cast<uint32_t>(nind);
       if (KIND == FLUVIAL) {
         atomicAdd(&flux0[l], r.a0 * r.s0);
         atomicAdd(&flux1[l], r.a1 * r.s1);
@@ -812,6 +837,10 @@ __global__ void __launch_bounds__(256)
         atomicAdd(&flux0[l], r.a0 * r.s0);
         atomicAdd(&fluxV[2 * l], r.a1 * r.svx);
         atomicAdd(&fluxV[2 * l + 1], r.a1 * r.svy);
+      }
+      if (fluxA) {
+        const float att = (KIND == FLUVIAL) ? r.a1 : r.a0;
+        for (int c = 0; c < 3; ++c) atomicAdd(&fluxA[3 * l + c], att * r.sa[c]);
       }
     }
     if (!advance<KIND>(r, q, k)) break;
@@ -835,14 +864,19 @@ __global__ void k_fold_steps(unsigned long long* total, const unsigned long long
 // measured too: more exits per step and no better occupancy — 64x64 it is; what is
 // left to choose is how many lanes serve a tile.
 struct RoundShape { int tr, tc, nt; };
-static constexpr RoundShape kShapes[] = {{64, 64, 512}, {64, 64, 768}};
-constexpr int kNumShapes = sizeof(kShapes) / sizeof(kShapes[0]);
+static constexpr RoundShape kShapes[] = {{64, 64, 512}, {64, 64, 768}, {64, 64, 1024}};
+constexpr int kNumShapes = 2;       // selectable; shape 2 serves the launches that carry colour:
+constexpr int kShapeColour = 2;     // 7 / 6 LDS planes leave room for one work-group per CU
 
 template <int KIND, int DEP, typename... A>
 static void launch_round(int shape, unsigned grid, hipStream_t st, A... a) {
   switch (shape) {
-    case 1: k_tiled_round<KIND, DEP, 64, 64, 768><<<grid, 768, 0, st>>>(a...); break;
-    default: k_tiled_round<KIND, DEP, 64, 64, 512><<<grid, 512, 0, st>>>(a...); break;
+    case 1: k_tiled_round<KIND, DEP, 64, 64, 768, false><<<grid, 768, 0, st>>>(a...); break;
+    case kShapeColour:
+      if constexpr (DEP == 1)  // colour only with the compare-and-swap deposits
+        k_tiled_round<KIND, 1, 64, 64, 1024, true><<<grid, 1024, 0, st>>>(a...);
+      break;
+    default: k_tiled_round<KIND, DEP, 64, 64, 512, false><<<grid, 512, 0, st>>>(a...); break;
   }
 }
 
@@ -858,6 +892,8 @@ template <int KIND>
 struct TiledRun {
   // arguments
   float *flux0, *flux1, *fluxV;
+  float* fluxA = nullptr;                // colour flux (vec3), optional
+  const float* albedoSource = nullptr;   // colour of the cell a particle starts on
   soil_rng* rng;
   int64_t N;
   const float *layers, *waterSource, *waterHeight, *velocity;
@@ -914,6 +950,10 @@ struct TiledRun {
                                                    : (KIND == FLUVIAL ? 1 : 0)) % kNumShapes;
     shape_late = env_int("SOIL_TILED_LATE", shape_early) % kNumShapes;
     switch_round = env_int("SOIL_TILED_SWITCH", 1 << 30);
+    if (fluxA) {
+      shape_early = shape_late = kShapeColour;
+      deposit = 0;  // compare-and-swap deposits
+    }
     // A round is worth its fixed cost while it advances particles faster than the
     // finishing launch would (4 L2 atomics per step at 22.7 G/s = 5.7 G steps/s).
     // Particles that zig-zag along a tile edge get a handful of steps per round; on
@@ -925,7 +965,7 @@ struct TiledRun {
       int dev = 0, cus = 256;
       SOIL_HIP(hipGetDevice(&dev));
       SOIL_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-      resident_groups = env_int("SOIL_TILED_SLOTS", cus * (KIND == FLUVIAL ? 2 : 3));
+      resident_groups = env_int("SOIL_TILED_SLOTS", cus * (fluxA ? 1 : KIND == FLUVIAL ? 2 : 3));
     }
 
     const int64_t max_tiles = std::max(tiles_of(shape_early), tiles_of(shape_late));
@@ -991,7 +1031,7 @@ struct TiledRun {
     SOIL_HIP(hipMemsetAsync(count, 0, b_cnt, st));
     SOIL_HIP(hipMemsetAsync(steps_run, 0, sizeof(unsigned long long), st));
     k_tiled_spawn<KIND><<<blocks_for(N, 256), 256, 0, st>>>(
-        cur, dest, rank, count, rng, N, p4, waterSource, d, s, p, tiles_w_of(shape_of(0)),
+        cur, dest, rank, count, rng, N, p4, waterSource, albedoSource, d, s, p, tiles_w_of(shape_of(0)),
         ts_of(shape_of(0)), steps_per_round);
     SOIL_LAUNCH_CHECK();
     n_src = N;  // slots of `cur` to look at (spawn output, then survivor slots)
@@ -1047,7 +1087,7 @@ struct TiledRun {
     if (live == 0 || round >= p.maxage + 2) return finish_steps();
     if (round > 0 && (static_cast<int64_t>(live) <= tail || rate < finish_rate)) {
       k_tiled_finish<KIND><<<blocks_for(n_src, 256), 256, 0, st>>>(
-          cur, dest, n_src, flux0, flux1, fluxV, p4, remote0, steps_run, d, s, p);
+          cur, dest, n_src, flux0, flux1, fluxV, fluxA, p4, remote0, steps_run, d, s, p);
       SOIL_LAUNCH_CHECK();
       return finish_steps();
     }
@@ -1059,7 +1099,7 @@ struct TiledRun {
                             static_cast<const PRec*>(cur), static_cast<const uint32_t*>(order),
                             static_cast<const uint2*>(block_list),
                             static_cast<const uint32_t*>(start), flux0, flux1,
-                            reinterpret_cast<float2*>(fluxV), static_cast<const float4*>(p4),
+                            reinterpret_cast<float2*>(fluxV), fluxA, static_cast<const float4*>(p4),
                             remote0, steps_run, d, s, p, tiles_w, steps_per_round,
                             ts_of(sh_next), tiles_w_of(sh_next), chunk_cap);
     else
@@ -1067,7 +1107,7 @@ struct TiledRun {
                             static_cast<const PRec*>(cur), static_cast<const uint32_t*>(order),
                             static_cast<const uint2*>(block_list),
                             static_cast<const uint32_t*>(start), flux0, flux1,
-                            reinterpret_cast<float2*>(fluxV), static_cast<const float4*>(p4),
+                            reinterpret_cast<float2*>(fluxV), fluxA, static_cast<const float4*>(p4),
                             remote0, steps_run, d, s, p, tiles_w, steps_per_round,
                             ts_of(sh_next), tiles_w_of(sh_next), chunk_cap);
     SOIL_LAUNCH_CHECK();
@@ -1082,24 +1122,26 @@ struct TiledRun {
 };
 
 template <int KIND>
-static TiledRun<KIND> make_run(float* flux0, float* flux1, float* fluxV, soil_rng* rng, int64_t N,
+static TiledRun<KIND> make_run(float* flux0, float* flux1, float* fluxV, float* fluxA,
+                               const float* albedoSource, soil_rng* rng, int64_t N,
                                const float* layers, const float* waterSource,
                                const float* waterHeight, const float* velocity, float* remote0,
                                const Dom& d, Scale3 s, const Param& p, hipStream_t st) {
   TiledRun<KIND> r;
   r.flux0 = flux0, r.flux1 = flux1, r.fluxV = fluxV, r.rng = rng, r.N = N;
+  r.fluxA = fluxA, r.albedoSource = fluxA ? albedoSource : nullptr;
   r.layers = layers, r.waterSource = waterSource, r.waterHeight = waterHeight, r.velocity = velocity;
   r.remote0 = remote0, r.d = d, r.s = s, r.p = p, r.st = st;
   return r;
 }
 
 template <int KIND>
-static int run_tiled(float* flux0, float* flux1, float* fluxV, soil_rng* rng, int64_t N,
-                     const float* layers, const float* waterSource, const float* waterHeight,
+static int run_tiled(float* flux0, float* flux1, float* fluxV, float* fluxA,
+                     const float* albedoSource, soil_rng* rng, int64_t N, const float* layers, const float* waterSource, const float* waterHeight,
                      const float* velocity, float* remote0, const Dom& d, Scale3 s, const Param& p,
                      hipStream_t st) {
-  TiledRun<KIND> r = make_run<KIND>(flux0, flux1, fluxV, rng, N, layers, waterSource, waterHeight,
-                                    velocity, remote0, d, s, p, st);
+  TiledRun<KIND> r = make_run<KIND>(flux0, flux1, fluxV, fluxA, albedoSource, rng, N, layers,
+                                    waterSource, waterHeight, velocity, remote0, d, s, p, st);
   if (int rc = r.begin(); rc != SOIL_OK) return rc;
   while (!r.done)
     if (int rc = r.advance(); rc != SOIL_OK) return rc;
@@ -1122,10 +1164,12 @@ int launch_pair_tiled(const soil_erosion_planes& P, soil_rng* rng_fluvial, soil_
   SOIL_HIP(hipEventRecord(fork, st));
   SOIL_HIP(hipStreamWaitEvent(sA, fork, 0));
   SOIL_HIP(hipStreamWaitEvent(sB, fork, 0));
-  TiledRun<FLUVIAL> A = make_run<FLUVIAL>(P.waterFlux, P.massFlux, P.velocityFlux, rng_fluvial, N,
+  TiledRun<FLUVIAL> A = make_run<FLUVIAL>(P.waterFlux, P.massFlux, P.velocityFlux, nullptr, nullptr,
+                                          rng_fluvial, N,
                                           P.layers, P.rainfall, P.waterHeight, P.velocity, remote0,
                                           d, s, p, sA);
-  TiledRun<DEBRIS> B = make_run<DEBRIS>(P.debrisFlux, nullptr, P.debrisVelocityFlux, rng_debris, N,
+  TiledRun<DEBRIS> B = make_run<DEBRIS>(P.debrisFlux, nullptr, P.debrisVelocityFlux, nullptr, nullptr,
+                                        rng_debris, N,
                                         P.layers, nullptr, nullptr, P.debrisVelocity, remote0, d, s,
                                         p, sB);
   // The early rounds of either launch keep the VALUs >90 % busy on their own, so the
@@ -1152,19 +1196,21 @@ int launch_pair_tiled(const soil_erosion_planes& P, soil_rng* rng_fluvial, soil_
   return SOIL_OK;
 }
 
-int launch_fluvial_tiled(float* waterFlux, float* massFlux, float* velocityFlux, soil_rng* rng,
-                         int64_t N, const float* layers, const float* waterSource,
-                         const float* waterHeight, const float* velocity, float* remote0,
-                         const Dom& d, Scale3 s, const Param& p, hipStream_t st) {
-  return run_tiled<FLUVIAL>(waterFlux, massFlux, velocityFlux, rng, N, layers, waterSource,
-                             waterHeight, velocity, remote0, d, s, p, st);
+int launch_fluvial_tiled(float* waterFlux, float* massFlux, float* velocityFlux, float* albedoFlux,
+                         soil_rng* rng, int64_t N, const float* layers, const float* waterSource,
+                         const float* waterHeight, const float* velocity,
+                         const float* albedoSource, float* remote0, const Dom& d, Scale3 s,
+                         const Param& p, hipStream_t st) {
+  return run_tiled<FLUVIAL>(waterFlux, massFlux, velocityFlux, albedoFlux, albedoSource, rng, N,
+                            layers, waterSource, waterHeight, velocity, remote0, d, s, p, st);
 }
 
-int launch_debris_tiled(float* massFlux, float* velocityFlux, soil_rng* rng, int64_t N,
-                        const float* layers, const float* velocity, float* remote0, const Dom& d,
-                        Scale3 s, const Param& p, hipStream_t st) {
-  return run_tiled<DEBRIS>(massFlux, nullptr, velocityFlux, rng, N, layers, nullptr, nullptr,
-                           velocity, remote0, d, s, p, st);
+int launch_debris_tiled(float* massFlux, float* velocityFlux, float* albedoFlux, soil_rng* rng,
+                        int64_t N, const float* layers, const float* velocity,
+                        const float* albedoSource, float* remote0, const Dom& d, Scale3 s,
+                        const Param& p, hipStream_t st) {
+  return run_tiled<DEBRIS>(massFlux, nullptr, velocityFlux, albedoFlux, albedoSource, rng, N, layers,
+                           nullptr, nullptr, velocity, remote0, d, s, p, st);
 }
 
 }  // namespace soil

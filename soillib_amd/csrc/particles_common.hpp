@@ -48,13 +48,15 @@ __global__ void __launch_bounds__(1024)
     k_tile_scan(uint32_t* start, const uint32_t* count, int64_t tiles);
 
 // tiled launch shape (erosion_particles_tiled.hip)
-int launch_fluvial_tiled(float* waterFlux, float* massFlux, float* velocityFlux, soil_rng* rng,
-                         int64_t N, const float* layers, const float* waterSource,
-                         const float* waterHeight, const float* velocity, float* remote0,
-                         const Dom& d, Scale3 s, const Param& p, hipStream_t st);
-int launch_debris_tiled(float* massFlux, float* velocityFlux, soil_rng* rng, int64_t N,
-                        const float* layers, const float* velocity, float* remote0, const Dom& d,
-                        Scale3 s, const Param& p, hipStream_t st);
+int launch_fluvial_tiled(float* waterFlux, float* massFlux, float* velocityFlux, float* albedoFlux,
+                         soil_rng* rng, int64_t N, const float* layers, const float* waterSource,
+                         const float* waterHeight, const float* velocity,
+                         const float* albedoSource, float* remote0, const Dom& d, Scale3 s,
+                         const Param& p, hipStream_t st);
+int launch_debris_tiled(float* massFlux, float* velocityFlux, float* albedoFlux, soil_rng* rng,
+                        int64_t N, const float* layers, const float* velocity,
+                        const float* albedoSource, float* remote0, const Dom& d, Scale3 s,
+                        const Param& p, hipStream_t st);
 // both launches of a step overlapped on two internal streams forked from / joined into `st`
 int launch_pair_tiled(const soil_erosion_planes& P, soil_rng* rng_fluvial, soil_rng* rng_debris,
                       int64_t N, float* remote0, const Dom& d, Scale3 s, const Param& p,

@@ -319,17 +319,20 @@ def test_transport_debris_parity(hip, oracle, particle_mode, H, W, N):
     layers = terrain(oracle, H, W, sediment=0.01)
     vel0 = (r.standard_normal((H, W, 2)) * 0.5).astype(np.float32)
     z1, z2 = np.zeros((H, W), np.float32), np.zeros((H, W, 2), np.float32)
-    o = dict(v=vel0.copy(), vf=z2.copy(), m=z1.copy(), mf=z1.copy())
+    asrc = r.random((H, W, 3)).astype(np.float32)          # colour of the debris source cells
+    z3 = np.zeros((H, W, 3), np.float32)
+    o = dict(v=vel0.copy(), vf=z2.copy(), m=z1.copy(), mf=z1.copy(), af=z3.copy())
     orng = oracle.rng_seed(N, 6, 0)
-    steps = oracle.transport_debris(layers, o["v"], o["vf"], o["m"], o["mf"], None, None, orng,
+    steps = oracle.transport_debris(layers, o["v"], o["vf"], o["m"], o["mf"], o["af"], asrc, orng,
                                     scale, op)
     assert steps > N and o["mf"].max() > 0
-    g = dict(v=to_gpu(vel0), vf=to_gpu(z2), m=to_gpu(z1), mf=to_gpu(z1))
+    g = dict(v=to_gpu(vel0), vf=to_gpu(z2), m=to_gpu(z1), mf=to_gpu(z1), af=to_gpu(z3))
     grng = rng_to_gpu(oracle.rng_seed(N, 6, 0))
     soil.particle_steps(reset=True)
-    soil.transport_debris(to_gpu(layers), g["v"], g["vf"], g["m"], g["mf"], None, None, None, grng,
-                          scale, pp)
+    soil.transport_debris(to_gpu(layers), g["v"], g["vf"], g["m"], g["mf"], None, g["af"],
+                          to_gpu(asrc), grng, scale, pp)
     assert soil.particle_steps(reset=True) == steps
+    np.testing.assert_allclose(to_np(g["af"]), o["af"], rtol=1e-3, atol=1e-5)
     for k in ("mf", "vf"):
         _flux_close(to_np(g[k]), o[k], "debris flux " + k)
     for k in ("m", "v"):
