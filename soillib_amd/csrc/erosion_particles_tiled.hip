@@ -66,7 +66,7 @@ struct alignas(16) PRec {  // parked particle, 64 bytes
   float s1, svx, svy;    // fluvial: source_m, source_v        | debris: -, source_v
   int32_t iter;
   uint32_t ind;          // global flat index of the last cell deposited into (erosion.cu:60,105)
-  float sa[3];           // colour source = source_m | source_d times albedoSource[spawn cell] (:91 / :299)
+  float sa0, sa1, sa2;   // colour source = source_m | source_d times albedoSource[spawn cell] (:91 / :299)
 };
 static_assert(sizeof(PRec) == 64, "PRec must be one 64-byte line");
 
@@ -298,9 +298,9 @@ __global__ void __launch_bounds__(256)
         r.svy = Q * q.y;
       }
       const float source_mass = (KIND == FLUVIAL) ? r.s1 : r.s0;
-#pragma unroll
-      for (int c = 0; c < 3; ++c)  // :91 / :299
-        r.sa[c] = albedoSource ? source_mass * albedoSource[3 * l + c] : 0.0f;
+      r.sa0 = albedoSource ? source_mass * albedoSource[3 * l] : 0.0f;  // :91 / :299
+      r.sa1 = albedoSource ? source_mass * albedoSource[3 * l + 1] : 0.0f;
+      r.sa2 = albedoSource ? source_mass * albedoSource[3 * l + 2] : 0.0f;
       tile = queue_key(static_cast<int>(d.x0), pos.x, pos.y, spx, spy,
                        param.maxage > 0x7fffffffull ? 0x7fffffffu : static_cast<uint32_t>(param.maxage),
                        tiles_w, ts, steps_per_round);
@@ -697,7 +697,7 @@ __global__ void __launch_bounds__(NT)
         }
         if (ALB) {  // colour rides on the mass attenuation, :110-112 / :315-317
           const float att = (KIND == FLUVIAL) ? r.a1 : r.a0;
-          v[kFluxPlanes] = att * r.sa[0], v[kFluxPlanes + 1] = att * r.sa[1], v[kFluxPlanes + 2] = att * r.sa[2];
+          v[kFluxPlanes] = att * r.sa0, v[kFluxPlanes + 1] = att * r.sa1, v[kFluxPlanes + 2] = att * r.sa2;
           p[kFluxPlanes] = &s_c0[c], p[kFluxPlanes + 1] = &s_c1[c], p[kFluxPlanes + 2] = &s_c2[c];
         }
 #pragma unroll
@@ -840,7 +840,9 @@ __global__ void __launch_bounds__(256)
       }
       if (fluxA) {
         const float att = (KIND == FLUVIAL) ? r.a1 : r.a0;
-        for (int c = 0; c < 3; ++c) atomicAdd(&fluxA[3 * l + c], att * r.sa[c]);
+        atomicAdd(&fluxA[3 * l], att * r.sa0);
+        atomicAdd(&fluxA[3 * l + 1], att * r.sa1);
+        atomicAdd(&fluxA[3 * l + 2], att * r.sa2);
       }
     }
     if (!advance<KIND>(r, q, k)) break;
