@@ -17,7 +17,6 @@ and, for example/erosion_gpu_multiscale.py:
 `erode` runs soillib_amd.erosion.ErosionModel on the caller's tensors: `data.*`
 are the transported fields, `track.*` the flux accumulators.
 """
-import ctypes as C
 
 from . import _abi, silt
 from . import soil as _live

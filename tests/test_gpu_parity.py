@@ -14,7 +14,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from util import (assert_bit_equal, copy_param, product_param, rng_to_gpu, script_param, terrain,
+from util import (assert_bit_equal, product_param, rng_to_gpu, script_param, terrain,
                   to_gpu, to_np)
 
 pytestmark = pytest.mark.gpu

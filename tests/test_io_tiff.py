@@ -14,7 +14,6 @@ import numpy as np
 import pytest
 
 PIL = pytest.importorskip("PIL.Image")
-from PIL import TiffImagePlugin  # noqa: E402
 
 
 @pytest.fixture(scope="module")
