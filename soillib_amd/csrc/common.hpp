@@ -113,18 +113,32 @@ __device__ __forceinline__ float length2(float x, float y) {  // erosion_map.cu:
 
 // erosion_map.cu:56-78 (and its duplicate path.cu:27-49).  IEEE division by
 // zero and fmaxf/fminf NaN handling are load-bearing here.
+//
+// The reference takes fmax of the times to both faces of the cell, (x_neg - px) / dx
+// and (x_pos - px) / dx.  x_neg - px <= 0 <= x_pos - px for every finite px, and IEEE
+// division is monotonic and sign-symmetric, so for dx > 0 the maximum IS the second
+// quotient and for dx < 0 the first, bit for bit (signed zeros included; a NaN px or
+// dx gives NaN either way): one division per axis instead of two.  A zero dx divides
+// to infinities whose maximum depends on both numerators: that case keeps both.
+__device__ __forceinline__ float stepsize_both(float neg, float pos, float d) {
+  return fmaxf(neg / d, pos / d);
+}
 __device__ __forceinline__ float stepsize(float px, float py, float dx, float dy) {
   const float tmax = kSqrt2;
   const float x_neg = floorf(px);
   const float y_neg = floorf(py);
   const float x_pos = 1.0f + x_neg;
   const float y_pos = 1.0f + y_neg;
-  const float tx_neg = (x_neg - px) / dx;
-  const float tx_pos = (x_pos - px) / dx;
-  const float tx = fminf(fmaxf(tx_neg, tx_pos), tmax);
-  const float ty_neg = (y_neg - py) / dy;
-  const float ty_pos = (y_pos - py) / dy;
-  const float ty = fminf(fmaxf(ty_neg, ty_pos), tmax);
+  float tx, ty;
+  if (dx * dy == 0.0f) {  // a zero (or underflowing) direction component: as written
+    tx = stepsize_both(x_neg - px, x_pos - px, dx);
+    ty = stepsize_both(y_neg - py, y_pos - py, dy);
+  } else {
+    tx = ((dx > 0.0f ? x_pos : x_neg) - px) / dx;
+    ty = ((dy > 0.0f ? y_pos : y_neg) - py) / dy;
+  }
+  tx = fminf(tx, tmax);
+  ty = fminf(ty, tmax);
   return 0.5f * (tx + ty);
 }
 

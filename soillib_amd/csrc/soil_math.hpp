@@ -30,6 +30,11 @@ SOIL_HD float bits2f(uint32_t u) { return __builtin_bit_cast(float, u); }
 SOIL_HD uint32_t f2bits(float f) { return __builtin_bit_cast(uint32_t, f); }
 SOIL_HD float pow2i(int n) { return bits2f(static_cast<uint32_t>(n + 127) << 23); }  // n in [-126,127]
 
+// y * 2^n for y in [0.7, 1.42].  The contract spells this (y * 2^(n/2)) * 2^(n - n/2):
+// the first product is exact, the second rounds the exact value once, which is what
+// ldexp does in one instruction (v_ldexp_f32), overflow to +inf included.
+SOIL_HD float scale2(float y, int n) { return __builtin_ldexpf(y, n); }
+
 SOIL_HD float exp_poly(float r) {  // ~ exp(r) on |r| <= ln2/2
   float p = 1.9875691500E-4f;
   p = p * r + 1.3981999507E-3f;
@@ -48,10 +53,7 @@ SOIL_HD float expf_(float x) {
   float r = x - n * 0.693145752f;
   r = r - n * 1.42860677e-6f;
   const float y = exp_poly(r);
-  const int ni = static_cast<int>(n);
-  const int n1 = ni / 2;
-  const int n2 = ni - n1;
-  return (y * pow2i(n1)) * pow2i(n2);
+  return scale2(y, static_cast<int>(n));
 }
 
 SOIL_HD float log2f_(float x) {
@@ -91,10 +93,7 @@ SOIL_HD float powf_(float x, float y) {
   const float n = __builtin_rintf(t);
   const float r = (t - n) * 0.693147182f;
   const float v = exp_poly(r);
-  const int ni = static_cast<int>(n);
-  const int n1 = ni / 2;
-  const int n2 = ni - n1;
-  return (v * pow2i(n1)) * pow2i(n2);
+  return scale2(v, static_cast<int>(n));
 }
 
 // Philox4x32-10 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as
