@@ -156,7 +156,10 @@ int soil_rng_seed(soil_rng* rng, int64_t n, uint64_t seed, uint64_t offset, void
  *   op 2: out[i] = powf_(a[i], b[i])  stand-in for __powf
  *   op 3: out[i] = uniform in (0,1] of stream (seed = bits of a[i],
  *                  subsequence = i, offset = bits of b[i])  — Philox4x32-10
- *   op 4: out[i] = a[i] * b[i] (plain product; exposes denormal flushing) */
+ *   op 4: out[i] = a[i] * b[i] (plain product; exposes denormal flushing)
+ *   op 5: out[i] = a[i] / b[i] (the compiler's IEEE division)
+ *   op 6: out[i] = quot0(a[i], recip(b[i])), the shared-reciprocal quotient of the
+ *                  particle step (soil_math.hpp); equals op 5 on plain operands */
 int soil_selftest_math(float* out, const float* a, const float* b, int64_t n, int op,
                        void* stream);
 

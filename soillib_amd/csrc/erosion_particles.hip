@@ -424,6 +424,7 @@ static bool use_staged(int64_t N) {
 // queues): grids and launches beyond 2^31 stay on the staged shape
 static bool use_tiled(int64_t N, const Dom& d) {
   if (d.H * d.W > 0x7fffffffll || N > 0x7fffffffll) return false;
+  if (d.H >= (1 << 24) || d.W >= (1 << 24)) return false;  // its cell index is a 24-bit multiply-add
   if (g_particle_mode == 3) return true;
   return g_particle_mode == 0 && N >= 32768;
 }

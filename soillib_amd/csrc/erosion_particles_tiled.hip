@@ -108,7 +108,8 @@ __device__ __forceinline__ uint32_t queue_key(int x0, float px, float py, float 
 struct StepConst {
   float Hf, Wf, eps, g, lenL, nu, tau, kd, fD, evap, theta, kdd, kds, tau_y, fx, fy;
   int x0, lo, hi, W;  // slab origin, rows with a full stencil (local, inclusive), width
-  uint32_t maxage;
+  uint32_t maxage, Wu, base;  // base = x0 * W: local -> global cell index
+  bool plain;                 // launch constants in the plain range of quot()
 };
 
 template <int KIND>
@@ -134,22 +135,25 @@ __device__ __forceinline__ StepConst make_const(const Dom& d, Scale3 s, const Pa
   k.lo = static_cast<int>(stencil_lo(d));
   k.hi = static_cast<int>(stencil_hi(d));
   k.W = static_cast<int>(d.W);
+  k.Wu = static_cast<uint32_t>(d.W);
+  // lenL and tau + nu as operands of quot(): see advance()
+  k.plain = k.lenL >= 0x1p-30f && k.lenL <= 0x1p30f && k.tau + k.nu >= 0.0f && k.tau + k.nu <= 0x1p8f;
+  k.base = static_cast<uint32_t>(d.x0 * d.W);
   k.maxage = p.maxage > 0x7fffffffull ? 0x7fffffffu : static_cast<uint32_t>(p.maxage);
   return k;
 }
 
 // The body of one loop iteration AFTER the bookkeeping at its top (oob, ++iter,
-// escape) and the deposit: erosion.cu:116-137 / :321-347.  `f` = {grad, vel} of
-// the current cell, `wh` its water height.  Returns false when the walk ends.
-// `q` is the cell's record of k_tiled_pack.
+// escape) and the deposit: erosion.cu:116-137 / :321-347.  `q` is the cell's record
+// of k_tiled_pack.  Returns false when the walk ends.  Written with `/` throughout:
+// the definition, and the path of every lane whose operands are not plain.
 template <int KIND>
-__device__ __forceinline__ bool advance(PRec& r, const float4 q, const StepConst& k) {
-  const float v_norm = length2(r.spx, r.spy);            // :116 / :321
+__device__ __forceinline__ bool advance_slow(PRec& r, const float4 q, const StepConst& k,
+                                          const float v_norm) {
   const float ux = r.spx / v_norm, uy = r.spy / v_norm;  // :117 / :322
   const float v_step = stepsize(r.px, r.py, ux, uy);     // :118 / :323
   const float dL = v_step * k.lenL;                      // :119 / :324
   const float ds = dL / v_norm;                          // :120 / :325
-  if (v_norm < k.eps) return false;                      // :121-122 / :326-327
   if (KIND == FLUVIAL) {
     const float ax = q.x + k.fx;  // :126
     const float ay = q.y + k.fy;
@@ -178,6 +182,61 @@ __device__ __forceinline__ bool advance(PRec& r, const float4 q, const StepConst
     r.a1 = r.a1 * expf_(-dL * decay_v);                                       // :346
   }
   r.px += v_step * ux;  // :137 / :347
+  r.py += v_step * uy;
+  return true;
+}
+
+// The fluvial iteration with the shared-reciprocal quotients of soil_math.hpp.  The
+// `v_norm < eps` exit (:121-122) is taken first: nothing the reference computes
+// before it has an effect when it fires.  Everything is computed on the assumption
+// that the operands are plain; `ok` collects the evidence, and a lane without it
+// redoes the step with advance_slow (ok is tested in the positive, so a NaN anywhere
+// lands there too).  What sends a lane there at 8192^2: a direction component of
+// exactly zero (0.04 % of the steps) and NaN walkers (0.02 %) — 2 % of the wave-steps
+// run both paths.  34.2 -> 33.4 ms per launch.
+//
+// Debris stays on advance_slow: on bare rock (debrisHeight = eps) its velocity
+// shrinks by ~1e-8 per step, so direction components underflow, decay_d runs to
+// 1e25 and beyond (the scaled regime of the division) and after special-casing all
+// of that 1.3 % of the lanes — more than half of the waves — still needed the slow
+// path on top of the fast one (14.9 vs 13.4 ms).
+template <int KIND>
+__device__ __forceinline__ bool advance(PRec& r, const float4 q, const StepConst& k) {
+  const float v_norm = length2(r.spx, r.spy);  // :116 / :321
+  if (v_norm < k.eps) return false;            // eps = 1e-12 > 2^-40: v_norm is plain from below
+  if (KIND == DEBRIS) return advance_slow<KIND>(r, q, k, v_norm);
+  bool ok = k.plain && v_norm <= kDenHi;
+  const Recip rn = recip(v_norm);
+  // a direction is only ever a denominator for numerators <= 1: plain down to 2^-60
+  // (and then |spx| = |ux| v_norm >= 2^-100, a plain numerator in hindsight)
+  constexpr float kDirLo = 0x1p-60f;
+  const float ux = quot(r.spx, rn), uy = quot(r.spy, rn);  // :117
+  ok = ok && fminf(fabsf(ux), fabsf(uy)) >= kDirLo;
+  // stepsize() with one quotient per axis (see there), :118
+  const float x_neg = floorf(r.px), y_neg = floorf(r.py);
+  const float nx = ((ux > 0.0f) ? 1.0f + x_neg : x_neg) - r.px;
+  const float ny = ((uy > 0.0f) ? 1.0f + y_neg : y_neg) - r.py;
+  const float tx = fminf(quot(nx, recip(ux)), kSqrt2);
+  const float ty = fminf(quot(ny, recip(uy)), kSqrt2);
+  const float v_step = 0.5f * (tx + ty);
+  const float dL = v_step * k.lenL;  // :119
+  // dL = -0 is what a walker stuck on a cell corner computes until it dies of age
+  // (both face times -0; 1 % of all steps): quot0
+  const float ds = quot0(dL, rn);  // :120
+  // nx, ny: +0 or not tiny; dL: a zero or not tiny.  One min3 decides the common case
+  if (fminf(fminf(fabsf(nx), fabsf(ny)), fabsf(dL)) < kNumLo)
+    ok = ok && plain_num(nx) && plain_num(ny) && (dL == 0.0f || fabsf(dL) >= kNumLo);
+  // D = 1 + dL * (tau + nu) lies in [1, 2^40] by k.plain (dL in [0, sqrt2 * lenL])
+  const Recip rd = recip(1.0f + dL * (k.tau + k.nu));
+  if (!ok) return advance_slow<KIND>(r, q, k, v_norm);
+  const float ax = q.x + k.fx, ay = q.y + k.fy;           // :126
+  const float w0 = quot(1.0f, rd), w1 = quot0(dL, rd);    // :127
+  r.spx = w0 * r.spx + w1 * ax;
+  r.spy = w0 * r.spy + w1 * ay;
+  r.a1 = r.a1 * expf_(-ds * k.kd);    // att_m :134
+  r.a0 = r.a0 * expf_(-ds * k.evap);  // att_w :135
+  r.a2 = r.a2 * expf_(-dL * q.z);     // att_v :136
+  r.px += v_step * ux;                // :137
   r.py += v_step * uy;
   return true;
 }
@@ -678,13 +737,14 @@ __global__ void __launch_bounds__(NT)
       // the cell's record comes from the packed plane through L1/L2 (the tile's
       // 64 KiB are touched ~4x per round); issued first, the gather's latency
       // hides under the deposit and the other waves of the SIMD
-      const int64_t lcell = static_cast<int64_t>(lx) * k.W + cy;
+      // rows, W < 2^24 and H*W < 2^31 (use_tiled): one v_mad_u32_u24 per index
+      const uint32_t lcell = __umul24(static_cast<uint32_t>(lx), k.Wu) + static_cast<uint32_t>(cy);
       const float4 q = p4[lcell];
       constexpr int kFluxPlanes = (KIND == FLUVIAL) ? 4 : 3;
       CasDeposit<kFluxPlanes + (ALB ? 3 : 0)> dep;
-      const int64_t nind = static_cast<int64_t>(cx) * k.W + cy;  // :103 / :309
-      if (static_cast<uint32_t>(nind) != r.ind) {                // :104-113 / :310-318
-        r.ind = static_cast<uint32_t>(nind);
+      const uint32_t nind = lcell + k.base;  // global cell: cx * W + cy, :103 / :309
+      if (nind != r.ind) {                   // :104-113 / :310-318
+        r.ind = nind;
         // DEP 0: native ds_add_f32, fire and forget; DEP 1: CasDeposit
         float v[kFluxPlanes + 3];
         float* p[kFluxPlanes + 3];

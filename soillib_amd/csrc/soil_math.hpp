@@ -96,6 +96,48 @@ SOIL_HD float powf_(float x, float y) {
   return scale2(v, static_cast<int>(n));
 }
 
+// IEEE quotients that share a denominator (device only).
+//
+// A particle step (erosion_particles_tiled.hip) divides nine (debris: eleven) times,
+// by four (five) different numbers.
+// The compiler expands every fp32 `/` into v_div_scale x2, v_rcp, a Newton step on
+// the reciprocal, three residual corrections of the quotient (the last one being
+// v_div_fmas) and v_div_fixup.  For operands in the plain range below the scale
+// instructions are the identity, v_div_fmas is a plain fma and the fix-up passes the
+// value through (ISA guide, V_DIV_SCALE/V_DIV_FMAS/V_DIV_FIXUP), so what is left is
+//      r = rcp(b); r = fma(fma(-b, r, 1), r, r)
+//      q = a * r;  q = fma(fma(-b, q, a), r, q);  q = fma(fma(-b, q, a), r, q)
+// — the same instructions on the same values, hence the same bits — and r only
+// depends on b.  recip()/quot() spell that sequence out so that r is computed once
+// per denominator.  What "plain" has to guarantee (V_DIV_SCALE): b and 1/b normal,
+// exponent(a) - exponent(b) < 96, a/b normal, exponent(a) > 23 (|a| >= 2^-103).
+// |b| in [2^-40, 2^40] with |a| in [2^-80, 2^50] does; so does any pair whose quotient
+// turns out in [2^-60, 2^90] over such a b.  a == +0 runs through the chain to the
+// correctly signed zero, -0 needs quot0().  Anything else — denormals, infinities,
+// zero or NaN denominators — has to take the written-out `/`.
+struct Recip { float b, r; };
+__device__ __forceinline__ Recip recip(float b) {
+  float r = __builtin_amdgcn_rcpf(b);
+  r = __builtin_fmaf(__builtin_fmaf(-b, r, 1.0f), r, r);
+  return {b, r};
+}
+__device__ __forceinline__ float quot(float a, const Recip d) {
+  float q = a * d.r;
+  q = __builtin_fmaf(__builtin_fmaf(-d.b, q, a), d.r, q);
+  return __builtin_fmaf(__builtin_fmaf(-d.b, q, a), d.r, q);
+}
+// A zero numerator of either sign: the first product already is the IEEE answer (zero,
+// sign of a times sign of b); the corrections after it would turn -0 into +0.
+__device__ __forceinline__ float quot0(float a, const Recip d) {
+  const float q0 = a * d.r, q = quot(a, d);
+  return (a == 0.0f) ? q0 : q;
+}
+constexpr float kDenLo = 0x1p-40f, kDenHi = 0x1p40f;  // denominators
+constexpr float kNumLo = 0x1p-60f;                      // numerators (given a plain denominator)
+__device__ __forceinline__ bool plain_den(float b) { return fabsf(b) >= kDenLo && fabsf(b) <= kDenHi; }
+// +0 or of plain magnitude (the caller bounds it from above)
+__device__ __forceinline__ bool plain_num(float a) { return f2bits(a) == 0u || fabsf(a) >= kNumLo; }
+
 // Philox4x32-10 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as
 // easy as 1, 2, 3", SC'11).  Only word 0 of the block is consumed per draw.
 SOIL_HD uint32_t philox4x32_10_w0(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,

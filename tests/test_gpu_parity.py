@@ -59,6 +59,42 @@ def test_denormals_are_not_flushed(hip):
     assert_bit_equal(_selftest(hip, a, b, 4), a * b, "denormal product")
 
 
+def test_shared_reciprocal_quotient_is_the_ieee_quotient(hip):
+    """quot0(a, recip(b)) (soil_math.hpp) against the compiler's `/` on the device and
+    numpy's on the host, over the plain range the particle step uses it on: random
+    mantissas x every exponent combination, mantissa extremes, and +0 numerators."""
+    r = np.random.default_rng(11)
+    n = 1 << 22
+    man = lambda k: r.integers(0, 1 << 23, k, dtype=np.uint32)
+    def build(sign, exp, m):
+        return ((sign.astype(np.uint32) << 31) | (exp.astype(np.uint32) << 23) | m).view(np.float32)
+    for rep in range(4):
+        eb = r.integers(127 - 40, 127 + 40, n)                 # |b| in [2^-40, 2^40)
+        ea = r.integers(127 - 80, 127 + 50, n)                 # |a| in [2^-80, 2^50)
+        a = build(r.integers(0, 2, n), ea, man(n))
+        b = build(r.integers(0, 2, n), eb, man(n))
+        if rep == 1:                                           # quotients next to 1: a ~ b
+            a = (b.view(np.uint32) + r.integers(-3, 4, n).astype(np.uint32)).view(np.float32)
+        if rep == 2:                                           # mantissa extremes
+            edge = np.array([0, 1, 2, 0x7fffff, 0x7ffffe, 0x400000, 0x3fffff, 0x555555], np.uint32)
+            a = build(r.integers(0, 2, n), ea, edge[r.integers(0, 8, n)])
+            b = build(r.integers(0, 2, n), eb, edge[r.integers(0, 8, n)])
+        if rep == 3:                                           # zeros of both signs in the mix
+            a[::5] = 0.0
+            a[1::5] = -0.0
+        ieee = _selftest(hip, a, b, 5)
+        fast = _selftest(hip, a, b, 6)
+        assert_bit_equal(ieee, a / b, "device `/` vs numpy (rep %d)" % rep)
+        assert_bit_equal(fast, ieee, "quot0 vs `/` (rep %d)" % rep)
+    # any normal numerator: accepted by the size of the quotient (debris' decay_d)
+    a = build(r.integers(0, 2, n), r.integers(1, 255, n), man(n))
+    b = build(r.integers(0, 2, n), r.integers(127 - 40, 127 + 40, n), man(n))
+    ieee, fast = _selftest(hip, a, b, 5), _selftest(hip, a, b, 6)
+    keep = (np.abs(fast) >= 2.0 ** -60) & (np.abs(fast) <= 2.0 ** 90)
+    assert keep.sum() > n // 4
+    assert_bit_equal(fast[keep], ieee[keep], "quot0 vs `/`, accepted by the quotient")
+
+
 def test_philox_uniform_bit_exact(hip, oracle):
     n = 5000
     seeds = np.full(n, 7, np.uint32).view(np.float32)
