@@ -159,7 +159,8 @@ int soil_rng_seed(soil_rng* rng, int64_t n, uint64_t seed, uint64_t offset, void
  *   op 4: out[i] = a[i] * b[i] (plain product; exposes denormal flushing)
  *   op 5: out[i] = a[i] / b[i] (the compiler's IEEE division)
  *   op 6: out[i] = quot0(a[i], recip(b[i])), the shared-reciprocal quotient of the
- *                  particle step (soil_math.hpp); equals op 5 on plain operands */
+ *                  particle step (soil_math.hpp); equals op 5 on plain operands
+ *   op 7: out[i] = expf_flat(a[i]), the branch-free twin of op 0 */
 int soil_selftest_math(float* out, const float* a, const float* b, int64_t n, int op,
                        void* stream);
 

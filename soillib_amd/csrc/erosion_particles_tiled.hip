@@ -233,10 +233,10 @@ __device__ __forceinline__ bool advance(PRec& r, const float4 q, const StepConst
   const float w0 = quot(1.0f, rd), w1 = quot0(dL, rd);    // :127
   r.spx = w0 * r.spx + w1 * ax;
   r.spy = w0 * r.spy + w1 * ay;
-  r.a1 = r.a1 * expf_(-ds * k.kd);    // att_m :134
-  r.a0 = r.a0 * expf_(-ds * k.evap);  // att_w :135
-  r.a2 = r.a2 * expf_(-dL * q.z);     // att_v :136
-  r.px += v_step * ux;                // :137
+  r.a1 = r.a1 * expf_flat(-ds * k.kd);    // att_m :134
+  r.a0 = r.a0 * expf_flat(-ds * k.evap);  // att_w :135
+  r.a2 = r.a2 * expf_flat(-dL * q.z);     // att_v :136
+  r.px += v_step * ux;                    // :137
   r.py += v_step * uy;
   return true;
 }
@@ -617,9 +617,14 @@ struct CasDeposit {
     // once the particles share channels) hands the add to the native atomic instead of
     // retrying: nothing was written by the failed swap, ds_add_f32 needs no answer, and
     // a k-way collision costs k lane-slots of the LDS pipe instead of k round trips
+    bool lost = false;
 #pragma unroll
-    for (int j = 0; j < NP; ++j)
-      if (g[j] != o[j]) atomicAdd(p[j], v[j]);
+    for (int j = 0; j < NP; ++j) lost = lost || g[j] != o[j];
+    if (lost) {  // one branch in the common case
+#pragma unroll
+      for (int j = 0; j < NP; ++j)
+        if (g[j] != o[j]) atomicAdd(p[j], v[j]);
+    }
     pending = false;
   }
 };

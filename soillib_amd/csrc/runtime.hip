@@ -175,6 +175,7 @@ __global__ void k_selftest_math(float* __restrict__ out, const float* __restrict
     case 3: r = rng_uniform_at(f2bits(a[i]), static_cast<uint64_t>(i), f2bits(b[i])); break;
     case 5: r = a[i] / b[i]; break;
     case 6: r = quot0(a[i], recip(b[i])); break;
+    case 7: r = expf_flat(a[i]); break;
     default: r = a[i] * b[i]; break;
   }
   out[i] = r;
@@ -341,7 +342,7 @@ int soil_selftest_math(float* out, const float* a, const float* b, int64_t n, in
                        void* stream) {
   SOIL_DEVICE();
   SOIL_REQUIRE(out && a && b, "selftest_math: null argument");
-  SOIL_REQUIRE(op >= 0 && op <= 6, "selftest_math: unknown op");
+  SOIL_REQUIRE(op >= 0 && op <= 7, "selftest_math: unknown op");
   if (n <= 0) return SOIL_OK;
   k_selftest_math<<<blocks_for(n, 256), 256, 0, as_stream(stream)>>>(out, a, b, n, op);
   SOIL_LAUNCH_CHECK();

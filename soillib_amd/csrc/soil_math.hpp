@@ -55,6 +55,18 @@ SOIL_HD float expf_(float x) {
   const float y = exp_poly(r);
   return scale2(y, static_cast<int>(n));
 }
+// The same values in straight-line code: the three exits become two selects (a NaN
+// runs through the arithmetic as a NaN; what the saturated cases compute is
+// discarded).  For call sites where saturation is the exception — three of them per
+// fluvial particle step — so the exits never skip anything for a whole wave and only
+// cost exec-mask bookkeeping.
+__device__ __forceinline__ float expf_flat(float x) {
+  const float n = __builtin_rintf(x * 1.44269504f);
+  float r = x - n * 0.693145752f;
+  r = r - n * 1.42860677e-6f;
+  const float y = scale2(exp_poly(r), static_cast<int>(n));
+  return (x > 88.72283f) ? __builtin_inff() : ((x < -87.0f) ? 0.0f : y);
+}
 
 SOIL_HD float log2f_(float x) {
   if (x != x) return x;

@@ -45,6 +45,7 @@ def test_spec_math_bit_exact(hip, oracle):
                         [0.0, -0.0, np.inf, -np.inf, np.nan, 88.7, 88.73, -87.0, -87.1]]
                        ).astype(np.float32)
     assert_bit_equal(_selftest(hip, x, x, 0), oracle.expf(x), "expf_")
+    assert_bit_equal(_selftest(hip, x, x, 7), oracle.expf(x), "expf_flat")
     xp = np.concatenate([np.exp(r.uniform(-80, 80, 30000)), [0.0, 1.0, 2.0, 1e-39, np.inf]]
                         ).astype(np.float32)
     assert_bit_equal(_selftest(hip, xp, xp, 1), oracle.log2f(xp), "log2f_")
