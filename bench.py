@@ -237,6 +237,25 @@ def main():
         final = {"height_min": float(np.nanmin(hh)), "height_max": float(np.nanmax(hh)),
                  "nonfinite_cells": int((~np.isfinite(hh)).sum())}
 
+    probe = None
+    if rank == 0:
+        # what a plain stream reaches on THIS box (outside the timed region): t += o over two
+        # 8192^2 planes, 12 bytes per element.  Boxes of the pool differ by ~25 % here,
+        # and the fused cell kernel moves with them.
+        a = silt.tensor(silt.float32, silt.shape(8192, 8192), silt.gpu)
+        b = silt.tensor(silt.float32, silt.shape(8192, 8192), silt.gpu)
+        silt.set(a, 0.0)
+        silt.set(b, 1.0)
+        pe = Events(_abi, 2)
+        for i in range(13):
+            if i == 3:
+                pe.record(0)
+            silt.add(a, b)
+        pe.record(1)
+        _abi.check(lib.soil_device_synchronize())
+        probe = {"kernel": "k_add (t += o), 2 x 8192^2 f32 planes, 12 B/element",
+                 "achieved": 12.0 * 8192 * 8192 * 10 / (pe.ms(0, 1) * 1e-3) / 1e9, "unit": "GB/s"}
+        del a, b
     if world > 1 or os.environ.get("SOIL_BENCH_FORCE_SLAB") == "1":
         runner.shutdown()
     if rank != 0:
@@ -281,6 +300,7 @@ def main():
         "roofline": {"bound": "hbm", "kernel": "k_erode_cells_fused", "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic,
+                     "stream_probe": probe,
                      "algorithmic_bytes_per_launch": CELL_BYTES * cells_rank,
                      "avg_launch_ms": t_cells * 1e3},
     }
