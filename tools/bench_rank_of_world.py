@@ -1,0 +1,80 @@
+"""What ONE rank of a `world`-GPU run computes per step, measured on a single GPU.
+
+The sharded step (soillib_amd.parallel.SlabRunner) is run as an interior rank of an
+emulated world with a communicator that moves nothing: every kernel the rank would
+launch runs at its real size (slab + ghost rows, all world*N particle streams
+replayed, halo adds), only the wire time is missing.  Dividing the world = 1 time by
+these gives the compute-side ceiling of the weak-scaling efficiency bench.py --gpus N
+can reach; what xGMI adds comes on top.
+
+    python tools/bench_rank_of_world.py [--worlds 1,2,4,8] [--size 8192] [--steps 4]
+"""
+import argparse
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+
+
+class NullComm:
+    class ReduceOp:
+        SUM, MAX = "sum", "max"
+
+    class P2POp:
+        def __init__(self, op, tensor, peer):
+            self.op, self.tensor, self.peer = op, tensor, peer
+
+    isend, irecv = "isend", "irecv"
+
+    class _Req:
+        def wait(self):
+            pass
+
+    def batch_isend_irecv(self, ops):
+        return [self._Req() for _ in ops]
+
+    def all_reduce(self, t, op="sum"):
+        pass
+
+    def barrier(self):
+        pass
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--worlds", default="1,2,4,8")
+    ap.add_argument("--size", type=int, default=8192)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=2)
+    args = ap.parse_args()
+    from soillib_amd import soil
+    from soillib_amd.parallel import SlabRunner
+    from util import script_param
+    base = None
+    for world in [int(w) for w in args.worlds.split(",")]:
+        param = script_param(soil.param_t())
+        r = SlabRunner(rows_per_rank=args.size, W=args.size, param=param, particles_div=8, seed=0,
+                       comm=NullComm(), rank=world // 2, world=world)
+        for _ in range(args.warmup):
+            r.step()
+        r.sync()
+        soil.particle_steps(reset=True)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            r.step()
+        r.sync()
+        ms = (time.perf_counter() - t0) / args.steps * 1e3
+        steps = soil.particle_steps(reset=True) / args.steps
+        base = base or ms
+        print("world %d rank %d: rows %d (+%d ghost), N %d: %.2f ms/step, %.2f G particle steps, "
+              "compute-side efficiency %.3f" % (world, r.rank, args.size, r.rows - args.size, r.N,
+                                                ms, steps / 1e9, base / ms), flush=True)
+        del r
+        from soillib_amd import silt
+        silt.empty_cache()
+
+
+if __name__ == "__main__":
+    main()
