@@ -167,8 +167,11 @@ def main():
     param = script_param(soil)
     if world > 1 or os.environ.get("SOIL_BENCH_FORCE_SLAB") == "1":
         from soillib_amd import parallel
+        # weak scaling: every slab is a piece of the same kind of landscape — cell size
+        # (20/S) and noise wavelength per cell as at N = 1, the domain just gets longer
         runner = parallel.SlabRunner(rows_per_rank=S, W=S, param=param,
-                                     particles_div=args.particles_div, seed=0)
+                                     particles_div=args.particles_div, seed=0,
+                                     scale=[20.0 / S, 20.0 / S, 4.0], noise_rows=S)
         H_global, W = runner.H, S
     else:
         H_global, W = S, S

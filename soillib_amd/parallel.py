@@ -167,10 +167,13 @@ class SlabRunner:
     """The sharded erosion model; `step()` advances the global grid by one step."""
 
     def __init__(self, rows_per_rank, W, param, particles_div=8, seed=0, ops=None, scale=None,
-                 noise_seed=3.0, init=True, comm=None, rank=None, world=None):
+                 noise_seed=3.0, init=True, comm=None, rank=None, world=None, noise_rows=None):
         """`comm` is a torch.distributed-like module (P2POp, isend, irecv,
         batch_isend_irecv, all_reduce, barrier); the default is torch.distributed
-        itself.  Tests inject an in-process stand-in to drive several slabs on one GPU."""
+        itself.  Tests inject an in-process stand-in to drive several slabs on one GPU.
+        `noise_rows`: the row extent the initial noise heightmap is normalised by (default:
+        the global height, i.e. the same landscape stretched over more rows as the world
+        grows; weak-scaling runs pass `rows_per_rank` to keep the terrain statistics per cell)."""
         if comm is None:
             import torch.distributed as dist
         else:
@@ -218,7 +221,8 @@ class SlabRunner:
                                 ops.alloc((self._peer_ghost(self.down),) + tail) if self.down is not None else None)
         if init:
             bed = ops.alloc((self.rows, self.W))
-            ops.noise_rows(bed, self.H, self.W, self.x0, noise_seed)
+            ops.noise_rows(bed, self.H if noise_rows is None else int(noise_rows), self.W, self.x0,
+                           noise_seed)
             ops.layers_from_bedrock(self.P["layers"], bed)
             self.fill(self.P["rainfall"], 1.0)
 

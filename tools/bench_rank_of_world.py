@@ -56,7 +56,8 @@ def main():
     for world in [int(w) for w in args.worlds.split(",")]:
         param = script_param(soil.param_t())
         r = SlabRunner(rows_per_rank=args.size, W=args.size, param=param, particles_div=8, seed=0,
-                       comm=NullComm(), rank=world // 2, world=world)
+                       comm=NullComm(), rank=world // 2, world=world,
+                       scale=[20.0 / args.size, 20.0 / args.size, 4.0], noise_rows=args.size)
         for _ in range(args.warmup):
             r.step()
         r.sync()
