@@ -416,8 +416,11 @@ __device__ __forceinline__ uint32_t wave_append(uint32_t* counter, bool pred) {
 __global__ void __launch_bounds__(256)
     k_tiled_scatter(uint32_t* __restrict__ order, const uint32_t* __restrict__ start,
                     const uint32_t* __restrict__ dest, const uint32_t* __restrict__ rank,
-                    int64_t n_src) {
+                    int64_t n_src, uint32_t* __restrict__ clear, int64_t n_clear) {
   const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  // the section counters of the round that follows, zeroed on the side (saves a fill
+  // launch per round)
+  for (int64_t c = i; c < n_clear; c += static_cast<int64_t>(gridDim.x) * 256) clear[c] = 0u;
   if (i >= n_src) return;
   const uint32_t key = dest[i];
   if (key != kNoTile) order[start[key] + rank[i]] = static_cast<uint32_t>(i);
@@ -1159,8 +1162,8 @@ struct TiledRun {
       return finish_steps();
     }
     SOIL_HIP(hipEventRecord(ev0, st));
-    k_tiled_scatter<<<blocks_for(n_src, 256), 256, 0, st>>>(order, start, dest, rank, n_src);
-    SOIL_HIP(hipMemsetAsync(count_next, 0, b_cnt, st));
+    k_tiled_scatter<<<blocks_for(n_src, 256), 256, 0, st>>>(
+        order, start, dest, rank, n_src, count_next, static_cast<int64_t>(b_cnt / sizeof(uint32_t)));
     if (deposit == 1)
       launch_round<KIND, 0>(sh, blocks, st, next, dest, rank, count_next,
                             static_cast<const PRec*>(cur), static_cast<const uint32_t*>(order),
