@@ -749,3 +749,59 @@ def test_transport_edge_cases(hip, oracle, particle_mode, maxage, N):
     assert soil.particle_steps(reset=True) == steps
     for k in ("wf", "mf", "vf", "df", "dvf"):
         _flux_close(to_np(g[k]), o[k], "edge case flux " + k)
+
+
+@pytest.mark.parametrize("case", ["negative_shear", "tiny_cells", "huge_cells", "flat_axis", "force"])
+def test_transport_fluvial_outside_the_plain_range(hip, oracle, case):
+    """The tiled fluvial step takes its quotients from shared reciprocals when the launch
+    constants and the lane's operands are plain (soil_math.hpp) and falls back to the
+    written-out divisions otherwise.  Cases that sit on the other side of that switch —
+    constants the fast path refuses, cell sizes far from 1, terrain whose gradient (hence
+    a direction component) is exactly zero along one axis — against the oracle."""
+    from soillib_amd import soil
+    H, W, N = 96, 80, 6000
+    op = script_param(oracle.default_param())
+    op.maxage = 96
+    scale = (20.0 / H, 20.0 / W, 4.0)
+    r = np.random.default_rng(77)
+    layers = terrain(oracle, H, W, sediment=0.01)
+    vel0 = (r.standard_normal((H, W, 2)) * 2).astype(np.float32)
+    if case == "negative_shear":
+        op.bedShearWater = -0.5                    # tau + nu < 0: not plain, every lane slow
+    elif case == "tiny_cells":
+        scale = (1e-11, 1e-11, 4.0)                # lenL below 2^-30
+    elif case == "huge_cells":
+        scale = (3e9, 3e9, 4.0)                    # lenL above 2^30
+    elif case == "flat_axis":                      # heights and speeds vary along x only
+        layers = np.repeat(layers[:, :1], W, axis=1).copy()
+        vel0[..., 1] = 0.0
+    elif case == "force":
+        op.force[0], op.force[1] = 0.3, -0.2
+    pp = product_param(op)
+    rain = np.ones((H, W), np.float32)
+    wh0 = (r.random((H, W)) * 0.1).astype(np.float32)
+    z1, z2 = np.zeros((H, W), np.float32), np.zeros((H, W, 2), np.float32)
+    o = dict(wf=z1.copy(), mf=z1.copy(), vf=z2.copy())
+    orng = oracle.rng_seed(N, 3, 10)
+    steps = oracle.particles_fluvial(o["wf"], o["mf"], o["vf"], None, orng, layers, rain, wh0, vel0,
+                                     None, scale, op)
+    import ctypes as C
+    from soillib_amd import _abi
+    out = {}
+    for mode, name in ((1, "direct"), (3, "tiled")):
+        assert hip.soil_set_particle_mode(mode) == 0
+        g = {k: to_gpu(v) for k, v in dict(wf=z1, mf=z1, vf=z2).items()}
+        grng = rng_to_gpu(oracle.rng_seed(N, 3, 10))
+        dom = _abi.Domain(H, W, 0, H, 0, H)
+        soil.particle_steps(reset=True)
+        lay, gr, gw, gv = to_gpu(layers), to_gpu(rain), to_gpu(wh0), to_gpu(vel0)   # kept alive
+        _abi.check(hip.soil_particles_fluvial_slab(
+            g["wf"].c_ptr, g["mf"].c_ptr, g["vf"].c_ptr, None, grng.c_ptr, N, lay.c_ptr,
+            gr.c_ptr, gw.c_ptr, gv.c_ptr, None, None, C.byref(dom),
+            _abi.vec(scale, 3), pp._ref(), None))
+        out[name] = (soil.particle_steps(reset=True), {k: to_np(v) for k, v in g.items()})
+    hip.soil_set_particle_mode(0)
+    for name, (n, flux) in out.items():
+        assert n == steps, "%s: %d steps, oracle %d" % (name, n, steps)
+        for k in ("wf", "mf", "vf"):
+            _flux_close(flux[k], o[k], "%s %s flux %s" % (case, name, k))
