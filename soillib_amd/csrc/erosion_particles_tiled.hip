@@ -603,6 +603,24 @@ __global__ void __launch_bounds__(1024)
 // and a lane that lost a race falls back to the native atomic.  ds_add_f32 needs no such care but
 // occupies the LDS pipe ~170 cycles per wave instruction on gfx950 (2.6 per lane;
 // tools/microbench/lds_atomic.hip), a ds_cmpst ~6.
+// Sum over the 64 lanes of a wave, delivered in lane 63; all lanes must be active.
+// Row-wise Hillis-Steele over DPP shifts (zeros shift in), then lane 15 of a row is
+// broadcast into the next row and lane 31 into the upper half.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+  return v + bits2f(static_cast<uint32_t>(__builtin_amdgcn_update_dpp(
+                 0, static_cast<int>(f2bits(v)), CTRL, ROW_MASK, 0xf, true)));
+}
+__device__ __forceinline__ float wave_sum63(float v) {
+  v = dpp_add<0x111, 0xf>(v);  // row_shr:1
+  v = dpp_add<0x112, 0xf>(v);  // row_shr:2
+  v = dpp_add<0x114, 0xf>(v);  // row_shr:4
+  v = dpp_add<0x118, 0xf>(v);  // row_shr:8   lane 15 of each row: the row's sum
+  v = dpp_add<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+  v = dpp_add<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3: lane 63 holds the total
+  return v;
+}
+
 template <int NP>
 struct CasDeposit {
   float* p[NP];
@@ -619,21 +637,49 @@ struct CasDeposit {
     for (int j = 0; j < NP; ++j) g[j] = swap(p[j], o[j], v[j]);
     pending = true;
   }
-  __device__ __forceinline__ void finish() {
-    if (!pending) return;
-    // a lane that lost its race (another walker hit the same cell in between — common
-    // once the particles share channels) hands the add to the native atomic instead of
-    // retrying: nothing was written by the failed swap, ds_add_f32 needs no answer, and
-    // a k-way collision costs k lane-slots of the LDS pipe instead of k round trips
-    bool lost = false;
+  // Convergent: every lane of the wave calls it (pending or not), once per iteration.
+  // A lane that lost its race (another walker hit the same cell in between — common
+  // once the particles share channels) does not retry: nothing was written by the
+  // failed swap, and a k-way collision would cost k round trips.
+  //  * few losers in the wave: each hands its adds to the native atomic (no answer
+  //    needed; k lane-slots of the LDS pipe);
+  //  * many (a wave walking a channel: most lanes stand on a handful of cells): the
+  //    losers of one cell add their values up in registers (a masked wave sum over DPP)
+  //    and one lane issues the atomic — on the hot tiles that set the length of a
+  //    round on small grids, ds_add_f32 at 2.6 cycles per lane was all the LDS pipe did.
+  // `cell` is the lane's cell index in the tile (any value when nothing is pending).
+  __device__ __forceinline__ void finish(int cell, int agg_min, int agg_groups) {
+    bool lostj[NP], lost = false;
 #pragma unroll
-    for (int j = 0; j < NP; ++j) lost = lost || g[j] != o[j];
-    if (lost) {  // one branch in the common case
-#pragma unroll
-      for (int j = 0; j < NP; ++j)
-        if (g[j] != o[j]) atomicAdd(p[j], v[j]);
+    for (int j = 0; j < NP; ++j) {
+      lostj[j] = pending && g[j] != o[j];
+      lost = lost || lostj[j];
     }
     pending = false;
+    uint64_t todo = __ballot(lost);
+    if (todo == 0) return;  // the common case
+    const int lane = static_cast<int>(threadIdx.x & 63u);
+    if (__popcll(todo) >= agg_min) {
+      for (int it = 0; todo != 0 && it < agg_groups; ++it) {
+        const int leader = __ffsll(static_cast<long long>(todo)) - 1;
+        const int c0 = __builtin_amdgcn_readlane(cell, leader);
+        const bool in = lost && cell == c0;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+          const float sum = wave_sum63((in && lostj[j]) ? v[j] : 0.0f);
+          const float total = bits2f(static_cast<uint32_t>(
+              __builtin_amdgcn_readlane(static_cast<int>(f2bits(sum)), 63)));
+          if (lane == leader && total != 0.0f) atomicAdd(p[j], total);
+        }
+        todo &= ~__ballot(in);
+      }
+      lost = lost && ((todo >> lane) & 1ull) != 0;  // cells beyond the budget: one by one
+    }
+    if (lost) {
+#pragma unroll
+      for (int j = 0; j < NP; ++j)
+        if (lostj[j]) atomicAdd(p[j], v[j]);
+    }
   }
 };
 
@@ -648,7 +694,7 @@ __global__ void __launch_bounds__(NT)
                   float* __restrict__ remote0, unsigned long long* __restrict__ steps, Dom d,
                   Scale3 s, Param param, int tiles_w, int off_r, int off_c, int steps_per_round,
                   TileShape ts_next,
-                  int tiles_w_next, uint32_t chunk_cap) {
+                  int tiles_w_next, uint32_t chunk_cap, int agg_min, int agg_groups) {
   constexpr int kCells = TR * TC, kBlock = NT, kPer = (kCells + NT - 1) / NT;
   // this work-group's share of its tile's queue (k_queue_prepare's block list)
   const uint2 job = block_list[blockIdx.x];
@@ -745,6 +791,8 @@ __global__ void __launch_bounds__(NT)
       parked = parked || park;
       have = step;
     }
+    constexpr int kFluxPlanes = (KIND == FLUVIAL) ? 4 : 3;
+    CasDeposit<kFluxPlanes + (ALB ? 3 : 0)> dep;
     if (step) {
       ++r.iter;
       --budget;
@@ -755,8 +803,6 @@ __global__ void __launch_bounds__(NT)
       // rows, W < 2^24 and H*W < 2^31 (use_tiled): one v_mad_u32_u24 per index
       const uint32_t lcell = __umul24(static_cast<uint32_t>(lx), k.Wu) + static_cast<uint32_t>(cy);
       const float4 q = p4[lcell];
-      constexpr int kFluxPlanes = (KIND == FLUVIAL) ? 4 : 3;
-      CasDeposit<kFluxPlanes + (ALB ? 3 : 0)> dep;
       const uint32_t nind = lcell + k.base;  // global cell: cx * W + cy, :103 / :309
       if (nind != r.ind) {                   // :104-113 / :310-318
         r.ind = nind;
@@ -787,8 +833,8 @@ __global__ void __launch_bounds__(NT)
         if (DEP == 1) dep.begin();
       }
       have = advance<KIND>(r, q, k);
-      if (DEP == 1) dep.finish();
     }
+    if (DEP == 1) dep.finish(c, agg_min, agg_groups);
   }
   {  // everything still parked goes out together (convergent: aggregate the counters)
     const uint32_t slot = wave_append(&s_out, parked);
@@ -1004,6 +1050,7 @@ struct TiledRun {
   int shape_of(uint64_t r) const { return r >= static_cast<uint64_t>(switch_round) ? shape_late : shape_early; }
   // the tile grid of round r: shifted by half a tile on odd rounds (TileShape)
   bool stagger = true;
+  int agg_min = 48, agg_groups = 4;
   TileShape ts_of(int sh, uint64_t r) const {
     const bool odd = stagger && (r & 1);
     return TileShape{__builtin_ctz(kShapes[sh].tr), __builtin_ctz(kShapes[sh].tc),
@@ -1053,6 +1100,13 @@ struct TiledRun {
     }
 
     // measured (1024^2 .. 8192^2): fluvial 1-6 % faster; debris, whose walks are short, 2 % slower
+    // wave-aggregated adds for the losers of a compare-and-swap round (CasDeposit::finish):
+    // from how many losers per wave on, and for how many distinct cells.  Swept at
+    // 1024^2 / 2048^2 / 8192^2 (tools/sweep_agg.sh): 48 / 4 gives 3.7 / 6.5 / 46.2 ms per
+    // step against 3.8 / 7.2 / 46.1 without; from 24 losers on the VALU work it adds
+    // costs the large grids more than the LDS pipe gains (46.9), from 8 on 72 ms.
+    agg_min = env_int("SOIL_TILED_AGG_MIN", 48);
+    agg_groups = env_int("SOIL_TILED_AGG_GROUPS", 4);
     stagger = env_int("SOIL_TILED_STAGGER", KIND == FLUVIAL ? 1 : 2) == 1;
     const int64_t max_tiles = std::max(std::max(tiles_of(shape_early, 0), tiles_of(shape_late, 0)),
                                        std::max(tiles_of(shape_early, 1), tiles_of(shape_late, 1)));
@@ -1190,7 +1244,7 @@ struct TiledRun {
                             reinterpret_cast<float2*>(fluxV), fluxA, static_cast<const float4*>(p4),
                             remote0, steps_run, d, s, p, tiles_w, ts_cur.off_r, ts_cur.off_c,
                             steps_per_round, ts_of(sh_next, round + 1),
-                            tiles_w_of(sh_next, round + 1), chunk_cap);
+                            tiles_w_of(sh_next, round + 1), chunk_cap, agg_min, agg_groups);
     else
       launch_round<KIND, 1>(sh, blocks, st, next, dest, rank, count_next,
                             static_cast<const PRec*>(cur), static_cast<const uint32_t*>(order),
@@ -1199,7 +1253,7 @@ struct TiledRun {
                             reinterpret_cast<float2*>(fluxV), fluxA, static_cast<const float4*>(p4),
                             remote0, steps_run, d, s, p, tiles_w, ts_cur.off_r, ts_cur.off_c,
                             steps_per_round, ts_of(sh_next, round + 1),
-                            tiles_w_of(sh_next, round + 1), chunk_cap);
+                            tiles_w_of(sh_next, round + 1), chunk_cap, agg_min, agg_groups);
     SOIL_LAUNCH_CHECK();
     SOIL_HIP(hipEventRecord(ev1, st));
     timed = true;
