@@ -40,10 +40,11 @@
 // shape; only the order of the fp32 additions into a cell differs.
 //
 // Measured at 8192^2, N = 8.4 M, maxage 256 (ms per launch, fluvial / debris):
-// direct 418 / 115; fields+flux in LDS with ds_add_f32 84 / 36; this file 36 / 14.
-// The round kernel issues VALU instructions on >80 % of all SIMD cycles
-// (profiles/): what is left is the instruction count of the step itself (nine
-// IEEE divisions, a square root and three exponentials per fluvial step).
+// direct 418 / 115; fields+flux in LDS with ds_add_f32 84 / 36; this file 31.7 / 13.1.
+// The round kernel issues VALU instructions on 75-79 % of all SIMD cycles in the
+// rounds that carry the work (profiles/); a fluvial step is ~230 vector instructions,
+// most of them the reference's arithmetic (seven IEEE quotients over four
+// denominators, a square root, three exponentials), see advance() and DESIGN.md 3.2.
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
