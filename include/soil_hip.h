@@ -315,7 +315,7 @@ int soil_particles_pair_slab(const soil_erosion_planes* planes, soil_rng* rng_fl
  * thread n = particle n, 5-point stencil gathers), 2 = staged (packed field
  * plane + tile-ordered particles), 3 = tiled (per-tile particle queues, one
  * gather of pre-digested cell terms per step, flux tiles in LDS).  Auto picks
- * tiled for N >= 32768 (grids up to 2^31 cells), staged for N >= 1024, else direct.  All
+ * tiled for N >= 45000 (grids up to 2^31 cells), staged for N >= 1024, else direct.  All
  * shapes produce the same trajectories and deposits; only the order of the
  * fp32 additions into a cell differs.  For ablation and tests. */
 int soil_set_particle_mode(int mode);
