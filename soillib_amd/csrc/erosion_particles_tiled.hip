@@ -278,10 +278,12 @@ template <int KIND>
 __global__ void __launch_bounds__(256)
     k_tiled_pack(float4* __restrict__ q4, const float2* __restrict__ layers,
                  const float2* __restrict__ velocity, const float* __restrict__ waterHeight,
-                 Dom d, Scale3 s, Param param, int64_t row_lo, int64_t cells) {
-  const int64_t t = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
-  if (t >= cells) return;
-  const int64_t lx = row_lo + t / d.W, y = t % d.W;
+                 Dom d, Scale3 s, Param param, int64_t row_lo, int64_t row_end) {
+  // threads along the row, a work-group walks a band of rows (common.hpp: grid_rows)
+  const int64_t y = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (y >= d.W) return;
+  SOIL_ROW_LOOP(band, row_end - row_lo) {
+  const int64_t lx = row_lo + band;
   const int64_t l = lx * d.W + y;
   const float2 grad = glocal(layers, d, s, d.x0 + lx, y, param.exitSlope);
   const float2 vel = velocity[l];
@@ -299,6 +301,7 @@ __global__ void __launch_bounds__(256)
     const float nu = param.viscosityDebris;
     q4[l] = make_float4(-(g * grad.x) + nu * vel.x, -(g * grad.y) + nu * vel.y,
                         length2(grad.x, grad.y) - param.critSlopeBedrock, 0.0f);
+  }
   }
 }
 
@@ -1165,11 +1168,10 @@ struct TiledRun {
   int begin() {
     if (int rc = setup(); rc != SOIL_OK) return rc;
     const int64_t lo = stencil_lo(d), hi = stencil_hi(d);
-    const int64_t cells = (hi - lo + 1) * d.W;
-    if (cells > 0)
-      k_tiled_pack<KIND><<<blocks_for(cells, 256), 256, 0, st>>>(
+    if (hi >= lo)
+      k_tiled_pack<KIND><<<grid_rows(hi - lo + 1, d.W, 256), 256, 0, st>>>(
           p4, reinterpret_cast<const float2*>(layers), reinterpret_cast<const float2*>(velocity),
-          waterHeight, d, s, p, lo, cells);
+          waterHeight, d, s, p, lo, hi + 1);
     SOIL_HIP(hipMemsetAsync(count, 0, b_cnt, st));
     SOIL_HIP(hipMemsetAsync(steps_run, 0, sizeof(unsigned long long), st));
     k_tiled_spawn<KIND><<<blocks_for(N, 256), 256, 0, st>>>(
