@@ -46,6 +46,7 @@
 // most of them the reference's arithmetic (seven IEEE quotients over four
 // denominators, a square root, three exponentials), see advance() and DESIGN.md 3.2.
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -455,7 +456,7 @@ struct TiledHostWord {  // pinned, device-mapped
   uint32_t blocks;  // work-groups the round needs (entries of the block list)
   unsigned long long steps;
   uint32_t chunk;   // particles of a tile's queue one work-group takes at most
-  uint32_t pad;
+  uint32_t seq;     // written last: the number of the k_queue_prepare launch that filled the word
 };
 
 constexpr int kPanel = 16384;  // tiles per LDS panel of k_queue_prepare
@@ -464,7 +465,15 @@ __global__ void __launch_bounds__(1024)
     k_queue_prepare(uint32_t* __restrict__ start, uint32_t* __restrict__ tile_order,
                     uint2* __restrict__ block_list, const uint4* __restrict__ count4,
                     int64_t tiles, int lanes, int slots,
-                    const unsigned long long* __restrict__ steps_run, TiledHostWord* host) {
+                    const unsigned long long* __restrict__ steps_run, TiledHostWord* host,
+                    uint32_t seq) {
+  // the host spins on host->seq (TiledRun::wait_word): everything it reads is stored, and
+  // fenced out to system scope, before the number
+  auto publish = [&](uint32_t blocks) {
+    host->blocks = blocks;
+    __threadfence_system();
+    __atomic_store_n(&host->seq, seq, __ATOMIC_RELEASE);
+  };
   // Global traffic is coalesced (thread t takes tiles t, t + 1024, ...); the scan wants
   // each thread on a run of consecutive tiles, so the per-tile totals go through LDS.
   __shared__ uint32_t tot[kPanel];
@@ -559,7 +568,7 @@ __global__ void __launch_bounds__(1024)
     if (!cut && t > 0) block_list[pos] = make_uint2(static_cast<uint32_t>(i), 0u);
   }
   if (!cut) {  // the common case on large grids: one work-group per non-empty tile
-    if (tid == 0) host->blocks = static_cast<uint32_t>(tiles) - hist[255];
+    if (tid == 0) publish(static_cast<uint32_t>(tiles) - hist[255]);
     return;
   }
   __syncthreads();
@@ -596,7 +605,7 @@ __global__ void __launch_bounds__(1024)
     if (tid == 1023) carry += part[1023];
     __syncthreads();
   }
-  if (tid == 0) host->blocks = carry;
+  if (tid == 0) publish(carry);
 }
 
 // ---- one round: advance the particles of one tile against LDS ---------------------
@@ -1046,6 +1055,7 @@ struct TiledRun {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   // progress
   uint64_t round = 0;
+  uint32_t* seq_ctr = nullptr;  // number of the last k_queue_prepare launch (TiledHostWord::seq)
   int64_t n_src = 0;
   unsigned long long steps_before = 0;
   bool timed = false, done = false;
@@ -1141,14 +1151,17 @@ struct TiledRun {
     // pinned word + events, one set per (thread, kind)
     static thread_local TiledHostWord *t_host = nullptr, *t_host_dev = nullptr;
     static thread_local hipEvent_t t_ev0 = nullptr, t_ev1 = nullptr;
+    static thread_local uint32_t t_seq = 0;  // numbers the launches that fill t_host, across runs
     if (!t_host) {
       SOIL_HIP(hipHostMalloc(reinterpret_cast<void**>(&t_host), sizeof(TiledHostWord), hipHostMallocMapped));
       SOIL_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&t_host_dev), t_host, 0));
+      t_host->seq = 0;
       SOIL_HIP(hipEventCreate(&t_ev0));
       SOIL_HIP(hipEventCreate(&t_ev1));
     }
     host = t_host;
     host_dev = t_host_dev;
+    seq_ctr = &t_seq;
     ev0 = t_ev0;
     ev1 = t_ev1;
     return SOIL_OK;
@@ -1160,8 +1173,26 @@ struct TiledRun {
     k_queue_prepare<<<1, 1024, 0, st>>>(start, tile_order, block_list,
                                         reinterpret_cast<const uint4*>(count), tiles,
                                         kShapes[shape_of(round)].nt, resident_groups, steps_run,
-                                        host_dev);
+                                        host_dev, ++*seq_ctr);
     SOIL_LAUNCH_CHECK();
+    return SOIL_OK;
+  }
+
+  // Wait for the word of the last queue_scan.  Polling the pinned word sees it a few
+  // microseconds after the kernel stored it; hipStreamSynchronize adds the runtime's
+  // completion handling on top — per round, 25 rounds per step.  Falls back to the
+  // runtime's wait (and its error reporting) when the word does not show up soon.
+  int wait_word() {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t spins = 0;; ++spins) {
+      if (__atomic_load_n(&host->seq, __ATOMIC_ACQUIRE) == *seq_ctr) return SOIL_OK;
+      if ((spins & 1023u) == 1023u &&
+          std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20))
+        break;
+    }
+    SOIL_HIP(hipStreamSynchronize(st));
+    if (__atomic_load_n(&host->seq, __ATOMIC_ACQUIRE) != *seq_ctr)
+      return fail(SOIL_ERR_HIP, "tiled transport: the queue word of the round never arrived");
     return SOIL_OK;
   }
 
@@ -1192,7 +1223,7 @@ struct TiledRun {
 
   int advance() {
     if (done) return SOIL_OK;
-    SOIL_HIP(hipStreamSynchronize(st));
+    if (int rc = wait_word(); rc != SOIL_OK) return rc;
     const uint32_t live = host->live;  // particles queued for this round
     const unsigned blocks = host->blocks;
     const uint32_t chunk_cap = host->chunk;
@@ -1204,7 +1235,12 @@ struct TiledRun {
     double rate = 1e30;  // steps per second of the round just done
     if (timed) {
       float ms = 0.0f;
-      SOIL_HIP(hipEventElapsedTime(&ms, ev0, ev1));
+      // ev1 precedes the kernel whose word just arrived; should the runtime not have
+      // noticed yet, this round simply goes without a rate
+      if (hipEventElapsedTime(&ms, ev0, ev1) != hipSuccess) {
+        (void)hipGetLastError();
+        ms = 0.0f;
+      }
       if (ms > 0.0f) rate = static_cast<double>(steps_now - steps_before) / (ms * 1e-3);
     }
     steps_before = steps_now;
