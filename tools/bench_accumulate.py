@@ -30,6 +30,17 @@ h = soil.noise(silt.shape(S, S), npar, host=silt.gpu)
 silt.multiply(h, 100.0)
 rain = silt.tensor(silt.float32, silt.shape(S, S), silt.gpu)
 silt.set(rain, 1.0)
+if rank == 0:                                        # pit fill of the same DEM (config 3's other half)
+    soil.fill_depressions(h, soil.d8)
+    _abi.check(lib.soil_device_synchronize())
+    t0 = time.perf_counter()
+    filled = soil.fill_depressions(h, soil.d8)
+    _abi.check(lib.soil_device_synchronize())
+    dt = time.perf_counter() - t0
+    a, b = filled.cpu().numpy(), h.cpu().numpy()
+    print("fill_depressions %dx%d D8: %.2f ms; %d cells raised, max %.3f" % (
+        S, S, dt * 1e3, int((a > b).sum()), float((a - b).max())))
+    h = filled
 parallel.multiflow(h, rain, world, 10.0)            # warm-up (allocates the workspaces)
 _abi.check(lib.soil_device_synchronize())
 t0 = time.perf_counter()
