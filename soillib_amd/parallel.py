@@ -9,11 +9,14 @@ step EXACT (same trajectories, same deposits as the single-GPU run; only the
 fp32 summation order of the flux differs) with nearest-neighbour traffic only:
 
   per step                         exchanged with each neighbour
-  1 particles (own spawn rows)     -
-  2 flux halo-accumulate           G rows x 7 floats (5 flux planes) -> added
-  3 fused cell phase, owned rows   (interior rows overlap with 2 on a 2nd stream)
-  4 field halo                     G rows of layers, velocity, waterHeight,
-                                   debrisVelocity -> neighbour's ghost rows
+  1 fluvial particles              -
+  2 debris particles               overlapped: flux halo-accumulate of the fluvial planes
+                                   (G rows x 4 floats -> added by the owner)
+  3 flux halo of the debris planes G rows x 3 floats (exposed)
+  4 cell phase, bands next to the  -
+    neighbours
+  5 cell phase, interior rows      overlapped: field halo — G rows of layers, velocity,
+                                   waterHeight, debrisVelocity -> neighbour's ghost rows
 
 Every rank replays all world*N particle streams (two Philox draws each) and
 traces the ones whose spawn row it owns (soil_particles_*_slab), so the set of
@@ -31,7 +34,9 @@ import ctypes as C
 import os
 
 FIELD_PLANES = ("layers", "velocity", "waterHeight", "debrisVelocity")
-FLUX_PLANES = ("waterFlux", "massFlux", "velocityFlux", "debrisFlux", "debrisVelocityFlux")
+FLUX_FLUVIAL = ("waterFlux", "massFlux", "velocityFlux")      # final after the fluvial launch
+FLUX_DEBRIS = ("debrisFlux", "debrisVelocityFlux")            # final after the debris launch
+FLUX_PLANES = FLUX_FLUVIAL + FLUX_DEBRIS
 PLANE_CHANNELS = {
     "layers": 2, "layers_next": 2, "height": 1, "uplift": 1, "rainfall": 1, "waterHeight": 1,
     "waterFlux": 1, "mass": 1, "massFlux": 1, "velocity": 2, "velocityFlux": 2, "debris": 1,
@@ -255,10 +260,10 @@ class SlabRunner:
             return []
         return dist.batch_isend_irecv(ops_)
 
-    def flux_exchange_start(self):
+    def flux_exchange_start(self, planes=FLUX_PLANES):
         """Ship the flux deposited into my ghost rows to their owners."""
         sends, recvs = [], []
-        for name in FLUX_PLANES:
+        for name in planes:
             t = self.P[name]
             su, sd = self.stage[name]
             if self.up is not None:
@@ -269,10 +274,10 @@ class SlabRunner:
                 recvs.append((sd, self.down))
         return self._exchange(sends, recvs)
 
-    def flux_exchange_finish(self, reqs):
+    def flux_exchange_finish(self, reqs, planes=FLUX_PLANES):
         for r in reqs:
             r.wait()
-        for name in FLUX_PLANES:
+        for name in planes:
             t = self.P[name]
             su, sd = self.stage[name]
             if su is not None:      # the up neighbour's lower ghost rows = my first owned rows
@@ -303,6 +308,7 @@ class SlabRunner:
         ops, P = self.ops, self.P
         ops.seed(self.rng, self.seed, self.step_index * self.N)
         ops.zero(self.remote0)
+        early = ()          # flux planes whose halo is exchanged before the debris launch ends
         if ev: ev.record(0)
         if hasattr(ops, "particles_pair") and not self.serial_particles:
             # the debris launch draws from a tensor of its own, seeded where the fluvial
@@ -315,6 +321,12 @@ class SlabRunner:
             ops.particles_fluvial(P, self.rng, self.N, self.dom, self.scale, self.param,
                                   self.remote0)
             if ev: ev.record(1)
+            if self.world > 1:
+                # the fluvial flux is final: its halo travels, and is added, while the
+                # debris launch runs
+                with ops.fork_comm():
+                    self.flux_exchange_finish(self.flux_exchange_start(FLUX_FLUVIAL), FLUX_FLUVIAL)
+                early = FLUX_FLUVIAL
             ops.particles_debris(P, self.rng, self.N, self.dom, self.scale, self.param,
                                  self.remote0)
         if ev: ev.record(2)
@@ -328,15 +340,20 @@ class SlabRunner:
             # rows whose flux is complete without the neighbours' contribution
             i0 = min(self.r1, self.r0 + (self._peer_ghost(self.up) if self.up is not None else 0))
             i1 = max(i0, self.r1 - (self._peer_ghost(self.down) if self.down is not None else 0))
-            with ops.fork_comm():
-                reqs = self.flux_exchange_start()
-            ops.cells(P, self.dom, i0, i1, self.scale, self.param)      # overlaps the exchange
-            with ops.fork_comm():
-                self.flux_exchange_finish(reqs)
-            ops.join_comm()
+            # 1. the rest of the flux halo (exposed: the bands below need it)
+            late = tuple(n for n in FLUX_PLANES if n not in early)
+            self.flux_exchange_finish(self.flux_exchange_start(late), late)
+            ops.join_comm()                      # ... and the part that travelled early
+            # 2. the bands next to the neighbours first: they are what the neighbours' ghost
+            #    rows get
             ops.cells(P, self.dom, self.r0, i0, self.scale, self.param)
             ops.cells(P, self.dom, i1, self.r1, self.scale, self.param)
-            self.field_exchange("layers_next")
+            # 3. the field halo travels while the interior rows are computed (they are
+            #    G rows away from anything the exchange reads or writes)
+            with ops.fork_comm():
+                self.field_exchange("layers_next")
+            ops.cells(P, self.dom, i0, i1, self.scale, self.param)
+            ops.join_comm()
         if ev: ev.record(3)
         P["layers"], P["layers_next"] = P["layers_next"], P["layers"]
         self.step_index += 1
