@@ -26,20 +26,24 @@ __device__ __forceinline__ bool slab_escape(const Dom& d, int64_t gx) {
   return lx < stencil_lo(d) || lx > stencil_hi(d);
 }
 
-// first two draws of particle n: spawn position (erosion.cu:56-59 / :269-272)
+__device__ __forceinline__ bool owns_spawn(const Dom& d, float px) {
+  const int64_t sx = cell_of(px) - d.x0;
+  return sx >= d.r0 && sx < d.r1;
+}
+// first two draws of particle n: spawn position (erosion.cu:56-59 / :269-272).  The row
+// decides who traces the particle: a slab that does not own it (7 of 8 streams on an
+// 8-GPU run) leaves the second draw out — the stream still moves on by two.
 __device__ __forceinline__ float2 spawn_position(soil_rng* __restrict__ rng, int64_t n,
                                                  const Dom& d) {
   soil_rng st = rng[n];
   const float u1 = rng_uniform_at(st.seed, static_cast<uint64_t>(n), st.offset);
-  const float u2 = rng_uniform_at(st.seed, static_cast<uint64_t>(n), st.offset + 1);
+  const float x = 0.5f + u1 * static_cast<float>(d.H - 1);
+  float y = 0.0f;
+  if (owns_spawn(d, x))
+    y = 0.5f + rng_uniform_at(st.seed, static_cast<uint64_t>(n), st.offset + 1) * static_cast<float>(d.W - 1);
   st.offset += 2;
   rng[n] = st;  // the state persists in the tensor, like curandState
-  return make_float2(0.5f + u1 * static_cast<float>(d.H - 1),
-                     0.5f + u2 * static_cast<float>(d.W - 1));
-}
-__device__ __forceinline__ bool owns_spawn(const Dom& d, float px) {
-  const int64_t sx = cell_of(px) - d.x0;
-  return sx >= d.r0 && sx < d.r1;
+  return make_float2(x, y);
 }
 
 // exclusive scan of per-tile counts, start[tiles] = total (one 1024-thread group;
