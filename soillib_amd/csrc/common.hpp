@@ -63,14 +63,18 @@ int step_counter(unsigned long long** out);
 // consecutive rows in one work-group the rows x-1, x of a 3x3 stencil come out of
 // that CU's L1 instead of being fetched again by a work-group on another XCD.
 constexpr int kRowBand = 16;
+// grid.y is capped at 65535: a work-group of a taller grid (> 1 M rows) walks several bands
 inline dim3 grid_rows(int64_t H, int64_t W, int threads) {
+  const int64_t bands = (H + kRowBand - 1) / kRowBand;
   return dim3(static_cast<unsigned>((W + threads - 1) / threads),
-              static_cast<unsigned>((H + kRowBand - 1) / kRowBand));
+              static_cast<unsigned>(bands < 65535 ? bands : 65535));
 }
-#define SOIL_ROW_LOOP(x, H)                                                        \
-  for (int64_t x = static_cast<int64_t>(blockIdx.y) * ::soil::kRowBand,            \
-               x##_end = (x + ::soil::kRowBand < (H)) ? x + ::soil::kRowBand : (H); \
-       x < x##_end; ++x)
+#define SOIL_ROW_LOOP(x, H)                                                          \
+  for (int64_t x##_band = blockIdx.y; x##_band * ::soil::kRowBand < (H);             \
+       x##_band += gridDim.y)                                                        \
+    for (int64_t x = x##_band * ::soil::kRowBand,                                    \
+                 x##_end = (x + ::soil::kRowBand < (H)) ? x + ::soil::kRowBand : (H); \
+         x < x##_end; ++x)
 
 inline hipStream_t as_stream(void* s) { return static_cast<hipStream_t>(s); }
 inline unsigned blocks_for(int64_t n, int threads) {

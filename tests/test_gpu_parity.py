@@ -805,3 +805,16 @@ def test_transport_fluvial_outside_the_plain_range(hip, oracle, case):
         assert n == steps, "%s: %d steps, oracle %d" % (name, n, steps)
         for k in ("wf", "mf", "vf"):
             _flux_close(flux[k], o[k], "%s %s flux %s" % (case, name, k))
+
+
+def test_row_band_kernels_on_a_very_tall_grid(hip, oracle):
+    """More than 65535 row bands (grid.y's limit): a work-group walks several bands."""
+    from soillib_amd import soil
+    H, W = 16 * 65535 + 123, 3
+    r = np.random.default_rng(4)
+    h = r.standard_normal((H, W)).astype(np.float32)
+    gh = to_gpu(h)
+    s3 = (0.4, 1.7, 3.0)
+    assert_bit_equal(to_np(soil.normal(gh, s3)), oracle.normal(h, s3), "normal on a tall grid")
+    flow = soil.steepest(gh, soil.d8)
+    assert_bit_equal(to_np(flow), oracle.steepest(h, D8), "steepest on a tall grid")
