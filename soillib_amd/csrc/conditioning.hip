@@ -143,7 +143,14 @@ static int fill_impl(float* out, const float* height, int64_t H, int64_t W, hipS
   const size_t ntiles = static_cast<size_t>(tiles_w) * tiles_h, b_dirty = (ntiles + 255) & ~size_t{255};
   void* base = nullptr;
   if (int rc = workspace_get(4, 256 + 2 * b_dirty, &base); rc != SOIL_OK) return rc;
-  int* changed = static_cast<int*>(base);
+  // "some tile moved in this launch": a pinned, device-mapped word the tiles write straight
+  // into (a device-to-host copy is a 25-50 us blit kernel on this stack, per launch)
+  static thread_local int *t_flag = nullptr, *t_flag_dev = nullptr;
+  if (!t_flag) {
+    SOIL_HIP(hipHostMalloc(reinterpret_cast<void**>(&t_flag), sizeof(int), hipHostMallocMapped));
+    SOIL_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&t_flag_dev), t_flag, 0));
+  }
+  int* changed = t_flag_dev;
   unsigned char* dirty_prev = static_cast<unsigned char*>(base) + 256;
   unsigned char* dirty_next = dirty_prev + b_dirty;
   SOIL_HIP(hipMemsetAsync(dirty_prev, 1, ntiles, st));  // first launch: every tile
@@ -153,16 +160,14 @@ static int fill_impl(float* out, const float* height, int64_t H, int64_t W, hipS
   // no terrain reaches, typical counts are a few times the number of tiles per side
   const int64_t max_launches = 4 * (static_cast<int64_t>(tiles_w) + tiles_h) * kFT + 16;
   for (int64_t launch = 0; launch < max_launches; ++launch) {
-    SOIL_HIP(hipMemsetAsync(changed, 0, sizeof(int), st));
+    *t_flag = 0;  // the stream is idle here: the previous launch was waited for
     SOIL_HIP(hipMemsetAsync(dirty_next, 0, ntiles, st));
     k_fill_relax<K><<<static_cast<unsigned>(ntiles), kFBlock, 0, st>>>(
         out, height, H, W, tiles_w, tiles_h, 4 * kFT, changed, dirty_prev, dirty_next);
     std::swap(dirty_prev, dirty_next);
     SOIL_LAUNCH_CHECK();
-    int flag = 0;
-    SOIL_HIP(hipMemcpyAsync(&flag, changed, sizeof(int), hipMemcpyDeviceToHost, st));
     SOIL_HIP(hipStreamSynchronize(st));
-    if (!flag) return SOIL_OK;
+    if (!__atomic_load_n(t_flag, __ATOMIC_ACQUIRE)) return SOIL_OK;
   }
   return fail(SOIL_ERR_HIP, "fill_depressions: did not converge");
 }
