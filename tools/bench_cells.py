@@ -14,6 +14,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--size", type=int, default=8192)
 ap.add_argument("--iters", type=int, default=50)
 ap.add_argument("--skew", type=int, default=0, help="bytes of extra offset per plane")
+ap.add_argument("--arena", action="store_true", help="carve the planes out of big device allocations")
+ap.add_argument("--chunk-mb", type=int, default=16384, help="size of one arena allocation (MiB)")
 args = ap.parse_args()
 lib = _abi.lib()
 S = args.size
@@ -34,7 +36,27 @@ def skew_alloc(dtype, shape):
     return silt.tensor.from_device(raw.ptr + off, dtype, silt.shape(*shape), keepalive=raw)
 
 
-m = ErosionModel(S, S, (20.0 / S, 20.0 / S, 4.0), p, 1024, alloc=skew_alloc if args.skew else None)
+_arena = {"raw": None, "off": 0, "all": []}
+
+
+def arena_alloc(dtype, shape):
+    n = 1
+    for d in shape:
+        n *= d
+    chunk = args.chunk_mb * 1024 * 1024
+    nbytes = (n * dtype.itemsize + 2097151) // 2097152 * 2097152 + args.skew
+    if _arena["raw"] is None or _arena["off"] + nbytes > chunk:
+        _arena["raw"] = silt.tensor(silt.float32, silt.shape(chunk // 4), silt.gpu)
+        _arena["all"].append(_arena["raw"])
+        _arena["off"] = 0
+    off = _arena["off"]
+    _arena["off"] += nbytes
+    return silt.tensor.from_device(_arena["raw"].ptr + off, dtype, silt.shape(*shape),
+                                   keepalive=_arena["raw"])
+
+
+m = ErosionModel(S, S, (20.0 / S, 20.0 / S, 4.0), p, 1024,
+                 alloc=arena_alloc if args.arena else (skew_alloc if args.skew else None))
 npar = soil.noise_t()
 npar.seed = 3.0
 npar.ext = [S, S]
