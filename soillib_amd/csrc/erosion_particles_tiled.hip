@@ -461,6 +461,29 @@ struct TiledHostWord {  // pinned, device-mapped
 
 constexpr int kPanel = 16384;  // tiles per LDS panel of k_queue_prepare
 
+// inclusive prefix sum over the lanes of a wave / the 1024 threads of k_queue_prepare's
+// work-group (two barriers; `wsum`: 16 words of LDS)
+__device__ __forceinline__ uint32_t wave_scan(uint32_t v) {
+  const int lane = static_cast<int>(threadIdx.x & 63u);
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t t = __shfl_up(v, off, 64);
+    if (lane >= off) v += t;
+  }
+  return v;
+}
+__device__ __forceinline__ uint32_t block_scan_1024(uint32_t v, uint32_t* wsum) {
+  const int wave = static_cast<int>(threadIdx.x >> 6), lane = static_cast<int>(threadIdx.x & 63u);
+  v = wave_scan(v);
+  __syncthreads();  // wsum may still be read from the previous call
+  if (lane == 63) wsum[wave] = v;
+  __syncthreads();
+  uint32_t before = 0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) before += (w < wave) ? wsum[w] : 0u;
+  return v + before;
+}
+
 __global__ void __launch_bounds__(1024)
     k_queue_prepare(uint32_t* __restrict__ start, uint32_t* __restrict__ tile_order,
                     uint2* __restrict__ block_list, const uint4* __restrict__ count4,
@@ -479,7 +502,7 @@ __global__ void __launch_bounds__(1024)
   __shared__ uint32_t tot[kPanel];
   __shared__ uint32_t part[1024];
   __shared__ uint32_t hist[256], base[256];
-  __shared__ uint32_t carry, s_batches, s_longest, s_cap;
+  __shared__ uint32_t carry, s_batches, s_longest, s_cap, wsum[16];
   const int tid = threadIdx.x;
   constexpr int kRun = kPanel / 1024;  // consecutive tiles per thread within a panel
   // bucket 255: empty tiles; 254..0: 1-15, 16-31, ... particles (longest first)
@@ -506,15 +529,9 @@ __global__ void __launch_bounds__(1024)
     uint32_t sum = 0;
 #pragma unroll
     for (int j = 0; j < kRun; ++j) sum += tot[tid * kRun + j];
-    part[tid] = sum;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
-      const uint32_t v = (tid >= off) ? part[tid - off] : 0u;
-      __syncthreads();
-      part[tid] += v;
-      __syncthreads();
-    }
-    uint32_t run = carry + part[tid] - sum;
+    const uint32_t incl = block_scan_1024(sum, wsum);
+    if (tid == 1023) part[1023] = incl;  // the panel's total
+    uint32_t run = carry + incl - sum;
 #pragma unroll
     for (int j = 0; j < kRun; ++j) {  // tot[] becomes the exclusive prefix
       const uint32_t t = tot[tid * kRun + j];
@@ -550,12 +567,12 @@ __global__ void __launch_bounds__(1024)
     const uint32_t share = (s_batches + slots - 1) / slots;
     s_cap = (share > 0 ? share : 1u) * static_cast<uint32_t>(lanes);  // chunk capacity
     host->chunk = s_cap;
-    uint32_t r = 0;
-    for (int k = 0; k < 256; ++k) {
-      base[k] = r;
-      r += hist[k];
-    }
     carry = 0;
+  }
+  {  // first slot of every bucket: exclusive scan of the histogram
+    const uint32_t h = tid < 256 ? hist[tid] : 0u;
+    const uint32_t incl = block_scan_1024(h, wsum);
+    if (tid < 256) base[tid] = incl - h;
   }
   __syncthreads();
   const uint32_t chunk_cap = s_cap;
@@ -584,15 +601,9 @@ __global__ void __launch_bounds__(1024)
     uint32_t sum = 0;
 #pragma unroll
     for (int j = 0; j < kRun; ++j) sum += tot[tid * kRun + j];
-    part[tid] = sum;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-      const uint32_t v = (tid >= off) ? part[tid - off] : 0u;
-      __syncthreads();
-      part[tid] += v;
-      __syncthreads();
-    }
-    uint32_t run = carry + part[tid] - sum;
+    const uint32_t incl = block_scan_1024(sum, wsum);
+    if (tid == 1023) part[1023] = incl;  // the panel's total
+    uint32_t run = carry + incl - sum;
 #pragma unroll
     for (int j = 0; j < kRun; ++j) {
       const int i = tid * kRun + j;
