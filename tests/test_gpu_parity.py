@@ -818,3 +818,68 @@ def test_row_band_kernels_on_a_very_tall_grid(hip, oracle):
     assert_bit_equal(to_np(soil.normal(gh, s3)), oracle.normal(h, s3), "normal on a tall grid")
     flow = soil.steepest(gh, soil.d8)
     assert_bit_equal(to_np(flow), oracle.steepest(h, D8), "steepest on a tall grid")
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_transport_random_parameter_sets(hip, oracle, seed):
+    """Fluvial and debris transport on the tiled shape under parameter sets drawn at random
+    (log-uniform over several decades around the script's values, random cell sizes, an
+    external force every other draw) against the oracle: same walks step for step, flux
+    within the summation-order tolerance."""
+    from soillib_amd import soil
+    import ctypes as C
+    from soillib_amd import _abi
+    r = np.random.default_rng(1000 + seed)
+    H, W, N = int(r.integers(70, 140)), int(r.integers(70, 140)), 6000
+    op = script_param(oracle.default_param())
+    op.maxage = int(r.integers(40, 130))
+    lu = lambda lo, hi: float(np.exp(r.uniform(np.log(lo), np.log(hi))))
+    op.gravity = lu(1.0, 30.0)
+    op.evapRate = lu(1e-5, 1e-2)
+    op.viscosityWater = lu(1e-7, 1e-2)
+    op.bedShearWater = lu(0.05, 60.0)
+    op.frictionFactor = lu(0.01, 1.0)
+    op.depositionRateFluvial = lu(1e-7, 1e-2)
+    op.suspensionRateFluvial = lu(1e-5, 1e-2)
+    op.fluvialExponent = lu(0.01, 1.5)
+    op.viscosityDebris = lu(1e-4, 0.1)
+    op.bedShearDebris = lu(1e-3, 1.0)
+    op.yieldStress = lu(1e-3, 1e7)
+    op.critSlopeBedrock = lu(0.02, 0.8)
+    op.landslideRateDebris = lu(1e-4, 1e-1)
+    op.suspensionRateDebris = lu(1e-5, 1e-2)
+    op.depositionRateDebris = lu(1e-5, 1e-2)
+    if seed % 2:
+        op.force[0], op.force[1] = float(r.normal(0, 0.3)), float(r.normal(0, 0.3))
+    pp = product_param(op)
+    scale = (lu(0.01, 3.0), lu(0.01, 3.0), lu(0.5, 8.0))
+    layers = terrain(oracle, H, W, sediment=0.01, rng_seed=seed)
+    rain = (0.5 + r.random((H, W))).astype(np.float32)
+    wh0 = (r.random((H, W)) * lu(1e-3, 1.0)).astype(np.float32)
+    vel0 = (r.standard_normal((H, W, 2)) * lu(0.01, 5.0)).astype(np.float32)
+    z1, z2 = np.zeros((H, W), np.float32), np.zeros((H, W, 2), np.float32)
+    o = dict(wf=z1.copy(), mf=z1.copy(), vf=z2.copy(), df=z1.copy(), dvf=z2.copy())
+    orng = oracle.rng_seed(N, 11, 5 * seed)
+    steps_f = oracle.particles_fluvial(o["wf"], o["mf"], o["vf"], None, orng, layers, rain, wh0, vel0,
+                                       None, scale, op)
+    steps_d = oracle.particles_debris(o["df"], o["dvf"], None, orng, layers, vel0, None, scale, op)
+    assert hip.soil_set_particle_mode(3) == 0
+    try:
+        g = {k: to_gpu(v) for k, v in dict(wf=z1, mf=z1, vf=z2, df=z1, dvf=z2).items()}
+        grng = rng_to_gpu(oracle.rng_seed(N, 11, 5 * seed))
+        lay, gr, gw, gv = to_gpu(layers), to_gpu(rain), to_gpu(wh0), to_gpu(vel0)
+        dom = _abi.Domain(H, W, 0, H, 0, H)
+        soil.particle_steps(reset=True)
+        _abi.check(hip.soil_particles_fluvial_slab(
+            g["wf"].c_ptr, g["mf"].c_ptr, g["vf"].c_ptr, None, grng.c_ptr, N, lay.c_ptr, gr.c_ptr,
+            gw.c_ptr, gv.c_ptr, None, None, C.byref(dom), _abi.vec(scale, 3), pp._ref(), None))
+        got_f = soil.particle_steps(reset=True)
+        _abi.check(hip.soil_particles_debris_slab(
+            g["df"].c_ptr, g["dvf"].c_ptr, None, grng.c_ptr, N, lay.c_ptr, gv.c_ptr, None, None,
+            C.byref(dom), _abi.vec(scale, 3), pp._ref(), None))
+        got_d = soil.particle_steps(reset=True)
+    finally:
+        hip.soil_set_particle_mode(0)
+    assert (got_f, got_d) == (steps_f, steps_d)
+    for k in ("wf", "mf", "vf", "df", "dvf"):
+        _flux_close(to_np(g[k]), o[k], "random parameters, flux " + k)
