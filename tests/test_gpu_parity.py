@@ -883,3 +883,48 @@ def test_transport_random_parameter_sets(hip, oracle, seed):
     assert (got_f, got_d) == (steps_f, steps_d)
     for k in ("wf", "mf", "vf", "df", "dvf"):
         _flux_close(to_np(g[k]), o[k], "random parameters, flux " + k)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_fused_cells_random_parameter_sets_bit_exact(hip, oracle, seed):
+    """The fused cell phase under parameter sets drawn at random (log-uniform over decades,
+    random cell sizes, vector and ragged widths) against the oracle, bit for bit."""
+    from soillib_amd import _abi
+    r = np.random.default_rng(2000 + seed)
+    H, W = int(r.integers(40, 120)), int(r.integers(10, 30)) * 4 + (seed % 2)   # W % 4 == 0 and != 0
+    inp = _cell_inputs(oracle, H, W, seed=seed)
+    op = script_param(oracle.default_param())
+    lu = lambda lo, hi: float(np.exp(r.uniform(np.log(lo), np.log(hi))))
+    op.timeStep = lu(1.0, 1e4)
+    op.lrate = lu(0.01, 2.0)
+    op.gravity = lu(1.0, 30.0)
+    op.uplift = lu(1e-4, 1.0)
+    op.rainfall = lu(0.01, 10.0)
+    op.frictionFactor = lu(0.01, 1.0)
+    op.fluvialExponent = lu(0.01, 1.5)
+    op.suspensionRateFluvial = lu(1e-5, 1e-2)
+    op.depositionRateFluvial = lu(1e-7, 1e-2)
+    op.critSlopeBedrock = lu(0.02, 0.8)
+    op.critSlopeSediment = lu(0.02, 0.8)
+    op.landslideRateDebris = lu(1e-4, 1e-1)
+    op.densityWater = lu(100.0, 2000.0)
+    op.densityDebris = lu(500.0, 4000.0)
+    pp = product_param(op)
+    scale = (lu(0.01, 3.0), lu(0.01, 3.0), lu(0.5, 8.0))
+    want = oracle.erode_cells(inp["layers"], inp["uplift"], inp["rainfall"], inp["waterFlux"],
+                              inp["massFlux"], inp["velocityFlux"], inp["debrisFlux"],
+                              inp["debrisVelocityFlux"], scale, op)
+    g = {k: to_gpu(v) for k, v in inp.items()}
+    out1 = lambda: to_gpu(np.full((H, W), np.nan, np.float32))
+    out2 = lambda: to_gpu(np.full((H, W, 2), np.nan, np.float32))
+    g.update(layers_next=out2(), height=out1(), waterHeight=out1(), mass=out1(), velocity=out2(),
+             debris=out1(), debrisVelocity=out2())
+    planes = _abi.ErosionPlanes()
+    for name in _abi._PLANES:
+        setattr(planes, name, g[name].ptr)
+    dom = _abi.Domain(H, W, 0, H, 0, H)
+    _abi.check(hip.soil_erode_cells_fused(C.byref(planes), C.byref(dom), _abi.vec(scale, 3),
+                                          pp._ref(), None))
+    for name in ("layers_next", "height", "waterHeight", "mass", "velocity", "debris",
+                 "debrisVelocity"):
+        assert_bit_equal(to_np(g[name]), want[name], "fused %s, random parameters" % name)
