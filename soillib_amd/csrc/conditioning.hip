@@ -147,7 +147,7 @@ static int fill_impl(float* out, const float* height, int64_t H, int64_t W, hipS
   // into (a device-to-host copy is a 25-50 us blit kernel on this stack, per launch)
   static thread_local int *t_flag = nullptr, *t_flag_dev = nullptr;
   if (!t_flag) {
-    SOIL_HIP(hipHostMalloc(reinterpret_cast<void**>(&t_flag), sizeof(int), hipHostMallocMapped));
+    SOIL_HIP(hipHostMalloc(reinterpret_cast<void**>(&t_flag), sizeof(int), hipHostMallocMapped | hipHostMallocCoherent));
     SOIL_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&t_flag_dev), t_flag, 0));
   }
   int* changed = t_flag_dev;

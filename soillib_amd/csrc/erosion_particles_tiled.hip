@@ -1164,7 +1164,7 @@ struct TiledRun {
     static thread_local hipEvent_t t_ev0 = nullptr, t_ev1 = nullptr;
     static thread_local uint32_t t_seq = 0;  // numbers the launches that fill t_host, across runs
     if (!t_host) {
-      SOIL_HIP(hipHostMalloc(reinterpret_cast<void**>(&t_host), sizeof(TiledHostWord), hipHostMallocMapped));
+      SOIL_HIP(hipHostMalloc(reinterpret_cast<void**>(&t_host), sizeof(TiledHostWord), hipHostMallocMapped | hipHostMallocCoherent));
       SOIL_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&t_host_dev), t_host, 0));
       t_host->seq = 0;
       SOIL_HIP(hipEventCreate(&t_ev0));
