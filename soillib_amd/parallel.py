@@ -186,16 +186,24 @@ class SlabRunner:
         self.dist = dist
         self.rank = int(os.environ.get("RANK", "0")) if rank is None else int(rank)
         self.world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else int(world)
-        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        # SOIL_DEVICE / SOIL_DIST_BACKEND: which GPU and which torch.distributed backend, when
+        # they are not LOCAL_RANK and RCCL (several ranks sharing one GPU over gloo: tests)
+        local_rank = int(os.environ.get("SOIL_DEVICE", os.environ.get("LOCAL_RANK", "0")))
         if ops is None:
             ops = HipOps(local_rank)
         self.ops = ops
         if comm is None and not dist.is_initialized():
-            backend = "nccl" if isinstance(ops, HipOps) else "gloo"
+            backend = os.environ.get("SOIL_DIST_BACKEND") or (
+                "nccl" if isinstance(ops, HipOps) else "gloo")
             kw = {}
             if backend == "nccl":
                 kw["device_id"] = ops.device
             dist.init_process_group(backend=backend, **kw)
+        # RCCL orders its transfers with the stream they are issued on; gloo moving device
+        # tensors (tests: several ranks on one GPU) does not, so the host waits for the
+        # device before every exchange there
+        self._host_ordered = (comm is None and isinstance(ops, HipOps)
+                              and dist.get_backend() != "nccl")
         self.S, self.W, self.param = int(rows_per_rank), int(W), param
         self.H = self.world * self.S
         self.scale = list(scale) if scale is not None else [20.0 / self.H, 20.0 / self.W, 4.0]
@@ -258,6 +266,8 @@ class SlabRunner:
                [dist.P2POp(dist.irecv, t, peer) for t, peer in recvs]
         if not ops_:
             return []
+        if self._host_ordered:      # see __init__: the backend does not follow the stream
+            self.ops.sync()
         return dist.batch_isend_irecv(ops_)
 
     def flux_exchange_start(self, planes=FLUX_PLANES):

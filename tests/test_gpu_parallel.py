@@ -187,3 +187,47 @@ print("WORLD1_OK")
     res = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True,
                          text=True, timeout=600)
     assert "WORLD1_OK" in res.stdout, res.stdout[-2000:] + res.stderr[-3000:]
+
+
+def test_two_processes_share_one_gpu_over_gloo(hip, oracle, tmp_path):
+    """The sharded step with real process separation: two ranks launched by
+    torch.distributed.run, both on GPU 0, exchanging their halos through the gloo backend.
+    Everything but the wire (RCCL on a real node) is what bench.py --gpus 2 runs."""
+    import os
+    import subprocess
+    import sys
+    from soillib_amd import silt, soil
+    from soillib_amd.erosion import ErosionModel
+    world, S, W, maxage, steps = 2, 96, 128, 24, 3
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SOIL_DEVICE="0", SOIL_DIST_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    res = subprocess.run(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+         "--master-addr", "127.0.0.1", "--master-port", "29631",
+         os.path.join(root, "tests", "parallel_gpu_worker.py"), str(tmp_path), str(S), str(W),
+         str(maxage), str(steps)],
+        cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    parts = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % k)) for k in range(world)]
+    got = {k: np.concatenate([p[k] for p in parts], axis=0) for k in parts[0].files}
+
+    H = world * S
+    pp = script_param(soil.param_t())
+    pp.maxage = maxage
+    m = ErosionModel(H, W, (20.0 / H, 20.0 / W, 4.0), pp, H * W // 8, seed=0)
+    npar = soil.noise_t()
+    npar.seed = 3.0
+    npar.ext = [H, W]
+    bed = soil.noise(silt.shape(H, W), npar, host=silt.gpu)
+    layers0 = np.zeros((H, W, 2), np.float32)
+    layers0[..., 0] = to_np(bed)
+    m.set_layers(to_gpu(layers0))
+    silt.set(m.rainfall, 1.0)
+    for _ in range(steps):
+        m.step()
+    for k in got:
+        want = to_np(getattr(m, k))
+        np.testing.assert_allclose(got[k], want, rtol=1e-4,
+                                   atol=1e-5 * (np.nanmax(np.abs(want)) + 1e-30), err_msg=k)
