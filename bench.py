@@ -149,7 +149,8 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # SOIL_DEVICE: several ranks on one GPU (functional tests of the multi-rank path over gloo)
+    local_rank = int(os.environ.get("SOIL_DEVICE", os.environ.get("LOCAL_RANK", "0")))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
