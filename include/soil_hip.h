@@ -160,7 +160,12 @@ int soil_rng_seed(soil_rng* rng, int64_t n, uint64_t seed, uint64_t offset, void
  *   op 5: out[i] = a[i] / b[i] (the compiler's IEEE division)
  *   op 6: out[i] = quot0(a[i], recip(b[i])), the shared-reciprocal quotient of the
  *                  particle step (soil_math.hpp); equals op 5 on plain operands
- *   op 7: out[i] = expf_flat(a[i]), the branch-free twin of op 0 */
+ *   op 7: out[i] = expf_flat(a[i]), the branch-free twin of op 0
+ *   op 8: out[i] = att_exp(a[i]) = v_exp_f32(a[i] * log2e), the particle attenuations'
+ *                  exponential (the reference's __expf, erosion.cu:134-136,346)
+ *   op 9: bits of out[i] = floor_cell(a[i]): floor as int32, saturating, NaN -> INT_MAX
+ *   op 10: out[i] = sqrt_rn(a[i]), the particle step's square root; equals op 11 (sqrtf) for
+ *                  a[i] >= 2^-96, +0, +inf and NaN */
 int soil_selftest_math(float* out, const float* a, const float* b, int64_t n, int op,
                        void* stream);
 

@@ -47,19 +47,24 @@ def _deps_digest():
     return h.hexdigest()
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, variant=None, extra_flags=()):
+    """variant/extra_flags: a diagnostics build next to the product one, e.g.
+    build(variant="prof", extra_flags=["-DSOIL_PROF"]) -> lib/libsoil_hip_prof.so (load it
+    with SOIL_LIB=...; tools/prof_round.py)."""
     os.makedirs(LIBDIR, exist_ok=True)
     os.makedirs(OBJDIR, exist_ok=True)
-    stamp = os.path.join(LIBDIR, "libsoil_hip.digest")
-    digest = _deps_digest()
+    suffix = "_" + variant if variant else ""
+    LIB = os.path.join(LIBDIR, "libsoil_hip%s.so" % suffix)
+    stamp = os.path.join(LIBDIR, "libsoil_hip%s.digest" % suffix)
+    digest = _deps_digest() + " ".join(extra_flags)
     if not force and os.path.exists(LIB) and os.path.exists(stamp):
         if open(stamp).read().strip() == digest:
             return LIB
     hipcc = _hipcc()
 
     def compile_one(src):
-        obj = os.path.join(OBJDIR, src.replace(".hip", ".o"))
-        cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        obj = os.path.join(OBJDIR, src.replace(".hip", suffix + ".o"))
+        cmd = [hipcc] + FLAGS + list(extra_flags) + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

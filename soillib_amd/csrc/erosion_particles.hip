@@ -170,9 +170,9 @@ __device__ __forceinline__ void trace_fluvial(const Fields& F, const FluvialPlan
     const float decay_m = kd;                                      // :130
     const float decay_w = param.evapRate;                          // :131
     const float decay_v = 0.125f * fD / (eps + P.waterHeight[l]);  // :132
-    att_m = att_m * expf_(-ds * decay_m);                          // :134
-    att_w = att_w * expf_(-ds * decay_w);                          // :135
-    att_v = att_v * expf_(-dL * decay_v);                          // :136
+    att_m = att_m * att_exp(-ds * decay_m);                          // :134
+    att_w = att_w * att_exp(-ds * decay_w);                          // :135
+    att_v = att_v * att_exp(-dL * decay_v);                        // :136
     px += v_step * ux;                                             // :137
     py += v_step * uy;
   }
@@ -280,7 +280,7 @@ __device__ __forceinline__ void trace_debris(const Fields& F, const DebrisPlanes
     const float decay_d = ds * shearRate * excessStress / v_norm;         // :342
     const float decay_v = nu + tau / debrisHeight;                        // :343
     att_d = att_d * expf_(decay_d);                                       // :345
-    att_v = att_v * expf_(-dL * decay_v);                                 // :346
+    att_v = att_v * att_exp(-dL * decay_v);                               // :346
     px += v_step * ux;                                                    // :347
     py += v_step * uy;
   }

@@ -84,6 +84,16 @@ __device__ __forceinline__ int64_t tile_id(int x0, float px, float py, int tiles
   return static_cast<int64_t>((lx + ts.off_r) >> ts.shift_r) * tiles_w + ((cy + ts.off_c) >> ts.shift_c);
 }
 
+// Diagnostics build (-DSOIL_ABLATE): parts of the round kernel switched off by a bit mask (timing
+// experiments only — the results are wrong by construction).  SOIL_ABLATE=<mask> in the environment:
+// 1 no queue sections, 2 no deposits, 4 deposits as plain LDS stores, 8 no gather of the cell record
+#ifdef SOIL_ABLATE
+__device__ int soil_ablate = 0;
+#define ABLATED(bit) ((soil_ablate & (bit)) != 0)
+#else
+#define ABLATED(bit) false
+#endif
+
 // A tile's queue is kept in kNB sections by how long a walker is expected to stay:
 // the steps until it leaves the tile along its present direction (about one cell
 // per step) or runs out of life, against the round's step budget K — >= K, >= K/2,
@@ -107,7 +117,8 @@ __device__ __forceinline__ uint32_t queue_key(int x0, float px, float py, float 
   const float ty = uy > 0.0f ? (y_hi - py) / uy : (uy < 0.0f ? (y_lo - py) / uy : big);
   const float t = fminf(fminf(tx, ty), static_cast<float>(life));
   const float k = static_cast<float>(K);
-  const uint32_t section = t >= k ? 0u : (t >= 0.5f * k ? 1u : (t >= 0.25f * k ? 2u : 3u));
+  uint32_t section = t >= k ? 0u : (t >= 0.5f * k ? 1u : (t >= 0.25f * k ? 2u : 3u));
+  if (ABLATED(1)) section = 0u;
   return static_cast<uint32_t>(trow * tiles_w + tcol) * kNB + section;
 }
 
@@ -169,9 +180,9 @@ __device__ __forceinline__ bool advance_slow(PRec& r, const float4 q, const Step
     r.spx = w0 * r.spx + w1 * ax;
     r.spy = w0 * r.spy + w1 * ay;
     const float decay_v = q.z;  // :132
-    r.a1 = r.a1 * expf_(-ds * k.kd);                     // att_m :134
-    r.a0 = r.a0 * expf_(-ds * k.evap);                   // att_w :135
-    r.a2 = r.a2 * expf_(-dL * decay_v);                  // att_v :136
+    r.a1 = r.a1 * att_exp(-ds * k.kd);                   // att_m :134 (__expf: soil_math.hpp, att_exp)
+    r.a0 = r.a0 * att_exp(-ds * k.evap);                 // att_w :135
+    r.a2 = r.a2 * att_exp(-dL * decay_v);                // att_v :136
   } else {
     const float debrisHeight = k.eps + r.a0 * r.s0;  // :331
     const float ax = q.x;  // :332
@@ -186,7 +197,7 @@ __device__ __forceinline__ bool advance_slow(PRec& r, const float4 q, const Step
     const float decay_d = ds * shearRate * excessStress / v_norm;             // :342
     const float decay_v = k.nu + k.tau / debrisHeight;                        // :343
     r.a0 = r.a0 * expf_(decay_d);                                             // :345
-    r.a1 = r.a1 * expf_(-dL * decay_v);                                       // :346
+    r.a1 = r.a1 * att_exp(-dL * decay_v);                                     // :346 att_v: deposits only
   }
   r.px += v_step * ux;  // :137 / :347
   r.py += v_step * uy;
@@ -209,7 +220,8 @@ __device__ __forceinline__ bool advance_slow(PRec& r, const float4 q, const Step
 // path on top of the fast one (14.9 vs 13.4 ms).
 template <int KIND>
 __device__ __forceinline__ bool advance(PRec& r, const float4 q, const StepConst& k) {
-  const float v_norm = length2(r.spx, r.spy);  // :116 / :321
+  // :116 / :321.  sqrt_rn is sqrtf for everything that is not under eps = 1e-12 anyway
+  const float v_norm = sqrt_rn(r.spx * r.spx + r.spy * r.spy);
   if (v_norm < k.eps) return false;            // eps = 1e-12 > 2^-40: v_norm is plain from below
   if (KIND == DEBRIS) return advance_slow<KIND>(r, q, k, v_norm);
   bool ok = k.plain && v_norm <= kDenHi;
@@ -240,9 +252,9 @@ __device__ __forceinline__ bool advance(PRec& r, const float4 q, const StepConst
   const float w0 = quot(1.0f, rd), w1 = quot0(dL, rd);    // :127
   r.spx = w0 * r.spx + w1 * ax;
   r.spy = w0 * r.spy + w1 * ay;
-  r.a1 = r.a1 * expf_flat(-ds * k.kd);    // att_m :134
-  r.a0 = r.a0 * expf_flat(-ds * k.evap);  // att_w :135
-  r.a2 = r.a2 * expf_flat(-dL * q.z);     // att_v :136
+  r.a1 = r.a1 * att_exp(-ds * k.kd);    // att_m :134
+  r.a0 = r.a0 * att_exp(-ds * k.evap);  // att_w :135
+  r.a2 = r.a2 * att_exp(-dL * q.z);     // att_v :136
   r.px += v_step * ux;                    // :137
   r.py += v_step * uy;
   return true;
@@ -385,23 +397,31 @@ __global__ void __launch_bounds__(256)
 // lanes share their tile most of the time, so this removes ~95 % of the atomics
 // (and their same-address serialisation in L2).  Every lane of the wave must
 // call it; returns the lane's slot (old value + rank among its key group).
+// The groups are worked out first (ballots and lane reads only), then the leaders of
+// all groups issue their atomics in ONE instruction and hand the result to their
+// group: one memory round trip per wave, not one per distinct key (a wave's survivors
+// head for up to a dozen queue sections).
 __device__ __forceinline__ uint32_t wave_key_append(uint32_t* __restrict__ counter, bool valid,
                                                     int64_t key) {
   const int lane = threadIdx.x & 63;
   uint64_t todo = __ballot(valid);
-  uint32_t slot = 0;
+  int my_leader = lane;
+  uint32_t my_rank = 0, my_count = 0;
   while (todo) {
     const int leader = __ffsll(static_cast<long long>(todo)) - 1;
     const int64_t k0 = __shfl(key, leader, 64);
     const uint64_t group = __ballot(valid && key == k0);
-    uint32_t base = 0;
-    if (lane == leader) base = atomicAdd(&counter[k0], static_cast<uint32_t>(__popcll(group)));
-    base = __shfl(base, leader, 64);
-    if (valid && key == k0)
-      slot = base + static_cast<uint32_t>(__popcll(group & ((1ull << lane) - 1ull)));
+    if (valid && key == k0) {
+      my_leader = leader;
+      my_rank = static_cast<uint32_t>(__popcll(group & ((1ull << lane) - 1ull)));
+      my_count = static_cast<uint32_t>(__popcll(group));
+    }
     todo &= ~group;
   }
-  return slot;
+  uint32_t base = 0;
+  if (valid && lane == my_leader) base = atomicAdd(&counter[key], my_count);
+  base = __shfl(base, my_leader, 64);
+  return base + my_rank;
 }
 
 // convergent wave-aggregated slot allocation: every lane calls it
@@ -707,6 +727,26 @@ struct CasDeposit {
   }
 };
 
+// Diagnostics build (-DSOIL_PROF): s_memtime stamps at the seams of an iteration, summed per
+// wave into soil_prof[] (tools/prof_round.py reads them).  Not part of the product build.
+#ifdef SOIL_PROF
+__device__ unsigned long long soil_prof[2][16];
+#define PROF_DECL unsigned long long pt_last = __builtin_readcyclecounter(), pt_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned pt_iters = 0
+#define PROF_AT(i) { const unsigned long long pt_now = __builtin_readcyclecounter(); pt_acc[i] += pt_now - pt_last; pt_last = pt_now; }
+#define PROF_FLUSH(kind) { PROF_AT(9); __shared__ unsigned long long pt_sh[12]; if (threadIdx.x < 12) pt_sh[threadIdx.x] = 0; __syncthreads(); \
+    if ((threadIdx.x & 63u) == 0) { for (int i = 0; i < 10; ++i) atomicAdd(&pt_sh[i], pt_acc[i]); atomicAdd(&pt_sh[10], static_cast<unsigned long long>(pt_iters)); atomicAdd(&pt_sh[11], 1ull); } \
+    __syncthreads(); if (threadIdx.x < 12) atomicAdd(&soil_prof[kind][(threadIdx.x + blockIdx.x) % 12], pt_sh[(threadIdx.x + blockIdx.x) % 12]); }
+extern "C" int soil_prof_read(unsigned long long* out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(soil_prof), sizeof(unsigned long long) * 32) != hipSuccess) return 1;
+  if (reset) { unsigned long long z[32] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(soil_prof), z, sizeof(z)) != hipSuccess) return 1; }
+  return 0;
+}
+#else
+#define PROF_DECL
+#define PROF_AT(i)
+#define PROF_FLUSH(kind)
+#endif
+
 template <int KIND, int DEP, int TR, int TC, int NT, bool ALB>
 __global__ void __launch_bounds__(NT)
     k_tiled_round(PRec* __restrict__ out, uint32_t* __restrict__ dest, uint32_t* __restrict__ rank,
@@ -720,6 +760,7 @@ __global__ void __launch_bounds__(NT)
                   TileShape ts_next,
                   int tiles_w_next, uint32_t chunk_cap, int agg_min, int agg_groups) {
   constexpr int kCells = TR * TC, kBlock = NT, kPer = (kCells + NT - 1) / NT;
+  PROF_DECL;
   // this work-group's share of its tile's queue (k_queue_prepare's block list)
   const uint2 job = block_list[blockIdx.x];
   const int tile = static_cast<int>(job.x);
@@ -741,11 +782,18 @@ __global__ void __launch_bounds__(NT)
   __shared__ uint32_t s_next, s_out, s_steps;
   const int tid = threadIdx.x;
   if (tid == 0) {
-    s_next = 0;
+    s_next = kBlock;  // the first kBlock queue entries go to the lanes directly, see below
     s_out = 0;
     s_steps = 0;
   }
   const StepConst k = make_const<KIND>(d, s, param);
+  // Lane t starts on queue entry t — no counter involved, and the record's two dependent
+  // loads (slot index, then the 64-byte record) travel while the flux tile is zeroed.
+  // Only a queue longer than the work-group is handed out through s_next.
+  PRec r;
+  r.iter = -1;
+  bool have = static_cast<uint32_t>(tid) < cnt;
+  if (have) r = in[order[first + tid]];
 #pragma unroll
   for (int j = 0; j < kPer; ++j) {
     const int c = tid + j * kBlock;
@@ -758,13 +806,25 @@ __global__ void __launch_bounds__(NT)
   }
   __syncthreads();
 
+  // Cells of this tile a particle may take a step on: the tile, cut down to the rows whose
+  // stencil this slab holds (the whole grid on a single device) and to the grid's columns.
+  // One unsigned comparison per axis then answers "out of the grid?", "escaped the slab?"
+  // and "on another tile?" at once for a walker that carries on — the usual case; what
+  // exactly ended a walk is sorted out once, when it ends.
+  int r_lo = row0 > k.lo ? row0 : k.lo, r_hi = row0 + TR - 1 < k.hi ? row0 + TR - 1 : k.hi;
+  int c_lo = col0 > 0 ? col0 : 0, c_hi = col0 + TC - 1 < k.W - 1 ? col0 + TC - 1 : k.W - 1;
+  if (r_hi < r_lo || c_hi < c_lo) r_lo = r_hi = c_lo = c_hi = 0x40000000;  // nothing to step on
+  const uint32_t r_span = static_cast<uint32_t>(r_hi - r_lo), c_span = static_cast<uint32_t>(c_hi - c_lo);
+  const int row_org = k.x0 + r_lo;                // global row of local row r_lo
+  const int c_org = (r_lo - row0) * TC + (c_lo - col0);  // LDS cell of (r_lo, c_lo)
+  const uint32_t l_org = static_cast<uint32_t>(r_lo) * k.Wu + static_cast<uint32_t>(c_lo);  // its local cell index
+  const int last_iter = static_cast<int>(k.maxage) - 1;  // `++iter < maxage` passes while iter < maxage - 1
+
   // A lane that has to park its particle keeps the record in registers and idles;
   // the record is written out only when the lane takes another particle or the
   // loop is over: a tile starts a round with about one particle per lane, so
   // refills are the exception.
-  bool have = false, drained = false, parked = false;
-  PRec r;
-  r.iter = -1;
+  bool drained = cnt <= static_cast<uint32_t>(kBlock), parked = false;
   auto write_out = [&]() {
     const uint32_t slot = atomicAdd(&s_out, 1u);  // slots this tile's queue occupied
     const uint32_t to = queue_key(k.x0, r.px, r.py, r.spx, r.spy, k.maxage - static_cast<uint32_t>(r.iter),
@@ -774,61 +834,81 @@ __global__ void __launch_bounds__(NT)
     rank[first + slot] = atomicAdd(&count_next[to], 1u);
     parked = false;
   };
-  int budget = 0;  // steps this lane may still spend on its particle in this round
+  // r.iter may grow up to `limit` in this round: the round's step budget, or the particle's age
+  int limit = r.iter + steps_per_round < last_iter ? r.iter + steps_per_round : last_iter;
   uint32_t nsteps = 0;
+  PROF_AT(8);  // prologue: flux tile zeroed, first records loaded
   for (;;) {
+    PROF_AT(0);  // end of the previous iteration's tail
     if (!have && !drained) {  // take the next particle of this tile's queue
       const uint32_t i = atomicAdd(&s_next, 1u);
       if (i < cnt) {
         if (parked) write_out();
         r = in[order[first + i]];
         have = true;
-        budget = steps_per_round;
+        limit = r.iter + steps_per_round < last_iter ? r.iter + steps_per_round : last_iter;
       } else {
         drained = true;
       }
     }
     if (!__any(have)) break;
+    PROF_AT(1);  // refill
+#ifdef SOIL_PROF
+    ++pt_iters;
+#endif
 
     // top of the reference loop: while(!__oob(pos) && ++iter < maxage)  (:100 / :306),
-    // then the slab check.  The outcome is worked out as flags first, so that the
-    // particle state is only written inside the one `if (step)` region below (a
-    // chain of nested branches costs a register copy of the record per level).
+    // then the slab check, then "still on my tile, still within the round's budget?"
     bool step = false;
-    int lx = 0, cy = 0, c = 0, cx = 0;
+    uint32_t dr = 0, dc = 0;  // row, column counted from (r_lo, c_lo)
     if (have) {
-      const bool oob = r.px < 0 || r.py < 0 || r.px >= k.Hf || r.py >= k.Wf;  // erosion_map.cu:29-40
-      cx = cell32(r.px);
-      cy = cell32(r.py);
-      lx = cx - k.x0;
-      const bool esc = lx < k.lo || lx > k.hi;  // slab_escape
-      const int tr = lx - row0, tc = cy - col0;
-      c = tr * TC + tc;
-      const bool inside =
-          esc || (static_cast<unsigned>(tr) < TR && static_cast<unsigned>(tc) < TC);
-      // the particle stands on another tile, or its round budget is used up:
-      // park it (state untouched) and resume next round
-      const bool park = !oob && (!inside || budget == 0);
-      const bool aged = static_cast<uint32_t>(r.iter + 1) >= k.maxage;
-      step = !oob && !park && !aged && !esc;
-      if (!oob && !park && !aged && esc) park_remote<KIND>(r, remote0);
-      parked = parked || park;
-      have = step;
+      int ix = floor_cell(r.px), iy = floor_cell(r.py);
+      dr = static_cast<uint32_t>(ix - row_org);
+      dc = static_cast<uint32_t>(iy - c_lo);
+      step = dr <= r_span && dc <= c_span && r.iter < limit;
+      if (!step) {  // once per particle and round: what stopped it?
+        // ... unless it is a NaN walker (reference quirks): a NaN coordinate
+        // stands for cell 0 and is never out of bounds; floor_cell made it INT_MAX
+        if (r.px != r.px || r.py != r.py) {
+          ix = nan_cell(r.px, ix);
+          iy = nan_cell(r.py, iy);
+          dr = static_cast<uint32_t>(ix - row_org);
+          dc = static_cast<uint32_t>(iy - c_lo);
+          step = dr <= r_span && dc <= c_span && r.iter < limit;
+        }
+      }
+      if (!step) {
+        have = false;
+        // erosion_map.cu:29-40 on the floored coordinates (floor_cell, soil_math.hpp)
+        const bool oob = static_cast<uint32_t>(ix) >= static_cast<uint32_t>(d.H) ||
+                         static_cast<uint32_t>(iy) >= k.Wu;
+        const int lx = ix - k.x0;
+        const bool esc = lx < k.lo || lx > k.hi;  // slab_escape
+        const bool aged = r.iter >= last_iter;
+        // in the grid and with life left: its walk continues elsewhere — on another
+        // rank (only a NaN walker's deposit travels, park_remote) or, state untouched,
+        // in this slab's next round
+        if (!oob && !aged) {
+          if (esc) park_remote<KIND>(r, remote0);
+          else parked = true;
+        }
+      }
     }
+    PROF_AT(2);  // head
     constexpr int kFluxPlanes = (KIND == FLUVIAL) ? 4 : 3;
     CasDeposit<kFluxPlanes + (ALB ? 3 : 0)> dep;
+    const int c = c_org + static_cast<int>(dr) * TC + static_cast<int>(dc);  // LDS cell (any value when idle)
     if (step) {
       ++r.iter;
-      --budget;
       ++nsteps;
       // the cell's record comes from the packed plane through L1/L2 (the tile's
       // 64 KiB are touched ~4x per round); issued first, the gather's latency
       // hides under the deposit and the other waves of the SIMD
       // rows, W < 2^24 and H*W < 2^31 (use_tiled): one v_mad_u32_u24 per index
-      const uint32_t lcell = __umul24(static_cast<uint32_t>(lx), k.Wu) + static_cast<uint32_t>(cy);
-      const float4 q = p4[lcell];
+      const uint32_t lcell = l_org + __umul24(dr, k.Wu) + dc;
+      const float4 q = p4[ABLATED(8) ? l_org : lcell];
       const uint32_t nind = lcell + k.base;  // global cell: cx * W + cy, :103 / :309
-      if (nind != r.ind) {                   // :104-113 / :310-318
+      if (nind != r.ind && !ABLATED(2)) {    // :104-113 / :310-318
         r.ind = nind;
         // DEP 0: native ds_add_f32, fire and forget; DEP 1: CasDeposit
         float v[kFluxPlanes + 3];
@@ -847,18 +927,23 @@ __global__ void __launch_bounds__(NT)
         }
 #pragma unroll
         for (int j = 0; j < kFluxPlanes + (ALB ? 3 : 0); ++j) {
-          if (DEP == 1) {
+          if (ABLATED(4)) {
+            *p[j] = v[j];
+          } else if (DEP == 1) {
             dep.p[j] = p[j];
             dep.v[j] = v[j];
           } else {
             atomicAdd(p[j], v[j]);
           }
         }
-        if (DEP == 1) dep.begin();
+        if (DEP == 1 && !ABLATED(4)) dep.begin();
       }
+      PROF_AT(3);  // gather issued, deposit begun
       have = advance<KIND>(r, q, k);
+      PROF_AT(4);  // the step's arithmetic
     }
     if (DEP == 1) dep.finish(c, agg_min, agg_groups);
+    PROF_AT(5);  // deposit finished
   }
   {  // everything still parked goes out together (convergent: aggregate the counters)
     const uint32_t slot = wave_append(&s_out, parked);
@@ -874,7 +959,9 @@ __global__ void __launch_bounds__(NT)
     }
   }
   atomicAdd(&s_steps, nsteps);
+  PROF_AT(6);  // survivors written out
   __syncthreads();
+  PROF_AT(7);  // waiting for the slowest wave of the work-group
   if (tid == 0) atomicAdd(steps, static_cast<unsigned long long>(s_steps));
   for (uint32_t j = s_out + tid; j < cnt; j += kBlock) dest[first + j] = kNoTile;  // unused slots
 
@@ -939,6 +1026,7 @@ __global__ void __launch_bounds__(NT)
       }
     }
   }
+  PROF_FLUSH(KIND);  // [9]: flush of the tile's flux
 }
 
 // ---- the last launch: walk the remaining particles to the end against HBM ----------
@@ -1117,6 +1205,12 @@ struct TiledRun {
     // The rate of the round just done (step counter / HIP event time) decides.
     finish_rate = env_int("SOIL_TILED_FINISH_MRATE", 4000) * 1e6;
     verbose = std::getenv("SOIL_TILED_VERBOSE") != nullptr;
+#ifdef SOIL_ABLATE
+    {
+      const int mask = std::getenv("SOIL_ABLATE") ? std::atoi(std::getenv("SOIL_ABLATE")) : 0;
+      SOIL_HIP(hipMemcpyToSymbol(HIP_SYMBOL(soil_ablate), &mask, sizeof(int)));
+    }
+#endif
     {  // LDS decides: 64 KiB (fluvial) / 48 KiB (debris) of accumulators per 64x64 tile
       int dev = 0, cus = 256;
       SOIL_HIP(hipGetDevice(&dev));

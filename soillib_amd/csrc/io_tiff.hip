@@ -16,6 +16,8 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <exception>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -89,26 +91,33 @@ int open_file(const char* filename, File& f) {
   const uint16_t magic = f.u16(b + 2);
   SOIL_REQUIRE_IO(magic == 42 || magic == 43, "tiff: bad magic number");
   f.bigtiff = magic == 43;
-  uint64_t ifd = f.bigtiff ? f.u64(b + 8) : f.u32(b + 4);
-  const size_t n = f.bytes.size();
-  SOIL_REQUIRE_IO(ifd + (f.bigtiff ? 8 : 2) <= n, "tiff: IFD offset outside the file");
+  const uint64_t ifd = f.bigtiff ? f.u64(b + 8) : f.u32(b + 4);
+  const uint64_t n = f.bytes.size();
+  // Every bound below is written so that it cannot wrap: offsets and counts come straight
+  // from the file (libtiff rejects such headers with an error; so does this).
+  const uint64_t esz = f.bigtiff ? 20 : 12, head = f.bigtiff ? 8 : 2;
+  SOIL_REQUIRE_IO(f.bigtiff ? n >= 16 : true, "tiff: short BigTIFF header");
+  SOIL_REQUIRE_IO(ifd <= n && head <= n - ifd, "tiff: IFD offset outside the file");
   const uint64_t count = f.bigtiff ? f.u64(b + ifd) : f.u16(b + ifd);
-  const size_t esz = f.bigtiff ? 20 : 12, head = f.bigtiff ? 8 : 2;
-  SOIL_REQUIRE_IO(ifd + head + count * esz <= n, "tiff: IFD runs past the end of the file");
+  SOIL_REQUIRE_IO(count <= (n - ifd - head) / esz, "tiff: IFD runs past the end of the file");
   for (uint64_t i = 0; i < count; ++i) {
     const uint8_t* e = b + ifd + head + i * esz;
     Entry en;
     en.tag = f.u16(e);
     en.type = f.u16(e + 2);
     en.count = f.bigtiff ? f.u64(e + 4) : f.u32(e + 4);
-    const size_t bytes = type_size(en.type) * en.count;
-    const size_t inl = f.bigtiff ? 8 : 4;
+    const uint64_t tsz = type_size(en.type);
+    // an unknown field type or a count the file cannot hold: the tag is skipped, like
+    // libtiff warns and goes on (a payload is never larger than the file it sits in)
+    if (tsz == 0 || en.count > n / tsz) continue;
+    const uint64_t bytes = tsz * en.count;
+    const uint64_t inl = f.bigtiff ? 8 : 4;
     const uint8_t* v = e + (f.bigtiff ? 12 : 8);
     if (bytes <= inl) {
       en.data = v;
     } else {
       const uint64_t off = f.bigtiff ? f.u64(v) : f.u32(v);
-      if (off + bytes > n) continue;  // a damaged tag is skipped, like libtiff warns and goes on
+      if (off > n || bytes > n - off) continue;  // a damaged tag is skipped as well
       en.data = b + off;
     }
     f.entries.push_back(en);
@@ -410,6 +419,7 @@ int decode_image(const File& f, const Layout& L, D* dst) {
     }
   } else {
     SOIL_REQUIRE_IO(L.tw > 0 && L.th > 0, "tiff: tiled image without tile size");
+    SOIL_REQUIRE_IO(static_cast<uint64_t>(L.tw) * L.th * bps <= (1ull << 30), "tiff: unreasonable tile size");
     const size_t nx = (L.width + L.tw - 1) / L.tw, ny = (L.height + L.th - 1) / L.th;
     const size_t tile_row = static_cast<size_t>(L.tw) * bps;
     for (size_t ty = 0; ty < ny; ++ty)
@@ -451,6 +461,22 @@ OutTag tag_int(uint16_t tag, uint16_t type, uint64_t value) {
   return t;
 }
 
+// No exception crosses the C boundary: a damaged file that drives an allocation or a
+// container past its limits ends as SOIL_ERR_IO with a message, like libtiff's error return.
+template <typename F>
+int guarded(const char* what, F&& body) noexcept {
+  try {
+    return body();
+  } catch (const std::bad_alloc&) {
+    set_error(std::string(what) + ": out of memory (damaged file?)");
+  } catch (const std::exception& e) {
+    set_error(std::string(what) + ": " + e.what());
+  } catch (...) {
+    set_error(std::string(what) + ": unknown failure");
+  }
+  return SOIL_ERR_IO;
+}
+
 }  // namespace
 }  // namespace soil
 
@@ -459,6 +485,7 @@ using namespace soil;
 extern "C" {
 
 int soil_tiff_peek(const char* filename, soil_tiff_info* info) {
+  return guarded("soil_tiff_peek", [&]() -> int {
   SOIL_REQUIRE(info != nullptr, "soil_tiff_peek: null info");
   File f;
   if (int rc = open_file(filename, f); rc != SOIL_OK) return rc;
@@ -487,10 +514,12 @@ int soil_tiff_peek(const char* filename, soil_tiff_info* info) {
   info->n_metadata = count_of(SOIL_TIFFTAG_GDAL_METADATA);
   info->n_nodata = count_of(SOIL_TIFFTAG_GDAL_NODATA);
   return SOIL_OK;
+  });
 }
 
 int soil_tiff_tag(const char* filename, int tag, void* dst, uint64_t capacity_bytes,
                   uint64_t* written_bytes) {
+  return guarded("soil_tiff_tag", [&]() -> int {
   SOIL_REQUIRE(dst != nullptr && written_bytes != nullptr, "soil_tiff_tag: null output");
   File f;
   if (int rc = open_file(filename, f); rc != SOIL_OK) return rc;
@@ -513,9 +542,11 @@ int soil_tiff_tag(const char* filename, int tag, void* dst, uint64_t capacity_by
     *written_bytes = e->count * type_size(e->type);
   }
   return SOIL_OK;
+  });
 }
 
 int soil_tiff_read(const char* filename, void* dst, uint64_t dst_bytes) {
+  return guarded("soil_tiff_read", [&]() -> int {
   SOIL_REQUIRE(dst != nullptr, "soil_tiff_read: null destination");
   File f;
   if (int rc = open_file(filename, f); rc != SOIL_OK) return rc;
@@ -525,6 +556,7 @@ int soil_tiff_read(const char* filename, void* dst, uint64_t dst_bytes) {
   SOIL_REQUIRE_IO(L.bits == 8 || L.bits == 16 || L.bits == 32 || L.bits == 64, "tiff: unsupported BitsPerSample");
   SOIL_REQUIRE_IO(L.format >= 1 && L.format <= 3, "tiff: unsupported SampleFormat");
   SOIL_REQUIRE_IO(L.predictor >= 1 && L.predictor <= 3, "tiff: unsupported Predictor");
+  SOIL_REQUIRE_IO(L.width > 0 && L.height > 0, "tiff: empty image");
   SOIL_REQUIRE_IO(L.compression == 1 || L.compression == 5 || L.compression == 8 ||
                       L.compression == 32946 || L.compression == 32773,
                   "tiff: unsupported Compression (none, LZW, Deflate and PackBits are)");
@@ -532,10 +564,12 @@ int soil_tiff_read(const char* filename, void* dst, uint64_t dst_bytes) {
   const uint64_t need = static_cast<uint64_t>(L.width) * L.height * (wide ? 8 : 4);
   SOIL_REQUIRE(dst_bytes >= need, "soil_tiff_read: destination too small");
   return wide ? decode_image(f, L, static_cast<double*>(dst)) : decode_image(f, L, static_cast<float*>(dst));
+  });
 }
 
 int soil_tiff_write(const char* filename, const void* data, uint32_t width, uint32_t height,
                     uint32_t bits, const soil_geotiff_tags* geo) {
+  return guarded("soil_tiff_write", [&]() -> int {
   SOIL_REQUIRE(filename != nullptr && data != nullptr, "soil_tiff_write: null argument");
   SOIL_REQUIRE(bits == 32 || bits == 64, "soil_tiff_write: bits must be 32 or 64 (IEEE float)");
   SOIL_REQUIRE(width > 0 && height > 0, "soil_tiff_write: empty image");
@@ -654,6 +688,7 @@ int soil_tiff_write(const char* filename, const void* data, uint32_t width, uint
     return SOIL_ERR_IO;
   }
   return SOIL_OK;
+  });
 }
 
 }  // extern "C"

@@ -176,6 +176,10 @@ __global__ void k_selftest_math(float* __restrict__ out, const float* __restrict
     case 5: r = a[i] / b[i]; break;
     case 6: r = quot0(a[i], recip(b[i])); break;
     case 7: r = expf_flat(a[i]); break;
+    case 8: r = att_exp(a[i]); break;
+    case 9: r = bits2f(static_cast<uint32_t>(floor_cell(a[i]))); break;
+    case 10: r = sqrt_rn(a[i]); break;
+    case 11: r = sqrtf(a[i]); break;
     default: r = a[i] * b[i]; break;
   }
   out[i] = r;
@@ -342,7 +346,7 @@ int soil_selftest_math(float* out, const float* a, const float* b, int64_t n, in
                        void* stream) {
   SOIL_DEVICE();
   SOIL_REQUIRE(out && a && b, "selftest_math: null argument");
-  SOIL_REQUIRE(op >= 0 && op <= 7, "selftest_math: unknown op");
+  SOIL_REQUIRE(op >= 0 && op <= 11, "selftest_math: unknown op");
   if (n <= 0) return SOIL_OK;
   k_selftest_math<<<blocks_for(n, 256), 256, 0, as_stream(stream)>>>(out, a, b, n, op);
   SOIL_LAUNCH_CHECK();

@@ -150,6 +150,46 @@ __device__ __forceinline__ bool plain_den(float b) { return fabsf(b) >= kDenLo &
 // +0 or of plain magnitude (the caller bounds it from above)
 __device__ __forceinline__ bool plain_num(float a) { return f2bits(a) == 0u || fabsf(a) >= kNumLo; }
 
+
+// ---- device-only helpers of the particle step ----------------------------------------------
+
+// The attenuation factors of a particle (att_m, att_w, att_v: erosion.cu:134-136; debris att_v :346)
+// are __expf in the reference — the hardware's fast exponential, ex2.approx(x * log2e).  They only
+// scale what a particle deposits and never feed back into where it goes, so they take gfx950's
+// counterpart here: v_exp_f32(x * log2e), 1 ulp, two instructions instead of the ~22 of expf_.
+// (Debris' att_d, :345, does feed back into the speed; it stays on expf_ so that trajectories remain
+// bit-identical to the oracle's.)  Parity of the flux planes is a tolerance either way: fp32
+// summation order (tests/test_gpu_parity.py, _flux_close).
+__device__ __forceinline__ float att_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504f); }
+
+// floor(f) as an integer in one instruction (v_cvt_flr_i32_f32), saturating at the int32 range
+// — for a position inside the grid the same cell as the reference's float -> int truncation
+// (erosion_map.cu:42-47), and for one outside of it an index an unsigned comparison against the grid
+// size rejects (px in (-1, 0) floors to -1; -0.0 to 0, which `px < 0` lets pass as well).  A NaN
+// comes out as INT_MAX (measured; CUDA's conversion, which the reference relies on, gives 0): the
+// caller has to look at NaN positions itself, nan_cell() below.
+__device__ __forceinline__ int floor_cell(float f) {
+  int r;
+  asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(f));
+  return r;
+}
+__device__ __forceinline__ int nan_cell(float f, int cell) { return (f != f) ? 0 : cell; }
+
+// Correctly rounded square root for x >= 2^-96 (and +0, +inf, NaN): the compiler's own expansion of
+// sqrtf — v_sqrt_f32 (1 ulp), then the neighbours one ulp down and up are tried against the exact
+// residual x - y'*y — without its pre-scaling of arguments below 2^-96 and without the class test that
+// hands zero and infinity through (the residual tests leave those alone by themselves: they compare
+// false on NaN).  Below 2^-96 the result is merely close; the particle step only asks whether it is
+// under eps = 1e-12 there.
+__device__ __forceinline__ float sqrt_rn(float x) {
+  const float y = __builtin_amdgcn_sqrtf(x);
+  const float dn = bits2f(f2bits(y) - 1u), up = bits2f(f2bits(y) + 1u);
+  const float r_dn = __builtin_fmaf(-dn, y, x), r_up = __builtin_fmaf(-up, y, x);
+  float s = (r_dn <= 0.0f) ? dn : y;
+  s = (r_up > 0.0f) ? up : s;
+  return s;
+}
+
 // Philox4x32-10 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as
 // easy as 1, 2, 3", SC'11).  Only word 0 of the block is consumed per draw.
 SOIL_HD uint32_t philox4x32_10_w0(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,

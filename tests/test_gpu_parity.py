@@ -54,6 +54,41 @@ def test_spec_math_bit_exact(hip, oracle):
     assert_bit_equal(_selftest(hip, a, b, 2), oracle.powf(a, b), "powf_")
 
 
+def test_particle_step_primitives(hip):
+    """att_exp, floor_cell and sqrt_rn (soil_math.hpp), the three hardware-near pieces of the
+    particle step, against what they stand for."""
+    r = np.random.default_rng(3)
+    # att_exp: the reference's __expf; only ever sees arguments <= 0 of modest size
+    x = np.concatenate([-np.exp(r.uniform(-30, 4, 200000)), [0.0, -0.0, -87.0, -100.0, -1e30, np.nan]]
+                       ).astype(np.float32)
+    got = _selftest(hip, x, x, 8).astype(np.float64)
+    want = np.exp(x.astype(np.float64))
+    ok = np.isfinite(want) & (want > 1e-37)
+    # v_exp_f32 is good to 1 ulp; the product x * log2e carries half an ulp of |x| log2e into the
+    # exponent, i.e. |x| 2^-24 into the result (the same holds for CUDA's __expf)
+    err = np.abs(got[ok] / want[ok] - 1.0)
+    assert (err <= 2.0 ** -22 + np.abs(x[ok].astype(np.float64)) * 1.5 * 2.0 ** -24).all()
+    assert err[np.abs(x[ok]) < 1].max() < 2.0 ** -22               # where the attenuations live
+    assert (got[~ok & ~np.isnan(want)] < 2e-37).all() and np.isnan(got[-1])
+    # floor_cell: floor as int32, saturating, NaN -> INT_MAX (the kernels catch NaN themselves)
+    f = np.concatenate([r.uniform(-5, 70000, 200000), [0.0, -0.0, -0.25, -1.0, -1.5, 8191.999, 8192.0,
+                        16777215.0, 3e9, -3e9, np.inf, -np.inf, np.nan, 1e-45, -1e-45]]).astype(np.float32)
+    got = _selftest(hip, f, f, 9).view(np.int32)
+    want = np.floor(np.nan_to_num(f.astype(np.float64), nan=2.0 ** 31 - 1, posinf=2.0 ** 31 - 1,
+                                  neginf=-2.0 ** 31))
+    want = np.clip(want, -2.0 ** 31, 2.0 ** 31 - 1).astype(np.int64)
+    assert (got.astype(np.int64) == want).all()
+    # sqrt_rn: correctly rounded from 2^-96 up, and on +0, +inf, NaN
+    e = r.integers(127 - 96, 255, 1 << 20).astype(np.uint32)
+    m = r.integers(0, 1 << 23, 1 << 20, dtype=np.uint32)
+    v = np.concatenate([((e << 23) | m).view(np.float32),
+                        np.array([0.0, np.inf, np.nan, 2.0 ** -96, 1.0, 4.0, 2.0, 3.0], np.float32)])
+    assert_bit_equal(_selftest(hip, v, v, 10), np.sqrt(v), "sqrt_rn vs numpy")
+    assert_bit_equal(_selftest(hip, v, v, 11), np.sqrt(v), "device sqrtf vs numpy")
+    tiny = (r.uniform(0, 1, 1000) * 2.0 ** -100).astype(np.float32)
+    assert (_selftest(hip, tiny, tiny, 10) < 1e-12).all()          # all the step asks below 2^-96
+
+
 def test_denormals_are_not_flushed(hip):
     a = np.array([1e-30, 3e-39, 1.5e-38], np.float32)
     b = np.array([1e-10, 0.5, 0.25], np.float32)
@@ -290,7 +325,11 @@ def _flux_close(got, want, what):
     magnitude accumulated in each cell."""
     scale = np.nanmax(np.abs(want)) + 1e-30
     np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-6 * scale, err_msg=what)
-    assert ((got != 0) == (want != 0)).all(), what + ": different set of visited cells"
+    # the same set of visited cells.  Deposits that have decayed to the edge of the fp32 range are
+    # exempt: the oracle's expf_ flushes below e^-87, the attenuations' v_exp_f32 (att_exp,
+    # soil_math.hpp) below 2^-126 — a deposit of 1e-38 on one side, none on the other
+    assert (got[np.abs(want) > 1e-25 * scale] != 0).all(), what + ": different set of visited cells"
+    assert (np.abs(got[want == 0]) <= 1e-30 * scale).all(), what + ": different set of visited cells"
 
 
 @pytest.fixture(params=["direct", "staged", "tiled"])
@@ -430,6 +469,17 @@ def test_particles_on_slabs_equal_whole_grid(hip, oracle, particle_mode):
                                    atol=2e-6 * (np.nanmax(np.abs(whole[k])) + 1e-30), err_msg=k)
 
 
+def _close_but_for_stray_walks(got, want, rtol, atol, max_frac, what):
+    """Free-running multi-step comparison: from the second step on the two sides walk on terrains
+    that differ in the last bits (fp32 summation order of the deposits, the attenuations'
+    exponential), and a particle that stands within that of a cell boundary or of the `speed < eps`
+    exit goes another way — its deposits then sit in other cells.  All cells but a small fraction
+    must agree within the tolerance."""
+    bad = ~(np.abs(got - want) <= atol + rtol * np.abs(want))
+    bad &= ~(np.isnan(got) & np.isnan(want))
+    assert bad.mean() <= max_frac, "%s: %d of %d cells differ" % (what, bad.sum(), bad.size)
+
+
 def test_erosion_model_fused_equals_unfused_and_oracle(hip, oracle):
     """Three whole steps: fused step == stand-alone-op step (bit-exact cell phase,
     atomics aside) == oracle composition."""
@@ -471,7 +521,11 @@ def test_erosion_model_fused_equals_unfused_and_oracle(hip, oracle):
             ga, gb = to_np(getattr(a, name)), to_np(getattr(b, name))
             tol = dict(rtol=1e-4, atol=1e-5 * (np.nanmax(np.abs(st[key])) + 1e-30))
             np.testing.assert_allclose(ga, gb, err_msg="fused vs unfused " + name, **tol)
-            np.testing.assert_allclose(ga, st[key], err_msg="fused vs oracle " + name, **tol)
+            if step == 0:
+                np.testing.assert_allclose(ga, st[key], err_msg="fused vs oracle " + name, **tol)
+            else:
+                _close_but_for_stray_walks(ga, st[key], tol["rtol"], tol["atol"], 5e-3,
+                                           "fused vs oracle %s, step %d" % (name, step))
     assert np.abs(st["layers"] - layers0).max() > 0          # the terrain really eroded
     assert_bit_equal(to_np(a.height), to_np(a.layers)[..., 0] + to_np(a.layers)[..., 1], "height")
 
