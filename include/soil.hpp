@@ -152,6 +152,47 @@ inline void layer_merge(F height, const F layers) {
   check(soil_layer_merge(height.data(), layers.data(), height.elem(), nullptr));
 }
 
+// ---- the legacy step API (example/erosion_gpu.py:44-106; binding python/source/model.cpp:62-143,
+// commented out in the snapshot) -----------------------------------------------------------------
+struct map_t {  // model.cpp:67-97: terrain planes + pixel scale
+  map_t(const silt::shape shape, const silt::vec3 scale) : shape(shape), scale(scale) {}
+  silt::shape shape;
+  silt::vec3 scale;
+  F height, sediment, uplift, rainfall;  // height = bedrock surface
+  uint64_t steps_taken = 0;              // numbers the particle streams of the next step
+};
+struct data_t {  // model.cpp:103-140: transported quantities, or their flux accumulators ("track")
+  explicit data_t(const silt::shape shape) : shape(shape) {}
+  silt::shape shape;
+  F discharge, momentum, mass, debris, debris_momentum;
+};
+struct erode_param_t : param_t {  // `param.samples`: particles per step (erosion_gpu.py:77)
+  size_t samples = 8192;
+};
+// soil::erode — `steps` whole erosion steps on the model's planes, in place.  The loop, the
+// re-seeding of the particle streams and the layer double buffer are the library's (soil_erode).
+inline void erode(map_t& model, data_t& data, data_t& track, const erode_param_t& param,
+                  const int steps = 1) {
+  soil_erode_model m{};
+  m.height = model.height.data();
+  m.sediment = model.sediment.data();
+  m.uplift = model.uplift.data();
+  m.rainfall = model.rainfall.data();
+  m.discharge = data.discharge.data();
+  m.mass = data.mass.data();
+  m.momentum = data.momentum.data();
+  m.debris = data.debris.data();
+  m.debris_momentum = data.debris_momentum.data();
+  m.discharge_track = track.discharge.data();
+  m.mass_track = track.mass.data();
+  m.momentum_track = track.momentum.data();
+  m.debris_track = track.debris.data();
+  m.debris_momentum_track = track.debris_momentum.data();
+  check(soil_erode(&m, model.shape[0], model.shape[1], static_cast<int64_t>(param.samples), 0,
+                   model.steps_taken, steps, detail::s3(model.scale).v, &param, nullptr));
+  model.steps_taken += static_cast<uint64_t>(steps);
+}
+
 // ---- graph.hpp:49-63 ------------------------------------------------------------------------
 inline silt::tensor_t<int> direction(const F height, const edge_t edge) {
   silt::tensor_t<int> out(height.shape(), silt::GPU);

@@ -316,6 +316,46 @@ int soil_particles_pair_slab(const soil_erosion_planes* planes, soil_rng* rng_fl
                              soil_rng* rng_debris, int64_t N, float* remote0,
                              const soil_domain* dom, const float scale[3], const soil_param* param,
                              void* stream);
+/* ------------------------------------------------ erosion: whole steps */
+
+/* One whole erosion step on one device: re-seed the particle streams at
+ * (seed, subsequence n, offset step_index * N) — the `silt.seed(rng, seed, step * N)` of
+ * example/dem_process.py:81 —, both particle launches, the fused cell phase.  Planes as in
+ * soil_erode_cells_fused, single-device shapes (H, W[, 2]); `rng` holds N elements.  Reads
+ * planes->layers, writes planes->layers_next: the caller swaps the two handles afterwards.
+ * Everything is queued on `stream`; nothing synchronises. */
+int soil_erode_step(const soil_erosion_planes* planes, soil_rng* rng, int64_t N, uint64_t seed,
+                    uint64_t step_index, int64_t H, int64_t W, const float scale[3],
+                    const soil_param* param, void* stream);
+
+/* The containers of the legacy API (example/erosion_gpu.py:44-71): model_t, the `data` and the
+ * `track` buffers.  All float32 device planes of H*W cells ((H,W,2) for the momenta). */
+typedef struct soil_erode_model {
+  float* height;                /* inout  bedrock surface        (erosion_gpu.py:44-48)  */
+  float* sediment;              /* inout  sediment on top of it                           */
+  const float* uplift;          /* in                                                     */
+  const float* rainfall;        /* in                                                     */
+  float* discharge;             /* out    data.discharge = waterHeight (:59-63)           */
+  float* mass;                  /* out    data.mass                                       */
+  float* momentum;              /* out    data.momentum (H,W,2) = velocity                */
+  float* debris;                /* out    data.debris                                     */
+  float* debris_momentum;       /* out    data.debris_momentum (H,W,2)                    */
+  float* discharge_track;       /* scratch track.* (:65-71): zeroed on entry and on exit  */
+  float* mass_track;
+  float* momentum_track;        /* (H,W,2) */
+  float* debris_track;
+  float* debris_momentum_track; /* (H,W,2) */
+} soil_erode_model;
+
+/* soil::erode(model, data, track, param[, steps]) — the legacy composite the acceptance script
+ * calls (example/erosion_gpu.py:102-106; its binding survives only as a comment,
+ * python/source/model.cpp:142): `steps` erosion steps numbered first_step, first_step + 1, ...
+ * on the model's planes, in place.  The (H,W,2) layer double buffer and the N particle streams
+ * live in the library's workspace for the duration of the call (and stay cached for the next). */
+int soil_erode(const soil_erode_model* model, int64_t H, int64_t W, int64_t N, uint64_t seed,
+               uint64_t first_step, int steps, const float scale[3], const soil_param* param,
+               void* stream);
+
 /* Launch shape of the particle kernels: 0 = auto, 1 = direct (the reference's:
  * thread n = particle n, 5-point stencil gathers), 2 = staged (packed field
  * plane + tile-ordered particles), 3 = tiled (per-tile particle queues, one

@@ -72,6 +72,12 @@ def lib():
     return _LIB
 
 
+def set_threads(n):
+    """Threads of the oracle's per-cell loops (the particle loops take `threads=` per call);
+    results do not depend on it."""
+    lib().orc_set_threads(C.c_int(int(n)))
+
+
 def default_param():
     p = Param()
     lib().orc_param_default(C.byref(p))

@@ -276,6 +276,12 @@ static int orc_slab_escape(const orc_domain* d, int64_t gx) {
   return lx < lo || lx > hi;
 }
 
+/* Threads of the per-cell loops (rows are independent: every kernel writes its own cell only, so
+ * the results do not depend on this).  Set by orc_set_threads; 1 = serial, the default. */
+static int orc_cell_threads = 1;
+void orc_set_threads(int n) { orc_cell_threads = n > 1 ? n : 1; }
+#define ORC_ROWS _Pragma("omp parallel for schedule(static) num_threads(orc_cell_threads) if (orc_cell_threads > 1)")
+
 static void orc_atomic_add(float* p, float v, int threads) {
   if (threads > 1) {
 #pragma omp atomic
@@ -413,6 +419,7 @@ void orc_normalize_fluvial(const float* waterFlux, const float* massFlux,
                            const float scale[3], const orc_param* param) {
   const float A = scale[0] * scale[1];                                   /* :163 */
   const float norm = fabsf(1.0f * scale[1]) + fabsf(0.0f * scale[0]);    /* :165-166 */
+  ORC_ROWS
   for (int64_t lx = d->r0; lx < d->r1; ++lx)
     for (int64_t y = 0; y < d->W; ++y) {
       const int64_t n = lx * d->W + y;
@@ -561,6 +568,7 @@ void orc_normalize_debris(const float* massFlux, const float* velocityFlux, floa
                           const orc_param* param) {
   const float A = scale[0] * scale[1];                                /* :370 */
   const float norm = fabsf(1.0f * scale[1]) + fabsf(0.0f * scale[0]); /* :372-373 */
+  ORC_ROWS
   for (int64_t lx = d->r0; lx < d->r1; ++lx)
     for (int64_t y = 0; y < d->W; ++y) {
       const int64_t n = lx * d->W + y;
@@ -609,6 +617,7 @@ void orc_mass_transfer(float* deltas, const float* layers, const float* upliftBa
   const float eps = 1E-12f;                                /* :488 */
   const float L = orc_length2(scale[0], scale[1]);         /* :493 */
 
+  ORC_ROWS
   for (int64_t lx = d->r0; lx < d->r1; ++lx)
     for (int64_t y = 0; y < d->W; ++y) {
       const int64_t n = lx * d->W + y;
@@ -686,6 +695,7 @@ void orc_mass_creep(float* delta, const float* layers, const orc_domain* d, cons
                     const orc_param* param) {
   const float sz = scale[2];
   const float critSlope = param->critSlopeSediment; /* :674 */
+  ORC_ROWS
   for (int64_t lx = d->r0; lx < d->r1; ++lx)
     for (int64_t y = 0; y < d->W; ++y) {
       const int64_t gx = d->x0 + lx;
@@ -717,6 +727,7 @@ void orc_mass_creep(float* delta, const float* layers, const orc_domain* d, cons
 
 /* __layer_merge, erosion.cu:733-745 */
 void orc_layer_merge(float* height, const float* layers, int64_t n) {
+  ORC_ROWS
   for (int64_t i = 0; i < n; ++i) height[i] = layers[2 * i] + layers[2 * i + 1];
 }
 

@@ -95,6 +95,8 @@ void orc_mass_transfer(float* delta, const float* layers, const float* uplift, c
                        const orc_domain* dom, const float scale[3], const orc_param* param);
 void orc_mass_creep(float* delta, const float* layers, const orc_domain* dom,
                     const float scale[3], const orc_param* param);
+/* threads of the per-cell loops (results do not depend on it) */
+void orc_set_threads(int n);
 void orc_layer_merge(float* height, const float* layers, int64_t n);
 void orc_albedo_stratum(float* albedoBedrock, const float* uplift, const float* layers, int64_t n,
                         const float scale[3], const orc_param* param, const float colorA[3],

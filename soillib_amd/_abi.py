@@ -55,6 +55,16 @@ class ErosionPlanes(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in _PLANES]
 
 
+_ERODE_MODEL = ("height", "sediment", "uplift", "rainfall", "discharge", "mass", "momentum", "debris",
+                "debris_momentum", "discharge_track", "mass_track", "momentum_track", "debris_track",
+                "debris_momentum_track")
+
+
+class ErodeModel(C.Structure):
+    """soil_erode_model: the legacy model_t + data + track containers."""
+    _fields_ = [(n, C.c_void_p) for n in _ERODE_MODEL]
+
+
 vp, i64, u64, f32, cint = C.c_void_p, C.c_int64, C.c_uint64, C.c_float, C.c_int
 F3 = C.POINTER(C.c_float)
 
@@ -101,6 +111,10 @@ SIGNATURES = {
                                    [C.POINTER(Domain), F3, C.POINTER(Param), vp]),
     "soil_particles_pair_slab": (cint, [C.POINTER(ErosionPlanes), vp, vp, i64, vp,
                                         C.POINTER(Domain), F3, C.POINTER(Param), vp]),
+    "soil_erode_step": (cint, [C.POINTER(ErosionPlanes), vp, i64, u64, u64, i64, i64, F3,
+                               C.POINTER(Param), vp]),
+    "soil_erode": (cint, [C.POINTER(ErodeModel), i64, i64, i64, u64, u64, cint, F3, C.POINTER(Param),
+                          vp]),
     "soil_set_particle_mode": (cint, [cint]),
     "soil_ghost_rows": (i64, [C.POINTER(Param)]),
     "soil_particle_steps": (cint, [C.POINTER(u64), cint, vp]),

@@ -17,7 +17,7 @@ LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(HERE, "build")
 LIB = os.path.join(LIBDIR, "libsoil_hip.so")
 
-SOURCES = ["runtime.hip", "erosion_cells.hip", "erosion_particles.hip", "erosion_particles_tiled.hip", "graph.hip",
+SOURCES = ["runtime.hip", "erosion_cells.hip", "erosion_particles.hip", "erosion_particles_tiled.hip", "erosion_step.hip", "graph.hip",
            "stencil.hip", "path.hip", "noise.hip", "io_tiff.hip", "conditioning.hip"]
 
 # -ffp-contract=off / no fast-math: the numerical contract

@@ -1,0 +1,105 @@
+// erosion_step.hip — the step driver behind the C ABI: one whole erosion step, and the legacy
+// composite soil::erode, composed in C++ from the library's own entry points.
+//
+// The reference snapshot no longer holds soil::erode (only its commented-out binding,
+// python/source/model.cpp:142, and the call in example/erosion_gpu.py:102-106); what remains are the
+// kernels it was made of.  SURVEY.md 3.1 fixes the composition of one step:
+//     silt.seed(rng, seed, step * N)                        example/dem_process.py:81
+//     transport_fluvial, transport_debris (particle halves) erosion.cu:29-141, :245-351
+//     normalise x2, delta = 0, mass_transfer, mass_creep,   erosion.cu:143-187, :353-393, :453-574,
+//     layers += delta, layer_merge, track.* = 0             :633-710, dem_process.py:47, erosion.cu:733-745
+// — two particle launches and ONE fused cell kernel here (erosion_cells.hip).  The host language
+// above this file only forwards pointers: a C++ program gets the step loop, the re-seeding and the
+// buffer swap from the library (include/soil.hpp, soil::erode), exactly as the Python module does.
+#include "common.hpp"
+
+using namespace soil;
+
+extern "C" {
+
+int soil_erode_step(const soil_erosion_planes* planes, soil_rng* rng, int64_t N, uint64_t seed,
+                    uint64_t step_index, int64_t H, int64_t W, const float scale[3],
+                    const soil_param* param, void* stream) {
+  SOIL_DEVICE();
+  SOIL_REQUIRE(planes && rng && scale && param, "erode_step: null argument");
+  SOIL_REQUIRE(H > 0 && W > 0 && N > 0, "erode_step: empty grid or no particles");
+  const soil_erosion_planes& P = *planes;
+  SOIL_REQUIRE(P.layers && P.layers_next && P.uplift && P.rainfall && P.waterHeight && P.waterFlux &&
+                   P.mass && P.massFlux && P.velocity && P.velocityFlux && P.debris && P.debrisFlux &&
+                   P.debrisVelocity && P.debrisVelocityFlux,
+               "erode_step: every plane but `height` is required");
+  const soil_domain dom{H, W, 0, H, 0, H};
+  // one stream of draws per particle and step: (seed, subsequence n, offset step * N)
+  if (int rc = soil_rng_seed(rng, N, seed, step_index * static_cast<uint64_t>(N), stream); rc != SOIL_OK)
+    return rc;
+  if (int rc = soil_particles_fluvial_slab(P.waterFlux, P.massFlux, P.velocityFlux, nullptr, rng, N,
+                                           P.layers, P.rainfall, P.waterHeight, P.velocity, nullptr,
+                                           nullptr, &dom, scale, param, stream);
+      rc != SOIL_OK)
+    return rc;
+  if (int rc = soil_particles_debris_slab(P.debrisFlux, P.debrisVelocityFlux, nullptr, rng, N, P.layers,
+                                          P.debrisVelocity, nullptr, nullptr, &dom, scale, param,
+                                          stream);
+      rc != SOIL_OK)
+    return rc;
+  return soil_erode_cells_fused(planes, &dom, scale, param, stream);
+}
+
+int soil_erode(const soil_erode_model* model, int64_t H, int64_t W, int64_t N, uint64_t seed,
+               uint64_t first_step, int steps, const float scale[3], const soil_param* param,
+               void* stream) {
+  SOIL_DEVICE();
+  SOIL_REQUIRE(model && scale && param, "erode: null argument");
+  SOIL_REQUIRE(H > 0 && W > 0 && N > 0 && steps >= 0, "erode: empty grid, no particles or negative steps");
+  const soil_erode_model& M = *model;
+  SOIL_REQUIRE(M.height && M.sediment && M.uplift && M.rainfall && M.discharge && M.mass &&
+                   M.momentum && M.debris && M.debris_momentum && M.discharge_track &&
+                   M.mass_track && M.momentum_track && M.debris_track && M.debris_momentum_track,
+               "erode: null plane");
+  if (steps == 0) return SOIL_OK;
+  const int64_t n = H * W;
+  // what the library owns during the call: the double-buffered (H,W,2) layer plane and the
+  // particle streams (scratch like graph.cu:539-550 allocates per call; cached here)
+  auto align = [](size_t b) { return (b + 255) & ~static_cast<size_t>(255); };
+  const size_t b_layers = align(sizeof(float) * 2 * n), b_rng = align(sizeof(soil_rng) * N);
+  void* base = nullptr;
+  if (int rc = workspace_get(6, 2 * b_layers + b_rng, &base); rc != SOIL_OK) return rc;
+  char* w = static_cast<char*>(base);
+  float* layers = reinterpret_cast<float*>(w);
+  float* layers_next = reinterpret_cast<float*>(w + b_layers);
+  soil_rng* rng = reinterpret_cast<soil_rng*>(w + 2 * b_layers);
+  if (int rc = soil_layers_from_planes(layers, M.height, M.sediment, n, stream); rc != SOIL_OK) return rc;
+  // silt.set(track.*, 0): the particle kernels only ever add to the flux planes
+  for (float* t : {M.discharge_track, M.mass_track, M.debris_track})
+    if (int rc = soil_set_f32(t, 0.0f, n, stream); rc != SOIL_OK) return rc;
+  for (float* t : {M.momentum_track, M.debris_momentum_track})
+    if (int rc = soil_set_f32(t, 0.0f, 2 * n, stream); rc != SOIL_OK) return rc;
+  soil_erosion_planes P{};
+  P.height = nullptr;  // model.height is the bedrock plane here; it is split back out below
+  P.uplift = M.uplift;
+  P.rainfall = M.rainfall;
+  P.waterHeight = M.discharge;
+  P.waterFlux = M.discharge_track;
+  P.mass = M.mass;
+  P.massFlux = M.mass_track;
+  P.velocity = M.momentum;
+  P.velocityFlux = M.momentum_track;
+  P.debris = M.debris;
+  P.debrisFlux = M.debris_track;
+  P.debrisVelocity = M.debris_momentum;
+  P.debrisVelocityFlux = M.debris_momentum_track;
+  for (int s = 0; s < steps; ++s) {
+    P.layers = layers;
+    P.layers_next = layers_next;
+    if (int rc = soil_erode_step(&P, rng, N, seed, first_step + static_cast<uint64_t>(s), H, W, scale,
+                                 param, stream);
+        rc != SOIL_OK)
+      return rc;
+    float* t = layers;
+    layers = layers_next;
+    layers_next = t;
+  }
+  return soil_layers_to_planes(M.height, M.sediment, layers, n, stream);
+}
+
+}  // extern "C"

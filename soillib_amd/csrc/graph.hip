@@ -180,8 +180,10 @@ __global__ void __launch_bounds__(kGBlock)
 template <int K>
 __global__ void __launch_bounds__(kGBlock)
     k_rake_compress(Acc out, const Acc in, int64_t elem, int* __restrict__ flags, int round) {
-  if (flags[round % 3] == 0) return;
+  // the word round + 2 will read is cleared either way: a round that returns at once must not
+  // leave its predecessor's "work left" standing for the round three launches on
   if (blockIdx.x == 0 && threadIdx.x == 0) flags[(round + 2) % 3] = 0;
+  if (flags[round % 3] == 0) return;
   const int64_t n = static_cast<int64_t>(blockIdx.x) * kGBlock + threadIdx.x;
   bool pending = false;
   if (n < elem) {

@@ -14,13 +14,12 @@ and, for example/erosion_gpu_multiscale.py:
     soil.index(res), soil.buffer(dtype, elem, host) (`buf[:] = v`), soil.data_t(elem),
     soil.resize(dst, src, newres, oldres)
 
-`erode` runs soillib_amd.erosion.ErosionModel on the caller's tensors: `data.*`
+`erode` hands the caller's tensors to the library's step driver (soil_erode): `data.*`
 are the transported fields, `track.*` the flux accumulators.
 """
 
 from . import _abi, silt
 from . import soil as _live
-from .erosion import ErosionModel
 
 # legacy attribute -> live param_t field (SURVEY.md §8a; live names erosion.hpp:20-56)
 _LEGACY_PARAM = {
@@ -67,7 +66,7 @@ class map_t:
         self.sediment = None
         self.uplift = None
         self.rainfall = None
-        self._engine = None
+        self._step_index = 0   # erosion steps taken so far (numbers the particle streams)
 
 
 class data_t:
@@ -117,62 +116,35 @@ def resize(dst, src, newres, oldres):
     return dst
 
 
-def _engine(model, data, track, param):
-    H, W = model.shape[0], model.shape[1]
-    eng = model._engine
-    if eng is None or eng.N != param.samples:
-        for key in ("height", "sediment", "uplift", "rainfall"):
-            t = getattr(model, key)
-            if t is not None and t.elem() != H * W:
-                raise ValueError("erode: model.%s does not hold %d x %d cells" % (key, H, W))
-        # planes the caller owns are aliased, not copied
-        names = {
-            "uplift": model.uplift, "rainfall": model.rainfall,
-            "waterHeight": data.discharge, "mass": data.mass, "velocity": data.momentum,
-            "debris": data.debris, "debrisVelocity": data.debris_momentum,
-            "waterFlux": track.discharge, "massFlux": track.mass, "velocityFlux": track.momentum,
-            "debrisFlux": track.debris, "debrisVelocityFlux": track.debris_momentum,
-        }
-        for key, t in names.items():
-            if t is None or t.host is not silt.gpu or t.type is not silt.float32:
-                raise ValueError("erode: %s must be a float32 silt.gpu tensor" % key)
-        eng = ErosionModel.__new__(ErosionModel)
-        eng.H, eng.W = H, W
-        eng.scale = list(model.scale)
-        eng.param = param
-        eng.N = int(param.samples)
-        eng.seed = 0
-        eng.dom = _abi.Domain(H, W, 0, H, 0, H)
-        eng.rows = H
-        eng.step_index = 0
-        eng.layers = silt.tensor(silt.float32, silt.shape(H, W, 2), silt.gpu)
-        eng.layers_next = silt.tensor(silt.float32, silt.shape(H, W, 2), silt.gpu)
-        eng.height = silt.tensor(silt.float32, silt.shape(H, W), silt.gpu)
-        for key, t in names.items():
-            setattr(eng, key, t)
-        eng.rng = silt.tensor(silt.rng, silt.shape(eng.N), silt.gpu)
-        eng.rng_debris = silt.tensor(silt.rng, silt.shape(eng.N), silt.gpu)
-        model._engine = eng
-    eng.param = param
-    return eng
-
-
 def erode(model, data, track, param, steps=1):
-    """One or more erosion steps on the legacy containers."""
-    eng = _engine(model, data, track, param)
-    lib = _abi.lib()
-    n = eng.H * eng.W
+    """soil.erode(model, data, track, param[, steps]) (example/erosion_gpu.py:102-106): one or
+    more erosion steps on the legacy containers, in place.  The step loop,
+    the re-seeding of the particle streams and the layer double buffer live in the library
+    (soil_erode, csrc/erosion_step.hip); the planes are handed over as they are bound at the
+    time of the call — a script may rebind model.uplift or resize its planes between calls."""
+    H, W = model.shape[0], model.shape[1]
     if model.sediment is None:
-        model.sediment = silt.tensor(silt.float32, silt.shape(eng.H, eng.W), silt.gpu)
+        model.sediment = silt.tensor(silt.float32, silt.shape(H, W), silt.gpu)
         silt.set(model.sediment, 0.0)
-    _abi.check(lib.soil_layers_from_planes(eng.layers.c_ptr, model.height.c_ptr,
-                                           model.sediment.c_ptr, n, _abi.stream()))
-    for t in (track.discharge, track.mass, track.momentum, track.debris, track.debris_momentum):
-        silt.set(t, 0.0)  # silt.set(track.*, 0): the kernels only add to the flux planes
-    for _ in range(int(steps)):
-        eng.step()
-    _abi.check(lib.soil_layers_to_planes(model.height.c_ptr, model.sediment.c_ptr,
-                                         eng.layers.c_ptr, n, _abi.stream()))
+    m = _abi.ErodeModel()
+    planes = {
+        "height": (model.height, 1), "sediment": (model.sediment, 1), "uplift": (model.uplift, 1),
+        "rainfall": (model.rainfall, 1), "discharge": (data.discharge, 1), "mass": (data.mass, 1),
+        "momentum": (data.momentum, 2), "debris": (data.debris, 1),
+        "debris_momentum": (data.debris_momentum, 2), "discharge_track": (track.discharge, 1),
+        "mass_track": (track.mass, 1), "momentum_track": (track.momentum, 2),
+        "debris_track": (track.debris, 1), "debris_momentum_track": (track.debris_momentum, 2),
+    }
+    for key, (t, channels) in planes.items():
+        if t is None or t.host is not silt.gpu or t.type is not silt.float32:
+            raise ValueError("erode: %s must be a float32 silt.gpu tensor" % key)
+        if t.elem() != H * W * channels:
+            raise ValueError("erode: %s does not hold %d x %d cells" % (key, H, W))
+        setattr(m, key, t.ptr)
+    first = getattr(model, "_step_index", 0)
+    _abi.check(_abi.lib().soil_erode(_abi.C.byref(m), H, W, int(param.samples), 0, first, int(steps),
+                                     _abi.vec(model.scale, 3), param._ref(), _abi.stream()))
+    model._step_index = first + int(steps)
 
 
 def multiply(tensor, value):

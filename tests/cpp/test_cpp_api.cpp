@@ -4,6 +4,9 @@
 #include <cstdio>
 #include <soil.hpp>
 
+using soil::F;
+using silt::check;
+
 #define EXPECT(c) do { if (!(c)) { std::printf("FAIL %s:%d %s\n", __FILE__, __LINE__, #c); return 1; } } while (0)
 
 int main() {
@@ -40,6 +43,37 @@ int main() {
   double sum = 0, mag = 0;
   for (int i = 0; i < 64 * 64; ++i) { EXPECT(d[2 * i] == 0.0f); sum += d[2 * i + 1]; mag += std::fabs(d[2 * i + 1]); }
   EXPECT(mag > 0 && std::fabs(sum) < 1e-6 * mag + 1e-9);               // creep conserves sediment
+
+  // three whole steps through soil::erode (the library's step driver): the Python test runs the
+  // same three steps through its own binding and compares the sums printed here
+  {
+    const int S = 96;
+    const silt::shape sh(S, S), sh2(S, S, 2);
+    soil::noise_param_t q; q.seed = 3.0f; q.ext[0] = S; q.ext[1] = S;
+    soil::map_t model(sh, silt::vec3{20.f / S, 20.f / S, 4.f});
+    model.height = soil::noise(sh, q);
+    for (F* t : {&model.sediment, &model.uplift, &model.rainfall}) *t = F(sh);
+    silt::set(model.sediment, 0.0f); silt::set(model.uplift, 0.0f); silt::set(model.rainfall, 1.0f);
+    soil::data_t data(sh), track(sh);
+    for (soil::data_t* d : {&data, &track}) {
+      d->discharge = F(sh); d->mass = F(sh); d->debris = F(sh); d->momentum = F(sh2); d->debris_momentum = F(sh2);
+      for (F* t : {&d->discharge, &d->mass, &d->debris, &d->momentum, &d->debris_momentum}) silt::set(*t, 0.0f);
+    }
+    soil::erode_param_t ep;
+    ep.samples = S * S / 8; ep.maxage = 64; ep.timeStep = 1000.0f;
+    ep.critSlopeBedrock = 0.57f; ep.suspensionRateFluvial = 0.0008f;
+    soil::erode(model, data, track, ep, 2);
+    soil::erode(model, data, track, ep);          // a third step, numbered 2
+    EXPECT(model.steps_taken == 3);
+    uint64_t steps = 0;
+    check(soil_particle_steps(&steps, 0, nullptr));
+    double sh_ = 0, sd = 0, st = 0;
+    for (float v : model.height.to_host()) sh_ += v;
+    for (float v : data.discharge.to_host()) if (v == v) sd += v;
+    for (float v : track.discharge.to_host()) st += std::fabs(v);
+    EXPECT(st == 0.0);                             // the flux planes are left zeroed
+    std::printf("ERODE3 %llu %.9e %.9e\n", static_cast<unsigned long long>(steps), sh_, sd);
+  }
   std::printf("CPP_API_OK\n");
   return 0;
 }

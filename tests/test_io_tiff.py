@@ -180,6 +180,46 @@ def test_missing_or_foreign_file(soil, tmp_path):
 
 # ------------------------------------------------------------- writing
 
+def _crafted(kind):
+    """Headers a fuzzer would write: every one of them used to crash, hang or abort the process
+    (ADVICE r1); libtiff, which the reference reads files with, rejects them with an error."""
+    if kind == "bigtiff_entry_count_wraps":      # count * 20 wraps around 2^64
+        return b"II" + struct.pack("<HHH", 43, 8, 0) + struct.pack("<Q", 16) + \
+            struct.pack("<Q", (1 << 64) // 20 + 1) + b"\0" * 64
+    if kind == "long8_count_wraps":              # 8 * 2^61 == 0 mod 2^64: looked like an inline value
+        ifd = struct.pack("<Q", 2) + struct.pack("<HHQQ", 256, 16, 1 << 61, 0) + \
+            struct.pack("<HHQQ", 257, 4, 1, 4) + struct.pack("<Q", 0)
+        return b"II" + struct.pack("<HHH", 43, 8, 0) + struct.pack("<Q", 16) + ifd
+    if kind == "unknown_type_huge_count":        # type 99 has no size; 4e9 elements were pushed
+        ifd = struct.pack("<H", 3) + struct.pack("<HHII", 256, 99, 0xFFFFFFFF, 0) + \
+            struct.pack("<HHII", 257, 3, 1, 4) + struct.pack("<HHII", 273, 99, 0xFFFFFFFF, 8) + \
+            struct.pack("<I", 0)
+        return b"II" + struct.pack("<HI", 42, 8) + ifd
+    if kind == "ifd_offset_near_2_64":           # ifd + head wraps
+        return b"II" + struct.pack("<HHH", 43, 8, 0) + struct.pack("<Q", (1 << 64) - 4) + b"\0" * 32
+    if kind == "payload_offset_wraps":           # off + bytes wraps
+        ifd = struct.pack("<Q", 1) + struct.pack("<HHQQ", 256, 4, 4, (1 << 64) - 8) + struct.pack("<Q", 0)
+        return b"II" + struct.pack("<HHH", 43, 8, 0) + struct.pack("<Q", 16) + ifd
+    if kind == "giant_tile":                     # a tile of 2^32 x 2^32 samples
+        tags = [(256, 4, 1, 16), (257, 4, 1, 16), (258, 3, 1, 32), (259, 3, 1, 8), (339, 3, 1, 3),
+                (322, 4, 1, 0xFFFFFFFF), (323, 4, 1, 0xFFFFFFFF), (324, 4, 1, 8), (325, 4, 1, 16)]
+        ifd = struct.pack("<H", len(tags)) + b"".join(struct.pack("<HHII", *t) for t in tags) + \
+            struct.pack("<I", 0)
+        return b"II" + struct.pack("<HI", 42, 8) + ifd
+    raise KeyError(kind)
+
+
+@pytest.mark.parametrize("kind", ["bigtiff_entry_count_wraps", "long8_count_wraps",
+                                  "unknown_type_huge_count", "ifd_offset_near_2_64",
+                                  "payload_offset_wraps", "giant_tile"])
+def test_crafted_headers_are_rejected(soil, tmp_path, kind):
+    path = tmp_path / (kind + ".tiff")
+    path.write_bytes(_crafted(kind))
+    for cls in (soil.tiff, soil.geotiff):
+        with pytest.raises((RuntimeError, ValueError, OSError)):
+            cls(str(path))                        # peeks and reads; must raise, not crash
+
+
 def test_written_file_is_what_the_reference_emits(soil, dem, tmp_path):
     import silt
     sq = np.ascontiguousarray(dem[:, :64])
