@@ -11,7 +11,10 @@ Workload at N=1: BASELINE.json configs[3], the 8192^2 coupled hydraulic +
 thermal step on synthetic OpenSimplex2-FBm terrain (soil.noise, generated on
 the device), inputs resident in HBM before the timed region.  N>1: weak
 scaling, one 8192-row slab per GPU (global grid (N*8192) x 8192) with deep-halo
-exchange over RCCL (soillib_amd/parallel.py).
+exchange over RCCL (soillib_amd/parallel.py).  `--grid 16384` (or
+SOIL_BENCH_GRID=16384) is BASELINE.json configs[4] as written: STRONG scaling,
+the 16384^2 grid cut into N row slabs of 16384/N rows ("scaling": "strong";
+SOIL_BENCH_FORCE_SLAB=1 runs the N=1 point through the same slab code).
 
 Prints ONE JSON line (rank 0).  `value` is whole-job throughput of the FULL
 step; the per-phase split, the roofline of the HBM-bound fused cell kernel
@@ -137,6 +140,10 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--size", type=int, default=8192, help="rows per GPU and columns")
+    ap.add_argument("--grid", type=int, default=int(os.environ.get("SOIL_BENCH_GRID", "0")),
+                    help="STRONG scaling on a fixed grid x grid domain (BASELINE.json configs[4]: "
+                         "16384): every rank takes grid/N rows of all grid columns.  Default 0: "
+                         "weak scaling, one --size-row slab of --size columns per GPU")
     ap.add_argument("--particles-div", type=int, default=8, help="N = cells / this")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-size", type=int, default=1024)
@@ -163,19 +170,27 @@ def main():
     _abi.check(lib.soil_set_particle_mode(args.particle_mode))
 
     S = args.size
+    strong = args.grid > 0
+    if strong:
+        if args.grid % world:
+            raise SystemExit("--grid %d does not split into %d equal slabs" % (args.grid, world))
+        S = args.grid // world                   # rows per rank; the columns stay args.grid
+    Wcols = args.grid if strong else S
     if args.overlap_particles:
         os.environ["SOIL_STEP_PAIR"] = "1"       # the slab runner reads it too
     param = script_param(soil)
     if world > 1 or os.environ.get("SOIL_BENCH_FORCE_SLAB") == "1":
         from soillib_amd import parallel
         # weak scaling: every slab is a piece of the same kind of landscape — cell size
-        # (20/S) and noise wavelength per cell as at N = 1, the domain just gets longer
-        runner = parallel.SlabRunner(rows_per_rank=S, W=S, param=param,
+        # (20/S) and noise wavelength per cell as at N = 1, the domain just gets longer.
+        # strong scaling: the same grid x grid landscape whatever the world size.
+        runner = parallel.SlabRunner(rows_per_rank=S, W=Wcols, param=param,
                                      particles_div=args.particles_div, seed=0,
-                                     scale=[20.0 / S, 20.0 / S, 4.0], noise_rows=S)
-        H_global, W = runner.H, S
+                                     scale=[20.0 / Wcols, 20.0 / Wcols, 4.0],
+                                     noise_rows=Wcols if strong else S)
+        H_global, W = runner.H, Wcols
     else:
-        H_global, W = S, S
+        H_global, W = S, Wcols
         scale = (20.0 / H_global, 20.0 / W, 4.0)
         model = ErosionModel(H_global, W, scale, param, H_global * W // args.particles_div, seed=0)
         npar = soil.noise_t()
@@ -211,14 +226,14 @@ def main():
                 pass
         runner = _Single()
 
-    ev = Events(_abi, 4)
+    ev = Events(_abi, 6)
     serial = not (args.overlap_particles or os.environ.get("SOIL_STEP_PAIR") == "1")
     for _ in range(args.warmup):
         runner.step()
     runner.barrier()
     runner.sync()
     soil.particle_steps(reset=True)
-    phase = [0.0, 0.0, 0.0]
+    phase = [0.0, 0.0, 0.0, 0.0, 0.0]
     t0 = time.perf_counter()
     for _ in range(args.steps):
         runner.step(ev)
@@ -227,6 +242,9 @@ def main():
         phase[0] += ev.ms(0, 1)
         phase[1] += ev.ms(1, 2)
         phase[2] += ev.ms(2, 3)
+        if world > 1:   # what of the two halo exchanges is not hidden behind a kernel
+            phase[3] += ev.ms(2, 4)
+            phase[4] += ev.ms(5, 3)
     runner.sync()
     runner.barrier()
     elapsed = time.perf_counter() - t0
@@ -260,6 +278,12 @@ def main():
         probe = {"kernel": "k_add (t += o), 2 x 8192^2 f32 planes, 12 B/element",
                  "achieved": 12.0 * 8192 * 8192 * 10 / (pe.ms(0, 1) * 1e-3) / 1e9, "unit": "GB/s"}
         del a, b
+    halo = None
+    if world > 1:
+        hr = runner.halo_rows
+        halo = {"ghost_rows_bound": runner.G, "rows_shipped_vs_bound": (hr["flux"] + hr["field"]) / max(hr["full"], 1),
+                "reach_rows_last_steps": runner.reach_hist, "repeated_launches": runner.fallbacks,
+                "trimmed_by_measured_reach": bool(runner.trim)}
     if world > 1 or os.environ.get("SOIL_BENCH_FORCE_SLAB") == "1":
         runner.shutdown()
     if rank != 0:
@@ -268,7 +292,7 @@ def main():
     cells = H_global * W
     ms_step = elapsed / K * 1e3
     cells_rank = S * W
-    t_cells = phase[2] / K * 1e-3
+    t_cells = (phase[2] - phase[3] - phase[4]) / K * 1e-3
     achieved = CELL_BYTES * cells_rank / t_cells / 1e9
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic_fused_cells.json")
@@ -280,11 +304,11 @@ def main():
         except Exception:
             traffic = None
     out = {
-        "metric": "Mcells/s on %d^2 hydraulic-erosion step" % S,   # BASELINE.json's at the default size
+        "metric": "Mcells/s on %d^2 hydraulic-erosion step" % W,   # BASELINE.json's at the default size
         "value": cells / (elapsed / K) / 1e6,
         "unit": "Mcells/s",
         "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": ms_step,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {
             "workload": "%dx%d coupled hydraulic+thermal erosion step (fluvial+debris particle "
@@ -295,11 +319,15 @@ def main():
             "parallelism": "row-slabs x%d" % world if world > 1 else "single GPU",
         },
         "final_state": final,
+        "halo": halo,
         "particle_steps_per_step": psteps_rank * world // K,
         "gparticle_steps_per_s": psteps_rank * world / elapsed / 1e9,
         "phases_ms": ({"particles_fluvial": phase[0] / K, "particles_debris": phase[1] / K}
                       if serial else {"particles_fluvial+debris_overlapped": (phase[0] + phase[1]) / K}) | {
-                      "cells_fused": phase[2] / K},
+                      "cells_fused": phase[2] / K} | (
+                      {"cells_fused": (phase[2] - phase[3] - phase[4]) / K,
+                       "exchange_flux_exposed": phase[3] / K,
+                       "exchange_field_exposed": phase[4] / K} if world > 1 else {}),
         "cell_phase_mcells_per_s": cells_rank / t_cells / 1e6 * world,
         "roofline": {"bound": "hbm", "kernel": "k_erode_cells_fused", "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

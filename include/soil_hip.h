@@ -368,6 +368,15 @@ int soil_set_particle_mode(int mode);
  * leave it: ceil(sqrt(2) * maxage) + 2 (one __stepsize step moves a particle
  * by at most sqrt(2) cells, erosion_map.cu:61-76). */
 int64_t soil_ghost_rows(const soil_param* param);
+/* What of a slab's ghost zone this step's deposits reached: depth[0] = number of rows above the
+ * owned local rows [r0, r1) — counted from the boundary — down to the farthest one holding a
+ * value other than zero in `plane` ((rows, row_floats) floats), depth[1] = likewise below.
+ * Accumulates with max (clear `depth`, two device int32, first; call once per flux plane).  A
+ * slab only has to ship that many rows of flux to its neighbour, and next step's particles
+ * need the fields refreshed about that deep (soillib_amd/parallel.py).  No counterpart in the
+ * single-GPU reference. */
+int soil_ghost_extent(int32_t* depth, const float* plane, int64_t rows, int64_t row_floats,
+                      int64_t r0, int64_t r1, void* stream);
 /* Particle steps (loop iterations of erosion.cu:100 / :306 that pass the loop
  * head) executed by all particle launches on the current device since the last
  * reset; synchronises `stream`.  The reference has no counterpart: it is the

@@ -118,6 +118,7 @@ SIGNATURES = {
     "soil_set_particle_mode": (cint, [cint]),
     "soil_ghost_rows": (i64, [C.POINTER(Param)]),
     "soil_particle_steps": (cint, [C.POINTER(u64), cint, vp]),
+    "soil_ghost_extent": (cint, [vp, vp, i64, i64, i64, i64, vp]),
     "soil_fill_depressions": (cint, [vp, vp, i64, i64, cint, vp]),
     "soil_multiflow": (cint, [vp, vp, vp, i64, i64, cint, u64, u64, u64, u64, u64, f32, vp]),
     "soil_resize": (cint, [vp, vp, i64, i64, i64, i64, cint, vp]),

@@ -15,7 +15,43 @@
 
 using namespace soil;
 
+namespace soil {
+
+// How far into a slab's ghost rows did this step's deposits get?  One work-group per ghost row
+// looks for a value that is not zero; depth[0] = rows above the owned range [r0, r1) that hold one
+// (counted from the boundary), depth[1] = rows below.  Accumulates with max: the caller clears
+// `depth` and may call this for several planes.
+__global__ void __launch_bounds__(256)
+    k_ghost_extent(int32_t* __restrict__ depth, const float* __restrict__ plane, int64_t rows,
+                   int64_t row_floats, int64_t r0, int64_t r1) {
+  const int64_t ghost = static_cast<int64_t>(blockIdx.x);        // 0 .. r0 + (rows - r1) - 1
+  const int64_t lx = ghost < r0 ? ghost : r1 + (ghost - r0);
+  const float* row = plane + lx * row_floats;
+  bool hit = false;
+  for (int64_t i = threadIdx.x; i < row_floats && !hit; i += 256) hit = row[i] != 0.0f;  // NaN counts
+  if (__syncthreads_or(hit) && threadIdx.x == 0) {
+    if (lx < r0) atomicMax(&depth[0], static_cast<int32_t>(r0 - lx));
+    else atomicMax(&depth[1], static_cast<int32_t>(lx - r1 + 1));
+  }
+}
+
+}  // namespace soil
+
 extern "C" {
+
+int soil_ghost_extent(int32_t* depth, const float* plane, int64_t rows, int64_t row_floats,
+                      int64_t r0, int64_t r1, void* stream) {
+  SOIL_DEVICE();
+  SOIL_REQUIRE(depth && plane, "ghost_extent: null argument");
+  SOIL_REQUIRE(rows > 0 && row_floats > 0 && 0 <= r0 && r0 <= r1 && r1 <= rows,
+               "ghost_extent: bad row ranges");
+  const int64_t ghost = r0 + (rows - r1);
+  if (ghost == 0) return SOIL_OK;
+  k_ghost_extent<<<static_cast<unsigned>(ghost), 256, 0, as_stream(stream)>>>(depth, plane, rows,
+                                                                              row_floats, r0, r1);
+  SOIL_LAUNCH_CHECK();
+  return SOIL_OK;
+}
 
 int soil_erode_step(const soil_erosion_planes* planes, soil_rng* rng, int64_t N, uint64_t seed,
                     uint64_t step_index, int64_t H, int64_t W, const float scale[3],

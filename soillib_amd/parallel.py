@@ -18,6 +18,15 @@ fp32 summation order of the flux differs) with nearest-neighbour traffic only:
   5 cell phase, interior rows      overlapped: field halo — G rows of layers, velocity,
                                    waterHeight, debrisVelocity -> neighbour's ghost rows
 
+How much of the G rows really travels is decided by measurement, not by the bound: after each
+particle launch a rank looks how deep into its ghost rows the deposits got (`ghost_extent`; at
+the acceptance parameters ~190 of the 365 rows for water, none for debris) and ships exactly
+those rows of flux; the field halo is refreshed as deep as the walks of the last steps reached,
+plus a margin, and a launch whose deposits get within a row of the refreshed depth is REPEATED
+after the missing rows have been fetched (they are still unchanged at the neighbour's: the cell
+phase has not run yet), so the step stays exact whatever the prediction was.  The reach numbers
+of all ranks travel in two small all-reduces per step.
+
 Every rank replays all world*N particle streams (two Philox draws each) and
 traces the ones whose spawn row it owns (soil_particles_*_slab), so the set of
 trajectories is identical to a single-GPU run of the global grid.  Even the
@@ -136,6 +145,20 @@ class HipOps:
             C.byref(planes), self._p(rng), self._p(rng_debris), N, self._p(remote0), C.byref(dom),
             self.abi.vec(scale, 3), param._ref(), self._stream()))
 
+    def ghost_extent(self, planes, r0, r1):
+        """(rows above, rows below) the owned local rows [r0, r1) that hold a deposit in any of
+        `planes` — soil_ghost_extent; synchronises the current stream (two ints come back)."""
+        t = self.torch
+        if not hasattr(self, "_extent"):
+            self._extent = t.zeros(2, dtype=t.int32, device=self.device)
+        self._extent.zero_()
+        for p in planes:
+            self.abi.check(self.lib.soil_ghost_extent(
+                self._p(self._extent), self._p(p), p.shape[0], p.numel() // p.shape[0], r0, r1,
+                self._stream()))
+        up, down = self._extent.tolist()
+        return int(up), int(down)
+
     def add_cell0(self, P, remote0):
         """Global cell (0,0) += the all-reduced deposits of the other ranks' NaN walkers."""
         for plane, lo, n in (("waterFlux", 0, 1), ("massFlux", 1, 1), ("velocityFlux", 2, 2),
@@ -226,6 +249,18 @@ class SlabRunner:
         self.down = self.rank + 1 if self.rank < self.world - 1 else None
         # staging buffers for the flux halo-accumulate (one per plane and side)
         self.gu, self.gd = self.r0, self.rows - self.r1      # ghost rows above / below
+        # measured-reach trimming of the halos (module docstring); SOIL_HALO_FULL=1: always G rows
+        self.trim = (self.world > 1 and hasattr(ops, "ghost_extent")
+                     and os.environ.get("SOIL_HALO_FULL") != "1")
+        self.fresh_up, self.fresh_down = self.gu, self.gd   # ghost rows whose fields are up to date
+        self.reach_hist = []     # max reach over all ranks, last steps (the same on every rank)
+        self.fallbacks = 0       # launches repeated because the refreshed depth was too small
+        self.halo_rows = {"flux": 0, "field": 0, "full": 0}  # rows shipped so far vs the bound
+        self._ints = None
+        # (ghost rows above, below) whose fields every rank holds up to date: all of them at first
+        self._fresh_all = [(slab_layout(r, self.world, self.S, self.G)[2],
+                            slab_layout(r, self.world, self.S, self.G)[1] -
+                            slab_layout(r, self.world, self.S, self.G)[3]) for r in range(self.world)]
         self.stage = {}
         for name in FLUX_PLANES:
             ch = PLANE_CHANNELS[name]
@@ -270,57 +305,138 @@ class SlabRunner:
             self.ops.sync()
         return dist.batch_isend_irecv(ops_)
 
-    def flux_exchange_start(self, planes=FLUX_PLANES):
-        """Ship the flux deposited into my ghost rows to their owners."""
+    def _all_ints(self, values):
+        """Every rank's list of small non-negative ints, as [rank][i] (one all-reduce of a
+        zero-padded vector: works with any communicator that can sum)."""
+        k = len(values)
+        if self._ints is None or self._ints.shape[0] != self.world * k:
+            self._ints = self.ops.alloc((self.world * k,))
+        t = self._ints
+        self.ops.zero(t)
+        t[self.rank * k:(self.rank + 1) * k] = self._as_tensor(values, t)
+        if self._host_ordered:
+            self.ops.sync()
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        flat = [int(round(v)) for v in t.tolist()]
+        return [flat[r * k:(r + 1) * k] for r in range(self.world)]
+
+    @staticmethod
+    def _as_tensor(values, like):
+        import torch
+        return torch.tensor([float(v) for v in values], dtype=like.dtype, device=like.device)
+
+    def flux_exchange_start(self, planes=FLUX_PLANES, counts=None):
+        """Ship the flux deposited into my ghost rows to their owners.  counts = (send_up,
+        send_down, recv_up, recv_down) rows, nearest the boundary first; default: all of them."""
+        if counts is None:
+            counts = (self.gu, self.gd, self._peer_ghost(self.up), self._peer_ghost(self.down))
+        send_up, send_down, recv_up, recv_down = counts
         sends, recvs = [], []
         for name in planes:
             t = self.P[name]
             su, sd = self.stage[name]
             if self.up is not None:
-                sends.append((t[0:self.gu], self.up))
-                recvs.append((su, self.up))
+                if send_up:
+                    sends.append((t[self.r0 - send_up:self.r0], self.up))
+                if recv_up:
+                    recvs.append((su[0:recv_up], self.up))
             if self.down is not None:
-                sends.append((t[self.r1:self.rows], self.down))
-                recvs.append((sd, self.down))
-        return self._exchange(sends, recvs)
+                if send_down:
+                    sends.append((t[self.r1:self.r1 + send_down], self.down))
+                if recv_down:
+                    recvs.append((sd[0:recv_down], self.down))
+        self.halo_rows["flux"] += (send_up + send_down) * len(planes)
+        self.halo_rows["full"] += (self.gu + self.gd) * len(planes)
+        return self._exchange(sends, recvs), counts
 
-    def flux_exchange_finish(self, reqs, planes=FLUX_PLANES):
+    def flux_exchange_finish(self, started, planes=FLUX_PLANES):
+        reqs, (send_up, send_down, recv_up, recv_down) = started
         for r in reqs:
             r.wait()
         for name in planes:
             t = self.P[name]
             su, sd = self.stage[name]
-            if su is not None:      # the up neighbour's lower ghost rows = my first owned rows
-                self.ops.add(t[self.r0:self.r0 + su.shape[0]], su)
-                self.ops.zero(t[0:self.gu])
-            if sd is not None:
-                self.ops.add(t[self.r1 - sd.shape[0]:self.r1], sd)
-                self.ops.zero(t[self.r1:self.rows])
+            if su is not None and recv_up:   # the up neighbour's lower ghost rows = my first owned rows
+                self.ops.add(t[self.r0:self.r0 + recv_up], su[0:recv_up])
+            if sd is not None and recv_down:
+                self.ops.add(t[self.r1 - recv_down:self.r1], sd[0:recv_down])
+            if self.up is not None and send_up:
+                self.ops.zero(t[self.r0 - send_up:self.r0])
+            if self.down is not None and send_down:
+                self.ops.zero(t[self.r1:self.r1 + send_down])
 
-    def field_exchange(self, layers_key="layers"):
-        """Refresh the ghost rows of the fields the next step's particles read."""
+    def field_exchange(self, layers_key="layers", counts=None):
+        """Refresh the ghost rows of the fields the next step's particles read.  counts =
+        (need_up, need_down, give_up, give_down): rows I want from / owe to each neighbour,
+        nearest the boundary first; default: the whole ghost zones."""
+        if counts is None:
+            counts = (self.gu, self.gd, self._peer_ghost(self.up), self._peer_ghost(self.down))
+        need_up, need_down, give_up, give_down = counts
         sends, recvs = [], []
         for name in FIELD_PLANES:
             t = self.P[layers_key if name == "layers" else name]
             if self.up is not None:
-                n = self._peer_ghost(self.up)
-                sends.append((t[self.r0:self.r0 + n], self.up))
-                recvs.append((t[0:self.gu], self.up))
+                if give_up:
+                    sends.append((t[self.r0:self.r0 + give_up], self.up))
+                if need_up:
+                    recvs.append((t[self.r0 - need_up:self.r0], self.up))
             if self.down is not None:
-                n = self._peer_ghost(self.down)
-                sends.append((t[self.r1 - n:self.r1], self.down))
-                recvs.append((t[self.r1:self.rows], self.down))
+                if give_down:
+                    sends.append((t[self.r1 - give_down:self.r1], self.down))
+                if need_down:
+                    recvs.append((t[self.r1:self.r1 + need_down], self.down))
+        self.halo_rows["field"] += (give_up + give_down) * len(FIELD_PLANES)
+        self.halo_rows["full"] += (self._peer_ghost(self.up) + self._peer_ghost(self.down)) * len(FIELD_PLANES)
         for r in self._exchange(sends, recvs):
             r.wait()
+        self.fresh_up, self.fresh_down = need_up, need_down
+
+    # -- measured reach ----------------------------------------------------------
+    def _reach(self, planes):
+        """[rank] -> (rows above, rows below) its owned rows this launch's deposits got to."""
+        up, down = self.ops.ghost_extent([self.P[n] for n in planes], self.r0, self.r1)
+        return self._all_ints([up, down])
+
+    def _too_deep(self, reach):
+        """Did a launch, on any rank, get within a row of ghost rows that were not refreshed?
+        (The cell record of ghost row d is made of rows d - 1 .. d + 1.)  The answer is the same
+        on every rank: everybody knows everybody's reach and refreshed depth."""
+        for r, (up, down) in enumerate(reach):
+            f_up, f_down = self._fresh_all[r]
+            x0, rows, r0, r1 = slab_layout(r, self.world, self.S, self.G)
+            if (up >= f_up and f_up < r0) or (down >= f_down and f_down < rows - r1):
+                return True
+        return False
+
+    def _refresh_all(self):
+        """The prediction was too small: fetch the whole ghost zones of the fields as they stand
+        (the cell phase of this step has not touched them yet)."""
+        self.fallbacks += 1
+        self.field_exchange("layers")
+        self._fresh_all = [(slab_layout(r, self.world, self.S, self.G)[2],
+                            slab_layout(r, self.world, self.S, self.G)[1] -
+                            slab_layout(r, self.world, self.S, self.G)[3]) for r in range(self.world)]
+
+    def _predict_need(self):
+        """Ghost rows to refresh for the next step: as deep as the walks of the last steps got
+        anywhere, a quarter more and a few rows on top; everything while there is no history."""
+        if not self.reach_hist:
+            return self.gu, self.gd
+        want = int(1.25 * max(self.reach_hist)) + 18
+        if os.environ.get("SOIL_HALO_NEED"):    # tests: a prediction that is too small on purpose
+            want = int(os.environ["SOIL_HALO_NEED"])
+        return min(self.gu, want), min(self.gd, want)
 
     # -- one step ---------------------------------------------------------------
     def step(self, ev=None):
         ops, P = self.ops, self.P
+        trim = self.trim
         ops.seed(self.rng, self.seed, self.step_index * self.N)
         ops.zero(self.remote0)
         early = ()          # flux planes whose halo is exchanged before the debris launch ends
+        counts_f = counts_d = None
         if ev: ev.record(0)
-        if hasattr(ops, "particles_pair") and not self.serial_particles:
+        if hasattr(ops, "particles_pair") and not self.serial_particles and not trim:
             # the debris launch draws from a tensor of its own, seeded where the fluvial
             # launch leaves the shared one in the sequential order
             ops.seed(self.rng_debris, self.seed, self.step_index * self.N + 2)
@@ -330,20 +446,56 @@ class SlabRunner:
         else:
             ops.particles_fluvial(P, self.rng, self.N, self.dom, self.scale, self.param,
                                   self.remote0)
+            if trim:
+                reach_f = self._reach(FLUX_FLUVIAL)
+                if self._too_deep(reach_f):      # rare: repeat the launch on complete fields
+                    self._refresh_all()
+                    for name in FLUX_FLUVIAL:
+                        ops.zero(P[name])
+                    ops.zero(self.remote0)
+                    ops.seed(self.rng, self.seed, self.step_index * self.N)
+                    ops.particles_fluvial(P, self.rng, self.N, self.dom, self.scale, self.param,
+                                          self.remote0)
+                    reach_f = self._reach(FLUX_FLUVIAL)
+                me = reach_f[self.rank]
+                counts_f = (me[0], me[1],
+                            reach_f[self.up][1] if self.up is not None else 0,
+                            reach_f[self.down][0] if self.down is not None else 0)
             if ev: ev.record(1)
             if self.world > 1:
                 # the fluvial flux is final: its halo travels, and is added, while the
                 # debris launch runs
                 with ops.fork_comm():
-                    self.flux_exchange_finish(self.flux_exchange_start(FLUX_FLUVIAL), FLUX_FLUVIAL)
+                    self.flux_exchange_finish(self.flux_exchange_start(FLUX_FLUVIAL, counts_f),
+                                              FLUX_FLUVIAL)
                 early = FLUX_FLUVIAL
             ops.particles_debris(P, self.rng, self.N, self.dom, self.scale, self.param,
                                  self.remote0)
+            if trim:
+                reach_d = self._reach(FLUX_DEBRIS)
+                if self._too_deep(reach_d):
+                    self._refresh_all()
+                    for name in FLUX_DEBRIS:
+                        ops.zero(P[name])
+                    # the NaN walkers' debris deposits are entries 4..6 of remote0; the launch
+                    # draws where the fluvial one left the streams (two draws per particle on)
+                    ops.zero(self.remote0[4:8])
+                    ops.seed(self.rng, self.seed, self.step_index * self.N + 2)
+                    ops.particles_debris(P, self.rng, self.N, self.dom, self.scale, self.param,
+                                         self.remote0)
+                    reach_d = self._reach(FLUX_DEBRIS)
+                me = reach_d[self.rank]
+                counts_d = (me[0], me[1],
+                            reach_d[self.up][1] if self.up is not None else 0,
+                            reach_d[self.down][0] if self.down is not None else 0)
+                self.reach_hist = (self.reach_hist + [max(max(a, b) for a, b in reach_f + reach_d)])[-4:]
         if ev: ev.record(2)
         if self.world == 1:
             ops.cells(P, self.dom, self.r0, self.r1, self.scale, self.param)
         else:
             # NaN walkers of the other ranks -> global cell (0,0) (8 floats, latency only)
+            if self._host_ordered:
+                ops.sync()
             self.dist.all_reduce(self.remote0)
             if self.rank == 0:
                 ops.add_cell0(P, self.remote0)
@@ -352,17 +504,27 @@ class SlabRunner:
             i1 = max(i0, self.r1 - (self._peer_ghost(self.down) if self.down is not None else 0))
             # 1. the rest of the flux halo (exposed: the bands below need it)
             late = tuple(n for n in FLUX_PLANES if n not in early)
-            self.flux_exchange_finish(self.flux_exchange_start(late), late)
+            self.flux_exchange_finish(self.flux_exchange_start(late, counts_d if trim else None), late)
             ops.join_comm()                      # ... and the part that travelled early
+            if ev: ev.record(4)                  # 2 -> 4: flux halo not hidden by the debris launch
             # 2. the bands next to the neighbours first: they are what the neighbours' ghost
             #    rows get
             ops.cells(P, self.dom, self.r0, i0, self.scale, self.param)
             ops.cells(P, self.dom, i1, self.r1, self.scale, self.param)
             # 3. the field halo travels while the interior rows are computed (they are
             #    G rows away from anything the exchange reads or writes)
+            counts = None
+            if trim:     # as deep as next step's walks are expected to get; everybody says what it wants
+                need = self._predict_need()
+                wants = self._all_ints(list(need))
+                counts = (need[0], need[1],
+                          wants[self.up][1] if self.up is not None else 0,
+                          wants[self.down][0] if self.down is not None else 0)
+                self._fresh_all = [tuple(w) for w in wants]
             with ops.fork_comm():
-                self.field_exchange("layers_next")
+                self.field_exchange("layers_next", counts)
             ops.cells(P, self.dom, i0, i1, self.scale, self.param)
+            if ev: ev.record(5)                  # 5 -> 3: field halo not hidden by the interior rows
             ops.join_comm()
         if ev: ev.record(3)
         P["layers"], P["layers_next"] = P["layers_next"], P["layers"]

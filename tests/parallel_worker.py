@@ -69,6 +69,16 @@ class OracleOps:
                            P["layers"].numpy(), P["debrisVelocity"].numpy(), None, scale, param,
                            dom=self._dom(dom), remote0=remote0.numpy())
 
+    def ghost_extent(self, planes, r0, r1):
+        up = down = 0
+        for p in planes:
+            a = p.numpy().reshape(p.shape[0], -1)
+            rows = np.nonzero((a != 0).any(axis=1))[0]
+            if len(rows):
+                up = max(up, r0 - int(rows.min()))
+                down = max(down, int(rows.max()) - r1 + 1)
+        return max(up, 0), max(down, 0)
+
     def add_cell0(self, P, remote0):
         r = remote0.numpy()
         P["waterFlux"].numpy().ravel()[0] += r[0]
@@ -139,7 +149,8 @@ def main():
              velocity=runner.P["velocity"].numpy()[own], debris=runner.P["debris"].numpy()[own],
              height=runner.P["height"].numpy()[own],
              ghost_layers=runner.P["layers"].numpy(), x0=runner.x0, rows=runner.rows,
-             G=runner.G, H=runner.H)
+             G=runner.G, H=runner.H, fallbacks=runner.fallbacks,
+             halo_rows=np.array([runner.halo_rows[k] for k in ("flux", "field", "full")]))
     t = runner.max_over_ranks(float(runner.rank))
     assert t == runner.world - 1
     runner.barrier()

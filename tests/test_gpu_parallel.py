@@ -154,6 +154,36 @@ def test_slab_runner_on_one_gpu_matches_single_domain(hip, oracle, world, S, W, 
                                    atol=1e-5 * (np.nanmax(np.abs(want[k])) + 1e-30), err_msg=k)
 
 
+def test_strong_split_of_a_square_grid_matches_single_domain(hip, oracle):
+    """BASELINE.json configs[4] in the small: a square grid cut into row slabs of ALL its columns
+    (bench.py --grid), script parameters with maxage 256, hence the full 365-row halo on a
+    1024-row slab — the proportions of 16384^2 over 8 GPUs (2048-row slabs) and worse."""
+    from soillib_amd import silt, soil
+    from soillib_amd.erosion import ErosionModel
+    from test_gpu_parity import _close_but_for_stray_walks
+    world, S, W, maxage, steps = 2, 1024, 2048, 256, 2
+    op = script_param(oracle.default_param())
+    assert op.maxage == maxage
+    pp = product_param(op)
+    H = world * S
+    got = _run_world(world, S, W, pp, steps, maxage)
+    m = ErosionModel(H, W, (20.0 / H, 20.0 / W, 4.0), pp, H * W // 8, seed=0)
+    npar = soil.noise_t()
+    npar.seed = 3.0
+    npar.ext = [H, W]
+    bed = soil.noise(silt.shape(H, W), npar, host=silt.gpu)
+    layers0 = np.zeros((H, W, 2), np.float32)
+    layers0[..., 0] = to_np(bed)
+    m.set_layers(to_gpu(layers0))
+    silt.set(m.rainfall, 1.0)
+    for _ in range(steps):
+        m.step()
+    for k in got:
+        want = to_np(getattr(m, k))
+        _close_but_for_stray_walks(got[k], want, 1e-4, 1e-5 * (np.nanmax(np.abs(want)) + 1e-30), 1e-3,
+                                   "strong split, " + k)
+
+
 def test_slab_runner_world1_is_the_plain_model(hip, oracle):
     """world = 1 through torch.distributed itself (nccl, one rank)."""
     import os
