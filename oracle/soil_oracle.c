@@ -305,7 +305,7 @@ void orc_particles_fluvial(float* waterFlux, float* massFlux, float* velocityFlu
   int64_t steps_total = 0;
   const int nthreads = threads > 1 ? threads : 1;
 
-#pragma omp parallel for schedule(dynamic, 256) num_threads(nthreads) reduction(+ : steps_total)
+#pragma omp parallel for schedule(dynamic, 32) num_threads(nthreads) reduction(+ : steps_total)
   for (int64_t n = 0; n < N; ++n) {
     const float A = scale[0] * scale[1];                   /* :50 */
     const float Lx = scale[0], Ly = scale[1];              /* :51 */
@@ -460,7 +460,7 @@ void orc_particles_debris(float* massFlux, float* velocityFlux, float* albedoFlu
   int64_t steps_total = 0;
   const int nthreads = threads > 1 ? threads : 1;
 
-#pragma omp parallel for schedule(dynamic, 256) num_threads(nthreads) reduction(+ : steps_total)
+#pragma omp parallel for schedule(dynamic, 32) num_threads(nthreads) reduction(+ : steps_total)
   for (int64_t n = 0; n < N; ++n) {
     const float A = scale[0] * scale[1];               /* :263 */
     const float Lx = scale[0], Ly = scale[1];          /* :264 */

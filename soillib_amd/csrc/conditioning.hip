@@ -16,7 +16,20 @@
 // the update order: the kernel relaxes 64x64 tiles in LDS until they stop
 // changing (chaotic Gauss-Seidel inside a tile, Jacobi across tiles per launch)
 // and the host repeats launches until no tile changed.
+//
+// Started from +inf, information has to travel from the grid's edge to its middle, one tile per
+// launch (39 launches at 4096^2).  The iteration reaches the same fixed point from ANY surface
+// that lies on or above it and equals z next to the outlets (it only ever lowers cells, never
+// below w; and w is the only fixed point: walk the cells in the order of their w).  So the start
+// is taken from the same problem on a 4x coarser grid — each coarse cell the maximum of its
+// 4x4 block, filled recursively: a fine cell can always follow the coarse path through its
+// block's neighbours without meeting anything higher than the blocks' maxima — and what is left
+// to settle is the inside of the lakes: 14 launches at 4096^2 (and 2-8 on each of the four small
+// levels), 10.7 -> 3.7 ms; 16x coarsening leaves 22, 128x128 tiles are slower per launch than they save.
+#include <cstdio>
+#include <cstdlib>
 #include <utility>
+#include <vector>
 
 #include "common.hpp"
 
@@ -113,10 +126,30 @@ __global__ void __launch_bounds__(kFBlock)
   }
 }
 
-// w = z where a neighbour is an outlet (or z is NaN), +inf elsewhere
+constexpr int kFC = 4;  // coarsening factor per level
+
+// block maxima (NaN cells skipped: leaving an outlet out only raises the start, which stays valid)
+__global__ void __launch_bounds__(kFBlock)
+    k_fill_coarsen(float* __restrict__ zc, const float* __restrict__ z, int64_t H, int64_t W,
+                   int64_t Hc, int64_t Wc) {
+  const int64_t n = static_cast<int64_t>(blockIdx.x) * kFBlock + threadIdx.x;
+  if (n >= Hc * Wc) return;
+  const int64_t X = n / Wc, Y = n % Wc;
+  float m = -__builtin_inff();
+  for (int64_t x = X * kFC; x < (X + 1) * kFC && x < H; ++x)
+    for (int64_t y = Y * kFC; y < (Y + 1) * kFC && y < W; ++y) {
+      const float v = z[x * W + y];
+      if (v == v) m = fmaxf(m, v);
+    }
+  zc[n] = m;
+}
+
+// w = z where a neighbour is an outlet (or z is NaN); elsewhere the coarse level's surface of the
+// cell's block (`wc`, see the header) or +inf on the coarsest level
 template <int K>
 __global__ void __launch_bounds__(kFBlock)
-    k_fill_init(float* __restrict__ w, const float* __restrict__ z, int64_t H, int64_t W) {
+    k_fill_init(float* __restrict__ w, const float* __restrict__ z, int64_t H, int64_t W,
+                const float* __restrict__ wc, int64_t Wc) {
   const int64_t n = static_cast<int64_t>(blockIdx.x) * kFBlock + threadIdx.x;
   if (n >= H * W) return;
   const int64_t x = n / W, y = n % W;
@@ -133,16 +166,63 @@ __global__ void __launch_bounds__(kFBlock)
       if (nv != nv) outlet = true;
     }
   }
-  w[n] = outlet ? zv : __builtin_inff();
+  float start = __builtin_inff();
+  if (wc) start = fmaxf(zv, wc[(x / kFC) * Wc + y / kFC]);  // >= zv anyway; the max guards -inf blocks
+  w[n] = outlet ? zv : start;
+}
+
+// one level: `out` = fill of `height` (H x W), started from the coarse surface `wc` (or +inf)
+template <int K>
+static int fill_level(float* out, const float* height, int64_t H, int64_t W, const float* wc,
+                      int64_t Wc, unsigned char* dirty_prev, unsigned char* dirty_next, int* flag_host,
+                      int* flag_dev, hipStream_t st) {
+  const int tiles_w = static_cast<int>((W + kFT - 1) / kFT);
+  const int tiles_h = static_cast<int>((H + kFT - 1) / kFT);
+  const size_t ntiles = static_cast<size_t>(tiles_w) * tiles_h;
+  SOIL_HIP(hipMemsetAsync(dirty_prev, 1, ntiles, st));  // first launch: every tile
+  k_fill_init<K><<<blocks_for(H * W, kFBlock), kFBlock, 0, st>>>(out, height, H, W, wc, Wc);
+  SOIL_LAUNCH_CHECK();
+  // a launch moves information at least one tile further; H*W launches is a bound
+  // no terrain reaches
+  const int64_t max_launches = 4 * (static_cast<int64_t>(tiles_w) + tiles_h) * kFT + 16;
+  static const int per_check = std::getenv("SOIL_FILL_PER_CHECK") ? std::atoi(std::getenv("SOIL_FILL_PER_CHECK")) : 2;
+  static const bool verbose = std::getenv("SOIL_FILL_VERBOSE") != nullptr;
+  for (int64_t launch = 0; launch < max_launches; launch += per_check) {
+    *flag_host = 0;  // the stream is idle here: the previous launches were waited for
+    // several launches per look at the flag: a launch whose predecessor moved nothing costs a
+    // few microseconds (every tile returns at once), a host round trip ~20
+    for (int k = 0; k < per_check; ++k) {
+      SOIL_HIP(hipMemsetAsync(dirty_next, 0, ntiles, st));
+      k_fill_relax<K><<<static_cast<unsigned>(ntiles), kFBlock, 0, st>>>(
+          out, height, H, W, tiles_w, tiles_h, 4 * kFT, flag_dev, dirty_prev, dirty_next);
+      std::swap(dirty_prev, dirty_next);
+    }
+    SOIL_LAUNCH_CHECK();
+    SOIL_HIP(hipStreamSynchronize(st));
+    if (verbose) std::fprintf(stderr, "[fill] %lld x %lld: launches %lld..%lld moved=%d\n", (long long)H, (long long)W, (long long)launch, (long long)launch + per_check - 1, *flag_host);
+    if (!__atomic_load_n(flag_host, __ATOMIC_ACQUIRE)) return SOIL_OK;
+  }
+  return fail(SOIL_ERR_HIP, "fill_depressions: did not converge");
 }
 
 template <int K>
 static int fill_impl(float* out, const float* height, int64_t H, int64_t W, hipStream_t st) {
-  const int tiles_w = static_cast<int>((W + kFT - 1) / kFT);
-  const int tiles_h = static_cast<int>((H + kFT - 1) / kFT);
-  const size_t ntiles = static_cast<size_t>(tiles_w) * tiles_h, b_dirty = (ntiles + 255) & ~size_t{255};
+  // the pyramid: level 0 is the DEM itself, level l + 1 the 16x16 block maxima of level l
+  struct Level { int64_t H, W; size_t off_z, off_w; };
+  std::vector<Level> lv{{H, W, 0, 0}};
+  auto align = [](size_t b) { return (b + 255) & ~size_t{255}; };
+  const size_t ntiles0 = static_cast<size_t>((W + kFT - 1) / kFT) * ((H + kFT - 1) / kFT);
+  const size_t b_dirty = align(ntiles0);
+  size_t bytes = 256 + 2 * b_dirty;
+  while (lv.back().H * lv.back().W > 4 * kFT * kFT && std::getenv("SOIL_FILL_FLAT") == nullptr) {
+    const int64_t Hc = (lv.back().H + kFC - 1) / kFC, Wc = (lv.back().W + kFC - 1) / kFC;
+    const size_t b = align(sizeof(float) * Hc * Wc);
+    lv.push_back({Hc, Wc, bytes, bytes + b});
+    bytes += 2 * b;
+  }
   void* base = nullptr;
-  if (int rc = workspace_get(4, 256 + 2 * b_dirty, &base); rc != SOIL_OK) return rc;
+  if (int rc = workspace_get(4, bytes, &base); rc != SOIL_OK) return rc;
+  char* ws = static_cast<char*>(base);
   // "some tile moved in this launch": a pinned, device-mapped word the tiles write straight
   // into (a device-to-host copy is a 25-50 us blit kernel on this stack, per launch)
   static thread_local int *t_flag = nullptr, *t_flag_dev = nullptr;
@@ -150,26 +230,23 @@ static int fill_impl(float* out, const float* height, int64_t H, int64_t W, hipS
     SOIL_HIP(hipHostMalloc(reinterpret_cast<void**>(&t_flag), sizeof(int), hipHostMallocMapped | hipHostMallocCoherent));
     SOIL_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&t_flag_dev), t_flag, 0));
   }
-  int* changed = t_flag_dev;
-  unsigned char* dirty_prev = static_cast<unsigned char*>(base) + 256;
-  unsigned char* dirty_next = dirty_prev + b_dirty;
-  SOIL_HIP(hipMemsetAsync(dirty_prev, 1, ntiles, st));  // first launch: every tile
-  k_fill_init<K><<<blocks_for(H * W, kFBlock), kFBlock, 0, st>>>(out, height, H, W);
-  SOIL_LAUNCH_CHECK();
-  // a launch moves information at least one tile further; H*W launches is a bound
-  // no terrain reaches, typical counts are a few times the number of tiles per side
-  const int64_t max_launches = 4 * (static_cast<int64_t>(tiles_w) + tiles_h) * kFT + 16;
-  for (int64_t launch = 0; launch < max_launches; ++launch) {
-    *t_flag = 0;  // the stream is idle here: the previous launch was waited for
-    SOIL_HIP(hipMemsetAsync(dirty_next, 0, ntiles, st));
-    k_fill_relax<K><<<static_cast<unsigned>(ntiles), kFBlock, 0, st>>>(
-        out, height, H, W, tiles_w, tiles_h, 4 * kFT, changed, dirty_prev, dirty_next);
-    std::swap(dirty_prev, dirty_next);
+  unsigned char* dirty_a = reinterpret_cast<unsigned char*>(ws) + 256;
+  unsigned char* dirty_b = dirty_a + b_dirty;
+  auto zc = [&](size_t l) { return l == 0 ? height : reinterpret_cast<const float*>(ws + lv[l].off_z); };
+  auto wl = [&](size_t l) { return l == 0 ? out : reinterpret_cast<float*>(ws + lv[l].off_w); };
+  for (size_t l = 1; l < lv.size(); ++l) {
+    k_fill_coarsen<<<blocks_for(lv[l].H * lv[l].W, kFBlock), kFBlock, 0, st>>>(
+        reinterpret_cast<float*>(ws + lv[l].off_z), zc(l - 1), lv[l - 1].H, lv[l - 1].W, lv[l].H, lv[l].W);
     SOIL_LAUNCH_CHECK();
-    SOIL_HIP(hipStreamSynchronize(st));
-    if (!__atomic_load_n(t_flag, __ATOMIC_ACQUIRE)) return SOIL_OK;
   }
-  return fail(SOIL_ERR_HIP, "fill_depressions: did not converge");
+  for (size_t l = lv.size(); l-- > 0;) {  // coarsest first
+    const bool top = l + 1 == lv.size();
+    if (int rc = fill_level<K>(wl(l), zc(l), lv[l].H, lv[l].W, top ? nullptr : wl(l + 1),
+                               top ? 0 : lv[l + 1].W, dirty_a, dirty_b, t_flag, t_flag_dev, st);
+        rc != SOIL_OK)
+      return rc;
+  }
+  return SOIL_OK;
 }
 
 }  // namespace soil

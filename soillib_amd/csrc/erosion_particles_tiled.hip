@@ -218,46 +218,71 @@ __device__ __forceinline__ bool advance_slow(PRec& r, const float4 q, const Step
 // 1e25 and beyond (the scaled regime of the division) and after special-casing all
 // of that 1.3 % of the lanes — more than half of the waves — still needed the slow
 // path on top of the fast one (14.9 vs 13.4 ms).
+// The first half of the iteration needs neither the cell record nor anything from LDS — the norm
+// of the speed, the direction, the step length, the reciprocal of the implicit-Euler denominator
+// (:116-120 and the D of :127) — and is written apart (StepGeom) so that the round kernel can run it
+// while the gather of the record and the LDS reads of the deposit are in flight.
+struct StepGeom {
+  float v_norm, ux, uy, v_step, dL, ds;
+  Recip rd;
+  bool alive, ok;  // alive: past the `v_norm < eps` exit; ok: every operand plain (fluvial)
+};
 template <int KIND>
-__device__ __forceinline__ bool advance(PRec& r, const float4 q, const StepConst& k) {
+__device__ __forceinline__ StepGeom step_geom(const PRec& r, const StepConst& k) {
+  StepGeom g;
   // :116 / :321.  sqrt_rn is sqrtf for everything that is not under eps = 1e-12 anyway
-  const float v_norm = sqrt_rn(r.spx * r.spx + r.spy * r.spy);
-  if (v_norm < k.eps) return false;            // eps = 1e-12 > 2^-40: v_norm is plain from below
-  if (KIND == DEBRIS) return advance_slow<KIND>(r, q, k, v_norm);
-  bool ok = k.plain && v_norm <= kDenHi;
-  const Recip rn = recip(v_norm);
+  g.v_norm = sqrt_rn(r.spx * r.spx + r.spy * r.spy);
+  g.alive = !(g.v_norm < k.eps);  // eps = 1e-12 > 2^-40: v_norm is plain from below
+  g.ok = false;
+  g.ux = g.uy = g.v_step = g.dL = g.ds = 0.0f;
+  g.rd = Recip{1.0f, 1.0f};
+  if (KIND == DEBRIS) return g;
+  bool ok = k.plain && g.v_norm <= kDenHi;
+  const Recip rn = recip(g.v_norm);
   // a direction is only ever a denominator for numerators <= 1: plain down to 2^-60
   // (and then |spx| = |ux| v_norm >= 2^-100, a plain numerator in hindsight)
   constexpr float kDirLo = 0x1p-60f;
-  const float ux = quot(r.spx, rn), uy = quot(r.spy, rn);  // :117
-  ok = ok && fminf(fabsf(ux), fabsf(uy)) >= kDirLo;
+  g.ux = quot(r.spx, rn);  // :117
+  g.uy = quot(r.spy, rn);
+  ok = ok && fminf(fabsf(g.ux), fabsf(g.uy)) >= kDirLo;
   // stepsize() with one quotient per axis (see there), :118
   const float x_neg = floorf(r.px), y_neg = floorf(r.py);
-  const float nx = ((ux > 0.0f) ? 1.0f + x_neg : x_neg) - r.px;
-  const float ny = ((uy > 0.0f) ? 1.0f + y_neg : y_neg) - r.py;
-  const float tx = fminf(quot(nx, recip(ux)), kSqrt2);
-  const float ty = fminf(quot(ny, recip(uy)), kSqrt2);
-  const float v_step = 0.5f * (tx + ty);
-  const float dL = v_step * k.lenL;  // :119
+  const float nx = ((g.ux > 0.0f) ? 1.0f + x_neg : x_neg) - r.px;
+  const float ny = ((g.uy > 0.0f) ? 1.0f + y_neg : y_neg) - r.py;
+  const float tx = fminf(quot(nx, recip(g.ux)), kSqrt2);
+  const float ty = fminf(quot(ny, recip(g.uy)), kSqrt2);
+  g.v_step = 0.5f * (tx + ty);
+  g.dL = g.v_step * k.lenL;  // :119
   // dL = -0 is what a walker stuck on a cell corner computes until it dies of age
   // (both face times -0; 1 % of all steps): quot0
-  const float ds = quot0(dL, rn);  // :120
+  g.ds = quot0(g.dL, rn);  // :120
   // nx, ny: +0 or not tiny; dL: a zero or not tiny.  One min3 decides the common case
-  if (fminf(fminf(fabsf(nx), fabsf(ny)), fabsf(dL)) < kNumLo)
-    ok = ok && plain_num(nx) && plain_num(ny) && (dL == 0.0f || fabsf(dL) >= kNumLo);
+  if (fminf(fminf(fabsf(nx), fabsf(ny)), fabsf(g.dL)) < kNumLo)
+    ok = ok && plain_num(nx) && plain_num(ny) && (g.dL == 0.0f || fabsf(g.dL) >= kNumLo);
   // D = 1 + dL * (tau + nu) lies in [1, 2^40] by k.plain (dL in [0, sqrt2 * lenL])
-  const Recip rd = recip(1.0f + dL * (k.tau + k.nu));
-  if (!ok) return advance_slow<KIND>(r, q, k, v_norm);
-  const float ax = q.x + k.fx, ay = q.y + k.fy;           // :126
-  const float w0 = quot(1.0f, rd), w1 = quot0(dL, rd);    // :127
+  g.rd = recip(1.0f + g.dL * (k.tau + k.nu));
+  g.ok = ok;
+  return g;
+}
+// ... and the second half: the speed update, the attenuations, the move (:125-137 / :331-347)
+template <int KIND>
+__device__ __forceinline__ bool step_apply(PRec& r, const float4 q, const StepConst& k, const StepGeom& g) {
+  if (!g.alive) return false;
+  if (KIND == DEBRIS || !g.ok) return advance_slow<KIND>(r, q, k, g.v_norm);
+  const float ax = q.x + k.fx, ay = q.y + k.fy;                 // :126
+  const float w0 = quot(1.0f, g.rd), w1 = quot0(g.dL, g.rd);    // :127
   r.spx = w0 * r.spx + w1 * ax;
   r.spy = w0 * r.spy + w1 * ay;
-  r.a1 = r.a1 * att_exp(-ds * k.kd);    // att_m :134
-  r.a0 = r.a0 * att_exp(-ds * k.evap);  // att_w :135
-  r.a2 = r.a2 * att_exp(-dL * q.z);     // att_v :136
-  r.px += v_step * ux;                    // :137
-  r.py += v_step * uy;
+  r.a1 = r.a1 * att_exp(-g.ds * k.kd);    // att_m :134
+  r.a0 = r.a0 * att_exp(-g.ds * k.evap);  // att_w :135
+  r.a2 = r.a2 * att_exp(-g.dL * q.z);     // att_v :136
+  r.px += g.v_step * g.ux;                // :137
+  r.py += g.v_step * g.uy;
   return true;
+}
+template <int KIND>
+__device__ __forceinline__ bool advance(PRec& r, const float4 q, const StepConst& k) {
+  return step_apply<KIND>(r, q, k, step_geom<KIND>(r, k));
 }
 
 // a NaN walker's deposit for global cell (0,0) held by another rank (soil_hip.h)
@@ -674,12 +699,18 @@ struct CasDeposit {
   static __device__ __forceinline__ uint32_t swap(float* q, uint32_t expect, float add) {
     return atomicCAS(reinterpret_cast<uint32_t*>(q), expect, f2bits(bits2f(expect) + add));
   }
-  __device__ __forceinline__ void begin() {
+  __device__ __forceinline__ void load() {  // the old words: issued early, used by swap_all()
 #pragma unroll
     for (int j = 0; j < NP; ++j) o[j] = f2bits(*p[j]);
+  }
+  __device__ __forceinline__ void swap_all() {
 #pragma unroll
     for (int j = 0; j < NP; ++j) g[j] = swap(p[j], o[j], v[j]);
     pending = true;
+  }
+  __device__ __forceinline__ void begin() {
+    load();
+    swap_all();
   }
   // Convergent: every lane of the wave calls it (pending or not), once per iteration.
   // A lane that lost its race (another walker hit the same cell in between — common
@@ -898,6 +929,7 @@ __global__ void __launch_bounds__(NT)
     constexpr int kFluxPlanes = (KIND == FLUVIAL) ? 4 : 3;
     CasDeposit<kFluxPlanes + (ALB ? 3 : 0)> dep;
     const int c = c_org + static_cast<int>(dr) * TC + static_cast<int>(dc);  // LDS cell (any value when idle)
+    bool deposit = false;
     if (step) {
       ++r.iter;
       ++nsteps;
@@ -936,10 +968,23 @@ __global__ void __launch_bounds__(NT)
             atomicAdd(p[j], v[j]);
           }
         }
-        if (DEP == 1 && !ABLATED(4)) dep.begin();
+        if (DEP == 1 && !ABLATED(4)) {
+          if (KIND == FLUVIAL) {
+            dep.load();  // the old words travel while the geometry of the step is worked out
+            deposit = true;
+          } else {
+            dep.begin();
+          }
+        }
       }
       PROF_AT(3);  // gather issued, deposit begun
-      have = advance<KIND>(r, q, k);
+      if (KIND == FLUVIAL) {
+        const StepGeom geom = step_geom<KIND>(r, k);   // needs neither q nor LDS
+        if (deposit) dep.swap_all();                   // the swaps' round trip hides under step_apply
+        have = step_apply<KIND>(r, q, k, geom);
+      } else {
+        have = advance<KIND>(r, q, k);
+      }
       PROF_AT(4);  // the step's arithmetic
     }
     if (DEP == 1) dep.finish(c, agg_min, agg_groups);
@@ -1207,7 +1252,11 @@ struct TiledRun {
     verbose = std::getenv("SOIL_TILED_VERBOSE") != nullptr;
 #ifdef SOIL_ABLATE
     {
-      const int mask = std::getenv("SOIL_ABLATE") ? std::atoi(std::getenv("SOIL_ABLATE")) : 0;
+      // SOIL_ABLATE_AFTER=n: only from the n-th launch of this kind on (the terrain of the
+      // warm-up steps is then the real one)
+      static int launches = 0;
+      const int after = std::getenv("SOIL_ABLATE_AFTER") ? std::atoi(std::getenv("SOIL_ABLATE_AFTER")) : 0;
+      const int mask = (std::getenv("SOIL_ABLATE") && launches++ >= after) ? std::atoi(std::getenv("SOIL_ABLATE")) : 0;
       SOIL_HIP(hipMemcpyToSymbol(HIP_SYMBOL(soil_ablate), &mask, sizeof(int)));
     }
 #endif

@@ -419,10 +419,11 @@ class SlabRunner:
 
     def _predict_need(self):
         """Ghost rows to refresh for the next step: as deep as the walks of the last steps got
-        anywhere, a quarter more and a few rows on top; everything while there is no history."""
+        anywhere, a tenth more and ten rows on top (the reach moves by a row or two from step to step);
+        everything while there is no history."""
         if not self.reach_hist:
             return self.gu, self.gd
-        want = int(1.25 * max(self.reach_hist)) + 18
+        want = int(1.1 * max(self.reach_hist)) + 10
         if os.environ.get("SOIL_HALO_NEED"):    # tests: a prediction that is too small on purpose
             want = int(os.environ["SOIL_HALO_NEED"])
         return min(self.gu, want), min(self.gd, want)

@@ -14,6 +14,7 @@ from soillib_amd import _abi, silt, soil  # noqa: E402
 from soillib_amd.erosion import ErosionModel  # noqa: E402
 
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+WARM = int(sys.argv[2]) if len(sys.argv) > 2 else 1       # steps before the profiled ones
 lib = _abi.lib()
 param = bench.script_param(soil)
 model = ErosionModel(S, S, (20.0 / S, 20.0 / S, 4.0), param, S * S // 8, seed=0)
@@ -27,7 +28,7 @@ silt.set(model.uplift, 0.0)
 out = (C.c_ulonglong * 32)()
 names = ["tail->top", "refill", "head", "gather+deposit begin", "advance", "deposit finish",
          "survivors out", "barrier wait", "prologue", "flux flush"]
-for step in range(3):
+for step in range(WARM + 2):
     model.seed_step()
     model.particles_fluvial()
     model.particles_debris()
@@ -36,7 +37,7 @@ for step in range(3):
     model.step_index += 1
     _abi.check(lib.soil_device_synchronize())
     assert lib.soil_prof_read(out, 1) == 0
-    if step == 0:
+    if step < WARM:
         continue
     for kind in (0, 1):
         v = [out[kind * 16 + i] for i in range(16)]

@@ -1,8 +1,8 @@
 #!/bin/bash
 # Collects everything profiles/<name>/ holds, on the GPU box:
-#   gpurun --timeout 1500 -- 'tools/profile_final.sh r01_final'
-# then, back in the container:  python tools/profile_post.py r01_final
-name=${1:-r01_final}
+#   gpurun --timeout 2400 -- 'tools/profile_final.sh r02_final'
+# then, back in the container:  python tools/profile_post.py r02_final
+name=${1:-r02_final}
 out=/root/repo/gpurun_out/$name; rm -rf $out; mkdir -p $out
 cd /tmp; export TMPDIR=/tmp
 python /root/repo/bench.py --steps 10 --warmup 2 2>/dev/null | tail -1 > $out/bench_line.json
@@ -12,5 +12,13 @@ pmc fetch "FETCH_SIZE" 2
 pmc write "WRITE_SIZE" 2
 pmc valu "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_TRANS_F32" 1
 pmc lds "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_INSTS_SALU SQ_INSTS_BRANCH" 1
+# what the VALU counters read on instruction streams of known cost (the opcode classes of the
+# microbenchmark): the calibration of `valu_busy`
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --output-format csv -d $out/calib -o p -- /root/repo/tools/microbench/valu_issue > $out/valu_issue.txt 2>&1
+# the graph / stencil / conditioning kernels (BASELINE configs[2] and SURVEY 8a rows a8-a13)
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stencils -o s -- python /root/repo/tools/bench_stencils.py > $out/bench_stencils.txt 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/accumulate -o s -- python /root/repo/tools/bench_accumulate.py > $out/bench_accumulate.txt 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/stencils_fetch -o p -- python /root/repo/tools/bench_stencils.py > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/stencils_write -o p -- python /root/repo/tools/bench_stencils.py > /dev/null 2>&1
 python /root/repo/bench.py --size 1024 --steps 10000 --warmup 10 --no-cpu-baseline 2>/dev/null | tail -1 > $out/bench_c2_1024x10000.json
-find $out -name "*.csv" | head -30; du -sh $out
+find $out -name "*.csv" | head -40; du -sh $out

@@ -79,10 +79,16 @@ valu, lds = load("valu"), load("lds")
 summary = {
     "command": "rocprofv3 --kernel-trace --pmc <counters> --output-format csv -- python bench.py --steps 1 "
                "--warmup 1 --no-cpu-baseline (8192^2, second step); two passes, see tools/profile_final.sh",
-    "note": "counters are summed over the 8 XCDs; GRBM_GUI_ACTIVE/8 = shader cycles of the launch; peak VALU "
-            "issue = 1024 SIMDs x cycles / 4 cycles per wave64 instruction (packed instructions can exceed "
-            "it); lane utilisation = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU); lds_busy = "
-            "SQ_LDS_IDX_ACTIVE / (256 CUs x cycles), lds_bank_conflict likewise",
+    "note": "counters are summed over the 8 XCDs; GRBM_GUI_ACTIVE/8 = shader cycles of the launch.  "
+            "valu_busy = 4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x cycles): the share of all SIMD cycles "
+            "in which a vector instruction was executing (the counter ticks in quad-cycles) — the "
+            "roofline fraction of this kernel, whose bound is VALU issue.  There is no single 'peak "
+            "instructions per cycle': a wave64 v_fma/add/mul occupies a SIMD for 2 cycles, compares, "
+            "min/max, conversions, v_cndmask, DPP and the v_div_* helpers for 4, v_rcp/v_sqrt/v_exp for "
+            "8 (tools/microbench/valu_issue*.hip); cycles_per_valu_instruction = 1024 x cycles / "
+            "SQ_INSTS_VALU is what the mix averages to including idle time.  lane utilisation = "
+            "SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU); lds_busy = SQ_LDS_IDX_ACTIVE / (256 CUs "
+            "x cycles), lds_bank_conflict likewise",
 }
 for kind, label in ((0, "fluvial_rounds"), (1, "debris_rounds")):
     ra = [c for c in valu if "k_tiled_round<%d" % kind in c["name"]]
@@ -94,7 +100,9 @@ for kind, label in ((0, "fluvial_rounds"), (1, "debris_rounds")):
         rows.append({
             "round": i, "duration_us": round(a["dur_us"], 1), "shader_clock_ghz": round(cyc / a["dur_us"] / 1e3, 2),
             "SQ_INSTS_VALU": a["SQ_INSTS_VALU"], "SQ_INSTS_VALU_TRANS_F32": a["SQ_INSTS_VALU_TRANS_F32"],
-            "valu_issue_utilisation": round(a["SQ_INSTS_VALU"] / (1024 * cyc / 4), 3),
+            "valu_busy": round(4 * a["SQ_ACTIVE_INST_VALU"] / (1024 * cyc), 3),
+            "cycles_per_valu_instruction": round(1024 * cyc / a["SQ_INSTS_VALU"], 2),
+            "SQ_ACTIVE_INST_VALU": a["SQ_ACTIVE_INST_VALU"], "shader_cycles": cyc,
             "lane_utilisation": round(a["SQ_THREAD_CYCLES_VALU"] / (64 * a["SQ_ACTIVE_INST_VALU"]), 3),
             "waves_per_cu": round(4 * a["SQ_WAVE_CYCLES"] / (cyc * 256), 1),
             "SQ_INSTS_SALU": b["SQ_INSTS_SALU"], "SQ_INSTS_BRANCH": b["SQ_INSTS_BRANCH"],
@@ -104,4 +112,23 @@ for kind, label in ((0, "fluvial_rounds"), (1, "debris_rounds")):
         })
     summary[label] = rows
 json.dump(summary, open(os.path.join(dst, "pmc_round_kernel_valu.json"), "w"), indent=1)
+# 4. the roofline of the kernel that carries the step (bench.py copies it into `roofline_particles`)
+roof = {}
+for label in ("fluvial_rounds", "debris_rounds"):
+    rows = summary[label]
+    busy = sum(4 * r["SQ_ACTIVE_INST_VALU"] for r in rows)
+    total = sum(1024 * r["shader_cycles"] for r in rows)
+    roof[label] = {"valu_busy": round(busy / total, 3), "launches": len(rows),
+                   "time_ms": round(sum(r["duration_us"] for r in rows) / 1e3, 3),
+                   "valu_instructions": sum(r["SQ_INSTS_VALU"] for r in rows)}
+json.dump({
+    "kernel": "k_tiled_round (all launches of one 8192^2 step)", "bound": "valu-issue",
+    "achieved": sum(v["valu_busy"] * v["time_ms"] for v in roof.values()) / sum(v["time_ms"] for v in roof.values()),
+    "peak": 1.0, "unit": "share of SIMD cycles executing a vector instruction",
+    "per_kind": roof,
+    "source": "profiles/%s/pmc_round_kernel_valu.json (rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU "
+              "SQ_ACTIVE_INST_VALU ... GRBM_GUI_ACTIVE on `python bench.py --steps 1 --warmup 1`)" % name,
+    "issue_cost_model": "tools/microbench/valu_issue.hip, valu_issue2.hip: wave64 issue cycles per opcode "
+                        "class measured on this chip (2 / 4 / 8)",
+}, open(os.path.join(ROOT, "profiles", "particle_roofline.json"), "w"), indent=1)
 print("wrote", sorted(os.listdir(dst)))
