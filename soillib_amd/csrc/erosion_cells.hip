@@ -7,6 +7,7 @@
 #include <cstdlib>
 
 #include "cell_math.hpp"
+#include "window.hpp"
 
 namespace soil {
 
@@ -358,8 +359,7 @@ __global__ void __launch_bounds__(BLOCK)
     if (right_ok) right = make_float2(rx_, ry_);
   }
 
-  if (!active) return;
-
+  __shared__ float4 s_tile[BLOCK / 64][128];
   Row4 o_layers, o_vel, o_dvel;
   float o_h[kVec], o_wh[kVec], o_m[kVec], o_d[kVec];
 #pragma unroll
@@ -385,23 +385,45 @@ __global__ void __launch_bounds__(BLOCK)
     o_dvel.v[k] = r.db.velocity;
   }
 
-  store_row4<NT>(P.layers_next + n0, o_layers);
+  // A lane's four cells of a two-channel plane are 32 contiguous bytes: stored as they are, every
+  // store instruction of the wave would cover half of each 32-byte sector.  The wave's groups are
+  // consecutive in memory (n0 = 4 g, also across a row's end), so its 2 KiB go out as two
+  // instructions of 1 KiB of consecutive bytes each, swapped through LDS (window.hpp).
+  const int64_t wave_n0 = d.r0 * d.W + (g - lane) * kVec;  // n0 of the wave's lane 0
+  auto pair = [&](float2* plane, const Row4& r) {
+    store_pair_contiguous(reinterpret_cast<float4*>(plane + wave_n0),
+                          make_float4(r.v[0].x, r.v[0].y, r.v[1].x, r.v[1].y),
+                          make_float4(r.v[2].x, r.v[2].y, r.v[3].x, r.v[3].y),
+                          s_tile[threadIdx.x >> 6], active);
+  };
+  pair(P.layers_next, o_layers);
+  pair(P.velocity, o_vel);
+  pair(P.debrisVelocity, o_dvel);
+  {  // re-zero the two-channel flux planes (zeros need no swapping: lane i takes the i-th and the
+     // (64 + i)-th 16 bytes of the wave's stretch — every lane of the wave, its idle ones included)
+    const int n_real = 2 * __popcll(__ballot(active));
+    v4f* zv = reinterpret_cast<v4f*>(P.velocityFlux + wave_n0);
+    v4f* zd = reinterpret_cast<v4f*>(P.debrisVelocityFlux + wave_n0);
+    const v4f zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (lane < n_real) {
+      zv[lane] = zero4;
+      zd[lane] = zero4;
+    }
+    if (64 + lane < n_real) {
+      zv[64 + lane] = zero4;
+      zd[64 + lane] = zero4;
+    }
+  }
+  if (!active) return;
   if (P.height) store4<NT>(P.height + n0, o_h);
   store4<NT>(P.waterHeight + n0, o_wh);
   store4<NT>(P.mass + n0, o_m);
-  store_row4<NT>(P.velocity + n0, o_vel);
   store4<NT>(P.debris + n0, o_d);
-  store_row4<NT>(P.debrisVelocity + n0, o_dvel);
-  // re-zero the flux planes for the next step's atomics
+  // re-zero the scalar flux planes for the next step's atomics
   const float z[kVec] = {0.0f, 0.0f, 0.0f, 0.0f};
-  Row4 z2;
-#pragma unroll
-  for (int k = 0; k < kVec; ++k) z2.v[k] = make_float2(0.0f, 0.0f);
   store4<NT>(P.waterFlux + n0, z);
   store4<NT>(P.massFlux + n0, z);
   store4<NT>(P.debrisFlux + n0, z);
-  store_row4<NT>(P.velocityFlux + n0, z2);
-  store_row4<NT>(P.debrisVelocityFlux + n0, z2);
 }
 
 // scalar path for W % 4 != 0 (ragged widths): one thread per cell

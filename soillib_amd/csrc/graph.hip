@@ -9,6 +9,7 @@
 #include <unordered_map>
 
 #include "common.hpp"
+#include "window.hpp"
 
 namespace soil {
 
@@ -52,6 +53,56 @@ __global__ void __launch_bounds__(kGBlock)
       }
     }
     out[n] = next;  // :68
+  }
+}
+
+// __steepest / __direction with four cells per thread (window.hpp); the scalar kernel above
+// serves widths that are not a multiple of four.  The four diagonal slopes are quotients over
+// sqrt(2): shared-reciprocal quotients checked per group (QuotWatch, soil_math.hpp), redone as
+// written when in doubt.
+template <int K, bool STORE_K, bool WRITTEN>
+__device__ __forceinline__ bool steepest_group(int32_t oi[4], const RowWalk& w, const WinThread& t,
+                                               int64_t x, int64_t W, const Recip& rdiag) {
+  QuotWatch watch;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const float hlocal = w.mid.v[c + 1];  // :40
+    float smax = 0.0f;                    // :42
+    int32_t next = -1;                    // :43
+    const int64_t y = t.y0 + c;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {  // :46
+      const bool row_ok = kDX[k] < 0 ? w.has_up : (kDX[k] > 0 ? w.has_dn : true);
+      const bool col_ok = kDY[k] < 0 ? (c > 0 || t.y0 > 0) : (kDY[k] > 0 ? (c < 3 || t.y0 + 4 < W) : true);
+      if (!row_ok || !col_ok) continue;  // :51-52
+      const Row6& r = kDX[k] < 0 ? w.up : (kDX[k] > 0 ? w.dn : w.mid);
+      const float diff = hlocal - r.v[c + 1 + kDY[k]];
+      float scur;  // :56
+      if (k < 4) scur = diff / kShiftLen[k];  // length 1: the quotient is the difference
+      else scur = WRITTEN ? diff / kShiftLen[k] : watch(quot(diff, rdiag));
+      if (scur > smax) {  // :57-60
+        smax = scur;
+        next = STORE_K ? static_cast<int32_t>(k)
+                       : static_cast<int32_t>((x + kDX[k]) * W + (y + kDY[k]));
+      }
+    }
+    oi[c] = next;  // :68
+  }
+  return watch.doubtful();
+}
+
+template <int K, bool STORE_K>
+__global__ void __launch_bounds__(kWinBlock)
+    k_steepest4(int32_t* __restrict__ out, const float* __restrict__ height, int64_t H, int64_t W) {
+  const WinThread t = win_thread(W);
+  const Recip rdiag = recip(kSqrt2);
+  RowWalk w;
+  SOIL_WIN_ROWS(x, w, height, H, W, t.y0) {
+    int4 o;
+    int32_t* oi = reinterpret_cast<int32_t*>(&o);
+    if (K == 4 || steepest_group<K, STORE_K, false>(oi, w, t, x, W, rdiag))
+      (void)steepest_group<K, STORE_K, true>(oi, w, t, x, W, rdiag);
+    if (t.live) *reinterpret_cast<int4*>(out + x * W + t.y0) = o;
   }
 }
 
@@ -302,10 +353,17 @@ int soil_direction(int32_t* direction, const float* height, int64_t H, int64_t W
   SOIL_DEVICE();
   SOIL_REQUIRE(direction && height, "direction: null tensor");
   SOIL_REQUIRE(H > 0 && W > 0, "direction: empty grid");
-  const unsigned nb = blocks_for(H * W, kGBlock);
+  const bool wide = W % 4 == 0 && W >= 4;  // four cells per thread (window.hpp)
+  hipStream_t st = as_stream(stream);
   switch (edge) {
-    case SOIL_D4: k_steepest<4, true><<<grid_rows(H, W, kGBlock), kGBlock, 0, as_stream(stream)>>>(direction, height, H, W); break;
-    case SOIL_D8: k_steepest<8, true><<<grid_rows(H, W, kGBlock), kGBlock, 0, as_stream(stream)>>>(direction, height, H, W); break;
+    case SOIL_D4:
+      if (wide) k_steepest4<4, true><<<win_grid(H, W), kWinBlock, 0, st>>>(direction, height, H, W);
+      else k_steepest<4, true><<<grid_rows(H, W, kGBlock), kGBlock, 0, st>>>(direction, height, H, W);
+      break;
+    case SOIL_D8:
+      if (wide) k_steepest4<8, true><<<win_grid(H, W), kWinBlock, 0, st>>>(direction, height, H, W);
+      else k_steepest<8, true><<<grid_rows(H, W, kGBlock), kGBlock, 0, st>>>(direction, height, H, W);
+      break;
     default: return fail(SOIL_ERR_INVALID_ARGUMENT, "invalid edge enumerator");  // graph.cu:262
   }
   SOIL_LAUNCH_CHECK();
@@ -317,10 +375,17 @@ int soil_steepest(int32_t* graph, const float* height, int64_t H, int64_t W, int
   SOIL_DEVICE();
   SOIL_REQUIRE(graph && height, "steepest: null tensor");
   SOIL_REQUIRE(H > 0 && W > 0 && H * W <= INT32_MAX, "steepest: grid must have 1..2^31-1 cells");
-  const unsigned nb = blocks_for(H * W, kGBlock);
+  const bool wide = W % 4 == 0 && W >= 4;
+  hipStream_t st = as_stream(stream);
   switch (edge) {
-    case SOIL_D4: k_steepest<4, false><<<grid_rows(H, W, kGBlock), kGBlock, 0, as_stream(stream)>>>(graph, height, H, W); break;
-    case SOIL_D8: k_steepest<8, false><<<grid_rows(H, W, kGBlock), kGBlock, 0, as_stream(stream)>>>(graph, height, H, W); break;
+    case SOIL_D4:
+      if (wide) k_steepest4<4, false><<<win_grid(H, W), kWinBlock, 0, st>>>(graph, height, H, W);
+      else k_steepest<4, false><<<grid_rows(H, W, kGBlock), kGBlock, 0, st>>>(graph, height, H, W);
+      break;
+    case SOIL_D8:
+      if (wide) k_steepest4<8, false><<<win_grid(H, W), kWinBlock, 0, st>>>(graph, height, H, W);
+      else k_steepest<8, false><<<grid_rows(H, W, kGBlock), kGBlock, 0, st>>>(graph, height, H, W);
+      break;
     default: return fail(SOIL_ERR_INVALID_ARGUMENT, "invalid edge enumerator");  // graph.cu:88
   }
   SOIL_LAUNCH_CHECK();

@@ -151,6 +151,27 @@ __device__ __forceinline__ bool plain_den(float b) { return fabsf(b) >= kDenLo &
 __device__ __forceinline__ bool plain_num(float a) { return f2bits(a) == 0u || fabsf(a) >= kNumLo; }
 
 
+// Quotients of a stencil kernel over a denominator that is the same for every cell (a cell size,
+// sqrt(2)): quot() with the reciprocal refined once per thread, and the check of the plain range
+// made on the RESULTS of a whole group of cells at once — a quotient is beyond doubt when it is
+// zero (from a +0 numerator: differences of equal heights; the denominators are positive) or lies
+// in [2^-60, 2^90] (see above); Watch collects the extremes of the bit patterns, and a thread whose
+// group has a quotient outside (a denormal difference, an infinity, a NaN that is not the
+// kernels' own sentinel) redoes the group with the written-out divisions.
+struct QuotWatch {
+  uint32_t lo = 0xffffffffu, hi = 0u;
+  __device__ __forceinline__ float operator()(float q) {
+    const uint32_t u = f2bits(q) & 0x7fffffffu;
+    lo = min(lo, u - 1u);  // a zero wraps to the top: never the minimum
+    hi = max(hi, u);
+    return q;
+  }
+  __device__ __forceinline__ bool doubtful() const {
+    constexpr uint32_t kLoBits = (127u - 60u) << 23, kHiBits = (127u + 90u) << 23;
+    return lo < kLoBits - 1u || hi > kHiBits;
+  }
+};
+
 // ---- device-only helpers of the particle step ----------------------------------------------
 
 // The attenuation factors of a particle (att_m, att_w, att_v: erosion.cu:134-136; debris att_v :346)

@@ -1,6 +1,7 @@
 // stencil.hip — gradient / negslope / laplacian (grad.cu), separable Gaussian
 // blur (filter.cu) and the surface-normal map (op/normal.hpp).
 #include "common.hpp"
+#include "window.hpp"
 
 namespace soil {
 
@@ -92,6 +93,165 @@ __global__ void __launch_bounds__(kSBlock)
     const float LD = 0.5f * (vnn - v00) * hx + 0.5f * (vpp - v00) * hx + 0.5f * (vpn - v00) * hy +
                      0.5f * (vnp - v00) * hy;   // :179
     out[D * n + c] = 0.5f * LH + 0.5f * LD;    // :181
+  }
+}
+
+// ---- the same three stencils, four cells per thread (window.hpp) ------------------------------
+
+// The divisions of these kernels are by the cell size: with FAST they are quot() over a reciprocal
+// refined once per thread, checked per group of four cells (QuotWatch, soil_math.hpp), and redone
+// as written when in doubt — same bits either way.  `div(a, b, rb)`: a / b.
+struct DivWritten {
+  __device__ __forceinline__ float operator()(float a, float b, const Recip&) const { return a / b; }
+};
+struct DivShared {
+  QuotWatch* watch;
+  __device__ __forceinline__ float operator()(float a, float, const Recip& rb) const {
+    return (*watch)(quot(a, rb));
+  }
+};
+// a scale the shared-reciprocal quotient may divide by (positive, 2^-40 .. 2^40)
+static bool plain_scale(float v) { return v >= 0x1p-40f && v <= 0x1p40f; }
+
+// __gradient, grad.cu:22-87, for the four cells of a thread
+template <typename DIV>
+__device__ __forceinline__ void gradient_group(float of[8], const RowWalk& w, const WinThread& t,
+                                               int64_t W, Scale2 s, const Recip& rx, const Recip& ry,
+                                               DIV div) {
+  const float nan = __builtin_nanf("");
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float h = w.mid.v[k + 1];
+    const float hn0 = w.has_up ? w.up.v[k + 1] : nan;  // :35-38
+    const float hp0 = w.has_dn ? w.dn.v[k + 1] : nan;
+    const float h0n = (k > 0 || t.y0 > 0) ? w.mid.v[k] : nan;
+    const float h0p = (k < 3 || t.y0 + 4 < W) ? w.mid.v[k + 2] : nan;
+    const float gxn = div(h - hn0, s.x, rx);            // :46
+    const float gyn = div(h - h0n, s.y, ry);            // :50
+    const float gxp = div(hp0 - h, s.x, rx);            // :54
+    const float gyp = div(h0p - h, s.y, ry);            // :58
+    float gx = div(0.5f * (hp0 - hn0), s.x, rx);        // :62
+    float gy = div(0.5f * (h0p - h0n), s.y, ry);        // :63
+    if (gx != gx) gx = gxn;                             // :65-67
+    if (gx != gx) gx = gxp;
+    if (gx != gx) gx = 0.0f;
+    if (gy != gy) gy = gyn;  // :69-71
+    if (gy != gy) gy = gyp;
+    if (gy != gy) gy = 0.0f;
+    of[2 * k] = gx;  // :84-85
+    of[2 * k + 1] = gy;
+  }
+}
+
+template <bool FAST>
+__global__ void __launch_bounds__(kWinBlock)
+    k_gradient4(float2* __restrict__ out, const float* __restrict__ in, int64_t H, int64_t W, Scale2 s) {
+  __shared__ float4 s_tile[kWinBlock / 64][128];
+  const WinThread t = win_thread(W);
+  const Recip rx = recip(s.x), ry = recip(s.y);
+  RowWalk w;
+  SOIL_WIN_ROWS(x, w, in, H, W, t.y0) {
+    float4 o[2];
+    float* of = reinterpret_cast<float*>(o);
+    // at the grid's edge the NaN sentinels of :35-38 run through the quotients: written-out there
+    bool redo = !FAST || !w.has_up || !w.has_dn || t.y0 == 0 || t.y0 + 4 >= W;
+    if (!redo) {
+      // inside the grid all four neighbours exist: the gradient is the central difference (:62-63)
+      // and the one-sided ones (:46-58) are only its stand-ins for a NaN — which the check below
+      // sends to the written-out path together with everything else out of the plain range
+      QuotWatch watch;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        of[2 * k] = watch(quot(0.5f * (w.dn.v[k + 1] - w.up.v[k + 1]), rx));
+        of[2 * k + 1] = watch(quot(0.5f * (w.mid.v[k + 2] - w.mid.v[k]), ry));
+      }
+      redo = watch.doubtful();
+    }
+    if (redo) gradient_group(of, w, t, W, s, rx, ry, DivWritten{});
+    // the wave's 256 cells start at column y0 - 4 * lane (lanes past the row's end sit on the last group)
+    const int lane = static_cast<int>(threadIdx.x & 63u);
+    const int64_t wave_y0 = (static_cast<int64_t>(blockIdx.x) * kWinBlock + (threadIdx.x & ~63u)) * 4;
+    (void)lane;
+    store_pair_contiguous(reinterpret_cast<float4*>(out + x * W + wave_y0), o[0], o[1],
+                          s_tile[threadIdx.x >> 6], t.live);
+  }
+}
+
+// __negslope, grad.cu:101-131
+template <typename DIV>
+__device__ __forceinline__ void negslope_group(float of[4], const RowWalk& w, const WinThread& t,
+                                               int64_t W, Scale2 s, const Recip& rx, const Recip& ry,
+                                               DIV div) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float h = w.mid.v[k + 1];
+    float gx = 0.0f;  // :120-122, glm::max(a, b) = (a < b) ? b : a
+    if (w.has_up) {
+      const float c = div(h - w.up.v[k + 1], s.x, rx);
+      gx = (gx < c) ? c : gx;
+    }
+    if (w.has_dn) {
+      const float c = div(h - w.dn.v[k + 1], s.x, rx);
+      gx = (gx < c) ? c : gx;
+    }
+    float gy = 0.0f;  // :124-126
+    if (k > 0 || t.y0 > 0) {
+      const float c = div(h - w.mid.v[k], s.y, ry);
+      gy = (gy < c) ? c : gy;
+    }
+    if (k < 3 || t.y0 + 4 < W) {
+      const float c = div(h - w.mid.v[k + 2], s.y, ry);
+      gy = (gy < c) ? c : gy;
+    }
+    of[k] = sqrtf(gx * gx + gy * gy);  // :129
+  }
+}
+
+template <bool FAST>
+__global__ void __launch_bounds__(kWinBlock)
+    k_negslope4(float* __restrict__ out, const float* __restrict__ in, int64_t H, int64_t W, Scale2 s) {
+  const WinThread t = win_thread(W);
+  const Recip rx = recip(s.x), ry = recip(s.y);
+  RowWalk w;
+  SOIL_WIN_ROWS(x, w, in, H, W, t.y0) {
+    float4 o;
+    float* of = reinterpret_cast<float*>(&o);
+    bool redo = !FAST;
+    if (!redo) {
+      QuotWatch watch;
+      negslope_group(of, w, t, W, s, rx, ry, DivShared{&watch});
+      redo = watch.doubtful();
+    }
+    if (redo) negslope_group(of, w, t, W, s, rx, ry, DivWritten{});
+    if (t.live) *reinterpret_cast<float4*>(out + x * W + t.y0) = o;
+  }
+}
+
+// __laplacian<1>, grad.cu:147-183
+__global__ void __launch_bounds__(kWinBlock)
+    k_laplacian4(float* __restrict__ out, const float* __restrict__ in, int64_t H, int64_t W, Scale2 s) {
+  const WinThread t = win_thread(W);
+  const float hx = (1.0f / s.x / s.x);  // :175
+  const float hy = (1.0f / s.y / s.y);  // :176
+  RowWalk w;
+  SOIL_WIN_ROWS(x, w, in, H, W, t.y0) {
+    float4 o;
+    float* of = reinterpret_cast<float*>(&o);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float v00 = w.mid.v[k + 1];
+      const bool l = k > 0 || t.y0 > 0, r = k < 3 || t.y0 + 4 < W;
+      // clamp-to-self, :166-173: a neighbour outside the grid reads as the centre
+      const float vn0 = w.has_up ? w.up.v[k + 1] : v00, vp0 = w.has_dn ? w.dn.v[k + 1] : v00;
+      const float v0n = l ? w.mid.v[k] : v00, v0p = r ? w.mid.v[k + 2] : v00;
+      const float vnn = (w.has_up && l) ? w.up.v[k] : v00, vpp = (w.has_dn && r) ? w.dn.v[k + 2] : v00;
+      const float vpn = (w.has_dn && l) ? w.dn.v[k] : v00, vnp = (w.has_up && r) ? w.up.v[k + 2] : v00;
+      const float LH = (vn0 - v00) * hx + (vp0 - v00) * hx + (v0n - v00) * hy + (v0p - v00) * hy;  // :178
+      const float LD = 0.5f * (vnn - v00) * hx + 0.5f * (vpp - v00) * hx + 0.5f * (vpn - v00) * hy +
+                       0.5f * (vnp - v00) * hy;  // :179
+      of[k] = 0.5f * LH + 0.5f * LD;              // :181
+    }
+    if (t.live) *reinterpret_cast<float4*>(out + x * W + t.y0) = o;
   }
 }
 
@@ -284,8 +444,15 @@ int soil_gradient(float* out, const float* in, int64_t H, int64_t W, const float
   SOIL_DEVICE();
   SOIL_REQUIRE(out && in && scale, "gradient: null argument");
   SOIL_REQUIRE(H > 0 && W > 0, "gradient: empty grid");
-  k_gradient<<<grid_rows(H, W, kSBlock), kSBlock, 0, as_stream(stream)>>>(
-      reinterpret_cast<float2*>(out), in, H, W, Scale2{scale[0], scale[1]});
+  if (W % 4 == 0 && W >= 4 && plain_scale(scale[0]) && plain_scale(scale[1]))
+    k_gradient4<true><<<win_grid(H, W), kWinBlock, 0, as_stream(stream)>>>(
+        reinterpret_cast<float2*>(out), in, H, W, Scale2{scale[0], scale[1]});
+  else if (W % 4 == 0 && W >= 4)
+    k_gradient4<false><<<win_grid(H, W), kWinBlock, 0, as_stream(stream)>>>(
+        reinterpret_cast<float2*>(out), in, H, W, Scale2{scale[0], scale[1]});
+  else
+    k_gradient<<<grid_rows(H, W, kSBlock), kSBlock, 0, as_stream(stream)>>>(
+        reinterpret_cast<float2*>(out), in, H, W, Scale2{scale[0], scale[1]});
   SOIL_LAUNCH_CHECK();
   return SOIL_OK;
 }
@@ -295,8 +462,15 @@ int soil_negslope(float* out, const float* in, int64_t H, int64_t W, const float
   SOIL_DEVICE();
   SOIL_REQUIRE(out && in && scale, "negslope: null argument");
   SOIL_REQUIRE(H > 0 && W > 0, "negslope: empty grid");
-  k_negslope<<<grid_rows(H, W, kSBlock), kSBlock, 0, as_stream(stream)>>>(
-      out, in, H, W, Scale2{scale[0], scale[1]});
+  if (W % 4 == 0 && W >= 4 && plain_scale(scale[0]) && plain_scale(scale[1]))
+    k_negslope4<true><<<win_grid(H, W), kWinBlock, 0, as_stream(stream)>>>(out, in, H, W,
+                                                                           Scale2{scale[0], scale[1]});
+  else if (W % 4 == 0 && W >= 4)
+    k_negslope4<false><<<win_grid(H, W), kWinBlock, 0, as_stream(stream)>>>(out, in, H, W,
+                                                                            Scale2{scale[0], scale[1]});
+  else
+    k_negslope<<<grid_rows(H, W, kSBlock), kSBlock, 0, as_stream(stream)>>>(
+        out, in, H, W, Scale2{scale[0], scale[1]});
   SOIL_LAUNCH_CHECK();
   return SOIL_OK;
 }
@@ -307,7 +481,9 @@ int soil_laplacian(float* out, const float* in, int64_t H, int64_t W, int D, con
   SOIL_REQUIRE(out && in && scale, "laplacian: null argument");
   SOIL_REQUIRE(H > 0 && W > 0, "laplacian: empty grid");
   const Scale2 s{scale[0], scale[1]};
-  if (D == 1)  // grad.cu:196-198
+  if (D == 1 && W % 4 == 0 && W >= 4)  // grad.cu:196-198
+    k_laplacian4<<<win_grid(H, W), kWinBlock, 0, as_stream(stream)>>>(out, in, H, W, s);
+  else if (D == 1)
     k_laplacian<1><<<grid_rows(H, W, kSBlock), kSBlock, 0, as_stream(stream)>>>(out, in, H, W, s);
   else if (D == 2)  // grad.cu:200-202
     k_laplacian<2><<<grid_rows(H, 2 * W, kSBlock), kSBlock, 0, as_stream(stream)>>>(out, in, H, W, s);

@@ -595,6 +595,30 @@ def test_stencils_bit_exact(hip, oracle, H, W):
     assert_bit_equal(to_np(soil.normal(gh, s3)), oracle.normal(h, s3), "normal (gpu)")
 
 
+@pytest.mark.parametrize("H,W", [(70, 2052), (33, 1024), (100, 4), (65, 260)])
+def test_window_kernels_across_seams(hip, oracle, H, W):
+    """The four-cells-per-thread shape (window.hpp) where its seams are: rows wider than one
+    work-group's 1024 columns, a wave's first and last lane (which reload their halo column),
+    bands of 32 rows, a last group that ends the row, one group per row."""
+    from soillib_amd import soil
+    h = terrain(oracle, H, W)[..., 0].copy()
+    if W > 262:
+        h[5:9, 250:262] = h[6, 255]             # a flat patch across a wave boundary
+    h[1, 1] = 1e-30                             # a height difference the shared-reciprocal quotient
+    h[2, 1] = 3e-30                             # must hand to the written-out division
+    if H > 40:
+        h[40, 2] = np.inf
+    gh = to_gpu(h)
+    sc = (0.4, 1.7)
+    for edge in (D4, D8):
+        assert_bit_equal(to_np(soil.steepest(gh, edge)), oracle.steepest(h, edge), "steepest")
+        assert_bit_equal(to_np(soil.direction(gh, edge)), oracle.direction(h, edge), "direction")
+    assert_bit_equal(to_np(soil.gradient(gh, sc)), oracle.gradient(h, sc), "gradient")
+    assert_bit_equal(to_np(soil.negslope(gh, sc)), oracle.negslope(h, sc), "negslope")
+    t = np.random.default_rng(2).standard_normal((H, W, 1)).astype(np.float32)
+    assert_bit_equal(to_np(soil.laplacian(to_gpu(t), sc)), oracle.laplacian(t, sc), "laplacian")
+
+
 @pytest.mark.parametrize("H,W", [(70, 1500), (33, 1025), (300, 7)])
 def test_gaussian_blur_across_tile_seams(hip, oracle, H, W):
     """Grids wider than one 1024-float LDS segment and taller than one 32-row band."""
