@@ -255,6 +255,82 @@ __global__ void __launch_bounds__(kWinBlock)
   }
 }
 
+// __laplacian<2>, grad.cu:147-183, on a two-channel plane: a thread owns four cells = eight
+// consecutive floats of the (H, 2 W) matrix; the cells left and right of them come from the
+// neighbouring lanes (lanes 0 and 63 reload 8 bytes), three rows slide through registers.
+struct Row12 {
+  float v[12];  // [0,1] the cell left of the thread's four, [2..9] its own, [10,11] the cell right
+};
+__device__ __forceinline__ Row12 load_row12(const float* __restrict__ in, int64_t x, int64_t W,
+                                            int64_t y0, bool row_ok) {
+  const int lane = static_cast<int>(threadIdx.x & 63u);
+  const float* row = in + x * W * 2;
+  float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f), b = a;
+  if (row_ok) {
+    a = *reinterpret_cast<const float4*>(row + 2 * y0);
+    b = *reinterpret_cast<const float4*>(row + 2 * y0 + 4);
+  }
+  float l0 = __shfl_up(b.z, 1, 64), l1 = __shfl_up(b.w, 1, 64);
+  float r0 = __shfl_down(a.x, 1, 64), r1 = __shfl_down(a.y, 1, 64);
+  if (lane == 0) {
+    const bool ok = row_ok && y0 > 0;
+    l0 = ok ? row[2 * y0 - 2] : 0.0f;
+    l1 = ok ? row[2 * y0 - 1] : 0.0f;
+  }
+  if (lane == 63) {
+    const bool ok = row_ok && y0 + 4 < W;
+    r0 = ok ? row[2 * y0 + 8] : 0.0f;
+    r1 = ok ? row[2 * y0 + 9] : 0.0f;
+  }
+  return Row12{{l0, l1, a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, r0, r1}};
+}
+
+__global__ void __launch_bounds__(kWinBlock)
+    k_laplacian4x2(float* __restrict__ out, const float* __restrict__ in, int64_t H, int64_t W, Scale2 s) {
+  __shared__ float4 s_tile[kWinBlock / 64][128];
+  const WinThread t = win_thread(W);
+  const float hx = (1.0f / s.x / s.x);  // :175
+  const float hy = (1.0f / s.y / s.y);  // :176
+  const int64_t wave_y0 = (static_cast<int64_t>(blockIdx.x) * kWinBlock + (threadIdx.x & ~63u)) * 4;
+  for (int64_t band = blockIdx.y; band * kWinBand < H; band += gridDim.y) {
+    int64_t x = band * kWinBand;
+    const int64_t x_end = (x + kWinBand < H) ? x + kWinBand : H;
+    bool has_up = x > 0, has_dn = x + 1 < H;
+    Row12 up = load_row12(in, x - 1, W, t.y0, has_up), mid = load_row12(in, x, W, t.y0, true);
+    Row12 dn = load_row12(in, x + 1, W, t.y0, has_dn);
+    for (;;) {
+      float4 o[2];
+      float* of = reinterpret_cast<float*>(o);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const bool l = k > 0 || t.y0 > 0, r = k < 3 || t.y0 + 4 < W;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const int i = 2 + 2 * k + c;
+          const float v00 = mid.v[i];
+          // clamp-to-self, :166-173: a neighbour outside the grid reads as the centre
+          const float vn0 = has_up ? up.v[i] : v00, vp0 = has_dn ? dn.v[i] : v00;
+          const float v0n = l ? mid.v[i - 2] : v00, v0p = r ? mid.v[i + 2] : v00;
+          const float vnn = (has_up && l) ? up.v[i - 2] : v00, vpp = (has_dn && r) ? dn.v[i + 2] : v00;
+          const float vpn = (has_dn && l) ? dn.v[i - 2] : v00, vnp = (has_up && r) ? up.v[i + 2] : v00;
+          const float LH = (vn0 - v00) * hx + (vp0 - v00) * hx + (v0n - v00) * hy + (v0p - v00) * hy;  // :178
+          const float LD = 0.5f * (vnn - v00) * hx + 0.5f * (vpp - v00) * hx + 0.5f * (vpn - v00) * hy +
+                           0.5f * (vnp - v00) * hy;  // :179
+          of[2 * k + c] = 0.5f * LH + 0.5f * LD;      // :181
+        }
+      }
+      store_pair_contiguous(reinterpret_cast<float4*>(out + (x * W + wave_y0) * 2), o[0], o[1],
+                            s_tile[threadIdx.x >> 6], t.live);
+      if (++x >= x_end) break;
+      up = mid;
+      mid = dn;
+      has_up = true;
+      has_dn = x + 1 < H;
+      dn = load_row12(in, x + 1, W, t.y0, has_dn);
+    }
+  }
+}
+
 // __gaussian_blur / __blur, filter.cu:24-70.  The 33 tap weights depend on
 // sigma only; the host evaluates them once with the same expression as
 // filter.cu:47-48 instead of once per tap per cell.
@@ -485,7 +561,9 @@ int soil_laplacian(float* out, const float* in, int64_t H, int64_t W, int D, con
     k_laplacian4<<<win_grid(H, W), kWinBlock, 0, as_stream(stream)>>>(out, in, H, W, s);
   else if (D == 1)
     k_laplacian<1><<<grid_rows(H, W, kSBlock), kSBlock, 0, as_stream(stream)>>>(out, in, H, W, s);
-  else if (D == 2)  // grad.cu:200-202
+  else if (D == 2 && W % 4 == 0 && W >= 4)  // grad.cu:200-202
+    k_laplacian4x2<<<win_grid(H, W), kWinBlock, 0, as_stream(stream)>>>(out, in, H, W, s);
+  else if (D == 2)
     k_laplacian<2><<<grid_rows(H, 2 * W, kSBlock), kSBlock, 0, as_stream(stream)>>>(out, in, H, W, s);
   else
     return fail(SOIL_ERR_INVALID_ARGUMENT, "laplacian: channel count must be 1 or 2");

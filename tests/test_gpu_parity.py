@@ -615,8 +615,10 @@ def test_window_kernels_across_seams(hip, oracle, H, W):
         assert_bit_equal(to_np(soil.direction(gh, edge)), oracle.direction(h, edge), "direction")
     assert_bit_equal(to_np(soil.gradient(gh, sc)), oracle.gradient(h, sc), "gradient")
     assert_bit_equal(to_np(soil.negslope(gh, sc)), oracle.negslope(h, sc), "negslope")
-    t = np.random.default_rng(2).standard_normal((H, W, 1)).astype(np.float32)
-    assert_bit_equal(to_np(soil.laplacian(to_gpu(t), sc)), oracle.laplacian(t, sc), "laplacian")
+    for D in (1, 2):
+        t = np.random.default_rng(2).standard_normal((H, W, D)).astype(np.float32)
+        assert_bit_equal(to_np(soil.laplacian(to_gpu(t), sc)), oracle.laplacian(t, sc),
+                         "laplacian D=%d" % D)
 
 
 @pytest.mark.parametrize("H,W", [(70, 1500), (33, 1025), (300, 7)])
