@@ -422,10 +422,18 @@ int soil_multiflow(double* sum, const float* height, const float* source, int64_
  * build-defined, parity unpinned: out(c) = the lowest level at which
  * cell c can drain to an outlet (a step off the grid or onto a NaN cell) along `edge`
  * connectivity, i.e. the priority-flood surface; NaN cells stay NaN.  Exact in fp32
- * (only min/max), iterative tile relaxation in LDS; synchronises the stream. */
+ * (only min/max): tile relaxation in LDS, started from the recursively filled 4x coarser
+ * level (csrc/conditioning.hip); synchronises the stream. */
 int soil_fill_depressions(float* out, const float* height, int64_t H, int64_t W, int edge,
                           void* stream);
-/* Frees the cached accumulate workspace of the current device. */
+/* Scratch memory.  The reference allocates its scratch per call (graph.cu:539-550, :182-183;
+ * path.cu:195; filter.cu:77); this library keeps one cached block per device and purpose
+ * (accumulate, the particle launches of either kind, fill_depressions, soil_erode) and grows it
+ * on demand.  Contract: calls that use the same block must not overlap in time — ONE host thread
+ * per device drives the library (as in the reference: single host thread, GIL held throughout,
+ * model.cpp), or several threads that serialise their calls.  A call that finds its block too
+ * small synchronises the device before replacing it.
+ * soil_workspace_release frees all cached blocks of the current device. */
 int soil_workspace_release(void);
 
 /* ---------------------------------------------------------------- stencils */

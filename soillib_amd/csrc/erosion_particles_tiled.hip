@@ -690,7 +690,10 @@ __device__ __forceinline__ float wave_sum63(float v) {
   return v;
 }
 
-template <int NP>
+// The first 2 * NPAIRS planes come in pairs that share an 8-byte LDS word (p[2i + 1] == p[2i] + 1:
+// water | mass, velocity x | y): one 64-bit read and one 64-bit swap serve both — half the LDS
+// operations of a deposit; a lost swap of a pair is made up for plane by plane like any other.
+template <int NP, int NPAIRS = 0>
 struct CasDeposit {
   float* p[NP];
   float v[NP];
@@ -701,11 +704,30 @@ struct CasDeposit {
   }
   __device__ __forceinline__ void load() {  // the old words: issued early, used by swap_all()
 #pragma unroll
-    for (int j = 0; j < NP; ++j) o[j] = f2bits(*p[j]);
+    for (int i = 0; i < NPAIRS; ++i) {
+      const uint2 w = *reinterpret_cast<const uint2*>(p[2 * i]);
+      o[2 * i] = w.x;
+      o[2 * i + 1] = w.y;
+    }
+#pragma unroll
+    for (int j = 2 * NPAIRS; j < NP; ++j) o[j] = f2bits(*p[j]);
   }
   __device__ __forceinline__ void swap_all() {
 #pragma unroll
-    for (int j = 0; j < NP; ++j) g[j] = swap(p[j], o[j], v[j]);
+    for (int i = 0; i < NPAIRS; ++i) {
+      const unsigned long long expect = static_cast<unsigned long long>(o[2 * i]) |
+                                        (static_cast<unsigned long long>(o[2 * i + 1]) << 32);
+      const unsigned long long want =
+          static_cast<unsigned long long>(f2bits(bits2f(o[2 * i]) + v[2 * i])) |
+          (static_cast<unsigned long long>(f2bits(bits2f(o[2 * i + 1]) + v[2 * i + 1])) << 32);
+      const unsigned long long got = atomicCAS(reinterpret_cast<unsigned long long*>(p[2 * i]), expect, want);
+      // a pair is lost as a whole: make both halves read "lost" unless the whole word matched
+      const bool won = got == expect;
+      g[2 * i] = won ? o[2 * i] : ~o[2 * i];
+      g[2 * i + 1] = won ? o[2 * i + 1] : ~o[2 * i + 1];
+    }
+#pragma unroll
+    for (int j = 2 * NPAIRS; j < NP; ++j) g[j] = swap(p[j], o[j], v[j]);
     pending = true;
   }
   __device__ __forceinline__ void begin() {
@@ -806,10 +828,11 @@ __global__ void __launch_bounds__(NT)
 
   // flux accumulators as separate planes: lane addresses c map to 32 distinct
   // banks (an AoS float4 would put every lane of a deposit on 8 banks)
-  __shared__ float s_f0[kCells];                        // fluvial water | debris mass
-  __shared__ float s_f1[KIND == FLUVIAL ? kCells : 1];  // fluvial mass
-  __shared__ float s_fx[kCells], s_fy[kCells];          // velocity flux
+  // fluvial: water | mass interleaved (an 8-byte word per cell: CasDeposit's pairs); debris: mass
+  __shared__ __attribute__((aligned(8))) float s_a[KIND == FLUVIAL ? 2 * kCells : kCells];
+  __shared__ __attribute__((aligned(8))) float s_v[2 * kCells];  // velocity flux x | y interleaved
   __shared__ float s_c0[ALB ? kCells : 1], s_c1[ALB ? kCells : 1], s_c2[ALB ? kCells : 1];  // colour
+  constexpr int kA = (KIND == FLUVIAL) ? 2 : 1;  // floats of s_a per cell
   __shared__ uint32_t s_next, s_out, s_steps;
   const int tid = threadIdx.x;
   if (tid == 0) {
@@ -829,10 +852,10 @@ __global__ void __launch_bounds__(NT)
   for (int j = 0; j < kPer; ++j) {
     const int c = tid + j * kBlock;
     if (kCells % NT != 0 && c >= kCells) break;
-    s_f0[c] = 0.0f;
-    if (KIND == FLUVIAL) s_f1[c] = 0.0f;
-    s_fx[c] = 0.0f;
-    s_fy[c] = 0.0f;
+    s_a[kA * c] = 0.0f;
+    if (KIND == FLUVIAL) s_a[2 * c + 1] = 0.0f;
+    s_v[2 * c] = 0.0f;
+    s_v[2 * c + 1] = 0.0f;
     if (ALB) s_c0[c] = s_c1[c] = s_c2[c] = 0.0f;
   }
   __syncthreads();
@@ -927,7 +950,7 @@ __global__ void __launch_bounds__(NT)
     }
     PROF_AT(2);  // head
     constexpr int kFluxPlanes = (KIND == FLUVIAL) ? 4 : 3;
-    CasDeposit<kFluxPlanes + (ALB ? 3 : 0)> dep;
+    CasDeposit<kFluxPlanes + (ALB ? 3 : 0), (KIND == FLUVIAL) ? 2 : 1> dep;
     const int c = c_org + static_cast<int>(dr) * TC + static_cast<int>(dc);  // LDS cell (any value when idle)
     bool deposit = false;
     if (step) {
@@ -947,10 +970,11 @@ __global__ void __launch_bounds__(NT)
         float* p[kFluxPlanes + 3];
         if (KIND == FLUVIAL) {
           v[0] = r.a0 * r.s0, v[1] = r.a1 * r.s1, v[2] = r.a2 * r.svx, v[3] = r.a2 * r.svy;
-          p[0] = &s_f0[c], p[1] = &s_f1[c], p[2] = &s_fx[c], p[3] = &s_fy[c];
+          p[0] = &s_a[2 * c], p[1] = &s_a[2 * c + 1], p[2] = &s_v[2 * c], p[3] = &s_v[2 * c + 1];
         } else {
-          v[0] = r.a0 * r.s0, v[1] = r.a1 * r.svx, v[2] = r.a1 * r.svy;
-          p[0] = &s_f0[c], p[1] = &s_fx[c], p[2] = &s_fy[c];
+          // the pair (velocity x | y) first, the single plane after it: CasDeposit's order
+          v[0] = r.a1 * r.svx, v[1] = r.a1 * r.svy, v[2] = r.a0 * r.s0;
+          p[0] = &s_v[2 * c], p[1] = &s_v[2 * c + 1], p[2] = &s_a[c];
         }
         if (ALB) {  // colour rides on the mass attenuation, :110-112 / :315-317
           const float att = (KIND == FLUVIAL) ? r.a1 : r.a0;
@@ -1025,10 +1049,10 @@ __global__ void __launch_bounds__(NT)
       const int lx = row0 + c / TC, y = col0 + c % TC;
       const bool ok = c < kCells && lx >= 0 && y >= 0 && lx < static_cast<int>(d.rows) && y < k.W;
       l[j] = static_cast<int64_t>(lx) * k.W + y;
-      a0[j] = ok ? s_f0[c] : 0.0f;
-      a1[j] = (KIND == FLUVIAL && ok) ? s_f1[c] : 0.0f;
-      ax[j] = ok ? s_fx[c] : 0.0f;
-      ay[j] = ok ? s_fy[c] : 0.0f;
+      a0[j] = ok ? s_a[kA * c] : 0.0f;
+      a1[j] = (KIND == FLUVIAL && ok) ? s_a[2 * c + 1] : 0.0f;
+      ax[j] = ok ? s_v[2 * c] : 0.0f;
+      ay[j] = ok ? s_v[2 * c + 1] : 0.0f;
     }
     if (shared_tile) {  // uniform per work-group
 #pragma unroll
