@@ -40,11 +40,12 @@
 // shape; only the order of the fp32 additions into a cell differs.
 //
 // Measured at 8192^2, N = 8.4 M, maxage 256 (ms per launch, fluvial / debris):
-// direct 418 / 115; fields+flux in LDS with ds_add_f32 84 / 36; this file 31.7 / 13.1.
-// The round kernel issues VALU instructions on 75-79 % of all SIMD cycles in the
-// rounds that carry the work (profiles/); a fluvial step is ~230 vector instructions,
-// most of them the reference's arithmetic (seven IEEE quotients over four
-// denominators, a square root, three exponentials), see advance() and DESIGN.md 3.2.
+// direct 418 / 115; fields+flux in LDS with ds_add_f32 84 / 36; this file 27.4 / 12.1.
+// A fluvial step is ~170 vector + ~90 scalar instructions (seven IEEE quotients over four
+// denominators, a square root, three hardware exponentials, see step_geom / step_apply); the
+// vector pipes execute on ~60 % of all SIMD cycles (SQ_ACTIVE_INST_VALU, profiles/), and what
+// keeps them from more is concurrency: 16 B of LDS per cell cap a CU at ~1200 walkers in flight,
+// of which ~40 % are stepping at any time.
 #include <algorithm>
 #include <chrono>
 #include <cstdio>

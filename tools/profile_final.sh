@@ -12,6 +12,7 @@ pmc fetch "FETCH_SIZE" 2
 pmc write "WRITE_SIZE" 2
 pmc valu "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_TRANS_F32" 1
 pmc lds "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_INSTS_SALU SQ_INSTS_BRANCH" 1
+pmc mix "SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT GRBM_GUI_ACTIVE" 1
 # what the VALU counters read on instruction streams of known cost (the opcode classes of the
 # microbenchmark): the calibration of `valu_busy`
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --output-format csv -d $out/calib -o p -- /root/repo/tools/microbench/valu_issue > $out/valu_issue.txt 2>&1

@@ -80,13 +80,14 @@ summary = {
     "command": "rocprofv3 --kernel-trace --pmc <counters> --output-format csv -- python bench.py --steps 1 "
                "--warmup 1 --no-cpu-baseline (8192^2, second step); two passes, see tools/profile_final.sh",
     "note": "counters are summed over the 8 XCDs; GRBM_GUI_ACTIVE/8 = shader cycles of the launch.  "
-            "valu_busy = 4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x cycles): the share of all SIMD cycles "
-            "in which a vector instruction was executing (the counter ticks in quad-cycles) — the "
-            "roofline fraction of this kernel, whose bound is VALU issue.  There is no single 'peak "
-            "instructions per cycle': a wave64 v_fma/add/mul occupies a SIMD for 2 cycles, compares, "
-            "min/max, conversions, v_cndmask, DPP and the v_div_* helpers for 4, v_rcp/v_sqrt/v_exp for "
-            "8 (tools/microbench/valu_issue*.hip); cycles_per_valu_instruction = 1024 x cycles / "
-            "SQ_INSTS_VALU is what the mix averages to including idle time.  lane utilisation = "
+            "active_inst_valu_x4_per_cycle = 4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x cycles) is NOT a busy "
+            "share on gfx950: the counter ticks one quad-cycle per vector instruction whatever its issue "
+            "cost and two per transcendental (valu_calibration.json) — kept for reference only; the "
+            "roofline fraction of this kernel is priced from its instruction mix, "
+            "profiles/particle_roofline.json.  A wave64 v_fma/add/mul occupies a SIMD for 2 cycles, "
+            "compares, min/max, conversions, v_cndmask, DPP and the v_div_* helpers for 4, v_rcp/v_sqrt/"
+            "v_exp for 8 (tools/microbench/valu_issue*.hip); cycles_per_valu_instruction = 1024 x cycles "
+            "/ SQ_INSTS_VALU is wall time per instruction.  lane utilisation = "
             "SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU); lds_busy = SQ_LDS_IDX_ACTIVE / (256 CUs "
             "x cycles), lds_bank_conflict likewise",
 }
@@ -100,7 +101,7 @@ for kind, label in ((0, "fluvial_rounds"), (1, "debris_rounds")):
         rows.append({
             "round": i, "duration_us": round(a["dur_us"], 1), "shader_clock_ghz": round(cyc / a["dur_us"] / 1e3, 2),
             "SQ_INSTS_VALU": a["SQ_INSTS_VALU"], "SQ_INSTS_VALU_TRANS_F32": a["SQ_INSTS_VALU_TRANS_F32"],
-            "valu_busy": round(4 * a["SQ_ACTIVE_INST_VALU"] / (1024 * cyc), 3),
+            "active_inst_valu_x4_per_cycle": round(4 * a["SQ_ACTIVE_INST_VALU"] / (1024 * cyc), 3),
             "cycles_per_valu_instruction": round(1024 * cyc / a["SQ_INSTS_VALU"], 2),
             "SQ_ACTIVE_INST_VALU": a["SQ_ACTIVE_INST_VALU"], "shader_cycles": cyc,
             "lane_utilisation": round(a["SQ_THREAD_CYCLES_VALU"] / (64 * a["SQ_ACTIVE_INST_VALU"]), 3),
@@ -112,23 +113,97 @@ for kind, label in ((0, "fluvial_rounds"), (1, "debris_rounds")):
         })
     summary[label] = rows
 json.dump(summary, open(os.path.join(dst, "pmc_round_kernel_valu.json"), "w"), indent=1)
-# 4. the roofline of the kernel that carries the step (bench.py copies it into `roofline_particles`)
+# 4. the roofline of the kernel that carries the step (bench.py copies it into `roofline_particles`).
+#    SQ_ACTIVE_INST_VALU is no measure of a busy pipe on gfx950: it ticks one quad-cycle per vector
+#    instruction whatever its issue cost (2, 4 or ~16 cycles) and two per transcendental
+#    (valu_calibration.json).  The issue time is therefore priced from the instruction mix — the
+#    hardware's own type counters (pass `mix`) times the issue cost measured per opcode class
+#    (tools/microbench/valu_issue*.hip).
+COST = {"SQ_INSTS_VALU_ADD_F32": 2.0, "SQ_INSTS_VALU_MUL_F32": 2.0, "SQ_INSTS_VALU_FMA_F32": 2.0,
+        "SQ_INSTS_VALU_TRANS_F32": 8.0, "SQ_INSTS_VALU_CVT": 4.0,
+        "SQ_INSTS_VALU_INT32": 3.0,   # v_add/sub_u32 and shifts right 2, the rest 4
+        "other": 3.5}                 # moves and logic 2; compares, selects, min/max, DPP, readlane 4
 roof = {}
-for label in ("fluvial_rounds", "debris_rounds"):
-    rows = summary[label]
-    busy = sum(4 * r["SQ_ACTIVE_INST_VALU"] for r in rows)
-    total = sum(1024 * r["shader_cycles"] for r in rows)
-    roof[label] = {"valu_busy": round(busy / total, 3), "launches": len(rows),
-                   "time_ms": round(sum(r["duration_us"] for r in rows) / 1e3, 3),
-                   "valu_instructions": sum(r["SQ_INSTS_VALU"] for r in rows)}
-json.dump({
-    "kernel": "k_tiled_round (all launches of one 8192^2 step)", "bound": "valu-issue",
-    "achieved": sum(v["valu_busy"] * v["time_ms"] for v in roof.values()) / sum(v["time_ms"] for v in roof.values()),
-    "peak": 1.0, "unit": "share of SIMD cycles executing a vector instruction",
-    "per_kind": roof,
-    "source": "profiles/%s/pmc_round_kernel_valu.json (rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU "
-              "SQ_ACTIVE_INST_VALU ... GRBM_GUI_ACTIVE on `python bench.py --steps 1 --warmup 1`)" % name,
-    "issue_cost_model": "tools/microbench/valu_issue.hip, valu_issue2.hip: wave64 issue cycles per opcode "
-                        "class measured on this chip (2 / 4 / 8)",
-}, open(os.path.join(ROOT, "profiles", "particle_roofline.json"), "w"), indent=1)
+mix_ok = os.path.isdir(os.path.join(src, "mix"))
+mix = load("mix") if mix_ok else []
+for kind, label in ((0, "fluvial_rounds"), (1, "debris_rounds")):
+    rows = [c for c in mix if "k_tiled_round<%d" % kind in c["name"]]
+    rows = rows[len(rows) // 2:]
+    if not rows:
+        continue
+    n = sum(r["SQ_INSTS_VALU"] for r in rows)
+    typed = {k: sum(r.get(k, 0.0) for r in rows) for k in COST if k != "other"}
+    other = n - sum(typed.values())
+    issue = sum(typed[k] * COST[k] for k in typed) + other * COST["other"]
+    cycles = sum(1024 * r["GRBM_GUI_ACTIVE"] / 8 for r in rows)
+    roof[label] = {"valu_issue_share": round(issue / cycles, 3), "launches": len(rows),
+                   "time_ms": round(sum(r["dur_us"] for r in rows) / 1e3, 3), "valu_instructions": n,
+                   "issue_cycles_per_instruction": round(issue / n, 2),
+                   "wall_simd_cycles_per_instruction": round(cycles / n, 2),
+                   "mix": {k.replace("SQ_INSTS_VALU_", ""): round(v / n, 3) for k, v in typed.items()} | {
+                       "other": round(other / n, 3)}}
+if roof:
+    tot_t = sum(v["time_ms"] for v in roof.values())
+    json.dump({
+        "kernel": "k_tiled_round (all launches of one 8192^2 step)", "bound": "valu-issue",
+        "achieved": sum(v["valu_issue_share"] * v["time_ms"] for v in roof.values()) / tot_t,
+        "peak": 1.0, "unit": "share of SIMD cycles taken by the issue of vector instructions",
+        "per_kind": roof,
+        "issue_cost_cycles": COST,
+        "source": "profiles/%s: rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F32 "
+                  "SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT GRBM_GUI_ACTIVE on `python bench.py --steps 1 --warmup 1` "
+                  "(gpurun_out/%s/mix), priced with the wave64 issue cycles per opcode class measured by "
+                  "tools/microbench/valu_issue.hip / valu_issue2.hip (valu_issue.txt); SQ_ACTIVE_INST_VALU is "
+                  "not usable as a busy counter on gfx950 (valu_calibration.json)" % (name, name),
+    }, open(os.path.join(ROOT, "profiles", "particle_roofline.json"), "w"), indent=1)
+# 5. the graph / stencil / conditioning kernels: kernel stats of tools/bench_stencils.py and
+#    tools/bench_accumulate.py, HBM traffic per launch next to the algorithmic bytes
+for sub in ("stencils", "accumulate"):
+    d = os.path.join(src, sub)
+    if os.path.isdir(d):
+        for f in os.listdir(d):
+            if f.endswith("kernel_stats.csv"):
+                shutil.copy(os.path.join(d, f), os.path.join(dst, "%s_kernel_stats.csv" % sub))
+        txt = os.path.join(src, "bench_%s.txt" % sub)
+        if os.path.exists(txt):
+            shutil.copy(txt, os.path.join(dst, "bench_%s.txt" % sub))
+if os.path.isdir(os.path.join(src, "stencils_fetch")):
+    per = collections.defaultdict(dict)
+    for d, key in (("stencils_fetch", "FETCH_SIZE"), ("stencils_write", "WRITE_SIZE")):
+        acc = collections.defaultdict(list)
+        for c in load(d):
+            if key in c and "dur_us" in c:
+                acc[c["name"]].append((c[key], c["dur_us"]))
+        for k, v in acc.items():
+            per[k][key + "_KB_avg"] = sum(x for x, _ in v) / len(v)
+            per[k]["dur_us_avg_" + key.split("_")[0].lower()] = sum(t for _, t in v) / len(v)
+    for k, v in per.items():
+        if "FETCH_SIZE_KB_avg" in v and "WRITE_SIZE_KB_avg" in v:
+            v["hbm_bytes_per_launch"] = v["FETCH_SIZE_KB_avg"] * 1024 * 2 + v["WRITE_SIZE_KB_avg"] * 1024
+            v["achieved_GBs"] = v["hbm_bytes_per_launch"] / (v["dur_us_avg_fetch"] * 1e-6) / 1e9
+    json.dump({"note": "tools/bench_stencils.py at 8192^2 under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (two "
+                       "passes); FETCH_SIZE x2 as in traffic_fused_cells.json; durations from the kernel trace "
+                       "of the FETCH pass", "kernels": per},
+              open(os.path.join(dst, "pmc_stencils_fetch_write.json"), "w"), indent=1)
+
+# 6. calibration of valu_busy: the microbenchmark's opcode streams under the same counters
+if os.path.isdir(os.path.join(src, "calib")):
+    rows = []
+    for c in load("calib"):
+        if "SQ_ACTIVE_INST_VALU" in c and c.get("GRBM_GUI_ACTIVE"):
+            cyc = c["GRBM_GUI_ACTIVE"] / 8
+            rows.append({"kernel": c["name"], "dur_us": round(c.get("dur_us", 0), 1),
+                         "SQ_INSTS_VALU": c["SQ_INSTS_VALU"],
+                         "active_inst_valu_x4_per_cycle": round(4 * c["SQ_ACTIVE_INST_VALU"] / (1024 * cyc), 3),
+                         "active_quads_per_instruction": round(c["SQ_ACTIVE_INST_VALU"] / c["SQ_INSTS_VALU"], 3)})
+    json.dump({"note": "tools/microbench/valu_issue: streams of one opcode each (k<MODE>; the order of the "
+                       "launches is that of the program's output, valu_issue.txt; MODE = the enum of "
+                       "valu_issue.hip: 0 fma 1 mul 2 add 3 pk_fma 4 pk_mul 5 pk_add 6 rcp 7 sqrt 8 exp 9 log "
+                       "10 rsq 11 ldexp 12 floor 13 cvt 14 mad_u24 15 cndmask(vcc) 16 cmp 17 div_scale 18 div_fmas "
+                       "19 div_fixup 20 max 21 med3 22 mov 23 dpp add 24 readlane 25 and).  SQ_ACTIVE_INST_VALU "
+                       "reads one quad-cycle per instruction for every class (two for the transcendentals) — and "
+                       "so more than 1.0 'busy' on a saturating 2-cycle stream: it cannot serve as a busy counter",
+               "launches": rows}, open(os.path.join(dst, "valu_calibration.json"), "w"), indent=1)
+    if os.path.exists(os.path.join(src, "valu_issue.txt")):
+        shutil.copy(os.path.join(src, "valu_issue.txt"), os.path.join(dst, "valu_issue.txt"))
 print("wrote", sorted(os.listdir(dst)))
