@@ -227,6 +227,7 @@ struct StepGeom {
   float v_norm, ux, uy, v_step, dL, ds;
   Recip rd;
   bool alive, ok;  // alive: past the `v_norm < eps` exit; ok: every operand plain (fluvial)
+  // the exit itself as one plain comparison of v_norm (for wave ballots): !alive
 };
 template <int KIND>
 __device__ __forceinline__ StepGeom step_geom(const PRec& r, const StepConst& k) {
@@ -699,7 +700,15 @@ struct CasDeposit {
   float* p[NP];
   float v[NP];
   uint32_t o[NP], g[NP];
-  bool pending = false;
+  // Lanes that do not deposit in an iteration still take part in finish()'s ballots (their bits
+  // are masked out): give their words some value — any, no instruction — instead of none.
+  __device__ __forceinline__ void whatever() {
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      o[j] = __builtin_nondeterministic_value(o[j]);
+      g[j] = __builtin_nondeterministic_value(g[j]);
+    }
+  }
   static __device__ __forceinline__ uint32_t swap(float* q, uint32_t expect, float add) {
     return atomicCAS(reinterpret_cast<uint32_t*>(q), expect, f2bits(bits2f(expect) + add));
   }
@@ -729,13 +738,13 @@ struct CasDeposit {
     }
 #pragma unroll
     for (int j = 2 * NPAIRS; j < NP; ++j) g[j] = swap(p[j], o[j], v[j]);
-    pending = true;
   }
   __device__ __forceinline__ void begin() {
     load();
     swap_all();
   }
-  // Convergent: every lane of the wave calls it (pending or not), once per iteration.
+  // Convergent: every lane of the wave calls it, once per iteration; `pending` is the ballot of
+  // the lanes that deposited in this iteration (the others hold values of an earlier one).
   // A lane that lost its race (another walker hit the same cell in between — common
   // once the particles share channels) does not retry: nothing was written by the
   // failed swap, and a k-way collision would cost k round trips.
@@ -746,16 +755,20 @@ struct CasDeposit {
   //    and one lane issues the atomic — on the hot tiles that set the length of a
   //    round on small grids, ds_add_f32 at 2.6 cycles per lane was all the LDS pipe did.
   // `cell` is the lane's cell index in the tile (any value when nothing is pending).
-  __device__ __forceinline__ void finish(int cell, int agg_min, int agg_groups) {
-    bool lostj[NP], lost = false;
+  // The wave-level tests are ballots of plain comparisons and scalar mask arithmetic: a ballot of
+  // a combined predicate costs a v_cndmask + v_cmp pair on top (8 issue cycles).
+  __device__ __forceinline__ void finish(uint64_t pending, int cell, int agg_min, int agg_groups) {
+    uint64_t todo = 0;
 #pragma unroll
-    for (int j = 0; j < NP; ++j) {
-      lostj[j] = pending && g[j] != o[j];
-      lost = lost || lostj[j];
-    }
-    pending = false;
-    uint64_t todo = __ballot(lost);
+    for (int i = 0; i < NPAIRS; ++i) todo |= __builtin_amdgcn_ballot_w64(g[2 * i] != o[2 * i]);  // a pair is lost as a whole
+#pragma unroll
+    for (int j = 2 * NPAIRS; j < NP; ++j) todo |= __builtin_amdgcn_ballot_w64(g[j] != o[j]);
+    todo &= pending;
     if (todo == 0) return;  // the common case
+    bool lost = __builtin_amdgcn_inverse_ballot_w64(todo);
+    bool lostj[NP];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) lostj[j] = lost && g[j] != o[j];
     const int lane = static_cast<int>(threadIdx.x & 63u);
     if (__popcll(todo) >= agg_min) {
       for (int it = 0; todo != 0 && it < agg_groups; ++it) {
@@ -801,8 +814,17 @@ extern "C" int soil_prof_read(unsigned long long* out, int reset) {
 #define PROF_FLUSH(kind)
 #endif
 
+// Waves per SIMD the launch is meant to run with (bounds the register allocation): two
+// work-groups of 768 or three of 512 per CU are 6; the colour shape (1024, one per CU) 4.
+constexpr int round_waves_per_simd(int kind, int nt, bool alb) {
+  const int lds_groups = alb ? 1 : (kind == FLUVIAL ? 2 : 3);        // by LDS: 64 / 48 KiB tiles
+  const int groups = lds_groups * (nt / 64) > 32 ? 32 / (nt / 64) : lds_groups;  // by wave slots
+  return groups * (nt / 64) / 4;
+}
+__device__ __forceinline__ bool any_lane(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0; }
+
 template <int KIND, int DEP, int TR, int TC, int NT, bool ALB>
-__global__ void __launch_bounds__(NT)
+__global__ void __launch_bounds__(NT, round_waves_per_simd(KIND, NT, ALB))
     k_tiled_round(PRec* __restrict__ out, uint32_t* __restrict__ dest, uint32_t* __restrict__ rank,
                   uint32_t* __restrict__ count_next, const PRec* __restrict__ in,
                   const uint32_t* __restrict__ order, const uint2* __restrict__ block_list,
@@ -879,7 +901,8 @@ __global__ void __launch_bounds__(NT)
   // the record is written out only when the lane takes another particle or the
   // loop is over: a tile starts a round with about one particle per lane, so
   // refills are the exception.
-  bool drained = cnt <= static_cast<uint32_t>(kBlock), parked = false;
+  // `more`: the queue holds entries beyond the ones handed out so far (uniform per wave)
+  bool more = cnt > static_cast<uint32_t>(kBlock), parked = false;
   auto write_out = [&]() {
     const uint32_t slot = atomicAdd(&s_out, 1u);  // slots this tile's queue occupied
     const uint32_t to = queue_key(k.x0, r.px, r.py, r.spx, r.spy, k.maxage - static_cast<uint32_t>(r.iter),
@@ -892,47 +915,154 @@ __global__ void __launch_bounds__(NT)
   // r.iter may grow up to `limit` in this round: the round's step budget, or the particle's age
   int limit = r.iter + steps_per_round < last_iter ? r.iter + steps_per_round : last_iter;
   uint32_t nsteps = 0;
+  constexpr int kFluxPlanes = (KIND == FLUVIAL) ? 4 : 3;
+  // what a particle adds to the cell it stands on, and where (LDS cell c): :104-113 / :310-318
+  auto deposit_terms = [&](int c, float* v, float** pp) {
+    if (KIND == FLUVIAL) {
+      v[0] = r.a0 * r.s0, v[1] = r.a1 * r.s1, v[2] = r.a2 * r.svx, v[3] = r.a2 * r.svy;
+      pp[0] = &s_a[2 * c], pp[1] = &s_a[2 * c + 1], pp[2] = &s_v[2 * c], pp[3] = &s_v[2 * c + 1];
+    } else {
+      // the pair (velocity x | y) first, the single plane after it: CasDeposit's order
+      v[0] = r.a1 * r.svx, v[1] = r.a1 * r.svy, v[2] = r.a0 * r.s0;
+      pp[0] = &s_v[2 * c], pp[1] = &s_v[2 * c + 1], pp[2] = &s_a[c];
+    }
+    if (ALB) {  // colour rides on the mass attenuation, :110-112 / :315-317
+      const float att = (KIND == FLUVIAL) ? r.a1 : r.a0;
+      v[kFluxPlanes] = att * r.sa0, v[kFluxPlanes + 1] = att * r.sa1, v[kFluxPlanes + 2] = att * r.sa2;
+      pp[kFluxPlanes] = &s_c0[c], pp[kFluxPlanes + 1] = &s_c1[c], pp[kFluxPlanes + 2] = &s_c2[c];
+    }
+  };
   PROF_AT(8);  // prologue: flux tile zeroed, first records loaded
   for (;;) {
-    PROF_AT(0);  // end of the previous iteration's tail
-    if (!have && !drained) {  // take the next particle of this tile's queue
+    if (more && !have) {  // take the next particle of this tile's queue
       const uint32_t i = atomicAdd(&s_next, 1u);
       if (i < cnt) {
         if (parked) write_out();
         r = in[order[first + i]];
         have = true;
         limit = r.iter + steps_per_round < last_iter ? r.iter + steps_per_round : last_iter;
-      } else {
-        drained = true;
       }
     }
-    if (!__any(have)) break;
+    if (more) more = __builtin_amdgcn_readfirstlane(static_cast<int>(*const_cast<volatile uint32_t*>(&s_next))) < static_cast<int>(cnt);
+    if (!any_lane(have)) break;
     PROF_AT(1);  // refill
-#ifdef SOIL_PROF
-    ++pt_iters;
-#endif
 
-    // top of the reference loop: while(!__oob(pos) && ++iter < maxage)  (:100 / :306),
-    // then the slab check, then "still on my tile, still within the round's budget?"
-    bool step = false;
-    uint32_t dr = 0, dc = 0;  // row, column counted from (r_lo, c_lo)
-    if (have) {
+    // ---- the stepping loop.  Top of the reference loop: while(!__oob(pos) && ++iter < maxage)
+    // (:100 / :306), the slab check, "still on my tile, still within the round's budget?" — one
+    // unsigned comparison per axis (see r_span above) and the step budget.  A lane whose walker
+    // cannot step on just drops out (`run`); what stopped it is sorted out once, after the loop,
+    // for all lanes of the wave together — inside the loop every wave would walk through that
+    // rare path on almost every iteration (64 lanes, one stop per ~20 steps each).  NaN
+    // coordinates (reference quirks) read as "out of range" here: floor_cell turns
+    // them into INT_MAX.
+    // The wave-level tests are ballots of plain comparisons combined with scalar mask
+    // arithmetic (`runm`: lanes still stepping), the per-lane predicate comes back from the mask
+    // (inverse ballot: free): the ballot of a combined predicate costs a v_cndmask + v_cmp pair.
+    uint64_t runm = __builtin_amdgcn_ballot_w64(have);
+    for (;;) {
+#ifdef SOIL_PROF
+      ++pt_iters;
+#endif
+      const uint32_t dr = static_cast<uint32_t>(floor_cell(r.px) - row_org);  // row, column counted
+      const uint32_t dc = static_cast<uint32_t>(floor_cell(r.py) - c_lo);     // from (r_lo, c_lo)
+      const uint64_t stepm = __builtin_amdgcn_ballot_w64(dr <= r_span) & __builtin_amdgcn_ballot_w64(dc <= c_span) &
+                             __builtin_amdgcn_ballot_w64(r.iter < limit) & runm;
+      const uint64_t stoppedm = runm & ~stepm;
+      runm = stepm;
+      if (stepm == 0) break;
+      if (more && stoppedm != 0) break;  // a longer queue: the freed lanes take new particles first
+      PROF_AT(2);  // head
+      CasDeposit<kFluxPlanes + (ALB ? 3 : 0), (KIND == FLUVIAL) ? 2 : 1> dep;
+      dep.whatever();
+      const int c = c_org + static_cast<int>(dr) * TC + static_cast<int>(dc);  // LDS cell (any value when idle)
+      // rows, W < 2^24 and H*W < 2^31 (use_tiled): one v_mad_u32_u24 per index
+      const uint32_t lcell = l_org + __umul24(dr, k.Wu) + dc;
+      const uint32_t nind = lcell + k.base;  // global cell: cx * W + cy, :103 / :309
+      // :104 / :310 — lanes that deposit in this iteration
+      const uint64_t freshm = (ABLATED(2) || ABLATED(4)) ? 0 : (__builtin_amdgcn_ballot_w64(nind != r.ind) & stepm);
+      float v_norm = 1.0f;
+      if (__builtin_amdgcn_inverse_ballot_w64(stepm)) {
+        ++r.iter;
+        ++nsteps;
+        // the cell's record comes from the packed plane through L1/L2 (the tile's
+        // 64 KiB are touched ~4x per round); issued first, the gather's latency
+        // hides under the deposit and the other waves of the SIMD
+        const float4 q = p4[ABLATED(8) ? l_org : lcell];
+        bool deposit = false;
+        if (nind != r.ind && !ABLATED(2)) {    // :104-113 / :310-318
+          r.ind = nind;
+          // DEP 0: native ds_add_f32, fire and forget; DEP 1: CasDeposit
+          float v[kFluxPlanes + 3];
+          float* pp[kFluxPlanes + 3];
+          deposit_terms(c, v, pp);
+#pragma unroll
+          for (int j = 0; j < kFluxPlanes + (ALB ? 3 : 0); ++j) {
+            if (ABLATED(4)) {
+              *pp[j] = v[j];
+            } else if (DEP == 1) {
+              dep.p[j] = pp[j];
+              dep.v[j] = v[j];
+            } else {
+              atomicAdd(pp[j], v[j]);
+            }
+          }
+          if (DEP == 1 && !ABLATED(4)) {
+            if (KIND == FLUVIAL) {
+              dep.load();  // the old words travel while the geometry of the step is worked out
+              deposit = true;
+            } else {
+              dep.begin();
+            }
+          }
+        }
+        PROF_AT(3);  // gather issued, deposit begun
+        const StepGeom geom = step_geom<KIND>(r, k);             // needs neither q nor LDS
+        if (KIND == FLUVIAL && deposit) dep.swap_all();          // the swaps' round trip hides under step_apply
+        v_norm = geom.v_norm;
+        if (!step_apply<KIND>(r, q, k, geom)) have = false;      // :121-122 / :326-327: the walk is over
+        PROF_AT(4);  // the step's arithmetic
+      }
+      runm &= ~__builtin_amdgcn_ballot_w64(v_norm < k.eps);      // ... the same exit, for the wave
+      if (DEP == 1) dep.finish(freshm, c, agg_min, agg_groups);
+      PROF_AT(5);  // deposit finished
+    }
+    const bool run = __builtin_amdgcn_inverse_ballot_w64(runm);
+
+    // ---- once per particle and round: what stopped it?
+    if (have && !run) {
       int ix = floor_cell(r.px), iy = floor_cell(r.py);
-      dr = static_cast<uint32_t>(ix - row_org);
-      dc = static_cast<uint32_t>(iy - c_lo);
-      step = dr <= r_span && dc <= c_span && r.iter < limit;
-      if (!step) {  // once per particle and round: what stopped it?
-        // ... unless it is a NaN walker (reference quirks): a NaN coordinate
-        // stands for cell 0 and is never out of bounds; floor_cell made it INT_MAX
-        if (r.px != r.px || r.py != r.py) {
+      if (r.px != r.px || r.py != r.py) {
+        // A NaN walker: a NaN coordinate stands for cell 0 (the reference's float -> int
+        // conversion) and is never out of bounds.  On the tile that holds that cell it walks
+        // on, here, in the reference's own terms (0.02 % of all steps): it adds its sources to
+        // the cell once and then idles there until it dies of age.
+        for (;;) {
           ix = nan_cell(r.px, ix);
           iy = nan_cell(r.py, iy);
-          dr = static_cast<uint32_t>(ix - row_org);
-          dc = static_cast<uint32_t>(iy - c_lo);
-          step = dr <= r_span && dc <= c_span && r.iter < limit;
+          const uint32_t dr = static_cast<uint32_t>(ix - row_org), dc = static_cast<uint32_t>(iy - c_lo);
+          if (!(dr <= r_span && dc <= c_span && r.iter < limit)) break;
+          ++r.iter;
+          ++nsteps;
+          const uint32_t lcell = l_org + __umul24(dr, k.Wu) + dc;
+          const float4 q = p4[lcell];
+          const uint32_t nind = lcell + k.base;
+          if (nind != r.ind) {
+            r.ind = nind;
+            float v[kFluxPlanes + 3];
+            float* pp[kFluxPlanes + 3];
+            deposit_terms(c_org + static_cast<int>(dr) * TC + static_cast<int>(dc), v, pp);
+#pragma unroll
+            for (int j = 0; j < kFluxPlanes + (ALB ? 3 : 0); ++j) atomicAdd(pp[j], v[j]);
+          }
+          if (!advance<KIND>(r, q, k)) {  // :121-122 / :326-327
+            have = false;
+            break;
+          }
+          ix = floor_cell(r.px);
+          iy = floor_cell(r.py);
         }
       }
-      if (!step) {
+      if (have) {
         have = false;
         // erosion_map.cu:29-40 on the floored coordinates (floor_cell, soil_math.hpp)
         const bool oob = static_cast<uint32_t>(ix) >= static_cast<uint32_t>(d.H) ||
@@ -949,71 +1079,7 @@ __global__ void __launch_bounds__(NT)
         }
       }
     }
-    PROF_AT(2);  // head
-    constexpr int kFluxPlanes = (KIND == FLUVIAL) ? 4 : 3;
-    CasDeposit<kFluxPlanes + (ALB ? 3 : 0), (KIND == FLUVIAL) ? 2 : 1> dep;
-    const int c = c_org + static_cast<int>(dr) * TC + static_cast<int>(dc);  // LDS cell (any value when idle)
-    bool deposit = false;
-    if (step) {
-      ++r.iter;
-      ++nsteps;
-      // the cell's record comes from the packed plane through L1/L2 (the tile's
-      // 64 KiB are touched ~4x per round); issued first, the gather's latency
-      // hides under the deposit and the other waves of the SIMD
-      // rows, W < 2^24 and H*W < 2^31 (use_tiled): one v_mad_u32_u24 per index
-      const uint32_t lcell = l_org + __umul24(dr, k.Wu) + dc;
-      const float4 q = p4[ABLATED(8) ? l_org : lcell];
-      const uint32_t nind = lcell + k.base;  // global cell: cx * W + cy, :103 / :309
-      if (nind != r.ind && !ABLATED(2)) {    // :104-113 / :310-318
-        r.ind = nind;
-        // DEP 0: native ds_add_f32, fire and forget; DEP 1: CasDeposit
-        float v[kFluxPlanes + 3];
-        float* p[kFluxPlanes + 3];
-        if (KIND == FLUVIAL) {
-          v[0] = r.a0 * r.s0, v[1] = r.a1 * r.s1, v[2] = r.a2 * r.svx, v[3] = r.a2 * r.svy;
-          p[0] = &s_a[2 * c], p[1] = &s_a[2 * c + 1], p[2] = &s_v[2 * c], p[3] = &s_v[2 * c + 1];
-        } else {
-          // the pair (velocity x | y) first, the single plane after it: CasDeposit's order
-          v[0] = r.a1 * r.svx, v[1] = r.a1 * r.svy, v[2] = r.a0 * r.s0;
-          p[0] = &s_v[2 * c], p[1] = &s_v[2 * c + 1], p[2] = &s_a[c];
-        }
-        if (ALB) {  // colour rides on the mass attenuation, :110-112 / :315-317
-          const float att = (KIND == FLUVIAL) ? r.a1 : r.a0;
-          v[kFluxPlanes] = att * r.sa0, v[kFluxPlanes + 1] = att * r.sa1, v[kFluxPlanes + 2] = att * r.sa2;
-          p[kFluxPlanes] = &s_c0[c], p[kFluxPlanes + 1] = &s_c1[c], p[kFluxPlanes + 2] = &s_c2[c];
-        }
-#pragma unroll
-        for (int j = 0; j < kFluxPlanes + (ALB ? 3 : 0); ++j) {
-          if (ABLATED(4)) {
-            *p[j] = v[j];
-          } else if (DEP == 1) {
-            dep.p[j] = p[j];
-            dep.v[j] = v[j];
-          } else {
-            atomicAdd(p[j], v[j]);
-          }
-        }
-        if (DEP == 1 && !ABLATED(4)) {
-          if (KIND == FLUVIAL) {
-            dep.load();  // the old words travel while the geometry of the step is worked out
-            deposit = true;
-          } else {
-            dep.begin();
-          }
-        }
-      }
-      PROF_AT(3);  // gather issued, deposit begun
-      if (KIND == FLUVIAL) {
-        const StepGeom geom = step_geom<KIND>(r, k);   // needs neither q nor LDS
-        if (deposit) dep.swap_all();                   // the swaps' round trip hides under step_apply
-        have = step_apply<KIND>(r, q, k, geom);
-      } else {
-        have = advance<KIND>(r, q, k);
-      }
-      PROF_AT(4);  // the step's arithmetic
-    }
-    if (DEP == 1) dep.finish(c, agg_min, agg_groups);
-    PROF_AT(5);  // deposit finished
+    PROF_AT(0);  // stops sorted out
   }
   {  // everything still parked goes out together (convergent: aggregate the counters)
     const uint32_t slot = wave_append(&s_out, parked);

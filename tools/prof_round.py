@@ -26,7 +26,7 @@ bench._interleave(lib, _abi, model.layers, bed)
 silt.set(model.rainfall, 1.0)
 silt.set(model.uplift, 0.0)
 out = (C.c_ulonglong * 32)()
-names = ["tail->top", "refill", "head", "gather+deposit begin", "advance", "deposit finish",
+names = ["stops sorted out", "refill", "head", "gather+deposit begin", "advance", "deposit finish",
          "survivors out", "barrier wait", "prologue", "flux flush"]
 for step in range(WARM + 2):
     model.seed_step()
