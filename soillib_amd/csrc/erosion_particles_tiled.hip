@@ -700,15 +700,6 @@ struct CasDeposit {
   float* p[NP];
   float v[NP];
   uint32_t o[NP], g[NP];
-  // Lanes that do not deposit in an iteration still take part in finish()'s ballots (their bits
-  // are masked out): give their words some value — any, no instruction — instead of none.
-  __device__ __forceinline__ void whatever() {
-#pragma unroll
-    for (int j = 0; j < NP; ++j) {
-      o[j] = __builtin_nondeterministic_value(o[j]);
-      g[j] = __builtin_nondeterministic_value(g[j]);
-    }
-  }
   static __device__ __forceinline__ uint32_t swap(float* q, uint32_t expect, float add) {
     return atomicCAS(reinterpret_cast<uint32_t*>(q), expect, f2bits(bits2f(expect) + add));
   }
@@ -731,20 +722,30 @@ struct CasDeposit {
           static_cast<unsigned long long>(f2bits(bits2f(o[2 * i]) + v[2 * i])) |
           (static_cast<unsigned long long>(f2bits(bits2f(o[2 * i + 1]) + v[2 * i + 1])) << 32);
       const unsigned long long got = atomicCAS(reinterpret_cast<unsigned long long*>(p[2 * i]), expect, want);
-      // a pair is lost as a whole: make both halves read "lost" unless the whole word matched
-      const bool won = got == expect;
-      g[2 * i] = won ? o[2 * i] : ~o[2 * i];
-      g[2 * i + 1] = won ? o[2 * i + 1] : ~o[2 * i + 1];
+      g[2 * i] = static_cast<uint32_t>(got);  // a pair is lost as a whole, see lost_plane()
+      g[2 * i + 1] = static_cast<uint32_t>(got >> 32);
     }
 #pragma unroll
     for (int j = 2 * NPAIRS; j < NP; ++j) g[j] = swap(p[j], o[j], v[j]);
+  }
+  // Nonzero when one of the swaps was lost.  Looking at the answers waits for them: call it after
+  // the work their round trip is to hide under.
+  __device__ __forceinline__ uint32_t lost_bits() const {
+    uint32_t d = 0;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) d |= g[j] ^ o[j];
+    return d;
+  }
+  __device__ __forceinline__ bool lost_plane(int j) const {
+    if (j < 2 * NPAIRS) return ((g[j & ~1] ^ o[j & ~1]) | (g[j | 1] ^ o[j | 1])) != 0u;
+    return g[j] != o[j];
   }
   __device__ __forceinline__ void begin() {
     load();
     swap_all();
   }
-  // Convergent: every lane of the wave calls it, once per iteration; `pending` is the ballot of
-  // the lanes that deposited in this iteration (the others hold values of an earlier one).
+  // Convergent: every lane of the wave calls it, once per iteration, with lost_bits() of its
+  // deposit (0: did not deposit, or won every swap).
   // A lane that lost its race (another walker hit the same cell in between — common
   // once the particles share channels) does not retry: nothing was written by the
   // failed swap, and a k-way collision would cost k round trips.
@@ -754,23 +755,16 @@ struct CasDeposit {
   //    losers of one cell add their values up in registers (a masked wave sum over DPP)
   //    and one lane issues the atomic — on the hot tiles that set the length of a
   //    round on small grids, ds_add_f32 at 2.6 cycles per lane was all the LDS pipe did.
-  // `cell` is the lane's cell index in the tile (any value when nothing is pending).
-  // The wave-level tests are ballots of plain comparisons and scalar mask arithmetic: a ballot of
-  // a combined predicate costs a v_cndmask + v_cmp pair on top (8 issue cycles).
-  __device__ __forceinline__ void finish(uint64_t pending, int cell, int agg_min, int agg_groups) {
-    uint64_t todo = 0;
-#pragma unroll
-    for (int i = 0; i < NPAIRS; ++i) todo |= __builtin_amdgcn_ballot_w64(g[2 * i] != o[2 * i]);  // a pair is lost as a whole
-#pragma unroll
-    for (int j = 2 * NPAIRS; j < NP; ++j) todo |= __builtin_amdgcn_ballot_w64(g[j] != o[j]);
-    todo &= pending;
+  // `cell` is the lane's cell index in the tile (any value for a lane that lost nothing).
+  __device__ __forceinline__ void finish(uint32_t lost_bits, int cell, int agg_min, int agg_groups) {
+    uint64_t todo = __builtin_amdgcn_ballot_w64(lost_bits != 0u);
     if (todo == 0) return;  // the common case
-    bool lost = __builtin_amdgcn_inverse_ballot_w64(todo);
-    bool lostj[NP];
-#pragma unroll
-    for (int j = 0; j < NP; ++j) lostj[j] = lost && g[j] != o[j];
+    bool lost = lost_bits != 0u;
     const int lane = static_cast<int>(threadIdx.x & 63u);
     if (__popcll(todo) >= agg_min) {
+      bool lostj[NP];
+#pragma unroll
+      for (int j = 0; j < NP; ++j) lostj[j] = lost && lost_plane(j);
       for (int it = 0; todo != 0 && it < agg_groups; ++it) {
         const int leader = __ffsll(static_cast<long long>(todo)) - 1;
         const int c0 = __builtin_amdgcn_readlane(cell, leader);
@@ -788,8 +782,14 @@ struct CasDeposit {
     }
     if (lost) {
 #pragma unroll
-      for (int j = 0; j < NP; ++j)
-        if (lostj[j]) atomicAdd(p[j], v[j]);
+      for (int i = 0; i < NPAIRS; ++i)
+        if (lost_plane(2 * i)) {
+          atomicAdd(p[2 * i], v[2 * i]);
+          atomicAdd(p[2 * i + 1], v[2 * i + 1]);
+        }
+#pragma unroll
+      for (int j = 2 * NPAIRS; j < NP; ++j)
+        if (lost_plane(j)) atomicAdd(p[j], v[j]);
     }
   }
 };
@@ -822,6 +822,19 @@ constexpr int round_waves_per_simd(int kind, int nt, bool alb) {
   return groups * (nt / 64) / 4;
 }
 __device__ __forceinline__ bool any_lane(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0; }
+// A value the compiler may not look through.  A ballot wants to be the ballot of a comparison of
+// register values (v_cmp writes the mask); given a predicate that was merged over divergent
+// branches the compiler keeps it as a lane mask and pays a v_cndmask + v_cmp pair per ballot to
+// turn it back into one.  Merging the compared VALUE instead and hiding it behind this keeps the
+// comparison at the ballot.
+__device__ __forceinline__ float opaque(float x) {
+  asm volatile("" : "+v"(x));
+  return x;
+}
+__device__ __forceinline__ uint32_t opaque(uint32_t x) {
+  asm volatile("" : "+v"(x));
+  return x;
+}
 
 template <int KIND, int DEP, int TR, int TC, int NT, bool ALB>
 __global__ void __launch_bounds__(NT, round_waves_per_simd(KIND, NT, ALB))
@@ -973,13 +986,11 @@ __global__ void __launch_bounds__(NT, round_waves_per_simd(KIND, NT, ALB))
       if (more && stoppedm != 0) break;  // a longer queue: the freed lanes take new particles first
       PROF_AT(2);  // head
       CasDeposit<kFluxPlanes + (ALB ? 3 : 0), (KIND == FLUVIAL) ? 2 : 1> dep;
-      dep.whatever();
+      uint32_t lost_bits = 0;
       const int c = c_org + static_cast<int>(dr) * TC + static_cast<int>(dc);  // LDS cell (any value when idle)
       // rows, W < 2^24 and H*W < 2^31 (use_tiled): one v_mad_u32_u24 per index
       const uint32_t lcell = l_org + __umul24(dr, k.Wu) + dc;
       const uint32_t nind = lcell + k.base;  // global cell: cx * W + cy, :103 / :309
-      // :104 / :310 — lanes that deposit in this iteration
-      const uint64_t freshm = (ABLATED(2) || ABLATED(4)) ? 0 : (__builtin_amdgcn_ballot_w64(nind != r.ind) & stepm);
       float v_norm = 1.0f;
       if (__builtin_amdgcn_inverse_ballot_w64(stepm)) {
         ++r.iter;
@@ -1009,10 +1020,10 @@ __global__ void __launch_bounds__(NT, round_waves_per_simd(KIND, NT, ALB))
           if (DEP == 1 && !ABLATED(4)) {
             if (KIND == FLUVIAL) {
               dep.load();  // the old words travel while the geometry of the step is worked out
-              deposit = true;
             } else {
               dep.begin();
             }
+            deposit = true;
           }
         }
         PROF_AT(3);  // gather issued, deposit begun
@@ -1020,10 +1031,11 @@ __global__ void __launch_bounds__(NT, round_waves_per_simd(KIND, NT, ALB))
         if (KIND == FLUVIAL && deposit) dep.swap_all();          // the swaps' round trip hides under step_apply
         v_norm = geom.v_norm;
         if (!step_apply<KIND>(r, q, k, geom)) have = false;      // :121-122 / :326-327: the walk is over
+        if (deposit) lost_bits = dep.lost_bits();                // the swaps' answers, only now
         PROF_AT(4);  // the step's arithmetic
       }
-      runm &= ~__builtin_amdgcn_ballot_w64(v_norm < k.eps);      // ... the same exit, for the wave
-      if (DEP == 1) dep.finish(freshm, c, agg_min, agg_groups);
+      runm &= ~__builtin_amdgcn_ballot_w64(opaque(v_norm) < k.eps);  // ... the same exit, for the wave
+      if (DEP == 1) dep.finish(opaque(lost_bits), c, agg_min, agg_groups);
       PROF_AT(5);  // deposit finished
     }
     const bool run = __builtin_amdgcn_inverse_ballot_w64(runm);
