@@ -56,13 +56,14 @@
 
 namespace soil {
 
-// A tile is TR rows x TC columns of cells (powers of two).  The acceptance workload
-// spawns one particle per 8 cells: a 64x64 tile starts with ~512 of them.
-// log2(TR), log2(TC) and the origin of the tile grid: tile (0,0) starts at local cell
+// A tile is TR rows x TC columns of cells (TC a power of two; TR is whatever fills the LDS of
+// a CU with a whole number of tiles).  The acceptance workload spawns one particle per 8 cells
+// (SURVEY 8d): a 64x64 tile starts with ~512 of them.
+// TR, log2(TC) and the origin of the tile grid: tile (0,0) starts at local cell
 // (-off_r, -off_c).  Odd rounds shift the grid by half a tile in both directions, so
 // a walker that zig-zags along a tile edge — parked after a step or two, round after
 // round — finds itself in the middle of a tile every other round.
-struct TileShape { int shift_r, shift_c, off_r, off_c; };
+struct TileShape { int tr, shift_c, off_r, off_c; };
 constexpr uint32_t kNoTile = 0xffffffffu;     // dest[] of an empty record slot
 
 enum Kind { FLUVIAL = 0, DEBRIS = 1 };
@@ -82,7 +83,8 @@ __device__ __forceinline__ int cell32(float f) { return (f != f) ? 0 : static_ca
 
 __device__ __forceinline__ int64_t tile_id(int x0, float px, float py, int tiles_w, TileShape ts) {
   const int lx = cell32(px) - x0, cy = cell32(py);  // lx >= 0: parked particles stand on owned rows
-  return static_cast<int64_t>((lx + ts.off_r) >> ts.shift_r) * tiles_w + ((cy + ts.off_c) >> ts.shift_c);
+  return static_cast<int64_t>(static_cast<uint32_t>(lx + ts.off_r) / static_cast<uint32_t>(ts.tr)) * tiles_w +
+         ((cy + ts.off_c) >> ts.shift_c);
 }
 
 // Diagnostics build (-DSOIL_ABLATE): parts of the round kernel switched off by a bit mask (timing
@@ -107,10 +109,12 @@ constexpr int kNB = 4;
 __device__ __forceinline__ uint32_t queue_key(int x0, float px, float py, float spx, float spy,
                                               uint32_t life, int tiles_w, TileShape ts, int K) {
   const int lx = cell32(px) - x0, cy = cell32(py);
-  const int trow = (lx + ts.off_r) >> ts.shift_r, tcol = (cy + ts.off_c) >> ts.shift_c;
-  const float x_lo = static_cast<float>((trow << ts.shift_r) - ts.off_r + x0);
+  // lx + off_r >= 0 (parked particles stand on owned rows): an unsigned division
+  const int trow = static_cast<int>(static_cast<uint32_t>(lx + ts.off_r) / static_cast<uint32_t>(ts.tr));
+  const int tcol = (cy + ts.off_c) >> ts.shift_c;
+  const float x_lo = static_cast<float>(trow * ts.tr - ts.off_r + x0);
   const float y_lo = static_cast<float>((tcol << ts.shift_c) - ts.off_c);
-  const float x_hi = x_lo + static_cast<float>(1 << ts.shift_r), y_hi = y_lo + static_cast<float>(1 << ts.shift_c);
+  const float x_hi = x_lo + static_cast<float>(ts.tr), y_hi = y_lo + static_cast<float>(1 << ts.shift_c);
   const float inv = __builtin_amdgcn_rsqf(spx * spx + spy * spy);
   const float ux = spx * inv, uy = spy * inv;
   const float big = 1.0e9f;
@@ -816,10 +820,19 @@ extern "C" int soil_prof_read(unsigned long long* out, int reset) {
 
 // Waves per SIMD the launch is meant to run with (bounds the register allocation): two
 // work-groups of 768 or three of 512 per CU are 6; the colour shape (1024, one per CU) 4.
-constexpr int round_waves_per_simd(int kind, int nt, bool alb) {
-  const int lds_groups = alb ? 1 : (kind == FLUVIAL ? 2 : 3);        // by LDS: 64 / 48 KiB tiles
-  const int groups = lds_groups * (nt / 64) > 32 ? 32 / (nt / 64) : lds_groups;  // by wave slots
-  return groups * (nt / 64) / 4;
+// LDS of one work-group of the round kernel: the flux accumulators of its tile (+ a few words)
+constexpr int kLdsPerCU = 160 * 1024;
+constexpr int round_lds_bytes(int kind, int tr, int tc, bool alb) {
+  return tr * tc * 4 * ((kind == FLUVIAL ? 4 : 3) + (alb ? 3 : 0)) + 16;
+}
+// ... work-groups of it a CU holds (LDS, 32 wave slots) and the waves per SIMD that makes — what the
+// register allocation is held to
+constexpr int round_groups_per_cu(int kind, int tr, int tc, int nt, bool alb) {
+  const int by_lds = kLdsPerCU / round_lds_bytes(kind, tr, tc, alb), by_waves = 32 / (nt / 64);
+  return by_lds < by_waves ? by_lds : by_waves;
+}
+constexpr int round_waves_per_simd(int kind, int tr, int tc, int nt, bool alb) {
+  return round_groups_per_cu(kind, tr, tc, nt, alb) * (nt / 64) / 4;
 }
 __device__ __forceinline__ bool any_lane(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0; }
 // A value the compiler may not look through.  A ballot wants to be the ballot of a comparison of
@@ -837,7 +850,7 @@ __device__ __forceinline__ uint32_t opaque(uint32_t x) {
 }
 
 template <int KIND, int DEP, int TR, int TC, int NT, bool ALB>
-__global__ void __launch_bounds__(NT, round_waves_per_simd(KIND, NT, ALB))
+__global__ void __launch_bounds__(NT, round_waves_per_simd(KIND, TR, TC, NT, ALB))
     k_tiled_round(PRec* __restrict__ out, uint32_t* __restrict__ dest, uint32_t* __restrict__ rank,
                   uint32_t* __restrict__ count_next, const PRec* __restrict__ in,
                   const uint32_t* __restrict__ order, const uint2* __restrict__ block_list,
@@ -916,6 +929,7 @@ __global__ void __launch_bounds__(NT, round_waves_per_simd(KIND, NT, ALB))
   // refills are the exception.
   // `more`: the queue holds entries beyond the ones handed out so far (uniform per wave)
   bool more = cnt > static_cast<uint32_t>(kBlock), parked = false;
+  constexpr int kRefillLanes = 16;
   auto write_out = [&]() {
     const uint32_t slot = atomicAdd(&s_out, 1u);  // slots this tile's queue occupied
     const uint32_t to = queue_key(k.x0, r.px, r.py, r.spx, r.spy, k.maxage - static_cast<uint32_t>(r.iter),
@@ -980,10 +994,11 @@ __global__ void __launch_bounds__(NT, round_waves_per_simd(KIND, NT, ALB))
       const uint32_t dc = static_cast<uint32_t>(floor_cell(r.py) - c_lo);     // from (r_lo, c_lo)
       const uint64_t stepm = __builtin_amdgcn_ballot_w64(dr <= r_span) & __builtin_amdgcn_ballot_w64(dc <= c_span) &
                              __builtin_amdgcn_ballot_w64(r.iter < limit) & runm;
-      const uint64_t stoppedm = runm & ~stepm;
       runm = stepm;
       if (stepm == 0) break;
-      if (more && stoppedm != 0) break;  // a longer queue: the freed lanes take new particles first
+      // a queue longer than the work-group: once enough lanes of the wave are free they take new
+      // particles (enough: leaving the loop and coming back costs about as much as two iterations)
+      if (more && __popcll(~stepm) >= kRefillLanes) break;
       PROF_AT(2);  // head
       CasDeposit<kFluxPlanes + (ALB ? 3 : 0), (KIND == FLUVIAL) ? 2 : 1> dep;
       uint32_t lost_bits = 0;
@@ -1236,30 +1251,77 @@ static int env_int(const char* name, int fallback) {
   const int v = e ? std::atoi(e) : fallback;
   return v > 0 ? v : fallback;
 }
+// NAME_F / NAME_D (fluvial / debris launches only) take precedence over NAME
+static int env_kind(const char* name, int kind, int fallback) {
+  char buf[96];
+  std::snprintf(buf, sizeof(buf), "%s_%c", name, kind == FLUVIAL ? 'F' : 'D');
+  return env_int(buf, env_int(name, fallback));
+}
 
 __global__ void k_fold_steps(unsigned long long* total, const unsigned long long* part) {
   atomicAdd(total, *part);
 }
 
-// Work-group shapes a round can use: tile rows x columns (powers of two) and threads.
+// Work-group shapes a round can use: tile rows x columns and threads.
 // Every round re-sorts the particles by tile, so the shape may change from round to
 // round (SOIL_TILED_LATE / SOIL_TILED_SWITCH).  Smaller tiles (32x64, 32x32) were
-// measured too: more exits per step and no better occupancy — 64x64 it is; what is
-// left to choose is how many lanes serve a tile.
+// measured too: more exits per step and no better occupancy.  What bounds the kernel is the
+// number of walkers a CU has in flight — one per 8 cells of LDS-resident tile — so the tile
+// heights are the ones that fill the 160 KiB of a CU with a whole number of tiles:
+//   fluvial (16 B/cell): 2 x 78 rows (79 still fit);  debris (12 B/cell): 3 x 68 (69 fit; with 70
+//   the CU takes only two work-groups although 3 x 53 772 B < 160 KiB: LDS is handed out in blocks
+//   of 1280 B).  Measured at 8192^2 against 64 rows: fluvial 25.9 -> 25.0 ms, debris 11.2 -> 11.0 ms
+//   (a quarter more walkers in flight buys 4 %: the round kernel is not bound by concurrency alone,
+//   DESIGN.md 3.2).  Also measured, and not kept: 3 x 52 rows x 512 lanes (fluvial 25.5), 4 x 52 x 384
+//   (debris 13.3), and small tiles for the sparse late rounds (32x32 x 64 lanes, 32x64 x 128: debris
+//   11.9-14.3 ms, fluvial 26.0-27.2 whatever the round they take over from).
 struct RoundShape { int tr, tc, nt; };
-static constexpr RoundShape kShapes[] = {{64, 64, 512}, {64, 64, 768}, {64, 64, 1024}};
-constexpr int kNumShapes = 2;       // selectable; shape 2 serves the launches that carry colour:
-constexpr int kShapeColour = 2;     // 7 / 6 LDS planes leave room for one work-group per CU
+constexpr int kShapeColour = 2;  // serves the launches that carry colour: 7 / 6 LDS planes, one work-group per CU
+constexpr int kShapeFull = 3;    // the LDS-filling tiles: fluvial 2 x 78 rows, debris 3 x 68 rows per CU
+constexpr int kNumShapes = 4;
+template <int KIND>
+struct Shapes {
+  static constexpr RoundShape v[kNumShapes] = {
+      {64, 64, 512}, {64, 64, 768}, {64, 64, 1024},
+      KIND == FLUVIAL ? RoundShape{78, 64, 768} : RoundShape{68, 64, 512}};
+};
 
+template <int KIND, int DEP, int SH, bool ALB, typename... A>
+static void launch_shape(unsigned grid, hipStream_t st, A... a) {
+  constexpr RoundShape S = Shapes<KIND>::v[SH];
+  static_assert(round_lds_bytes(KIND, S.tr, S.tc, ALB) <= kLdsPerCU, "tile does not fit the LDS");
+  k_tiled_round<KIND, DEP, S.tr, S.tc, S.nt, ALB><<<grid, S.nt, 0, st>>>(a...);
+}
+// work-groups of a shape's kernel one CU holds, as the runtime sees it
+template <int KIND, int SH, bool ALB>
+static int shape_occupancy() {
+  constexpr RoundShape S = Shapes<KIND>::v[SH];
+  int n = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_tiled_round<KIND, 1, S.tr, S.tc, S.nt, ALB>, S.nt, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    n = round_groups_per_cu(KIND, S.tr, S.tc, S.nt, ALB);
+  }
+  return n;
+}
+template <int KIND>
+static int occupancy_of(int shape) {
+  switch (shape) {
+    case 1: return shape_occupancy<KIND, 1, false>();
+    case kShapeColour: return shape_occupancy<KIND, kShapeColour, true>();
+    case kShapeFull: return shape_occupancy<KIND, kShapeFull, false>();
+    default: return shape_occupancy<KIND, 0, false>();
+  }
+}
 template <int KIND, int DEP, typename... A>
 static void launch_round(int shape, unsigned grid, hipStream_t st, A... a) {
   switch (shape) {
-    case 1: k_tiled_round<KIND, DEP, 64, 64, 768, false><<<grid, 768, 0, st>>>(a...); break;
+    case 1: launch_shape<KIND, DEP, 1, false>(grid, st, a...); break;
     case kShapeColour:
       if constexpr (DEP == 1)  // colour only with the compare-and-swap deposits
-        k_tiled_round<KIND, 1, 64, 64, 1024, true><<<grid, 1024, 0, st>>>(a...);
+        launch_shape<KIND, 1, kShapeColour, true>(grid, st, a...);
       break;
-    default: k_tiled_round<KIND, DEP, 64, 64, 512, false><<<grid, 512, 0, st>>>(a...); break;
+    case kShapeFull: if constexpr (DEP == 1) launch_shape<KIND, 1, kShapeFull, false>(grid, st, a...); break;
+    default: launch_shape<KIND, DEP, 0, false>(grid, st, a...); break;
   }
 }
 
@@ -1306,7 +1368,7 @@ struct TiledRun {
   int64_t n_src = 0;
   unsigned long long steps_before = 0;
   bool timed = false, done = false;
-  int resident_groups = 512;  // work-groups of a round kernel the chip holds at once
+  int resident_groups[2] = {512, 512};  // work-groups of a round kernel the chip holds at once (early, late shape)
 
   int shape_of(uint64_t r) const { return r >= static_cast<uint64_t>(switch_round) ? shape_late : shape_early; }
   // the tile grid of round r: shifted by half a tile on odd rounds (TileShape)
@@ -1314,15 +1376,15 @@ struct TiledRun {
   int agg_min = 48, agg_groups = 4;
   TileShape ts_of(int sh, uint64_t r) const {
     const bool odd = stagger && (r & 1);
-    return TileShape{__builtin_ctz(kShapes[sh].tr), __builtin_ctz(kShapes[sh].tc),
-                     odd ? kShapes[sh].tr / 2 : 0, odd ? kShapes[sh].tc / 2 : 0};
+    return TileShape{Shapes<KIND>::v[sh].tr, __builtin_ctz(Shapes<KIND>::v[sh].tc),
+                     odd ? Shapes<KIND>::v[sh].tr / 2 : 0, odd ? Shapes<KIND>::v[sh].tc / 2 : 0};
   }
   int tiles_w_of(int sh, uint64_t r) const {
-    return static_cast<int>((d.W + ts_of(sh, r).off_c + kShapes[sh].tc - 1) / kShapes[sh].tc);
+    return static_cast<int>((d.W + ts_of(sh, r).off_c + Shapes<KIND>::v[sh].tc - 1) / Shapes<KIND>::v[sh].tc);
   }
   int64_t tiles_of(int sh, uint64_t r) const {
     return static_cast<int64_t>(tiles_w_of(sh, r)) *
-           ((d.rows + ts_of(sh, r).off_r + kShapes[sh].tr - 1) / kShapes[sh].tr);
+           ((d.rows + ts_of(sh, r).off_r + Shapes<KIND>::v[sh].tr - 1) / Shapes<KIND>::v[sh].tr);
   }
 
   int setup() {
@@ -1337,11 +1399,32 @@ struct TiledRun {
     deposit = env_int("SOIL_TILED_DEP", 0);
     // measured at 8192^2 (N = cells/8): 768 threads on a 64x64 tile serve the fluvial
     // queues (about half of them hold 513..700 particles) in one batch, 45 vs 48 ms;
-    // the debris kernel keeps 3 work-groups of 512 per CU instead, 17 vs 20 ms
-    shape_early = (std::getenv("SOIL_TILED_SHAPE") ? env_int("SOIL_TILED_SHAPE", 0)
-                                                   : (KIND == FLUVIAL ? 1 : 0)) % kNumShapes;
-    shape_late = env_int("SOIL_TILED_LATE", shape_early) % kNumShapes;
-    switch_round = env_int("SOIL_TILED_SWITCH", 1 << 30);
+    // the debris kernel keeps 3 work-groups of 512 per CU instead, 17 vs 20 ms.  The
+    // LDS-filling tiles (kShapeFull) where the grid has tiles enough to fill the chip twice
+    // over with them; smaller grids want more, smaller work-groups.
+    int cus = 256;
+    {
+      int dev = 0;
+      SOIL_HIP(hipGetDevice(&dev));
+      SOIL_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    }
+    {
+      constexpr RoundShape F = Shapes<KIND>::v[kShapeFull];
+      const int64_t full_slots = static_cast<int64_t>(cus) * round_groups_per_cu(KIND, F.tr, F.tc, F.nt, false);
+      const int by_default = (deposit == 0 && tiles_of(kShapeFull, 0) >= 2 * full_slots) ? kShapeFull
+                                                                                          : (KIND == FLUVIAL ? 1 : 0);
+      shape_early = ((std::getenv("SOIL_TILED_SHAPE") || std::getenv(KIND == FLUVIAL ? "SOIL_TILED_SHAPE_F" : "SOIL_TILED_SHAPE_D"))
+                         ? env_kind("SOIL_TILED_SHAPE", KIND, 0)
+                         : by_default) % kNumShapes;
+    }
+    shape_late = env_kind("SOIL_TILED_LATE", KIND, shape_early) % kNumShapes;
+    if (deposit == 1) {  // the native-add variant exists for the 64-row shapes only
+      if (shape_early == kShapeFull) shape_early = KIND == FLUVIAL ? 1 : 0;
+      if (shape_late == kShapeFull) shape_late = KIND == FLUVIAL ? 1 : 0;
+    }
+    if (shape_early == kShapeColour) shape_early = 1;  // that shape goes with the colour planes only
+    if (shape_late == kShapeColour) shape_late = 1;
+    switch_round = env_kind("SOIL_TILED_SWITCH", KIND, 1 << 30);
     if (fluxA) {
       shape_early = shape_late = kShapeColour;
       deposit = 0;  // compare-and-swap deposits
@@ -1363,11 +1446,13 @@ struct TiledRun {
       SOIL_HIP(hipMemcpyToSymbol(HIP_SYMBOL(soil_ablate), &mask, sizeof(int)));
     }
 #endif
-    {  // LDS decides: 64 KiB (fluvial) / 48 KiB (debris) of accumulators per 64x64 tile
-      int dev = 0, cus = 256;
-      SOIL_HIP(hipGetDevice(&dev));
-      SOIL_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-      resident_groups = env_int("SOIL_TILED_SLOTS", cus * (fluxA ? 1 : KIND == FLUVIAL ? 2 : 3));
+    {  // LDS decides how many work-groups a CU holds
+      for (int which = 0; which < 2; ++which) {
+        const int sh = which ? shape_late : shape_early;
+        const int per_cu = occupancy_of<KIND>(sh);
+        if (verbose) std::fprintf(stderr, "[tiled kind %d] shape %d: %d work-groups per CU\n", KIND, sh, per_cu);
+        resident_groups[which] = env_int("SOIL_TILED_SLOTS", cus * (per_cu > 0 ? per_cu : 1));
+      }
     }
 
     // measured (1024^2 .. 8192^2): fluvial 1-6 % faster; debris, whose walks are short, 2 % slower
@@ -1429,7 +1514,8 @@ struct TiledRun {
     const int64_t tiles = tiles_of(shape_of(round), round);
     k_queue_prepare<<<1, 1024, 0, st>>>(start, tile_order, block_list,
                                         reinterpret_cast<const uint4*>(count), tiles,
-                                        kShapes[shape_of(round)].nt, resident_groups, steps_run,
+                                        Shapes<KIND>::v[shape_of(round)].nt,
+                                        resident_groups[round >= static_cast<uint64_t>(switch_round) ? 1 : 0], steps_run,
                                         host_dev, ++*seq_ctr);
     SOIL_LAUNCH_CHECK();
     return SOIL_OK;
@@ -1506,7 +1592,7 @@ struct TiledRun {
       SOIL_HIP(hipMemcpy(pre.data(), start, sizeof(uint32_t) * pre.size(), hipMemcpyDeviceToHost));
       for (int64_t t = 0; t < tiles; ++t) h[t] = pre[(t + 1) * kNB] - pre[t * kNB];
       std::sort(h.begin(), h.end());
-      const int lanes = kShapes[sh].nt;
+      const int lanes = Shapes<KIND>::v[sh].nt;
       uint64_t batches = 0, empty = 0, sparse = 0;
       for (uint32_t c : h) {
         batches += (c + lanes - 1) / lanes;

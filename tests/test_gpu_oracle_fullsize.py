@@ -119,3 +119,10 @@ def test_three_steps_at_1024(hip, oracle):
 
 def test_strip_4096x512_after_channels_formed(hip, oracle):
     _run(hip, oracle, 4096, 512, steps=2, warm_steps=3)
+
+
+def test_1024_with_the_lds_filling_tiles(hip, oracle, monkeypatch):
+    """The tile shape 8192^2 runs with by default (78 / 68 rows: not a power of two, queues
+    longer than the work-group), forced onto the 1024^2 case."""
+    monkeypatch.setenv("SOIL_TILED_SHAPE", "3")
+    _run(hip, oracle, 1024, 1024, steps=2)

@@ -335,10 +335,13 @@ def _flux_close(got, want, what):
     assert (np.abs(got[want == 0]) <= 1e-30 * scale).all(), what + ": different set of visited cells"
 
 
-@pytest.fixture(params=["direct", "staged", "tiled"])
-def particle_mode(request, hip):
-    """Both launch shapes of the particle kernels (soil_set_particle_mode)."""
-    assert hip.soil_set_particle_mode({"direct": 1, "staged": 2, "tiled": 3}[request.param]) == 0
+@pytest.fixture(params=["direct", "staged", "tiled", "tiled-full"])
+def particle_mode(request, hip, monkeypatch):
+    """The launch shapes of the particle kernels (soil_set_particle_mode).  "tiled-full": the tiled
+    shape with the LDS-filling tiles (78 / 68 rows) that large grids get by default."""
+    if request.param == "tiled-full":
+        monkeypatch.setenv("SOIL_TILED_SHAPE", "3")
+    assert hip.soil_set_particle_mode({"direct": 1, "staged": 2, "tiled": 3, "tiled-full": 3}[request.param]) == 0
     yield request.param
     hip.soil_set_particle_mode(0)
 
