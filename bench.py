@@ -82,6 +82,32 @@ class Events:
         return out.value
 
 
+def usable_cores():
+    """Hardware threads this process may really use: the affinity mask, cut down to the cgroup's
+    CPU quota when there is one (a container on a 256-thread host may own a handful)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    n = min(n, max(1, int(float(parts[0]) / float(parts[1]) + 0.5)))
+            else:
+                quota = int(parts[0])
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                    period = int(f.read().split()[0])
+                if quota > 0:
+                    n = min(n, max(1, int(quota / period + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)
+
+
 def cpu_baseline(size, seconds_hint=20.0):
     """Times the oracle (oracle/liboracle.so, the CPU restatement of the same
     kernels) on the host cores on a bounded sample of the same workload."""
@@ -89,7 +115,6 @@ def cpu_baseline(size, seconds_hint=20.0):
     from oracle import pyoracle as o
     H = W = size
     N = H * W // 8
-    cores = os.cpu_count() or 1
     p = o.default_param()
     sp = script_param(__import__("soillib_amd.soil", fromlist=["soil"]))
     for name, _ in p._fields_:
@@ -118,9 +143,26 @@ def cpu_baseline(size, seconds_hint=20.0):
     t0 = time.perf_counter()
     state, steps1 = one_step(state, 0, 1)
     t_single = time.perf_counter() - t0
-    o.set_threads(cores)                      # per-cell loops: OpenMP over rows
-    one_step(dict(state), 1, cores)           # thread teams spun up outside the timed region
-    reps = max(2, min(16, int(seconds_hint / max(4.0 * t_single / max(cores, 1), 0.05))))
+    # How many threads pay: the box reports its hardware threads, a container may be allowed a
+    # fraction of them, and the particle loops stop scaling where their atomic deposits collide.
+    # One step per candidate count (thread teams spun up by an untimed step first), best one kept.
+    avail = usable_cores()
+    cand = sorted({c for c in (2, 4, 8, 16, 32, 64, 128, 256, avail) if 2 <= c <= avail})
+    probe = {}
+    for c in cand:
+        o.set_threads(c)                      # per-cell loops: OpenMP over rows
+        one_step(dict(state), 1, c)
+        t0 = time.perf_counter()
+        one_step(dict(state), 1, c)
+        probe[c] = time.perf_counter() - t0
+        if probe[c] > 2.0 * min(probe.values()):
+            break                             # well past the knee
+    cores = min(probe, key=probe.get) if probe else 1
+    if probe and probe[cores] > t_single:
+        cores = 1
+    o.set_threads(cores)
+    t_probe = probe.get(cores, t_single)
+    reps = max(2, min(16, int(seconds_hint / max(t_probe, 0.05))))
     t0 = time.perf_counter()
     psteps = 0
     for i in range(reps):
@@ -132,8 +174,11 @@ def cpu_baseline(size, seconds_hint=20.0):
         "value": H * W / t_multi / 1e6, "unit": "Mcells/s", "cores": cores, "kind": "port",
         "sample": "%dx%d grid, N=%d particles, maxage 256, full step; 1 step on 1 thread "
                   "(%.2f Mcells/s) + %d steps with OpenMP on %d threads (particle loops over "
-                  "particles with atomic deposits, per-cell loops over rows)" % (
-                      H, W, N, H * W / t_single / 1e6, reps, cores),
+                  "particles with atomic deposits, per-cell loops over rows); thread count chosen "
+                  "by a one-step probe of %s of the %d usable hardware threads" % (
+                      H, W, N, H * W / t_single / 1e6, reps, cores,
+                      "/".join(str(c) for c in sorted(probe)), avail),
+        "threads_probe_s": {str(c): round(t, 4) for c, t in sorted(probe.items())},
         "value_1thread": H * W / t_single / 1e6,
         "mparticle_steps_per_s": psteps / reps / t_multi / 1e6,
     }
