@@ -198,8 +198,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-size", type=int, default=1024)
     ap.add_argument("--overlap-particles", action="store_true",
-                    help="issue the fluvial and debris launches overlapped on two streams "
-                         "(soil_particles_pair_slab) instead of back to back")
+                    help="multi-GPU slab runner: issue the fluvial and debris launches overlapped "
+                         "on two streams (soil_particles_pair_slab); on one GPU that is the default")
+    ap.add_argument("--sequential-particles", action="store_true",
+                    help="one GPU: the two particle launches back to back, each timed by itself")
     ap.add_argument("--particle-mode", type=int, default=0,
                     help="0 auto, 1 direct (reference launch shape), 2 staged — ablation")
     args = ap.parse_args()
@@ -227,7 +229,7 @@ def main():
         S = args.grid // world                   # rows per rank; the columns stay args.grid
     Wcols = args.grid if strong else S
     if args.overlap_particles:
-        os.environ["SOIL_STEP_PAIR"] = "1"       # the slab runner reads it too
+        os.environ["SOIL_STEP_PAIR"] = "1"       # the slab runner reads it (there overlap is opt-in)
     param = script_param(soil)
     if world > 1 or os.environ.get("SOIL_BENCH_FORCE_SLAB") == "1":
         from soillib_amd import parallel
@@ -280,7 +282,11 @@ def main():
         runner = _Single()
 
     ev = Events(_abi, 6)
-    serial = not (args.overlap_particles or os.environ.get("SOIL_STEP_PAIR") == "1")
+    # one GPU: the two particle launches overlapped, as the library's step driver runs them
+    # (soil_erode_step); --sequential-particles for the per-launch phase timings
+    serial = args.sequential_particles or os.environ.get("SOIL_STEP_PAIR") == "0"
+    if world > 1 or os.environ.get("SOIL_BENCH_FORCE_SLAB") == "1":   # slab runner: overlap is opt-in
+        serial = not (args.overlap_particles or os.environ.get("SOIL_STEP_PAIR") == "1")
     for _ in range(args.warmup):
         runner.step()
     runner.barrier()

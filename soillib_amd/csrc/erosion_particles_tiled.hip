@@ -1698,13 +1698,14 @@ int launch_pair_tiled(const soil_erosion_planes& P, soil_rng* rng_fluvial, soil_
                                         rng_debris, N,
                                         P.layers, nullptr, nullptr, P.debrisVelocity, remote0, d, s,
                                         p, sB);
-  // The early rounds of either launch keep the VALUs >90 % busy on their own, so the
-  // debris launch is held back until the fluvial one has done its maxage/K full rounds
-  // and thins out: its kernels then fill the slots the sparse late rounds leave idle.
+  // When the second launch starts: from the fluvial launch's round `delay` on.  Measured
+  // (tools/ab_pair_sizes.sh; ms per step, sequential | delay 1, 2, 4, 8): 1024^2 3.00 | 2.13 2.03 2.29
+  // 2.54; 2048^2 5.70 | 4.99 4.92 4.79 4.94; 4096^2 12.14 | 11.72 11.75 11.98 11.78; 8192^2 37.3 | 37.0
+  // (2) 37.2 (6) 37.3 (8): small grids are bound by the latency of each launch's chain of rounds, and two
+  // chains interleave; at 8192^2 either launch fills the chip by itself.
   static const int delay_env = env_int("SOIL_PAIR_DELAY", 0);
   if (int rc = A.begin(); rc != SOIL_OK) return rc;
-  const uint64_t delay = delay_env > 0 ? static_cast<uint64_t>(delay_env)
-                                       : (p.maxage + A.steps_per_round - 1) / A.steps_per_round;
+  const uint64_t delay = delay_env > 0 ? static_cast<uint64_t>(delay_env) : 2;
   bool b_started = false;
   while (!A.done || !B.done) {
     if (!b_started && (A.done || A.round >= delay)) {

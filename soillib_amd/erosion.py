@@ -113,12 +113,11 @@ class ErosionModel:
 
     # -- whole steps -----------------------------------------------------------
     def step(self):
-        """One erosion step: 2 particle launches + 1 fused cell launch.  SOIL_STEP_PAIR=1
-        issues the two launches overlapped on two streams (particles_pair; measured gain at
-        8192^2: 1 %, both launches are VALU-bound on their own — DESIGN.md §3.2)."""
-        if self.rows == self.H and os.environ.get("SOIL_STEP_PAIR") != "1":
-            # the whole grid on this device: the library's own step driver (soil_erode_step,
-            # csrc/erosion_step.hip) — seed, both particle launches, fused cell phase
+        """One erosion step: 2 particle launches + 1 fused cell launch.  With the whole grid on
+        this device it is the library's own step driver (soil_erode_step, csrc/erosion_step.hip:
+        seed, both particle launches overlapped on two streams, fused cell phase;
+        SOIL_STEP_PAIR=0 in the environment makes it run them one after the other)."""
+        if self.rows == self.H:
             planes = self._planes()
             _abi.check(_abi.lib().soil_erode_step(
                 C.byref(planes), self.rng.c_ptr, self.N, self.seed, self.step_index, self.H, self.W,
@@ -126,7 +125,7 @@ class ErosionModel:
             self.swap_layers()
             self.step_index += 1
             return
-        self.seed_step()
+        self.seed_step()                       # a slab of a larger grid (soillib_amd.parallel)
         if os.environ.get("SOIL_STEP_PAIR") == "1":
             self.particles_pair()
         else:

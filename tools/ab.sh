@@ -4,7 +4,7 @@ base=$1; shift
 for i in 1 2 3; do
   for which in base new; do
     if [ $which = base ]; then export SOIL_LIB=$base; else unset SOIL_LIB; fi
-    python bench.py --no-cpu-baseline "$@" 2>/dev/null | tail -1 | python -c "
+    python bench.py --no-cpu-baseline --sequential-particles "$@" 2>/dev/null | tail -1 | python -c "
 import json,sys
 d=json.loads(sys.stdin.read())
 print('$which', round(d['ms_per_step'],2), {k:round(v,2) for k,v in d['phases_ms'].items()})"
