@@ -510,6 +510,26 @@ struct TiledHostWord {  // pinned, device-mapped
   uint32_t seq;     // written last: the number of the k_queue_prepare launch that filled the word
 };
 
+#ifdef SOIL_PROF
+__device__ unsigned long long soil_prof_prepare[8];  // cycles between the stamps of k_queue_prepare, summed
+#define PREP_AT(i) if (threadIdx.x == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); atomicAdd(&soil_prof_prepare[i], now_ - prep_last_); prep_last_ = now_; }
+#define PREP_DECL unsigned long long prep_last_ = __builtin_readcyclecounter()
+#else
+#define PREP_AT(i)
+#define PREP_DECL
+#endif
+
+// A work-group's job in a round: the tile and its share of the tile's queue.  A queue longer than
+// the chip's share is served by `groups` work-groups (k_queue_prepare), each with accumulators of
+// its own that it adds to the global planes atomically (w = 1).
+__device__ __forceinline__ uint4 queue_share(uint32_t tile, uint32_t q_first, uint32_t q_cnt, uint32_t groups,
+                                             uint32_t q) {
+  const uint32_t per = (q_cnt + groups - 1) / groups;
+  const uint32_t off = q * per < q_cnt ? q * per : q_cnt;
+  const uint32_t cnt = q_cnt - off < per ? q_cnt - off : per;
+  return make_uint4(tile, q_first + off, cnt, groups > 1 ? 1u : 0u);
+}
+
 constexpr int kPanel = 16384;  // tiles per LDS panel of k_queue_prepare
 
 // inclusive prefix sum over the lanes of a wave / the 1024 threads of k_queue_prepare's
@@ -536,8 +556,8 @@ __device__ __forceinline__ uint32_t block_scan_1024(uint32_t v, uint32_t* wsum) 
 }
 
 __global__ void __launch_bounds__(1024)
-    k_queue_prepare(uint32_t* __restrict__ start, uint32_t* __restrict__ tile_order,
-                    uint2* __restrict__ block_list, const uint4* __restrict__ count4,
+    k_queue_prepare_panels(uint32_t* __restrict__ start, uint32_t* __restrict__ tile_order,
+                    uint4* __restrict__ block_list, const uint4* __restrict__ count4,
                     int64_t tiles, int lanes, int slots,
                     const unsigned long long* __restrict__ steps_run, TiledHostWord* host,
                     uint32_t seq) {
@@ -633,7 +653,7 @@ __global__ void __launch_bounds__(1024)
     const uint32_t t = c.x + c.y + c.z + c.w;
     const uint32_t pos = atomicAdd(&base[bucket(t)], 1u);
     tile_order[pos] = static_cast<uint32_t>(i);
-    if (!cut && t > 0) block_list[pos] = make_uint2(static_cast<uint32_t>(i), 0u);
+    if (!cut && t > 0) block_list[pos] = make_uint4(static_cast<uint32_t>(i), start[i * kNB], t, 0u);
   }
   if (!cut) {  // the common case on large grids: one work-group per non-empty tile
     if (tid == 0) publish(static_cast<uint32_t>(tiles) - hist[255]);
@@ -659,8 +679,11 @@ __global__ void __launch_bounds__(1024)
     for (int j = 0; j < kRun; ++j) {
       const int i = tid * kRun + j;
       const uint32_t g = tot[i];
-      if (i < n)
-        for (uint32_t q = 0; q < g; ++q) block_list[run + q] = make_uint2(tile_order[p0 + i], q);
+      if (i < n) {
+        const uint32_t tile = tile_order[p0 + i];
+        const uint32_t q_first = start[tile * kNB], c = start[(tile + 1) * kNB] - q_first;
+        for (uint32_t q = 0; q < g; ++q) block_list[run + q] = queue_share(tile, q_first, c, g, q);
+      }
       run += g;
     }
     __syncthreads();
@@ -668,6 +691,174 @@ __global__ void __launch_bounds__(1024)
     __syncthreads();
   }
   if (tid == 0) publish(carry);
+}
+
+// The same for up to kPanel tiles (every grid up to 8192^2 with 64-row tiles), with everything
+// between the one load of the counts and the stores of the results kept in registers and LDS.  The
+// scan above goes to global memory and back four times (counts three times, its own `start` and
+// `tile_order` once more when queues are cut); a round waits for this kernel, and on small grids
+// those round trips were most of it (20 us per launch at 1024^2, 25 launches per step).
+// Thread t owns tiles t, t + 1024, ... (coalesced loads and stores, counts in registers); the
+// scan runs over LDS with a pad word every 16 so that a thread's run of 16 consecutive tiles and
+// the strided accesses are both free of bank conflicts.
+__device__ __forceinline__ int pad16(int i) { return i + (i >> 4); }
+
+__global__ void __launch_bounds__(1024)
+    k_queue_prepare(uint32_t* __restrict__ start, uint4* __restrict__ block_list,
+                    const uint4* __restrict__ count4, int tiles, int lanes, int slots,
+                    const unsigned long long* __restrict__ steps_run, TiledHostWord* host, uint32_t seq) {
+  constexpr int kRun = kPanel / 1024;  // tiles per thread
+  __shared__ uint32_t pre[kPanel + kPanel / 16 + 2];  // totals, then their exclusive prefix (padded)
+  // tiles, longest queue first (uint16: kPanel / 2 words), and behind them the per-position group
+  // counts of the cut path (padded like pre[])
+  __shared__ uint16_t ord[kPanel + (kPanel + kPanel / 16 + 2)];
+  __shared__ uint32_t hist[256], base[256];
+  __shared__ uint32_t s_batches, s_longest, s_cap, s_total, s_published, wsum[16];
+  const int tid = threadIdx.x;
+  PREP_DECL;
+  // bucket 255: empty tiles; 254..0: 1-15, 16-31, ... particles (longest first)
+  auto bucket = [](uint32_t c) { return c == 0 ? 255u : 254u - (c >> 4 > 254u ? 254u : c >> 4); };
+  if (tid < 256) hist[tid] = 0;
+  if (tid == 0) s_batches = s_longest = 0;
+  __syncthreads();
+  uint4 c[kRun];
+  uint32_t my_batches = 0, my_longest = 0;
+#pragma unroll
+  for (int m = 0; m < kRun; ++m) {
+    const int i = tid + 1024 * m;
+    c[m] = make_uint4(0u, 0u, 0u, 0u);
+    if (i < tiles) c[m] = count4[i];
+    const uint32_t t = c[m].x + c[m].y + c[m].z + c[m].w;
+    pre[pad16(i)] = t;
+    if (i < tiles) {
+      atomicAdd(&hist[bucket(t)], 1u);
+      my_batches += (t + lanes - 1) / lanes;
+      my_longest = t > my_longest ? t : my_longest;
+    }
+  }
+  {  // one atomic per wave on the two scalars (1024 same-address LDS atomics cost microseconds)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      my_batches += __shfl_xor(my_batches, off, 64);
+      const uint32_t o = __shfl_xor(my_longest, off, 64);
+      my_longest = o > my_longest ? o : my_longest;
+    }
+    if ((tid & 63) == 0) {
+      atomicAdd(&s_batches, my_batches);
+      atomicMax(&s_longest, my_longest);
+    }
+  }
+  __syncthreads();
+  PREP_AT(0);  // counts loaded
+  {  // exclusive prefix of the totals, in place
+    uint32_t run[kRun], sum = 0;
+#pragma unroll
+    for (int j = 0; j < kRun; ++j) {
+      run[j] = pre[pad16(tid * kRun + j)];
+      sum += run[j];
+    }
+    const uint32_t incl = block_scan_1024(sum, wsum);
+    uint32_t at = incl - sum;
+#pragma unroll
+    for (int j = 0; j < kRun; ++j) {
+      pre[pad16(tid * kRun + j)] = at;
+      at += run[j];
+    }
+    if (tid == 1023) {
+      s_total = incl;
+      pre[pad16(kPanel)] = incl;  // entry `tiles` is the grand total (below kPanel the scan put it there)
+    }
+  }
+  {  // first slot of every bucket: exclusive scan of the histogram (the barriers of the scan
+     // also publish pre[])
+    const uint32_t h = tid < 256 ? hist[tid] : 0u;
+    const uint32_t incl = block_scan_1024(h, wsum);
+    if (tid < 256) base[tid] = incl - h;
+  }
+  if (tid == 0) {
+    const uint32_t total = s_total;
+    start[static_cast<int64_t>(tiles) * kNB] = total;  // particles queued in all
+    host->live = total;
+    host->steps = *steps_run;
+    const uint32_t share = (s_batches + slots - 1) / slots;
+    s_cap = (share > 0 ? share : 1u) * static_cast<uint32_t>(lanes);  // chunk capacity, see above
+    host->chunk = s_cap;
+  }
+  __syncthreads();
+  PREP_AT(1);  // scans, host word's first fields
+  const uint32_t chunk_cap = s_cap;
+  const bool cut = s_longest > chunk_cap;  // some queue needs more than one work-group
+  uint4* out = reinterpret_cast<uint4*>(start);
+#pragma unroll
+  for (int m = 0; m < kRun; ++m) {
+    const int i = tid + 1024 * m;
+    if (i >= tiles) break;
+    const uint32_t r = pre[pad16(i)], t = c[m].x + c[m].y + c[m].z + c[m].w;
+    out[i] = make_uint4(r, r + c[m].x, r + c[m].x + c[m].y, r + c[m].x + c[m].y + c[m].z);
+    const uint32_t pos = atomicAdd(&base[bucket(t)], 1u);
+    ord[pos] = static_cast<uint16_t>(i);
+    if (!cut && t > 0) block_list[pos] = make_uint4(static_cast<uint32_t>(i), r, t, 0u);
+  }
+  auto publish = [&](uint32_t blocks) {  // everything the host reads is stored and fenced first
+    host->blocks = blocks;
+    __threadfence_system();
+    __atomic_store_n(&host->seq, seq, __ATOMIC_RELEASE);
+  };
+  PREP_AT(2);  // start, order, jobs of uncut queues
+  if (!cut) {  // the common case on large grids: one work-group per non-empty tile
+    if (tid == 0) publish(static_cast<uint32_t>(tiles) - hist[255]);
+    PREP_AT(4);
+    return;
+  }
+  __syncthreads();
+  // queues cut into chunks: position p of the ordered list gets ceil(queue / cap) work-groups.
+  // The divisions run with one position per thread (strided); the scan takes the counts from LDS
+  // (`grp`, padded like `pre`) in runs of 16 per thread, which costs it additions only.
+  // (a round has at most tiles + slots work-groups: counts and their prefix fit 16 bits)
+  uint16_t* grp = ord + kPanel;
+#pragma unroll
+  for (int m = 0; m < kRun; ++m) {
+    const int pos = tid + 1024 * m;
+    uint32_t gq = 0;
+    if (pos < tiles) {
+      const int tile = ord[pos];
+      const uint32_t cnt = pre[pad16(tile + 1)] - pre[pad16(tile)];
+      gq = (cnt + chunk_cap - 1) / chunk_cap;
+    }
+    grp[pad16(pos)] = static_cast<uint16_t>(gq);
+  }
+  __syncthreads();
+  uint32_t incl;
+  {
+    uint32_t run[kRun], sum = 0;
+#pragma unroll
+    for (int j = 0; j < kRun; ++j) {
+      run[j] = grp[pad16(tid * kRun + j)];
+      sum += run[j];
+    }
+    incl = block_scan_1024(sum, wsum);
+    uint32_t at = incl - sum;
+#pragma unroll
+    for (int j = 0; j < kRun; ++j) {
+      grp[pad16(tid * kRun + j)] = static_cast<uint16_t>(at);
+      at += run[j];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int m = 0; m < kRun; ++m) {
+    const int pos = tid + 1024 * m;
+    if (pos >= tiles) break;
+    const uint32_t tile = ord[pos];
+    const uint32_t q_first = pre[pad16(tile)], cnt = pre[pad16(tile + 1)] - q_first;
+    const uint32_t gq = (cnt + chunk_cap - 1) / chunk_cap, at = grp[pad16(pos)];
+    for (uint32_t q = 0; q < gq; ++q) block_list[at + q] = queue_share(tile, q_first, cnt, gq, q);
+  }
+  if (tid == 1023) s_published = incl;
+  __syncthreads();
+  PREP_AT(3);  // jobs of cut queues
+  if (tid == 0) publish(s_published);
+  PREP_AT(4);  // published
 }
 
 // ---- one round: advance the particles of one tile against LDS ---------------------
@@ -812,6 +1003,11 @@ extern "C" int soil_prof_read(unsigned long long* out, int reset) {
   if (reset) { unsigned long long z[32] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(soil_prof), z, sizeof(z)) != hipSuccess) return 1; }
   return 0;
 }
+extern "C" int soil_prof_read_prepare(unsigned long long* out, int reset) {  // 8 words
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(soil_prof_prepare), sizeof(unsigned long long) * 8) != hipSuccess) return 1;
+  if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(soil_prof_prepare), z, sizeof(z)) != hipSuccess) return 1; }
+  return 0;
+}
 #else
 #define PROF_DECL
 #define PROF_AT(i)
@@ -853,7 +1049,7 @@ template <int KIND, int DEP, int TR, int TC, int NT, bool ALB>
 __global__ void __launch_bounds__(NT, round_waves_per_simd(KIND, TR, TC, NT, ALB))
     k_tiled_round(PRec* __restrict__ out, uint32_t* __restrict__ dest, uint32_t* __restrict__ rank,
                   uint32_t* __restrict__ count_next, const PRec* __restrict__ in,
-                  const uint32_t* __restrict__ order, const uint2* __restrict__ block_list,
+                  const uint32_t* __restrict__ order, const uint4* __restrict__ block_list,
                   const uint32_t* __restrict__ start, float* __restrict__ flux0,
                   float* __restrict__ flux1, float2* __restrict__ fluxV,
                   float* __restrict__ fluxA, const float4* __restrict__ p4,
@@ -864,14 +1060,11 @@ __global__ void __launch_bounds__(NT, round_waves_per_simd(KIND, TR, TC, NT, ALB
   constexpr int kCells = TR * TC, kBlock = NT, kPer = (kCells + NT - 1) / NT;
   PROF_DECL;
   // this work-group's share of its tile's queue (k_queue_prepare's block list)
-  const uint2 job = block_list[blockIdx.x];
+  const uint4 job = block_list[blockIdx.x];
   const int tile = static_cast<int>(job.x);
-  const uint32_t q_first = start[tile * kNB], q_cnt = start[(tile + 1) * kNB] - q_first;
-  const uint32_t groups = (q_cnt + chunk_cap - 1) / chunk_cap, per = (q_cnt + groups - 1) / groups;
-  const uint32_t first = q_first + job.y * per;
-  if (job.y * per >= q_cnt) return;
-  const uint32_t cnt = (q_cnt - job.y * per < per) ? q_cnt - job.y * per : per;
-  const bool shared_tile = groups > 1;  // other work-groups deposit into the same cells
+  const uint32_t first = job.y, cnt = job.z;
+  if (cnt == 0) return;
+  const bool shared_tile = job.w != 0;  // other work-groups deposit into the same cells
   // local row, column of the tile's first cell (negative on the rim of a shifted grid)
   const int row0 = (tile / tiles_w) * TR - off_r, col0 = (tile % tiles_w) * TC - off_c;
 
@@ -1356,7 +1549,7 @@ struct TiledRun {
   PRec *cur = nullptr, *next = nullptr;
   uint32_t *dest = nullptr, *rank = nullptr, *order = nullptr, *count = nullptr,
            *count_next = nullptr, *start = nullptr, *tile_order = nullptr;
-  uint2* block_list = nullptr;  // (tile, group) of every work-group of the round
+  uint4* block_list = nullptr;  // (tile, first, count, shared) of every work-group of the round
   float4* p4 = nullptr;
   unsigned long long *steps_global = nullptr, *steps_run = nullptr;
   size_t b_cnt = 0;
@@ -1472,7 +1665,7 @@ struct TiledRun {
     b_cnt = align(sizeof(uint32_t) * (max_tiles * kNB + 1));
     void* base = nullptr;
     // one workspace per kind: the two launches of a step may be in flight together
-    const size_t b_blk = align(sizeof(uint2) * (max_tiles + N / 128 + 1));
+    const size_t b_blk = align(sizeof(uint4) * (max_tiles + N / 128 + 1));
     int rc = workspace_get(KIND == FLUVIAL ? 2 : 5, 2 * b_rec + 3 * b_idx + 4 * b_cnt + b_blk + b_p4 + 256, &base);
     if (rc != SOIL_OK) return rc;
     char* w = static_cast<char*>(base);
@@ -1486,7 +1679,7 @@ struct TiledRun {
     count_next = reinterpret_cast<uint32_t*>(w);  w += b_cnt;
     start = reinterpret_cast<uint32_t*>(w);       w += b_cnt;
     tile_order = reinterpret_cast<uint32_t*>(w);  w += b_cnt;
-    block_list = reinterpret_cast<uint2*>(w);     w += b_blk;
+    block_list = reinterpret_cast<uint4*>(w);     w += b_blk;
     steps_run = reinterpret_cast<unsigned long long*>(w);
     rc = step_counter(&steps_global);
     if (rc != SOIL_OK) return rc;
@@ -1512,11 +1705,17 @@ struct TiledRun {
   // scan of the queues the next round starts from + what the host needs to decide
   int queue_scan() {
     const int64_t tiles = tiles_of(shape_of(round), round);
-    k_queue_prepare<<<1, 1024, 0, st>>>(start, tile_order, block_list,
-                                        reinterpret_cast<const uint4*>(count), tiles,
-                                        Shapes<KIND>::v[shape_of(round)].nt,
-                                        resident_groups[round >= static_cast<uint64_t>(switch_round) ? 1 : 0], steps_run,
-                                        host_dev, ++*seq_ctr);
+    const int lanes = Shapes<KIND>::v[shape_of(round)].nt;
+    const int slots = resident_groups[round >= static_cast<uint64_t>(switch_round) ? 1 : 0];
+    // SOIL_TILED_PANELS=1: the many-tiles variant whatever the grid (tests)
+    const bool panels = tiles > kPanel || std::getenv("SOIL_TILED_PANELS") != nullptr;
+    if (!panels)
+      k_queue_prepare<<<1, 1024, 0, st>>>(start, block_list, reinterpret_cast<const uint4*>(count),
+                                          static_cast<int>(tiles), lanes, slots, steps_run, host_dev, ++*seq_ctr);
+    else
+      k_queue_prepare_panels<<<1, 1024, 0, st>>>(start, tile_order, block_list,
+                                                 reinterpret_cast<const uint4*>(count), tiles, lanes, slots,
+                                                 steps_run, host_dev, ++*seq_ctr);
     SOIL_LAUNCH_CHECK();
     return SOIL_OK;
   }
@@ -1621,7 +1820,7 @@ struct TiledRun {
     if (deposit == 1)
       launch_round<KIND, 0>(sh, blocks, st, next, dest, rank, count_next,
                             static_cast<const PRec*>(cur), static_cast<const uint32_t*>(order),
-                            static_cast<const uint2*>(block_list),
+                            static_cast<const uint4*>(block_list),
                             static_cast<const uint32_t*>(start), flux0, flux1,
                             reinterpret_cast<float2*>(fluxV), fluxA, static_cast<const float4*>(p4),
                             remote0, steps_run, d, s, p, tiles_w, ts_cur.off_r, ts_cur.off_c,
@@ -1630,7 +1829,7 @@ struct TiledRun {
     else
       launch_round<KIND, 1>(sh, blocks, st, next, dest, rank, count_next,
                             static_cast<const PRec*>(cur), static_cast<const uint32_t*>(order),
-                            static_cast<const uint2*>(block_list),
+                            static_cast<const uint4*>(block_list),
                             static_cast<const uint32_t*>(start), flux0, flux1,
                             reinterpret_cast<float2*>(fluxV), fluxA, static_cast<const float4*>(p4),
                             remote0, steps_run, d, s, p, tiles_w, ts_cur.off_r, ts_cur.off_c,

@@ -335,13 +335,16 @@ def _flux_close(got, want, what):
     assert (np.abs(got[want == 0]) <= 1e-30 * scale).all(), what + ": different set of visited cells"
 
 
-@pytest.fixture(params=["direct", "staged", "tiled", "tiled-full"])
+@pytest.fixture(params=["direct", "staged", "tiled", "tiled-full", "tiled-panels"])
 def particle_mode(request, hip, monkeypatch):
     """The launch shapes of the particle kernels (soil_set_particle_mode).  "tiled-full": the tiled
-    shape with the LDS-filling tiles (78 / 68 rows) that large grids get by default."""
+    shape with the LDS-filling tiles (78 / 68 rows) that large grids get by default;
+    "tiled-panels": with the queue scan of grids of more than 16384 tiles."""
     if request.param == "tiled-full":
         monkeypatch.setenv("SOIL_TILED_SHAPE", "3")
-    assert hip.soil_set_particle_mode({"direct": 1, "staged": 2, "tiled": 3, "tiled-full": 3}[request.param]) == 0
+    if request.param == "tiled-panels":
+        monkeypatch.setenv("SOIL_TILED_PANELS", "1")
+    assert hip.soil_set_particle_mode(1 if request.param == "direct" else 2 if request.param == "staged" else 3) == 0
     yield request.param
     hip.soil_set_particle_mode(0)
 

@@ -46,3 +46,10 @@ for step in range(WARM + 2):
               % (step, ("fluvial", "debris")[kind], v[10], v[11], tot / max(v[10], 1)))
         for i in range(10):
             print("   %-22s %5.1f %%  %7.0f ticks/iteration" % (names[i], 100.0 * v[i] / tot, v[i] / max(v[10], 1)))
+
+prep = (C.c_ulonglong * 8)()
+if lib.soil_prof_read_prepare(prep, 1) == 0:
+    tot = sum(prep[:5])
+    print("k_queue_prepare, thread 0, cycles summed over all launches: counts loaded %d | scans %d | start+order+jobs %d | "
+          "cut jobs %d | published %d  (shares %s)" % (prep[0], prep[1], prep[2], prep[3], prep[4],
+          " ".join("%.0f%%" % (100.0 * prep[i] / max(tot, 1)) for i in range(5))))
