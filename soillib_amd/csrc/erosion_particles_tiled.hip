@@ -1583,7 +1583,10 @@ struct TiledRun {
   int setup() {
     // steps a particle may take per round: bounds the time a work-group waits for
     // its longest walker
-    steps_per_round = env_int("SOIL_TILED_STEPS", 32);
+    // (fluvial walkers live out their 256 steps and stay on a 78-row tile longer than debris
+    // walkers do: 8192^2, ms per launch at 24 / 28 / 32 / 36 / 40 / 48 / 64 steps: fluvial 27.6 26.5 24.9
+    // 24.1 23.8 23.8 23.7, debris 11.6 11.1 10.9 10.95 11.0 11.05 11.3)
+    steps_per_round = env_kind("SOIL_TILED_STEPS", KIND, KIND == FLUVIAL ? 40 : 32);
     // the finishing launch pays ~4 L2 atomics per step (22.7 G/s), a round a fixed
     // cost that grows with the number of tiles: N/40 within [4096, 200000] is where
     // they cross for 512^2 .. 8192^2 grids with N = cells/8
