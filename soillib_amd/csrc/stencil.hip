@@ -448,6 +448,118 @@ __global__ void __launch_bounds__(kSBlock)
   SOIL_ROW_LOOP(x, H) normal_cell(out, in, x, y, H, W, s);
 }
 
+// The same with the window shape (window.hpp): a thread owns four consecutive cells of a row and
+// walks a band of rows with rows x - 2 .. x + 2 of its four columns in registers; the two columns
+// either side of its cells in row x come from the neighbouring lanes.  One 16-byte load per row
+// instead of nine gathers per cell, and the wave's 3 KiB of normals leave through LDS as three
+// store instructions of 1 KiB of consecutive bytes each (stored as they are, a lane's 48 bytes
+// would make every instruction cover a third of each sector).
+struct RowN {
+  float4 c;          // the thread's four cells
+  float l2, l1, r1, r2;  // columns y0 - 2, y0 - 1, y0 + 4, y0 + 5 (NaN outside the grid)
+};
+__device__ __forceinline__ RowN load_row_n(const float* __restrict__ in, int64_t x, int64_t H,
+                                           int64_t W, int64_t y0, bool halo) {
+  const float nan = __builtin_nanf("");
+  const int lane = static_cast<int>(threadIdx.x & 63u);
+  const bool row_ok = x >= 0 && x < H;
+  RowN r;
+  r.c = make_float4(nan, nan, nan, nan);
+  const float* row = in + x * W;
+  if (row_ok) r.c = *reinterpret_cast<const float4*>(row + y0);
+  r.l2 = r.l1 = r.r1 = r.r2 = nan;
+  if (halo) {  // uniform: every lane of the wave shuffles
+    r.l2 = __shfl_up(r.c.z, 1, 64);
+    r.l1 = __shfl_up(r.c.w, 1, 64);
+    r.r1 = __shfl_down(r.c.x, 1, 64);
+    r.r2 = __shfl_down(r.c.y, 1, 64);
+    if (lane == 0) {
+      r.l2 = (row_ok && y0 >= 2) ? row[y0 - 2] : nan;
+      r.l1 = (row_ok && y0 >= 1) ? row[y0 - 1] : nan;
+    }
+    if (lane == 63) {
+      r.r1 = (row_ok && y0 + 4 < W) ? row[y0 + 4] : nan;
+      r.r2 = (row_ok && y0 + 5 < W) ? row[y0 + 5] : nan;
+    }
+  }
+  return r;
+}
+// lerp5_axis on five samples in registers (NaN: outside the grid)
+__device__ __forceinline__ float lerp5_regs(float fm2, float fm1, float f0, float fp1, float fp2) {
+  auto fin = [](float v) { return (v - v) == 0.0f; };
+  if (fin(fm2) && fin(fm1) && fin(fp1) && fin(fp2))
+    return ((fm2 - 8.0f * fm1) + (8.0f * fp1 - fp2)) / 12.0f;
+  if (fin(fm1) && fin(fp1)) return 0.5f * (fp1 - fm1);
+  if (fin(fp1) && fin(f0)) return fp1 - f0;
+  if (fin(fm1) && fin(f0)) return f0 - fm1;
+  return 0.0f;
+}
+__device__ __forceinline__ float at4(const float4& v, int k) {
+  return k == 0 ? v.x : k == 1 ? v.y : k == 2 ? v.z : v.w;
+}
+
+__global__ void __launch_bounds__(kWinBlock)
+    k_normal4(float* __restrict__ out, const float* __restrict__ in, int64_t H, int64_t W, Scale3 s) {
+  __shared__ float4 s_tile[kWinBlock / 64][192];
+  const WinThread t = win_thread(W);
+  const int lane = static_cast<int>(threadIdx.x & 63u);
+  float4* tile = s_tile[threadIdx.x >> 6];
+  const int64_t wave_y0 = (static_cast<int64_t>(blockIdx.x) * kWinBlock + (threadIdx.x & ~63u)) * 4;
+  for (int64_t band = blockIdx.y; band * kWinBand < H; band += gridDim.y) {
+    int64_t x = band * kWinBand;
+    const int64_t x_end = (x + kWinBand < H) ? x + kWinBand : H;
+    // rows x - 2 .. x + 2; the halo columns are wanted for the row a cell's y-derivative is taken
+    // in, the centre one: loaded with every row that will get there (not the two above the band)
+    float4 m2 = load_row_n(in, x - 2, H, W, t.y0, false).c, m1 = load_row_n(in, x - 1, H, W, t.y0, false).c;
+    RowN c0 = load_row_n(in, x, H, W, t.y0, true), p1 = load_row_n(in, x + 1, H, W, t.y0, true);
+    RowN p2 = load_row_n(in, x + 2, H, W, t.y0, true);
+    for (; x < x_end; ++x) {
+      float o[12];
+      // the row's six columns either side included: y0 - 2 .. y0 + 5
+      const float rowv[8] = {c0.l2, c0.l1, c0.c.x, c0.c.y, c0.c.z, c0.c.w, c0.r1, c0.r2};
+      // a thread past the end of the row sits on the last group (t.y0 = W - 4): its columns exist
+      const float nan = __builtin_nanf("");
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int64_t y = t.y0 + k;
+        const float f0 = rowv[k + 2];
+        const float dx = lerp5_regs(at4(m2, k), at4(m1, k), f0, at4(p1.c, k), at4(p2.c, k));
+        // columns outside the grid read NaN: the neighbours' registers hold them for lanes 0 / 63,
+        // inside the wave the shuffled values are real cells, and y - 2 >= 0, y + 2 < W decide
+        const float ym2 = (y - 2 >= 0) ? rowv[k] : nan, ym1 = (y - 1 >= 0) ? rowv[k + 1] : nan;
+        const float yp1 = (y + 1 < W) ? rowv[k + 3] : nan, yp2 = (y + 2 < W) ? rowv[k + 4] : nan;
+        const float dy = lerp5_regs(ym2, ym1, f0, yp1, yp2);
+        const float gx = dx * s.z / s.x;  // :31-32
+        const float gy = dy * s.z / s.y;
+        const float vx = -gx, vy = -gy, vz = 1.0f;  // :33
+        const float inv = 1.0f / sqrtf(vx * vx + vy * vy + vz * vz);
+        o[3 * k] = vx * inv;
+        o[3 * k + 1] = vy * inv;
+        o[3 * k + 2] = vz * inv;
+      }
+      {  // the wave's 64 x 48 bytes, contiguous in memory, as three instructions of 1 KiB each
+        const int n = 3 * __popcll(__ballot(t.live));  // float4s of the wave that are real
+        tile[3 * lane] = make_float4(o[0], o[1], o[2], o[3]);
+        tile[3 * lane + 1] = make_float4(o[4], o[5], o[6], o[7]);
+        tile[3 * lane + 2] = make_float4(o[8], o[9], o[10], o[11]);
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's own writes have landed
+        __builtin_amdgcn_wave_barrier();
+        const float4 a = tile[lane], b = tile[64 + lane], c = tile[128 + lane];
+        float4* dst = reinterpret_cast<float4*>(out + 3 * (x * W + wave_y0));
+        if (lane < n) dst[lane] = a;
+        if (64 + lane < n) dst[64 + lane] = b;
+        if (128 + lane < n) dst[128 + lane] = c;
+        __builtin_amdgcn_wave_barrier();
+      }
+      m2 = m1;
+      m1 = c0.c;
+      c0 = p1;
+      p1 = p2;
+      if (x + 1 < x_end) p2 = load_row_n(in, x + 3, H, W, t.y0, true);
+    }
+  }
+}
+
 // soil.resize of the multiscale driver (example/erosion_gpu_multiscale.py:104-141).
 // The reference snapshot holds no definition of it; defined here as
 // bilinear resampling at corner-aligned positions: new cell (i, j) samples the old
@@ -600,8 +712,12 @@ int soil_normal(float* out, const float* in, int64_t H, int64_t W, const float s
   SOIL_DEVICE();
   SOIL_REQUIRE(out && in && scale, "normal: null argument");
   SOIL_REQUIRE(H > 0 && W > 0, "normal: empty grid");
-  k_normal<<<grid_rows(H, W, kSBlock), kSBlock, 0, as_stream(stream)>>>(
-      out, in, H, W, Scale3{scale[0], scale[1], scale[2]});
+  if (W % 4 == 0 && W >= 4)
+    k_normal4<<<win_grid(H, W), kWinBlock, 0, as_stream(stream)>>>(out, in, H, W,
+                                                                 Scale3{scale[0], scale[1], scale[2]});
+  else
+    k_normal<<<grid_rows(H, W, kSBlock), kSBlock, 0, as_stream(stream)>>>(
+        out, in, H, W, Scale3{scale[0], scale[1], scale[2]});
   SOIL_LAUNCH_CHECK();
   return SOIL_OK;
 }

@@ -628,6 +628,9 @@ def test_window_kernels_across_seams(hip, oracle, H, W):
         t = np.random.default_rng(2).standard_normal((H, W, D)).astype(np.float32)
         assert_bit_equal(to_np(soil.laplacian(to_gpu(t), sc)), oracle.laplacian(t, sc),
                          "laplacian D=%d" % D)
+    s3 = (0.4, 1.7, 3.0)                        # five rows / columns deep, inf and NaN samples
+    h[3, 3] = np.nan
+    assert_bit_equal(to_np(soil.normal(to_gpu(h), s3)), oracle.normal(h, s3), "normal")
 
 
 @pytest.mark.parametrize("H,W", [(70, 1500), (33, 1025), (300, 7)])

@@ -6,8 +6,11 @@ name=${1:-r02_final}
 out=/root/repo/gpurun_out/$name; rm -rf $out; mkdir -p $out
 cd /tmp; export TMPDIR=/tmp
 python /root/repo/bench.py --steps 10 --warmup 2 2>/dev/null | tail -1 > $out/bench_line.json
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o s -- python /root/repo/bench.py --steps 10 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
-pmc() { rocprofv3 --kernel-trace --pmc $2 --output-format csv -d $out/$1 -o p -- python /root/repo/bench.py --steps $3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1; }
+# the same step with the two particle launches one after the other: per-launch phase timings, and
+# kernel durations / counters that are not mixed with the other launch's kernels
+python /root/repo/bench.py --steps 10 --warmup 2 --no-cpu-baseline --sequential-particles 2>/dev/null | tail -1 > $out/bench_line_sequential.json
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o s -- python /root/repo/bench.py --steps 10 --warmup 2 --no-cpu-baseline --sequential-particles > /dev/null 2>&1
+pmc() { rocprofv3 --kernel-trace --pmc $2 --output-format csv -d $out/$1 -o p -- python /root/repo/bench.py --steps $3 --warmup 1 --no-cpu-baseline --sequential-particles > /dev/null 2>&1; }
 pmc fetch "FETCH_SIZE" 2
 pmc write "WRITE_SIZE" 2
 pmc valu "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_TRANS_F32" 1

@@ -43,7 +43,7 @@ def load(d):
 for f in os.listdir(os.path.join(src, "stats")):
     if f.endswith("kernel_stats.csv"):
         shutil.copy(os.path.join(src, "stats", f), os.path.join(dst, "kernel_stats.csv"))
-for f in ("bench_line.json", "bench_c2_1024x10000.json"):
+for f in ("bench_line.json", "bench_line_sequential.json", "bench_c2_1024x10000.json"):
     if os.path.exists(os.path.join(src, f)) and os.path.getsize(os.path.join(src, f)) > 2:
         shutil.copy(os.path.join(src, f), os.path.join(dst, f))
 
