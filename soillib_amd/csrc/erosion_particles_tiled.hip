@@ -40,12 +40,14 @@
 // shape; only the order of the fp32 additions into a cell differs.
 //
 // Measured at 8192^2, N = 8.4 M, maxage 256 (ms per launch, fluvial / debris):
-// direct 418 / 115; fields+flux in LDS with ds_add_f32 84 / 36; this file 27.4 / 12.1.
-// A fluvial step is ~170 vector + ~90 scalar instructions (seven IEEE quotients over four
-// denominators, a square root, three hardware exponentials, see step_geom / step_apply); the
-// vector pipes execute on ~60 % of all SIMD cycles (SQ_ACTIVE_INST_VALU, profiles/), and what
-// keeps them from more is concurrency: 16 B of LDS per cell cap a CU at ~1200 walkers in flight,
-// of which ~40 % are stepping at any time.
+// direct 418 / 115; fields+flux in LDS with ds_add_f32 84 / 36; this file 23.9 / 11.0.
+// A fluvial step is ~160 vector + ~110 scalar and branch instructions (seven IEEE quotients over
+// four denominators, a square root, three hardware exponentials, see step_geom / step_apply), mostly
+// one depending on the other; the vector pipes are issuing on ~40 % of all SIMD cycles
+// (profiles/particle_roofline.json).  What keeps them from more: a wave issues a dependent
+// instruction every ~11 cycles, 16 B of LDS per cell cap a CU at ~1280 walkers in flight, a
+// work-group holds its tile until its longest walker has taken the round's steps, and the LDS pipe
+// is 50-70 % busy with the deposits' random 64-bit accesses.
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
