@@ -146,23 +146,39 @@ __global__ void __launch_bounds__(kGBlock)
   }
 }
 
-// __slope, graph.cu:270-295
+// __slope, graph.cu:270-295.  Threads along the row, a work-group walks a band of rows: the
+// cell's own coordinates cost nothing, and the receiver's — `next / W`, `next % W`, 64-bit
+// divisions that were most of this kernel's instructions — come from the index difference when the
+// receiver is one of the eight neighbours (every graph steepest / direction / random_weighted
+// make); any other index takes the divisions.
 __global__ void __launch_bounds__(kGBlock)
     k_slope(float* __restrict__ slope, const float* __restrict__ tensor,
             const int32_t* __restrict__ flow, int64_t H, int64_t W, Scale2 s) {
-  const int64_t n = static_cast<int64_t>(blockIdx.x) * kGBlock + threadIdx.x;
-  if (n >= H * W) return;
-  const int64_t next = flow[n];  // :282
-  if (next < 0 || next == n) {   // :283-286
-    slope[n] = 0.0f;
-    return;
+  const int64_t y = static_cast<int64_t>(blockIdx.x) * kGBlock + threadIdx.x;
+  if (y >= W) return;
+  SOIL_ROW_LOOP(x, H) {
+    const int64_t n = x * W + y;
+    const int64_t next = flow[n];  // :282
+    if (next < 0 || next == n) {   // :283-286
+      slope[n] = 0.0f;
+      continue;
+    }
+    // row and column of the receiver relative to the cell: d = rd * W + cd with rd, cd in -1..1
+    const int64_t d = next - n;
+    const int64_t rd = d > 1 ? 1 : (d < -1 ? -1 : 0);
+    const int64_t cd = d - rd * W;
+    int64_t qx = x + rd, qy = y + cd;
+    if (cd < -1 || cd > 1 || qy < 0 || qy >= W) {  // not a neighbour (or W < 3): the general case
+      qx = next / W;
+      qy = next % W;
+    }
+    const float ix = static_cast<float>(x), iy = static_cast<float>(y);    // :288
+    const float nx = static_cast<float>(qx), ny = static_cast<float>(qy);  // :289
+    const float ival = tensor[n];                                          // :291
+    const float nval = tensor[next];                                       // :292
+    const float dx = s.x * (nx - ix), dy = s.y * (ny - iy);
+    slope[n] = (nval - ival) / sqrtf(dx * dx + dy * dy);  // :293
   }
-  const float ix = static_cast<float>(n / W), iy = static_cast<float>(n % W);        // :288
-  const float nx = static_cast<float>(next / W), ny = static_cast<float>(next % W);  // :289
-  const float ival = tensor[n];                                                      // :291
-  const float nval = tensor[next];                                                   // :292
-  const float dx = s.x * (nx - ix), dy = s.y * (ny - iy);
-  slope[n] = (nval - ival) / sqrtf(dx * dx + dy * dy);  // :293
 }
 
 // ---- accumulate --------------------------------------------------------------
@@ -413,7 +429,7 @@ int soil_slope(float* slope, const float* tensor, const int32_t* flow, int64_t H
   SOIL_DEVICE();
   SOIL_REQUIRE(slope && tensor && flow && scale, "slope: null argument");
   SOIL_REQUIRE(H > 0 && W > 0, "slope: empty grid");
-  k_slope<<<blocks_for(H * W, kGBlock), kGBlock, 0, as_stream(stream)>>>(
+  k_slope<<<grid_rows(H, W, kGBlock), kGBlock, 0, as_stream(stream)>>>(
       slope, tensor, flow, H, W, Scale2{scale[0], scale[1]});
   SOIL_LAUNCH_CHECK();
   return SOIL_OK;

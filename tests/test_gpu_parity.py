@@ -556,6 +556,17 @@ def test_flow_maps_bit_exact(hip, oracle, H, W, edge):
     flow = oracle.steepest(h, edge)
     assert_bit_equal(to_np(soil.slope(gh, to_gpu(flow), (0.3, 0.7))),
                      oracle.slope(h, flow, (0.3, 0.7)), "slope")
+    # any graph is a legal argument: receivers that are not neighbours (two rows down, across the
+    # row's end, anywhere), no receiver, the cell itself
+    r = np.random.default_rng(9)
+    wild = r.integers(-1, H * W, size=(H, W)).astype(np.int32)
+    idx = np.arange(H * W, dtype=np.int64).reshape(H, W)
+    wild[::3, ::2] = np.clip(idx[::3, ::2] + 2 * W, 0, H * W - 1)
+    wild[1::3, -1] = np.clip(idx[1::3, -1] + 1, 0, H * W - 1)        # wraps onto the next row
+    wild[2::3, 0] = np.clip(idx[2::3, 0] + W - 1, 0, H * W - 1)      # "down-left" from column 0
+    wild[5, 5] = idx[5, 5]
+    assert_bit_equal(to_np(soil.slope(gh, to_gpu(wild), (0.3, 0.7))),
+                     oracle.slope(h, wild, (0.3, 0.7)), "slope on an arbitrary graph")
     with pytest.raises(ValueError):
         soil.steepest(gh, 5)                    # invalid edge enumerator, graph.cu:88
 
