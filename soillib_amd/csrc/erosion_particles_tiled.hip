@@ -83,11 +83,6 @@ static_assert(sizeof(PRec) == 64, "PRec must be one 64-byte line");
 // float -> cell coordinate, 32-bit flavour of cell_of (positions are < 2^31)
 __device__ __forceinline__ int cell32(float f) { return (f != f) ? 0 : static_cast<int>(f); }
 
-__device__ __forceinline__ int64_t tile_id(int x0, float px, float py, int tiles_w, TileShape ts) {
-  const int lx = cell32(px) - x0, cy = cell32(py);  // lx >= 0: parked particles stand on owned rows
-  return static_cast<int64_t>(static_cast<uint32_t>(lx + ts.off_r) / static_cast<uint32_t>(ts.tr)) * tiles_w +
-         ((cy + ts.off_c) >> ts.shift_c);
-}
 
 // Diagnostics build (-DSOIL_ABLATE): parts of the round kernel switched off by a bit mask (timing
 // experiments only — the results are wrong by construction).  SOIL_ABLATE=<mask> in the environment:
@@ -508,7 +503,6 @@ struct TiledHostWord {  // pinned, device-mapped
   uint32_t live;    // particles queued for the round
   uint32_t blocks;  // work-groups the round needs (entries of the block list)
   unsigned long long steps;
-  uint32_t chunk;   // particles of a tile's queue one work-group takes at most
   uint32_t seq;     // written last: the number of the k_queue_prepare launch that filled the word
 };
 
@@ -639,7 +633,6 @@ __global__ void __launch_bounds__(1024)
     host->steps = *steps_run;
     const uint32_t share = (s_batches + slots - 1) / slots;
     s_cap = (share > 0 ? share : 1u) * static_cast<uint32_t>(lanes);  // chunk capacity
-    host->chunk = s_cap;
     carry = 0;
   }
   {  // first slot of every bucket: exclusive scan of the histogram
@@ -784,7 +777,6 @@ __global__ void __launch_bounds__(1024)
     host->steps = *steps_run;
     const uint32_t share = (s_batches + slots - 1) / slots;
     s_cap = (share > 0 ? share : 1u) * static_cast<uint32_t>(lanes);  // chunk capacity, see above
-    host->chunk = s_cap;
   }
   __syncthreads();
   PREP_AT(1);  // scans, host word's first fields
@@ -1052,13 +1044,13 @@ __global__ void __launch_bounds__(NT, round_waves_per_simd(KIND, TR, TC, NT, ALB
     k_tiled_round(PRec* __restrict__ out, uint32_t* __restrict__ dest, uint32_t* __restrict__ rank,
                   uint32_t* __restrict__ count_next, const PRec* __restrict__ in,
                   const uint32_t* __restrict__ order, const uint4* __restrict__ block_list,
-                  const uint32_t* __restrict__ start, float* __restrict__ flux0,
+                  float* __restrict__ flux0,
                   float* __restrict__ flux1, float2* __restrict__ fluxV,
                   float* __restrict__ fluxA, const float4* __restrict__ p4,
                   float* __restrict__ remote0, unsigned long long* __restrict__ steps, Dom d,
                   Scale3 s, Param param, int tiles_w, int off_r, int off_c, int steps_per_round,
                   TileShape ts_next,
-                  int tiles_w_next, uint32_t chunk_cap, int agg_min, int agg_groups) {
+                  int tiles_w_next, int agg_min, int agg_groups) {
   constexpr int kCells = TR * TC, kBlock = NT, kPer = (kCells + NT - 1) / NT;
   PROF_DECL;
   // this work-group's share of its tile's queue (k_queue_prepare's block list)
@@ -1773,7 +1765,6 @@ struct TiledRun {
     if (int rc = wait_word(); rc != SOIL_OK) return rc;
     const uint32_t live = host->live;  // particles queued for this round
     const unsigned blocks = host->blocks;
-    const uint32_t chunk_cap = host->chunk;
     const unsigned long long steps_now = host->steps;
     const int sh = shape_of(round), sh_next = shape_of(round + 1);
     const int64_t tiles = tiles_of(sh, round);
@@ -1825,21 +1816,19 @@ struct TiledRun {
     if (deposit == 1)
       launch_round<KIND, 0>(sh, blocks, st, next, dest, rank, count_next,
                             static_cast<const PRec*>(cur), static_cast<const uint32_t*>(order),
-                            static_cast<const uint4*>(block_list),
-                            static_cast<const uint32_t*>(start), flux0, flux1,
+                            static_cast<const uint4*>(block_list), flux0, flux1,
                             reinterpret_cast<float2*>(fluxV), fluxA, static_cast<const float4*>(p4),
                             remote0, steps_run, d, s, p, tiles_w, ts_cur.off_r, ts_cur.off_c,
                             steps_per_round, ts_of(sh_next, round + 1),
-                            tiles_w_of(sh_next, round + 1), chunk_cap, agg_min, agg_groups);
+                            tiles_w_of(sh_next, round + 1), agg_min, agg_groups);
     else
       launch_round<KIND, 1>(sh, blocks, st, next, dest, rank, count_next,
                             static_cast<const PRec*>(cur), static_cast<const uint32_t*>(order),
-                            static_cast<const uint4*>(block_list),
-                            static_cast<const uint32_t*>(start), flux0, flux1,
+                            static_cast<const uint4*>(block_list), flux0, flux1,
                             reinterpret_cast<float2*>(fluxV), fluxA, static_cast<const float4*>(p4),
                             remote0, steps_run, d, s, p, tiles_w, ts_cur.off_r, ts_cur.off_c,
                             steps_per_round, ts_of(sh_next, round + 1),
-                            tiles_w_of(sh_next, round + 1), chunk_cap, agg_min, agg_groups);
+                            tiles_w_of(sh_next, round + 1), agg_min, agg_groups);
     SOIL_LAUNCH_CHECK();
     SOIL_HIP(hipEventRecord(ev1, st));
     timed = true;
