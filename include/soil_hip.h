@@ -323,7 +323,13 @@ int soil_particles_pair_slab(const soil_erosion_planes* planes, soil_rng* rng_fl
  * example/dem_process.py:81 —, both particle launches, the fused cell phase.  Planes as in
  * soil_erode_cells_fused, single-device shapes (H, W[, 2]); `rng` holds N elements.  Reads
  * planes->layers, writes planes->layers_next: the caller swaps the two handles afterwards.
- * Everything is queued on `stream`; nothing synchronises. */
+ * The two particle launches are issued overlapped (as soil_particles_pair_slab does: two
+ * internal streams forked from `stream` and joined back into it; the fluvial launch draws
+ * from a scratch tensor of the library's workspace, the debris launch from `rng` seeded two
+ * draws on), with the results and the final state of `rng` of the sequential order;
+ * SOIL_STEP_PAIR=0 in the environment issues them one after the other on `stream`.  The host
+ * returns once the step is queued; it does wait, between the rounds of a particle launch, for
+ * the word that tells it how many work-groups the next round needs. */
 int soil_erode_step(const soil_erosion_planes* planes, soil_rng* rng, int64_t N, uint64_t seed,
                     uint64_t step_index, int64_t H, int64_t W, const float scale[3],
                     const soil_param* param, void* stream);
