@@ -121,6 +121,12 @@ def test_strip_4096x512_after_channels_formed(hip, oracle):
     _run(hip, oracle, 4096, 512, steps=2, warm_steps=3)
 
 
+def test_4096x2048_default_launch_shapes(hip, oracle):
+    """A grid large enough for the defaults of the big grids: LDS-filling tiles, 40-step fluvial
+    rounds, one work-group per tile."""
+    _run(hip, oracle, 4096, 2048, steps=1)
+
+
 def test_1024_with_the_lds_filling_tiles(hip, oracle, monkeypatch):
     """The tile shape 8192^2 runs with by default (78 / 68 rows: not a power of two, queues
     longer than the work-group), forced onto the 1024^2 case."""
