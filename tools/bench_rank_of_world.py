@@ -14,6 +14,10 @@ import os
 import sys
 import time
 
+# the stand-in communicator moves nothing, so the measured reach of the walks never comes back
+# as fresh ghost fields: with the halo trimming on, every step would take the repeat-launch path
+os.environ.setdefault("SOIL_HALO_FULL", "1")
+
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
 
