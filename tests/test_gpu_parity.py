@@ -789,6 +789,9 @@ def test_particle_pair_equals_sequential_launches(hip, S, maxage):
     silt.set(m.rainfall, 1.0)
     m.step()
     m.step()
+    # the step driver overlaps the launches too (scratch tensor for the fluvial draws): the caller's
+    # rng tensor ends where the sequential order leaves it, four draws into step 1's streams
+    assert (to_np(m.rng)["offset"] == 1 * m.N + 4).all()
     flux = ("waterFlux", "massFlux", "velocityFlux", "debrisFlux", "debrisVelocityFlux")
     out = {}
     for how in ("sequential", "pair"):
