@@ -46,8 +46,7 @@
 // one depending on the other; the vector pipes are issuing on ~40 % of all SIMD cycles
 // (profiles/particle_roofline.json).  What keeps them from more: a wave issues a dependent
 // instruction every ~11 cycles, 16 B of LDS per cell cap a CU at ~1280 walkers in flight, a
-// work-group holds its tile until its longest walker has taken the round's steps, and the LDS pipe
-// is 50-70 % busy with the deposits' random 64-bit accesses.
+// work-group holds its tile until its longest walker has taken the round's steps.
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -945,7 +944,7 @@ struct CasDeposit {
   //    and one lane issues the atomic — on the hot tiles that set the length of a
   //    round on small grids, ds_add_f32 at 2.6 cycles per lane was all the LDS pipe did.
   // `cell` is the lane's cell index in the tile (any value for a lane that lost nothing).
-  __device__ __forceinline__ void finish(uint32_t lost_bits, int cell, int agg_min, int agg_groups) {
+  __device__ __forceinline__ void finish(uint32_t lost_bits, int cell, int agg_min, int agg_groups, int retries) {
     uint64_t todo = __builtin_amdgcn_ballot_w64(lost_bits != 0u);
     if (todo == 0) return;  // the common case
     bool lost = lost_bits != 0u;
@@ -970,17 +969,49 @@ struct CasDeposit {
       lost = lost && ((todo >> lane) & 1ull) != 0;  // cells beyond the budget: one by one
     }
     if (lost) {
+      // The failed swap answered with what the word holds now: swap again against that — twice at
+      // most — before falling back to the native add.  A ds_add_f32 keeps the LDS pipe ~170
+      // cycles per instruction however few lanes take part, a ds_cmpst ~6: once walkers share
+      // channels (every round after the first) a quarter of all wave-iterations have a loser,
+      // and with four native adds each the pipe was 0.7 busy against 0.46 in the first round.
 #pragma unroll
-      for (int i = 0; i < NPAIRS; ++i)
-        if (lost_plane(2 * i)) {
+      for (int i = 0; i < NPAIRS; ++i) {
+        bool open = lost_plane(2 * i);
+        unsigned long long expect = static_cast<unsigned long long>(g[2 * i]) |
+                                    (static_cast<unsigned long long>(g[2 * i + 1]) << 32);
+#pragma unroll
+        for (int attempt = 0; attempt < kRetries; ++attempt) {
+          if (open && attempt < retries) {
+            const unsigned long long want =
+                static_cast<unsigned long long>(f2bits(bits2f(static_cast<uint32_t>(expect)) + v[2 * i])) |
+                (static_cast<unsigned long long>(f2bits(bits2f(static_cast<uint32_t>(expect >> 32)) + v[2 * i + 1])) << 32);
+            const unsigned long long got = atomicCAS(reinterpret_cast<unsigned long long*>(p[2 * i]), expect, want);
+            open = got != expect;
+            expect = got;
+          }
+        }
+        if (open) {
           atomicAdd(p[2 * i], v[2 * i]);
           atomicAdd(p[2 * i + 1], v[2 * i + 1]);
         }
+      }
 #pragma unroll
-      for (int j = 2 * NPAIRS; j < NP; ++j)
-        if (lost_plane(j)) atomicAdd(p[j], v[j]);
+      for (int j = 2 * NPAIRS; j < NP; ++j) {
+        bool open = lost_plane(j);
+        uint32_t expect = g[j];
+#pragma unroll
+        for (int attempt = 0; attempt < kRetries; ++attempt) {
+          if (open && attempt < retries) {
+            const uint32_t got = swap(p[j], expect, v[j]);
+            open = got != expect;
+            expect = got;
+          }
+        }
+        if (open) atomicAdd(p[j], v[j]);
+      }
     }
   }
+  static constexpr int kRetries = 2;  // at most
 };
 
 // Diagnostics build (-DSOIL_PROF): s_memtime stamps at the seams of an iteration, summed per
@@ -1050,7 +1081,7 @@ __global__ void __launch_bounds__(NT, round_waves_per_simd(KIND, TR, TC, NT, ALB
                   float* __restrict__ remote0, unsigned long long* __restrict__ steps, Dom d,
                   Scale3 s, Param param, int tiles_w, int off_r, int off_c, int steps_per_round,
                   TileShape ts_next,
-                  int tiles_w_next, int agg_min, int agg_groups) {
+                  int tiles_w_next, int agg_min, int agg_groups, int retries) {
   constexpr int kCells = TR * TC, kBlock = NT, kPer = (kCells + NT - 1) / NT;
   PROF_DECL;
   // this work-group's share of its tile's queue (k_queue_prepare's block list)
@@ -1237,7 +1268,7 @@ __global__ void __launch_bounds__(NT, round_waves_per_simd(KIND, TR, TC, NT, ALB
         PROF_AT(4);  // the step's arithmetic
       }
       runm &= ~__builtin_amdgcn_ballot_w64(opaque(v_norm) < k.eps);  // ... the same exit, for the wave
-      if (DEP == 1) dep.finish(opaque(lost_bits), c, agg_min, agg_groups);
+      if (DEP == 1) dep.finish(opaque(lost_bits), c, agg_min, agg_groups, retries);
       PROF_AT(5);  // deposit finished
     }
     const bool run = __builtin_amdgcn_inverse_ballot_w64(runm);
@@ -1560,7 +1591,7 @@ struct TiledRun {
   int shape_of(uint64_t r) const { return r >= static_cast<uint64_t>(switch_round) ? shape_late : shape_early; }
   // the tile grid of round r: shifted by half a tile on odd rounds (TileShape)
   bool stagger = true;
-  int agg_min = 48, agg_groups = 4;
+  int agg_min = 48, agg_groups = 4, retries = 2;
   TileShape ts_of(int sh, uint64_t r) const {
     const bool odd = stagger && (r & 1);
     return TileShape{Shapes<KIND>::v[sh].tr, __builtin_ctz(Shapes<KIND>::v[sh].tc),
@@ -1653,6 +1684,11 @@ struct TiledRun {
     // costs the large grids more than the LDS pipe gains (46.9), from 8 on 72 ms.
     agg_min = env_int("SOIL_TILED_AGG_MIN", 48);
     agg_groups = env_int("SOIL_TILED_AGG_GROUPS", 4);
+    // swaps a loser repeats against the answer of the failed one before it falls back to the native
+    // add (CasDeposit::finish).  Measured against none: 1024^2 1.89 -> 1.82 ms per step, 2048^2 (late
+    // steps) 4.06 -> 3.78, 4096^2 11.3 -> 10.9 (with one try: 11.3), 8192^2 within the noise between
+    // runs (36.3 -> 36.1; one try 35.3 in one run, 36.3 in another); four tries cost 1-2 % everywhere
+    retries = env_int("SOIL_TILED_RETRIES", 2);
     stagger = env_int("SOIL_TILED_STAGGER", KIND == FLUVIAL ? 1 : 2) == 1;
     const int64_t max_tiles = std::max(std::max(tiles_of(shape_early, 0), tiles_of(shape_late, 0)),
                                        std::max(tiles_of(shape_early, 1), tiles_of(shape_late, 1)));
@@ -1820,7 +1856,7 @@ struct TiledRun {
                             reinterpret_cast<float2*>(fluxV), fluxA, static_cast<const float4*>(p4),
                             remote0, steps_run, d, s, p, tiles_w, ts_cur.off_r, ts_cur.off_c,
                             steps_per_round, ts_of(sh_next, round + 1),
-                            tiles_w_of(sh_next, round + 1), agg_min, agg_groups);
+                            tiles_w_of(sh_next, round + 1), agg_min, agg_groups, retries);
     else
       launch_round<KIND, 1>(sh, blocks, st, next, dest, rank, count_next,
                             static_cast<const PRec*>(cur), static_cast<const uint32_t*>(order),
@@ -1828,7 +1864,7 @@ struct TiledRun {
                             reinterpret_cast<float2*>(fluxV), fluxA, static_cast<const float4*>(p4),
                             remote0, steps_run, d, s, p, tiles_w, ts_cur.off_r, ts_cur.off_c,
                             steps_per_round, ts_of(sh_next, round + 1),
-                            tiles_w_of(sh_next, round + 1), agg_min, agg_groups);
+                            tiles_w_of(sh_next, round + 1), agg_min, agg_groups, retries);
     SOIL_LAUNCH_CHECK();
     SOIL_HIP(hipEventRecord(ev1, st));
     timed = true;
