@@ -1052,8 +1052,11 @@ constexpr int round_groups_per_cu(int kind, int tr, int tc, int nt, bool alb) {
   const int by_lds = kLdsPerCU / round_lds_bytes(kind, tr, tc, alb), by_waves = 32 / (nt / 64);
   return by_lds < by_waves ? by_lds : by_waves;
 }
+// (a work-group's waves are dealt out over the four SIMDs: the fullest one holds ceil(waves / 4) of
+// each work-group — 640 or 896 lanes need 6 / 8 waves per SIMD where 768 need 6; measured as
+// "occupancy cliffs", 36 against 24 ms, when the bound said 5 / 7)
 constexpr int round_waves_per_simd(int kind, int tr, int tc, int nt, bool alb) {
-  return round_groups_per_cu(kind, tr, tc, nt, alb) * (nt / 64) / 4;
+  return round_groups_per_cu(kind, tr, tc, nt, alb) * ((nt / 64 + 3) / 4);
 }
 __device__ __forceinline__ bool any_lane(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0; }
 // A value the compiler may not look through.  A ballot wants to be the ballot of a comparison of
