@@ -1691,7 +1691,8 @@ struct TiledRun {
     // add (CasDeposit::finish).  Measured against none: 1024^2 1.89 -> 1.82 ms per step, 2048^2 (late
     // steps) 4.06 -> 3.78, 4096^2 11.3 -> 10.9 (with one try: 11.3), 8192^2 within the noise between
     // runs (36.3 -> 36.1; one try 35.3 in one run, 36.3 in another); four tries cost 1-2 % everywhere
-    retries = env_int("SOIL_TILED_RETRIES", 2);
+    retries = 2;
+    if (const char* e = std::getenv("SOIL_TILED_RETRIES")) retries = std::atoi(e) > 0 ? std::atoi(e) : 0;  // 0: none
     stagger = env_int("SOIL_TILED_STAGGER", KIND == FLUVIAL ? 1 : 2) == 1;
     const int64_t max_tiles = std::max(std::max(tiles_of(shape_early, 0), tiles_of(shape_late, 0)),
                                        std::max(tiles_of(shape_early, 1), tiles_of(shape_late, 1)));
