@@ -184,16 +184,38 @@ def cpu_baseline(size, seconds_hint=20.0):
     }
 
 
-def main():
+def _respawn(n):
+    """`python bench.py --gpus N` from a bare shell: start the N ranks (one per GPU) under
+    torch.distributed.run on 127.0.0.1 and hand their output through; rank 0 prints the line."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--size", type=int, default=8192, help="rows per GPU and columns")
     ap.add_argument("--grid", type=int, default=int(os.environ.get("SOIL_BENCH_GRID", "0")),
-                    help="STRONG scaling on a fixed grid x grid domain (BASELINE.json configs[4]: "
-                         "16384): every rank takes grid/N rows of all grid columns.  Default 0: "
-                         "weak scaling, one --size-row slab of --size columns per GPU")
+                    help="STRONG scaling on a fixed grid x grid domain as the line's `value` "
+                         "(BASELINE.json configs[4]: 16384): every rank takes grid/N rows of all "
+                         "grid columns.  Default 0: `value` is weak scaling, one --size-row slab of "
+                         "--size columns per GPU, and a run on more than one GPU appends the "
+                         "strong-scaling point of --strong-grid as `strong16384`")
+    ap.add_argument("--strong-grid", type=int,
+                    default=int(os.environ.get("SOIL_BENCH_STRONG_GRID", "16384")),
+                    help="grid of the strong-scaling block a multi-GPU run appends (0: none)")
     ap.add_argument("--particles-div", type=int, default=8, help="N = cells / this")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-size", type=int, default=1024)
@@ -204,97 +226,65 @@ def main():
                     help="one GPU: the two particle launches back to back, each timed by itself")
     ap.add_argument("--particle-mode", type=int, default=0,
                     help="0 auto, 1 direct (reference launch shape), 2 staged — ablation")
-    args = ap.parse_args()
+    return ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    # SOIL_DEVICE: several ranks on one GPU (functional tests of the multi-rank path over gloo)
-    local_rank = int(os.environ.get("SOIL_DEVICE", os.environ.get("LOCAL_RANK", "0")))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
-        args.gpus = world
 
-    from soillib_amd import _abi, silt, soil
-    from soillib_amd.erosion import ErosionModel
-    lib = _abi.lib()
-    _abi.check(lib.soil_set_device(local_rank))
-    _abi.check(lib.soil_set_particle_mode(args.particle_mode))
+class _Single:
+    """The whole grid on this GPU: the phases of soil_erode_step issued one by one so that HIP
+    events can be put between them."""
 
-    S = args.size
-    strong = args.grid > 0
-    if strong:
-        if args.grid % world:
-            raise SystemExit("--grid %d does not split into %d equal slabs" % (args.grid, world))
-        S = args.grid // world                   # rows per rank; the columns stay args.grid
-    Wcols = args.grid if strong else S
-    if args.overlap_particles:
-        os.environ["SOIL_STEP_PAIR"] = "1"       # the slab runner reads it (there overlap is opt-in)
-    param = script_param(soil)
-    if world > 1 or os.environ.get("SOIL_BENCH_FORCE_SLAB") == "1":
-        from soillib_amd import parallel
-        for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29671"), ("RANK", "0"),
-                     ("WORLD_SIZE", "1")):     # a one-rank world started without a launcher
-            os.environ.setdefault(k, v)
-        # weak scaling: every slab is a piece of the same kind of landscape — cell size
-        # (20/S) and noise wavelength per cell as at N = 1, the domain just gets longer.
-        # strong scaling: the same grid x grid landscape whatever the world size.
-        runner = parallel.SlabRunner(rows_per_rank=S, W=Wcols, param=param,
-                                     particles_div=args.particles_div, seed=0,
-                                     scale=[20.0 / Wcols, 20.0 / Wcols, 4.0],
-                                     noise_rows=Wcols if strong else S)
-        H_global, W = runner.H, Wcols
-    else:
-        H_global, W = S, Wcols
-        scale = (20.0 / H_global, 20.0 / W, 4.0)
-        model = ErosionModel(H_global, W, scale, param, H_global * W // args.particles_div, seed=0)
+    def __init__(self, H, W, param, particles_div, serial):
+        from soillib_amd import _abi, silt, soil
+        from soillib_amd.erosion import ErosionModel
+        self.abi, self.lib, self.serial = _abi, _abi.lib(), serial
+        self.H, self.W = H, W
+        scale = (20.0 / H, 20.0 / W, 4.0)
+        self.model = model = ErosionModel(H, W, scale, param, H * W // particles_div, seed=0)
         npar = soil.noise_t()
         npar.seed = 3.0
-        npar.ext = [H_global, W]
-        bed = soil.noise(silt.shape(H_global, W), npar, host=silt.gpu)
+        npar.ext = [H, W]
+        bed = soil.noise(silt.shape(H, W), npar, host=silt.gpu)
         # layers[..., 0] = bedrock noise, layers[..., 1] = 0 sediment
-        _interleave(lib, _abi, model.layers, bed)
+        _interleave(self.lib, _abi, model.layers, bed)
         silt.set(model.rainfall, 1.0)
         silt.set(model.uplift, 0.0)
 
-        class _Single:
-            def step(self_inner, ev=None):
-                model.seed_step()
-                if ev: ev.record(0)
-                if serial:
-                    model.particles_fluvial()
-                    if ev: ev.record(1)
-                    model.particles_debris()
-                else:                     # both launches overlapped on two streams
-                    model.particles_pair()
-                    if ev: ev.record(1)
-                if ev: ev.record(2)
-                model.cells_fused()
-                if ev: ev.record(3)
-                model.swap_layers()
-                model.step_index += 1
+    def step(self, ev=None):
+        model = self.model
+        model.seed_step()
+        if ev: ev.record(0)
+        if self.serial:
+            model.particles_fluvial()
+            if ev: ev.record(1)
+            model.particles_debris()
+        else:                     # both launches overlapped on two streams
+            model.particles_pair()
+            if ev: ev.record(1)
+        if ev: ev.record(2)
+        model.cells_fused()
+        if ev: ev.record(3)
+        model.swap_layers()
+        model.step_index += 1
 
-            def sync(self_inner):
-                _abi.check(lib.soil_device_synchronize())
+    def sync(self):
+        self.abi.check(self.lib.soil_device_synchronize())
 
-            def barrier(self_inner):
-                pass
-        runner = _Single()
+    def barrier(self):
+        pass
 
-    ev = Events(_abi, 6)
-    # one GPU: the two particle launches overlapped, as the library's step driver runs them
-    # (soil_erode_step); --sequential-particles for the per-launch phase timings
-    serial = args.sequential_particles or os.environ.get("SOIL_STEP_PAIR") == "0"
-    if world > 1 or os.environ.get("SOIL_BENCH_FORCE_SLAB") == "1":   # slab runner: overlap is opt-in
-        serial = not (args.overlap_particles or os.environ.get("SOIL_STEP_PAIR") == "1")
-    for _ in range(args.warmup):
+
+def timed_steps(runner, ev, steps, warmup, world):
+    """W untimed steps, then exactly K steps between barrier + device synchronise on both sides;
+    the elapsed wall time is the maximum over the ranks."""
+    from soillib_amd import soil
+    for _ in range(warmup):
         runner.step()
     runner.barrier()
     runner.sync()
     soil.particle_steps(reset=True)
     phase = [0.0, 0.0, 0.0, 0.0, 0.0]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         runner.step(ev)
         # events are read back after the step's work is queued; elapsed_ms
         # synchronises on the last event, so this also paces the host
@@ -309,12 +299,78 @@ def main():
     elapsed = time.perf_counter() - t0
     if world > 1:
         elapsed = runner.max_over_ranks(elapsed)
-    psteps_rank = soil.particle_steps(reset=True)   # this rank's particle steps in the timed region
+    return elapsed, phase, soil.particle_steps(reset=True)
+
+
+def slab_runner(S, Wcols, strong, param, particles_div):
+    from soillib_amd import parallel
+    for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29671"), ("RANK", "0"),
+                 ("WORLD_SIZE", "1")):     # a one-rank world started without a launcher
+        os.environ.setdefault(k, v)
+    # weak scaling: every slab is a piece of the same kind of landscape — cell size
+    # (20/S) and noise wavelength per cell as at N = 1, the domain just gets longer.
+    # strong scaling: the same grid x grid landscape whatever the world size.
+    return parallel.SlabRunner(rows_per_rank=S, W=Wcols, param=param,
+                               particles_div=particles_div, seed=0,
+                               scale=[20.0 / Wcols, 20.0 / Wcols, 4.0],
+                               noise_rows=Wcols if strong else S)
+
+
+def halo_report(runner):
+    hr = runner.halo_rows
+    return {"ghost_rows_bound": runner.G,
+            "rows_shipped_vs_bound": (hr["flux"] + hr["field"]) / max(hr["full"], 1),
+            "reach_rows_last_steps": runner.reach_hist, "repeated_launches": runner.fallbacks,
+            "trimmed_by_measured_reach": bool(runner.trim)}
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started by hand or by a driver as plain `python bench.py --gpus N`
+        raise SystemExit(_respawn(args.gpus))
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    # SOIL_DEVICE: several ranks on one GPU (functional tests of the multi-rank path over gloo)
+    local_rank = int(os.environ.get("SOIL_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    args.gpus = world
+
+    from soillib_amd import _abi, silt, soil
+    lib = _abi.lib()
+    _abi.check(lib.soil_set_device(local_rank))
+    _abi.check(lib.soil_set_particle_mode(args.particle_mode))
+
+    S = args.size
+    strong = args.grid > 0
+    if strong:
+        if args.grid % world:
+            raise SystemExit("--grid %d does not split into %d equal slabs" % (args.grid, world))
+        S = args.grid // world                   # rows per rank; the columns stay args.grid
+    Wcols = args.grid if strong else S
+    if args.overlap_particles:
+        os.environ["SOIL_STEP_PAIR"] = "1"       # the slab runner reads it (there overlap is opt-in)
+    param = script_param(soil)
+    slabbed = world > 1 or os.environ.get("SOIL_BENCH_FORCE_SLAB") == "1"
+    # one GPU: the two particle launches overlapped, as the library's step driver runs them
+    # (soil_erode_step); --sequential-particles for the per-launch phase timings
+    serial = args.sequential_particles or os.environ.get("SOIL_STEP_PAIR") == "0"
+    if slabbed:                                   # slab runner: overlap is opt-in
+        serial = not (args.overlap_particles or os.environ.get("SOIL_STEP_PAIR") == "1")
+    if slabbed:
+        runner = slab_runner(S, Wcols, strong, param, args.particles_div)
+        H_global, W = runner.H, Wcols
+    else:
+        H_global, W = S, Wcols
+        runner = _Single(H_global, W, param, args.particles_div, serial)
+
+    ev = Events(_abi, 6)
+    elapsed, phase, psteps_rank = timed_steps(runner, ev, args.steps, args.warmup, world)
     final = None
-    if world == 1 and os.environ.get("SOIL_BENCH_FORCE_SLAB") != "1":
+    if not slabbed:
         # sanity of the evolved terrain (outside the timed region): no NaN/inf may appear
         import numpy as np
-        hh = model.height.cpu().numpy()
+        hh = runner.model.height.cpu().numpy()
         final = {"height_min": float(np.nanmin(hh)), "height_max": float(np.nanmax(hh)),
                  "nonfinite_cells": int((~np.isfinite(hh)).sum())}
 
@@ -337,13 +393,17 @@ def main():
         probe = {"kernel": "k_add (t += o), 2 x 8192^2 f32 planes, 12 B/element",
                  "achieved": 12.0 * 8192 * 8192 * 10 / (pe.ms(0, 1) * 1e-3) / 1e9, "unit": "GB/s"}
         del a, b
-    halo = None
-    if world > 1:
-        hr = runner.halo_rows
-        halo = {"ghost_rows_bound": runner.G, "rows_shipped_vs_bound": (hr["flux"] + hr["field"]) / max(hr["full"], 1),
-                "reach_rows_last_steps": runner.reach_hist, "repeated_launches": runner.fallbacks,
-                "trimmed_by_measured_reach": bool(runner.trim)}
-    if world > 1 or os.environ.get("SOIL_BENCH_FORCE_SLAB") == "1":
+    halo = halo_report(runner) if world > 1 else None
+    nccl_ranks = None
+    if slabbed:
+        nccl_ranks = {"backend": runner.dist.get_backend(), "world_size": runner.dist.get_world_size()}
+
+    # ---- BASELINE.json configs[4]: the strong-scaling point, appended to a multi-GPU weak run ----
+    strong_block = None
+    G = args.strong_grid
+    if world > 1 and not strong and G > 0:
+        strong_block = strong_scaling_block(args, runner, ev, rank, world, param, G)
+    if slabbed:
         runner.shutdown()
     if rank != 0:
         return
@@ -385,13 +445,16 @@ def main():
         "config": {
             "workload": "%dx%d coupled hydraulic+thermal erosion step (fluvial+debris particle "
                         "transport, N=cells/%d, maxage 256, + fused cell phase), OpenSimplex2-FBm "
-                        "heightmap, example/erosion_gpu.py parameters" % (H_global, W,
-                                                                          args.particles_div),
+                        "heightmap, example/erosion_gpu.py parameters%s" % (
+                            H_global, W, args.particles_div,
+                            "; + `strong16384`: the %d^2 grid of BASELINE configs[4] cut into %d row "
+                            "slabs, same harness" % (G, world) if strong_block else ""),
             "grid": [H_global, W], "particles": cells // args.particles_div, "maxage": 256,
             "parallelism": "row-slabs x%d" % world if world > 1 else "single GPU",
         },
         "final_state": final,
         "halo": halo,
+        "nccl_ranks": nccl_ranks,
         "particle_steps_per_step": psteps_rank * world // K,
         "gparticle_steps_per_s": psteps_rank * world / elapsed / 1e9,
         "phases_ms": ({"particles_fluvial": phase[0] / K, "particles_debris": phase[1] / K}
@@ -409,6 +472,8 @@ def main():
                      "avg_launch_ms": t_cells * 1e3},
     }
     out["roofline_particles"] = proof
+    if strong_block:
+        out["strong16384"] = strong_block
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.cpu_size)
     try:  # anything RCCL/HIP left in the C stdio buffer goes out BEFORE the result line
@@ -416,6 +481,54 @@ def main():
     except Exception:
         pass
     print(json.dumps(out), flush=True)
+
+
+def strong_scaling_block(args, weak_runner, ev, rank, world, param, G):
+    """BASELINE.json configs[4] in the harness of the line above: the G x G grid cut into `world`
+    row slabs (K timed steps, max over ranks), then the same grid on rank 0's GPU alone
+    (`speedup_vs_1gpu` = the ratio of the two step times, both measured in this run)."""
+    from soillib_amd import _abi, silt
+    import torch
+    if G % world:
+        return {"skipped": "%d rows do not split into %d equal slabs" % (G, world)}
+    S = G // world
+    if weak_runner.G > S:
+        return {"skipped": "ghost depth %d exceeds the %d rows of a slab" % (weak_runner.G, S)}
+    dist = weak_runner.dist
+    # the weak run's planes go back to the allocator first
+    weak_runner.P.clear()
+    weak_runner.stage.clear()
+    weak_runner.rng = weak_runner.rng_debris = None
+    torch.cuda.empty_cache()
+    runner = slab_runner(S, G, True, param, args.particles_div)
+    K = args.steps
+    elapsed, phase, psteps = timed_steps(runner, ev, K, args.warmup, world)
+    block = {
+        "grid": [G, G], "scaling": "strong", "n_gpus": world, "rows_per_gpu": S,
+        "ms_per_step": elapsed / K * 1e3, "value": G * G / (elapsed / K) / 1e6, "unit": "Mcells/s",
+        "steps": K, "warmup": args.warmup,
+        "phases_ms": {"particles": (phase[0] + phase[1]) / K,
+                      "cells_fused": (phase[2] - phase[3] - phase[4]) / K,
+                      "exchange_flux_exposed": phase[3] / K,
+                      "exchange_field_exposed": phase[4] / K},
+        "halo": halo_report(runner),
+        "gparticle_steps_per_s": psteps * world / elapsed / 1e9,
+    }
+    runner.P.clear()
+    runner.stage.clear()
+    runner.rng = runner.rng_debris = None
+    torch.cuda.empty_cache()
+    # the same grid on one GPU (rank 0; the others wait at the barrier)
+    if rank == 0 and os.environ.get("SOIL_BENCH_NO_1GPU_REF") != "1":
+        k1 = max(2, min(K, 4))
+        single = _Single(G, G, param, args.particles_div, serial=False)
+        e1, _, _ = timed_steps(single, ev, k1, 1, 1)
+        block["one_gpu"] = {"ms_per_step": e1 / k1 * 1e3, "value": G * G / (e1 / k1) / 1e6,
+                            "steps": k1, "warmup": 1}
+        block["speedup_vs_1gpu"] = (e1 / k1) / (elapsed / K)
+        del single
+    dist.barrier()
+    return block
 
 
 def _interleave(lib, _abi, layers, bed):

@@ -29,6 +29,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <utility>
+#include <map>
+#include <utility>
 #include <vector>
 
 #include "common.hpp"
@@ -185,7 +187,12 @@ static int fill_level(float* out, const float* height, int64_t H, int64_t W, con
   // a launch moves information at least one tile further; H*W launches is a bound
   // no terrain reaches
   const int64_t max_launches = 4 * (static_cast<int64_t>(tiles_w) + tiles_h) * kFT + 16;
-  static const int per_check = std::getenv("SOIL_FILL_PER_CHECK") ? std::atoi(std::getenv("SOIL_FILL_PER_CHECK")) : 2;
+  // (a value below 1 or not a number would skip the launches and return the unrelaxed start)
+  static const int per_check = [] {
+    const char* e = std::getenv("SOIL_FILL_PER_CHECK");
+    const int v = e ? std::atoi(e) : 2;
+    return v >= 1 ? v : 2;
+  }();
   static const bool verbose = std::getenv("SOIL_FILL_VERBOSE") != nullptr;
   for (int64_t launch = 0; launch < max_launches; launch += per_check) {
     *flag_host = 0;  // the stream is idle here: the previous launches were waited for
@@ -207,7 +214,7 @@ static int fill_level(float* out, const float* height, int64_t H, int64_t W, con
 
 template <int K>
 static int fill_impl(float* out, const float* height, int64_t H, int64_t W, hipStream_t st) {
-  // the pyramid: level 0 is the DEM itself, level l + 1 the 16x16 block maxima of level l
+  // the pyramid: level 0 is the DEM itself, level l + 1 the 4x4 (kFC) block maxima of level l
   struct Level { int64_t H, W; size_t off_z, off_w; };
   std::vector<Level> lv{{H, W, 0, 0}};
   auto align = [](size_t b) { return (b + 255) & ~size_t{255}; };
@@ -225,11 +232,16 @@ static int fill_impl(float* out, const float* height, int64_t H, int64_t W, hipS
   char* ws = static_cast<char*>(base);
   // "some tile moved in this launch": a pinned, device-mapped word the tiles write straight
   // into (a device-to-host copy is a 25-50 us blit kernel on this stack, per launch)
-  static thread_local int *t_flag = nullptr, *t_flag_dev = nullptr;
-  if (!t_flag) {
-    SOIL_HIP(hipHostMalloc(reinterpret_cast<void**>(&t_flag), sizeof(int), hipHostMallocMapped | hipHostMallocCoherent));
-    SOIL_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&t_flag_dev), t_flag, 0));
+  // (one per host thread and device)
+  static thread_local std::map<int, std::pair<int*, int*>> t_flags;
+  int dev = 0;
+  SOIL_HIP(hipGetDevice(&dev));
+  auto& fl = t_flags[dev];
+  if (!fl.first) {
+    SOIL_HIP(hipHostMalloc(reinterpret_cast<void**>(&fl.first), sizeof(int), hipHostMallocMapped | hipHostMallocCoherent));
+    SOIL_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&fl.second), fl.first, 0));
   }
+  int *const t_flag = fl.first, *const t_flag_dev = fl.second;
   unsigned char* dirty_a = reinterpret_cast<unsigned char*>(ws) + 256;
   unsigned char* dirty_b = dirty_a + b_dirty;
   auto zc = [&](size_t l) { return l == 0 ? height : reinterpret_cast<const float*>(ws + lv[l].off_z); };

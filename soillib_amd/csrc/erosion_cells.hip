@@ -308,7 +308,10 @@ __device__ __forceinline__ CellResult fused_cell(const Nbhd& nb, float uplift, f
   return r;
 }
 
-template <bool XCD_REMAP, bool NT, int BLOCK = kBlock>
+// DIRECT: every lane stores its own 32 bytes of a two-channel plane (round 1's stores) instead of
+// swapping them through LDS into 1 KiB-contiguous instructions — kept for A/B inside bench.py
+// (SOIL_CELLS_VARIANT=4)
+template <bool XCD_REMAP, bool NT, int BLOCK = kBlock, bool DIRECT = false>
 __global__ void __launch_bounds__(BLOCK)
     k_erode_cells_fused(Planes P, Dom d, Scale3 s, Param p, int64_t groups_per_row,
                         int64_t total_groups) {
@@ -359,7 +362,7 @@ __global__ void __launch_bounds__(BLOCK)
     if (right_ok) right = make_float2(rx_, ry_);
   }
 
-  __shared__ float4 s_tile[BLOCK / 64][128];
+  __shared__ float4 s_tile[DIRECT ? 1 : BLOCK / 64][DIRECT ? 1 : 128];
   Row4 o_layers, o_vel, o_dvel;
   float o_h[kVec], o_wh[kVec], o_m[kVec], o_d[kVec];
 #pragma unroll
@@ -385,33 +388,46 @@ __global__ void __launch_bounds__(BLOCK)
     o_dvel.v[k] = r.db.velocity;
   }
 
-  // A lane's four cells of a two-channel plane are 32 contiguous bytes: stored as they are, every
-  // store instruction of the wave would cover half of each 32-byte sector.  The wave's groups are
-  // consecutive in memory (n0 = 4 g, also across a row's end), so its 2 KiB go out as two
-  // instructions of 1 KiB of consecutive bytes each, swapped through LDS (window.hpp).
-  const int64_t wave_n0 = d.r0 * d.W + (g - lane) * kVec;  // n0 of the wave's lane 0
-  auto pair = [&](float2* plane, const Row4& r) {
-    store_pair_contiguous(reinterpret_cast<float4*>(plane + wave_n0),
-                          make_float4(r.v[0].x, r.v[0].y, r.v[1].x, r.v[1].y),
-                          make_float4(r.v[2].x, r.v[2].y, r.v[3].x, r.v[3].y),
-                          s_tile[threadIdx.x >> 6], active);
-  };
-  pair(P.layers_next, o_layers);
-  pair(P.velocity, o_vel);
-  pair(P.debrisVelocity, o_dvel);
-  {  // re-zero the two-channel flux planes (zeros need no swapping: lane i takes the i-th and the
-     // (64 + i)-th 16 bytes of the wave's stretch — every lane of the wave, its idle ones included)
-    const int n_real = 2 * __popcll(__ballot(active));
-    v4f* zv = reinterpret_cast<v4f*>(P.velocityFlux + wave_n0);
-    v4f* zd = reinterpret_cast<v4f*>(P.debrisVelocityFlux + wave_n0);
-    const v4f zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
-    if (lane < n_real) {
-      zv[lane] = zero4;
-      zd[lane] = zero4;
+  if constexpr (DIRECT) {
+    if (active) {
+      store_row4<NT>(P.layers_next + n0, o_layers);
+      store_row4<NT>(P.velocity + n0, o_vel);
+      store_row4<NT>(P.debrisVelocity + n0, o_dvel);
+      Row4 z2;
+#pragma unroll
+      for (int k = 0; k < kVec; ++k) z2.v[k] = make_float2(0.0f, 0.0f);
+      store_row4<NT>(P.velocityFlux + n0, z2);
+      store_row4<NT>(P.debrisVelocityFlux + n0, z2);
     }
-    if (64 + lane < n_real) {
-      zv[64 + lane] = zero4;
-      zd[64 + lane] = zero4;
+  } else {
+    // A lane's four cells of a two-channel plane are 32 contiguous bytes: stored as they are, every
+    // store instruction of the wave would cover half of each 32-byte sector.  The wave's groups are
+    // consecutive in memory (n0 = 4 g, also across a row's end), so its 2 KiB go out as two
+    // instructions of 1 KiB of consecutive bytes each, swapped through LDS (window.hpp).
+    const int64_t wave_n0 = d.r0 * d.W + (g - lane) * kVec;  // n0 of the wave's lane 0
+    auto pair = [&](float2* plane, const Row4& r) {
+      store_pair_contiguous(reinterpret_cast<float4*>(plane + wave_n0),
+                            make_float4(r.v[0].x, r.v[0].y, r.v[1].x, r.v[1].y),
+                            make_float4(r.v[2].x, r.v[2].y, r.v[3].x, r.v[3].y),
+                            s_tile[threadIdx.x >> 6], active);
+    };
+    pair(P.layers_next, o_layers);
+    pair(P.velocity, o_vel);
+    pair(P.debrisVelocity, o_dvel);
+    {  // re-zero the two-channel flux planes (zeros need no swapping: lane i takes the i-th and the
+       // (64 + i)-th 16 bytes of the wave's stretch — every lane of the wave, its idle ones included)
+      const int n_real = 2 * __popcll(__ballot(active));
+      v4f* zv = reinterpret_cast<v4f*>(P.velocityFlux + wave_n0);
+      v4f* zd = reinterpret_cast<v4f*>(P.debrisVelocityFlux + wave_n0);
+      const v4f zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (lane < n_real) {
+        zv[lane] = zero4;
+        zd[lane] = zero4;
+      }
+      if (64 + lane < n_real) {
+        zv[64 + lane] = zero4;
+        zd[64 + lane] = zero4;
+      }
     }
   }
   if (!active) return;
@@ -648,12 +664,14 @@ int soil_erode_cells_fused(const soil_erosion_planes* pl, const soil_domain* dom
     const int64_t total = (d.r1 - d.r0) * groups_per_row;
     const unsigned nblk = blocks_for(total, kBlock);
     static const bool nt = [] { const char* e = std::getenv("SOIL_CELLS_NT"); return e && e[0] == '1'; }();  // measured slower than plain accesses; kept for A/B
-    static const int variant = [] { const char* e = std::getenv("SOIL_CELLS_VARIANT"); return e ? std::atoi(e) : 0; }();
+    const int variant = [] { const char* e = std::getenv("SOIL_CELLS_VARIANT"); return e ? std::atoi(e) : 0; }();  // read per call: bench.py alternates variants in one process
     const bool remap = nblk % 8 == 0 && nblk >= 64 && variant != 2;
     if (variant == 1 && (total % 512) == 0 && ((total / 512) % 8) == 0)
       k_erode_cells_fused<true, false, 512><<<static_cast<unsigned>(total / 512), 512, 0, st>>>(P, d, s3(scale), *param, groups_per_row, total);
     else if (variant == 3 && (total % 128) == 0 && ((total / 128) % 8) == 0)
       k_erode_cells_fused<true, false, 128><<<static_cast<unsigned>(total / 128), 128, 0, st>>>(P, d, s3(scale), *param, groups_per_row, total);
+    else if (variant == 4 && remap)
+      k_erode_cells_fused<true, false, kBlock, true><<<nblk, kBlock, 0, st>>>(P, d, s3(scale), *param, groups_per_row, total);
     else if (remap && nt)
       k_erode_cells_fused<true, true><<<nblk, kBlock, 0, st>>>(P, d, s3(scale), *param, groups_per_row, total);
     else if (remap)

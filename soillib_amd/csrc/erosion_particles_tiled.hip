@@ -51,6 +51,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <map>
 #include <vector>
 
 #include "particles_common.hpp"
@@ -1211,8 +1212,8 @@ __global__ void __launch_bounds__(NT, round_waves_per_simd(KIND, TR, TC, NT, ALB
 #ifdef SOIL_PROF
       ++pt_iters;
 #endif
-      const uint32_t dr = static_cast<uint32_t>(floor_cell(r.px) - row_org);  // row, column counted
-      const uint32_t dc = static_cast<uint32_t>(floor_cell(r.py) - c_lo);     // from (r_lo, c_lo)
+      const uint32_t dr = static_cast<uint32_t>(floor_cell(r.px)) - static_cast<uint32_t>(row_org);  // row, column counted
+      const uint32_t dc = static_cast<uint32_t>(floor_cell(r.py)) - static_cast<uint32_t>(c_lo);     // from (r_lo, c_lo); unsigned: floor_cell saturates, the wrap-around is meant
       const uint64_t stepm = __builtin_amdgcn_ballot_w64(dr <= r_span) & __builtin_amdgcn_ballot_w64(dc <= c_span) &
                              __builtin_amdgcn_ballot_w64(r.iter < limit) & runm;
       runm = stepm;
@@ -1287,7 +1288,7 @@ __global__ void __launch_bounds__(NT, round_waves_per_simd(KIND, TR, TC, NT, ALB
         for (;;) {
           ix = nan_cell(r.px, ix);
           iy = nan_cell(r.py, iy);
-          const uint32_t dr = static_cast<uint32_t>(ix - row_org), dc = static_cast<uint32_t>(iy - c_lo);
+          const uint32_t dr = static_cast<uint32_t>(ix) - static_cast<uint32_t>(row_org), dc = static_cast<uint32_t>(iy) - static_cast<uint32_t>(c_lo);
           if (!(dr <= r_span && dc <= c_span && r.iter < limit)) break;
           ++r.iter;
           ++nsteps;
@@ -1720,22 +1721,29 @@ struct TiledRun {
     steps_run = reinterpret_cast<unsigned long long*>(w);
     rc = step_counter(&steps_global);
     if (rc != SOIL_OK) return rc;
-    // pinned word + events, one set per (thread, kind)
-    static thread_local TiledHostWord *t_host = nullptr, *t_host_dev = nullptr;
-    static thread_local hipEvent_t t_ev0 = nullptr, t_ev1 = nullptr;
-    static thread_local uint32_t t_seq = 0;  // numbers the launches that fill t_host, across runs
-    if (!t_host) {
-      SOIL_HIP(hipHostMalloc(reinterpret_cast<void**>(&t_host), sizeof(TiledHostWord), hipHostMallocMapped | hipHostMallocCoherent));
-      SOIL_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&t_host_dev), t_host, 0));
-      t_host->seq = 0;
-      SOIL_HIP(hipEventCreate(&t_ev0));
-      SOIL_HIP(hipEventCreate(&t_ev1));
+    // pinned word + events, one set per (thread, device, kind): a host thread that moves on to
+    // another device (soil_set_device) must not poll a word or record events of the first one
+    struct HostSide {
+      TiledHostWord *host = nullptr, *host_dev = nullptr;
+      hipEvent_t ev0 = nullptr, ev1 = nullptr;
+      uint32_t seq = 0;  // numbers the launches that fill `host`, across runs
+    };
+    static thread_local std::map<int, HostSide> t_side;
+    int dev = 0;
+    SOIL_HIP(hipGetDevice(&dev));
+    HostSide& hs = t_side[dev];
+    if (!hs.host) {
+      SOIL_HIP(hipHostMalloc(reinterpret_cast<void**>(&hs.host), sizeof(TiledHostWord), hipHostMallocMapped | hipHostMallocCoherent));
+      SOIL_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&hs.host_dev), hs.host, 0));
+      hs.host->seq = 0;
+      SOIL_HIP(hipEventCreate(&hs.ev0));
+      SOIL_HIP(hipEventCreate(&hs.ev1));
     }
-    host = t_host;
-    host_dev = t_host_dev;
-    seq_ctr = &t_seq;
-    ev0 = t_ev0;
-    ev1 = t_ev1;
+    host = hs.host;
+    host_dev = hs.host_dev;
+    seq_ctr = &hs.seq;
+    ev0 = hs.ev0;
+    ev1 = hs.ev1;
     return SOIL_OK;
   }
 
@@ -1911,18 +1919,26 @@ static int run_tiled(float* flux0, float* flux1, float* fluxV, float* fluxA,
 // back into it; the host alternates between the two runs' decisions.
 int launch_pair_tiled(const soil_erosion_planes& P, soil_rng* rng_fluvial, soil_rng* rng_debris, int64_t N,
                       float* remote0, const Dom& d, Scale3 s, const Param& p, hipStream_t st) {
-  static thread_local hipStream_t sA = nullptr, sB = nullptr;
-  static thread_local hipEvent_t fork = nullptr, joinA = nullptr, joinB = nullptr;
-  if (!sA) {
-    SOIL_HIP(hipStreamCreateWithFlags(&sA, hipStreamNonBlocking));
-    SOIL_HIP(hipStreamCreateWithFlags(&sB, hipStreamNonBlocking));
-    SOIL_HIP(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
-    SOIL_HIP(hipEventCreateWithFlags(&joinA, hipEventDisableTiming));
-    SOIL_HIP(hipEventCreateWithFlags(&joinB, hipEventDisableTiming));
+  // forked streams and their events, one set per (thread, device)
+  struct Fork {
+    hipStream_t sA = nullptr, sB = nullptr;
+    hipEvent_t fork = nullptr, joinA = nullptr, joinB = nullptr;
+  };
+  static thread_local std::map<int, Fork> t_fork;
+  int dev = 0;
+  SOIL_HIP(hipGetDevice(&dev));
+  Fork& f = t_fork[dev];
+  if (!f.sA) {
+    SOIL_HIP(hipStreamCreateWithFlags(&f.sA, hipStreamNonBlocking));
+    SOIL_HIP(hipStreamCreateWithFlags(&f.sB, hipStreamNonBlocking));
+    SOIL_HIP(hipEventCreateWithFlags(&f.fork, hipEventDisableTiming));
+    SOIL_HIP(hipEventCreateWithFlags(&f.joinA, hipEventDisableTiming));
+    SOIL_HIP(hipEventCreateWithFlags(&f.joinB, hipEventDisableTiming));
   }
-  SOIL_HIP(hipEventRecord(fork, st));
-  SOIL_HIP(hipStreamWaitEvent(sA, fork, 0));
-  SOIL_HIP(hipStreamWaitEvent(sB, fork, 0));
+  const hipStream_t sA = f.sA, sB = f.sB;
+  SOIL_HIP(hipEventRecord(f.fork, st));
+  SOIL_HIP(hipStreamWaitEvent(sA, f.fork, 0));
+  SOIL_HIP(hipStreamWaitEvent(sB, f.fork, 0));
   TiledRun<FLUVIAL> A = make_run<FLUVIAL>(P.waterFlux, P.massFlux, P.velocityFlux, nullptr, nullptr,
                                           rng_fluvial, N,
                                           P.layers, P.rainfall, P.waterHeight, P.velocity, remote0,
@@ -1937,22 +1953,34 @@ int launch_pair_tiled(const soil_erosion_planes& P, soil_rng* rng_fluvial, soil_
   // (2) 37.2 (6) 37.3 (8): small grids are bound by the latency of each launch's chain of rounds, and two
   // chains interleave; at 8192^2 either launch fills the chip by itself.
   static const int delay_env = env_int("SOIL_PAIR_DELAY", 0);
-  if (int rc = A.begin(); rc != SOIL_OK) return rc;
   const uint64_t delay = delay_env > 0 ? static_cast<uint64_t>(delay_env) : 2;
-  bool b_started = false;
-  while (!A.done || !B.done) {
-    if (!b_started && (A.done || A.round >= delay)) {
-      if (int rc = B.begin(); rc != SOIL_OK) return rc;
-      b_started = true;
+  // Whatever happens in between, `st` is joined with both streams before this returns: rounds may
+  // still be in flight on the workspace the next call reuses.
+  auto run = [&]() -> int {
+    if (int rc = A.begin(); rc != SOIL_OK) return rc;
+    bool b_started = false;
+    while (!A.done || !B.done) {
+      if (!b_started && (A.done || A.round >= delay)) {
+        if (int rc = B.begin(); rc != SOIL_OK) return rc;
+        b_started = true;
+      }
+      if (int rc = A.advance(); rc != SOIL_OK) return rc;
+      if (b_started)
+        if (int rc = B.advance(); rc != SOIL_OK) return rc;
     }
-    if (int rc = A.advance(); rc != SOIL_OK) return rc;
-    if (b_started)
-      if (int rc = B.advance(); rc != SOIL_OK) return rc;
+    return SOIL_OK;
+  };
+  const int rc = run();
+  if (rc != SOIL_OK) {  // keep the first error's message; the joins below are best effort
+    if (hipEventRecord(f.joinA, sA) == hipSuccess) (void)hipStreamWaitEvent(st, f.joinA, 0);
+    if (hipEventRecord(f.joinB, sB) == hipSuccess) (void)hipStreamWaitEvent(st, f.joinB, 0);
+    (void)hipGetLastError();
+    return rc;
   }
-  SOIL_HIP(hipEventRecord(joinA, sA));
-  SOIL_HIP(hipEventRecord(joinB, sB));
-  SOIL_HIP(hipStreamWaitEvent(st, joinA, 0));
-  SOIL_HIP(hipStreamWaitEvent(st, joinB, 0));
+  SOIL_HIP(hipEventRecord(f.joinA, sA));
+  SOIL_HIP(hipEventRecord(f.joinB, sB));
+  SOIL_HIP(hipStreamWaitEvent(st, f.joinA, 0));
+  SOIL_HIP(hipStreamWaitEvent(st, f.joinB, 0));
   return SOIL_OK;
 }
 

@@ -30,7 +30,9 @@ __global__ void __launch_bounds__(256)
   const int64_t lx = ghost < r0 ? ghost : r1 + (ghost - r0);
   const float* row = plane + lx * row_floats;
   bool hit = false;
-  for (int64_t i = threadIdx.x; i < row_floats && !hit; i += 256) hit = row[i] != 0.0f;  // NaN counts
+  // any bit set counts: NaN, and -0.0 too (what a dead debris walker deposits: 0 times a negative
+  // source) — such a row is shipped and re-zeroed like in the untrimmed exchange
+  for (int64_t i = threadIdx.x; i < row_floats && !hit; i += 256) hit = f2bits(row[i]) != 0u;
   if (__syncthreads_or(hit) && threadIdx.x == 0) {
     if (lx < r0) atomicMax(&depth[0], static_cast<int32_t>(r0 - lx));
     else atomicMax(&depth[1], static_cast<int32_t>(lx - r1 + 1));
@@ -70,10 +72,9 @@ int soil_erode_step(const soil_erosion_planes* planes, soil_rng* rng, int64_t N,
   // One stream of draws per particle and step: (seed, subsequence n, offset step * N).  The
   // fluvial launch takes draws 0 and 1 of every stream, the debris launch draws 2 and 3.
   const uint64_t offset = step_index * static_cast<uint64_t>(N);
-  static const bool sequential = [] {
-    const char* e = std::getenv("SOIL_STEP_PAIR");
-    return e && e[0] == '0';
-  }();
+  // read on every call (one getenv per step): a host may switch it between steps
+  const char* pair_env = std::getenv("SOIL_STEP_PAIR");
+  const bool sequential = pair_env && pair_env[0] == '0';
   if (sequential) {  // one launch after the other on the caller's streams (diagnostics: phase timings)
     if (int rc = soil_rng_seed(rng, N, seed, offset, stream); rc != SOIL_OK) return rc;
     if (int rc = soil_particles_fluvial_slab(P.waterFlux, P.massFlux, P.velocityFlux, nullptr, rng, N,

@@ -1,0 +1,69 @@
+"""`python bench.py --gpus N` must start its N ranks by itself (the driver runs it from a bare
+shell, without torch.distributed.run and without WORLD_SIZE) and print ONE JSON line."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bare_env(**extra):
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "SOIL_BENCH_GRID"):
+        env.pop(k, None)
+    env.update(extra)
+    return env
+
+
+def test_bare_multi_gpu_bench_reaches_its_ranks_and_fails_loudly_without_a_device():
+    """No GPU here: the launcher must still come up, every rank must reach the library, and the
+    library must refuse to compute (no CPU fallback) — a non-zero exit with the reason in sight."""
+    from soillib_amd import _abi
+    if _abi.lib().soil_device_count() > 0:
+        pytest.skip("a HIP device is visible: the GPU variant of this test covers the spawn")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--grid", "2048",
+                          "--steps", "1", "--warmup", "0"], cwd=ROOT, env=_bare_env(),
+                         capture_output=True, text=True, timeout=600)
+    assert res.returncode != 0
+    assert "launch with torch.distributed.run" not in res.stdout + res.stderr
+    assert res.stderr.count("no usable HIP device") >= 2, res.stderr[-3000:]
+
+
+@pytest.mark.gpu
+def test_bare_multi_gpu_bench_prints_one_line_with_the_strong_scaling_block(hip):
+    """Two ranks on GPU 0 over gloo (the only wire one GPU offers): weak-scaling `value` + the
+    strong-scaling block (BASELINE configs[4] at test size) with speedup_vs_1gpu, rc 0."""
+    env = _bare_env(SOIL_DIST_BACKEND="gloo", SOIL_DEVICE="0")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--size", "1024",
+                          "--strong-grid", "2048", "--steps", "2", "--warmup", "1"],
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["config"]["grid"] == [2048, 1024]
+    assert out["value"] > 0 and out["steps"] == 2
+    assert out["nccl_ranks"]["world_size"] == 2
+    sb = out["strong16384"]
+    assert sb["grid"] == [2048, 2048] and sb["rows_per_gpu"] == 1024 and sb["scaling"] == "strong"
+    assert sb["value"] > 0 and sb["speedup_vs_1gpu"] > 0 and sb["one_gpu"]["ms_per_step"] > 0
+    assert sb["halo"]["repeated_launches"] >= 0
+    for k in ("exchange_flux_exposed", "exchange_field_exposed"):
+        assert k in sb["phases_ms"]
+
+
+@pytest.mark.gpu
+def test_bare_strong_grid_bench(hip):
+    """`--grid` makes the strong-scaling point the line's own value."""
+    env = _bare_env(SOIL_DIST_BACKEND="gloo", SOIL_DEVICE="0")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--grid", "2048",
+                          "--steps", "2", "--warmup", "1"],
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["scaling"] == "strong" and out["config"]["grid"] == [2048, 2048] and out["n_gpus"] == 2
