@@ -346,6 +346,40 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// Both launches of a step walk the same layers: one pass evaluates __glocal once per cell and
+// writes the two records (soil_particles_pair_slab; 0.68 + 0.55 ms -> one kernel at 8192^2).
+__global__ void __launch_bounds__(256)
+    k_tiled_pack_pair(float4* __restrict__ q_fluvial, float4* __restrict__ q_debris,
+                      const float2* __restrict__ layers, const float2* __restrict__ velocity,
+                      const float* __restrict__ waterHeight, const float2* __restrict__ debrisVelocity,
+                      Dom d, Scale3 s, Param param, int64_t row_lo, int64_t row_end) {
+  const int64_t y = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (y >= d.W) return;
+  SOIL_ROW_LOOP(band, row_end - row_lo) {
+  const int64_t lx = row_lo + band;
+  const int64_t l = lx * d.W + y;
+  const float2 grad = glocal(layers, d, s, d.x0 + lx, y, param.exitSlope);
+  const float2 vel = velocity[l], dvel = debrisVelocity[l];
+  const float g = param.gravity;
+  const float glen = length2(grad.x, grad.y);
+  {  // the fluvial record, as k_tiled_pack<FLUVIAL>
+    const float nu = param.viscosityWater;
+    const float fD = param.frictionFactor / 8.0f;  // :70
+    const float eps = 1E-12f;
+    const float v = length2(vel.x, vel.y);                                     // :83
+    const float shear = 0.125f * fD * param.densityWater * v * v;              // :84
+    const float power = powf_(shear * glen, param.fluvialExponent);            // :85
+    q_fluvial[l] = make_float4(-(g * grad.x) + nu * vel.x, -(g * grad.y) + nu * vel.y,
+                               0.125f * fD / (eps + waterHeight[l]), power);
+  }
+  {  // the debris record, as k_tiled_pack<DEBRIS>
+    const float nu = param.viscosityDebris;
+    q_debris[l] = make_float4(-(g * grad.x) + nu * dvel.x, -(g * grad.y) + nu * dvel.y,
+                              glen - param.critSlopeBedrock, 0.0f);
+  }
+  }
+}
+
 // ---- spawn: draws, ownership, trajectory initialisation (erosion.cu:49-96 / :262-302)
 
 template <int KIND>
@@ -1590,6 +1624,7 @@ struct TiledRun {
   int64_t n_src = 0;
   unsigned long long steps_before = 0;
   bool timed = false, done = false;
+  bool ready = false, skip_pack = false;  // setup() done; p4 filled by k_tiled_pack_pair
   int resident_groups[2] = {512, 512};  // work-groups of a round kernel the chip holds at once (early, late shape)
 
   int shape_of(uint64_t r) const { return r >= static_cast<uint64_t>(switch_round) ? shape_late : shape_early; }
@@ -1744,6 +1779,7 @@ struct TiledRun {
     seq_ctr = &hs.seq;
     ev0 = hs.ev0;
     ev1 = hs.ev1;
+    ready = true;
     return SOIL_OK;
   }
 
@@ -1784,9 +1820,10 @@ struct TiledRun {
   }
 
   int begin() {
-    if (int rc = setup(); rc != SOIL_OK) return rc;
+    if (!ready)
+      if (int rc = setup(); rc != SOIL_OK) return rc;
     const int64_t lo = stencil_lo(d), hi = stencil_hi(d);
-    if (hi >= lo)
+    if (hi >= lo && !skip_pack)
       k_tiled_pack<KIND><<<grid_rows(hi - lo + 1, d.W, 256), 256, 0, st>>>(
           p4, reinterpret_cast<const float2*>(layers), reinterpret_cast<const float2*>(velocity),
           waterHeight, d, s, p, lo, hi + 1);
@@ -1957,6 +1994,20 @@ int launch_pair_tiled(const soil_erosion_planes& P, soil_rng* rng_fluvial, soil_
   // Whatever happens in between, `st` is joined with both streams before this returns: rounds may
   // still be in flight on the workspace the next call reuses.
   auto run = [&]() -> int {
+    if (int rc = A.setup(); rc != SOIL_OK) return rc;
+    if (int rc = B.setup(); rc != SOIL_OK) return rc;
+    static const bool fused_pack = env_int("SOIL_PACK_PAIR", 1) == 1;   // 2: off (A/B)
+    if (fused_pack) {
+      const int64_t lo = stencil_lo(d), hi = stencil_hi(d);
+      if (hi >= lo)
+        k_tiled_pack_pair<<<grid_rows(hi - lo + 1, d.W, 256), 256, 0, sA>>>(
+            A.p4, B.p4, reinterpret_cast<const float2*>(P.layers), reinterpret_cast<const float2*>(P.velocity),
+            P.waterHeight, reinterpret_cast<const float2*>(P.debrisVelocity), d, s, p, lo, hi + 1);
+      SOIL_LAUNCH_CHECK();
+      SOIL_HIP(hipEventRecord(f.fork, sA));       // the debris launch reads its records from sB
+      SOIL_HIP(hipStreamWaitEvent(sB, f.fork, 0));
+      A.skip_pack = B.skip_pack = true;
+    }
     if (int rc = A.begin(); rc != SOIL_OK) return rc;
     bool b_started = false;
     while (!A.done || !B.done) {

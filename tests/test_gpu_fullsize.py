@@ -17,6 +17,8 @@ import ctypes as C
 import numpy as np
 import pytest
 
+from util import script_param
+
 pytestmark = pytest.mark.gpu
 
 
@@ -177,3 +179,106 @@ def test_device_noise_equals_host_generator_at_8192(hip):
     host = soil.noise(silt.shape(64, 64), small).numpy()          # host twin, a corner of a 64^2 grid
     dev64 = soil.noise(silt.shape(64, 64), small, host=silt.gpu).cpu().numpy()
     assert (host.view(np.uint32) == dev64.view(np.uint32)).all()
+
+
+def test_fill_depressions_properties_at_4096(hip):
+    """BASELINE config 3 as written: pit fill of a 4096^2 DEM.  Size-independent properties of the
+    priority-flood surface: on or above the DEM, idempotent bit for bit, no interior cell strictly
+    below all of its 8 neighbours, untouched where the DEM already drains (every raised cell sits
+    on a flat or rising path: it equals the minimum of its neighbours' fill or its own height)."""
+    from soillib_amd import silt, soil
+    S = 4096
+    p = soil.noise_t()
+    p.seed = 9.0
+    p.ext = [S, S]
+    h = soil.noise(silt.shape(S, S), p, host=silt.gpu)
+    silt.multiply(h, 100.0)
+    filled = soil.fill_depressions(h, soil.d8)
+    a, b = filled.cpu().numpy(), h.cpu().numpy()
+    assert (a >= b).all() and (a > b).any()
+    again = soil.fill_depressions(filled, soil.d8).cpu().numpy()
+    assert (again.view(np.uint32) == a.view(np.uint32)).all()
+    c = a[1:-1, 1:-1]
+    nb = np.minimum.reduce([a[:-2, 1:-1], a[2:, 1:-1], a[1:-1, :-2], a[1:-1, 2:],
+                            a[:-2, :-2], a[:-2, 2:], a[2:, :-2], a[2:, 2:]])
+    assert (nb <= c).all()
+    # the fixed point itself: w = max(z, min over neighbours of w) in the interior, w = z on the rim
+    assert (c.view(np.uint32) == np.maximum(b[1:-1, 1:-1], nb).view(np.uint32)).all()
+    for rim in (np.s_[0, :], np.s_[-1, :], np.s_[:, 0], np.s_[:, -1]):
+        assert (a[rim].view(np.uint32) == b[rim].view(np.uint32)).all()
+
+
+def test_whole_step_at_8192_direct_equals_tiled(hip):
+    """BASELINE config 4's grid through the product's tiled transport and through the reference's
+    launch shape (one lane per streamline, global atomics): the same number of particle steps
+    (identical trajectories), flux planes equal up to fp32 summation order, and a cell phase that
+    leaves the flux planes zero and the terrain finite."""
+    from soillib_amd import _abi, silt, soil
+    from soillib_amd.erosion import ErosionModel
+    S = 8192
+    N = S * S // 8
+    pp = script_param(soil.param_t())
+    scale = (20.0 / S, 20.0 / S, 4.0)
+    npar = soil.noise_t()
+    npar.seed = 3.0
+    npar.ext = [S, S]
+    bed = soil.noise(silt.shape(S, S), npar, host=silt.gpu)
+    m = ErosionModel(S, S, scale, pp, N, seed=0)
+    _abi.check(hip.soil_layers_from_planes(m.layers.c_ptr, bed.c_ptr, None, bed.elem(), None))
+    silt.set(m.rainfall, 1.0)
+    m.step()                       # a first step so that velocity / water fields are live
+    names = ("waterFlux", "massFlux", "velocityFlux", "debrisFlux", "debrisVelocityFlux")
+    got = {}
+    try:
+        for mode, label in ((3, "tiled"), (1, "direct")):
+            _abi.check(hip.soil_set_particle_mode(mode))
+            for n in names:
+                silt.set(getattr(m, n), 0.0)
+            soil.particle_steps(reset=True)
+            m.seed_step()
+            m.particles_fluvial()
+            m.particles_debris()
+            _abi.check(hip.soil_device_synchronize())
+            got[label] = (soil.particle_steps(reset=True), {n: getattr(m, n).cpu().numpy() for n in names})
+    finally:
+        _abi.check(hip.soil_set_particle_mode(0))
+    assert got["tiled"][0] == got["direct"][0] > 2.0e9
+    for n in names:
+        a, b = got["tiled"][1][n], got["direct"][1][n]
+        sc = np.nanmax(np.abs(b)) + 1e-30
+        # a channel cell sums 1e4..1e5 deposits at this size: the tolerance of the oracle tests at size
+        bad = ~(np.abs(a - b) <= 1e-4 * np.abs(b) + 2e-5 * sc) & ~(np.isnan(a) & np.isnan(b))
+        assert bad.sum() == 0, "%s: %d cells differ" % (n, bad.sum())
+        # conservation, whatever the order of the additions: plane sums in double
+        sa, sb = np.nansum(a.astype(np.float64)), np.nansum(b.astype(np.float64))
+        ref = np.nansum(np.abs(b).astype(np.float64)) + 1e-300
+        assert abs(sa - sb) <= 1e-6 * ref, (n, sa, sb)
+    m.cells_fused()
+    _abi.check(hip.soil_device_synchronize())
+    for n in names:
+        assert not getattr(m, n).cpu().numpy().any(), n + " not re-zeroed"
+    hh = m.height.cpu().numpy()
+    assert np.isfinite(hh).sum() >= hh.size - 1     # cell (0,0) may hold the NaN walkers' deposit
+
+
+def test_config1_geotiff_to_gpu_normal(hip, oracle, tmp_path):
+    """BASELINE config 1 with the tensor moved to the device: a 256^2 GeoTIFF written and read by
+    the library's own codec, .gpu(), soil.normal on the device == the CPU twin == the oracle."""
+    import silt
+    import soillib as soil
+    H = W = 256
+    p = soil.noise_t()
+    p.seed = 3.0
+    p.ext = [H, W]
+    height = soil.noise(silt.shape(H, W), p)
+    g = soil.geotiff(height)
+    g.meta.scale = [2.0, 2.0, 80.0]
+    path = str(tmp_path / "dem_256.tiff")
+    g.write(path)
+    image = soil.geotiff(path)
+    assert (image.tensor.numpy().reshape(-1).view(np.uint32) == height.numpy().reshape(-1).view(np.uint32)).all()
+    want = oracle.normal(height.numpy(), (2.0, 2.0, 80.0))
+    cpu = soil.normal(image.tensor, image.meta.scale).numpy()
+    dev = soil.normal(image.tensor.gpu(), image.meta.scale).cpu().numpy()
+    np.testing.assert_array_equal(cpu, want)
+    np.testing.assert_array_equal(dev, want)
