@@ -9,12 +9,16 @@ transport (N = H*W/8 particles, maxage 256), then the fused per-cell phase
 (normalise x2, mass transfer, creep, layer update, merge, flux re-zero).
 Workload at N=1: BASELINE.json configs[3], the 8192^2 coupled hydraulic +
 thermal step on synthetic OpenSimplex2-FBm terrain (soil.noise, generated on
-the device), inputs resident in HBM before the timed region.  N>1: weak
-scaling, one 8192-row slab per GPU (global grid (N*8192) x 8192) with deep-halo
-exchange over RCCL (soillib_amd/parallel.py).  `--grid 16384` (or
-SOIL_BENCH_GRID=16384) is BASELINE.json configs[4] as written: STRONG scaling,
-the 16384^2 grid cut into N row slabs of 16384/N rows ("scaling": "strong";
-SOIL_BENCH_FORCE_SLAB=1 runs the N=1 point through the same slab code).
+the device), inputs resident in HBM before the timed region.  `--gpus N` > 1 starts
+its N ranks itself (torch.distributed.run on 127.0.0.1, one per GPU) and runs the
+library's slab runner (soil_slab_step, include/soil_slab.h: row slabs, deep halos
+trimmed to the measured reach, RCCL send/recv groups on the library's streams):
+`value` is weak scaling, one 8192-row slab per GPU (global grid (N*8192) x 8192),
+and the line carries `strong16384`, BASELINE.json configs[4] as written — the
+16384^2 grid cut into N row slabs — with `speedup_vs_1gpu` measured in the same run.
+`--grid 16384` (or SOIL_BENCH_GRID=16384) makes that strong-scaling point the
+line's own `value` ("scaling": "strong"; SOIL_BENCH_FORCE_SLAB=1 runs the N=1
+point through the same slab code).
 
 Prints ONE JSON line (rank 0).  `value` is whole-job throughput of the FULL
 step; the per-phase split, the roofline of the HBM-bound fused cell kernel
@@ -73,8 +77,8 @@ class Events:
             abi.check(self.lib.soil_event_create(C.byref(e)))
             self.ev.append(e)
 
-    def record(self, i):
-        self.abi.check(self.lib.soil_event_record(self.ev[i], self.abi.stream()))
+    def record(self, i, stream=None):
+        self.abi.check(self.lib.soil_event_record(self.ev[i], stream if stream is not None else self.abi.stream()))
 
     def ms(self, i, j):
         out = C.c_float()
@@ -302,18 +306,16 @@ def timed_steps(runner, ev, steps, warmup, world):
     return elapsed, phase, soil.particle_steps(reset=True)
 
 
-def slab_runner(S, Wcols, strong, param, particles_div):
+def slab_runner(S, Wcols, strong, param, particles_div, comm, pair):
+    """One rank of the library's slab runner (soil_slab_create: csrc/slab_runner.hip)."""
     from soillib_amd import parallel
-    for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29671"), ("RANK", "0"),
-                 ("WORLD_SIZE", "1")):     # a one-rank world started without a launcher
-        os.environ.setdefault(k, v)
     # weak scaling: every slab is a piece of the same kind of landscape — cell size
     # (20/S) and noise wavelength per cell as at N = 1, the domain just gets longer.
     # strong scaling: the same grid x grid landscape whatever the world size.
     return parallel.SlabRunner(rows_per_rank=S, W=Wcols, param=param,
                                particles_div=particles_div, seed=0,
                                scale=[20.0 / Wcols, 20.0 / Wcols, 4.0],
-                               noise_rows=Wcols if strong else S)
+                               noise_rows=Wcols if strong else S, comm=comm, pair=pair)
 
 
 def halo_report(runner):
@@ -357,8 +359,11 @@ def main():
     serial = args.sequential_particles or os.environ.get("SOIL_STEP_PAIR") == "0"
     if slabbed:                                   # slab runner: overlap is opt-in
         serial = not (args.overlap_particles or os.environ.get("SOIL_STEP_PAIR") == "1")
+    comm = None
     if slabbed:
-        runner = slab_runner(S, Wcols, strong, param, args.particles_div)
+        from soillib_amd import parallel
+        comm = parallel.default_comm(device=True)      # RCCL inside the library; gloo by SOIL_DIST_BACKEND
+        runner = slab_runner(S, Wcols, strong, param, args.particles_div, comm, not serial)
         H_global, W = runner.H, Wcols
     else:
         H_global, W = S, Wcols
@@ -394,15 +399,13 @@ def main():
                  "achieved": 12.0 * 8192 * 8192 * 10 / (pe.ms(0, 1) * 1e-3) / 1e9, "unit": "GB/s"}
         del a, b
     halo = halo_report(runner) if world > 1 else None
-    nccl_ranks = None
-    if slabbed:
-        nccl_ranks = {"backend": runner.dist.get_backend(), "world_size": runner.dist.get_world_size()}
+    nccl_ranks = comm.describe() if slabbed else None    # what RCCL itself reports (ncclCommCount ...)
 
     # ---- BASELINE.json configs[4]: the strong-scaling point, appended to a multi-GPU weak run ----
     strong_block = None
     G = args.strong_grid
     if world > 1 and not strong and G > 0:
-        strong_block = strong_scaling_block(args, runner, ev, rank, world, param, G)
+        strong_block = strong_scaling_block(args, runner, ev, rank, world, param, G, comm, not serial)
     if slabbed:
         runner.shutdown()
     if rank != 0:
@@ -483,24 +486,17 @@ def main():
     print(json.dumps(out), flush=True)
 
 
-def strong_scaling_block(args, weak_runner, ev, rank, world, param, G):
+def strong_scaling_block(args, weak_runner, ev, rank, world, param, G, comm, pair):
     """BASELINE.json configs[4] in the harness of the line above: the G x G grid cut into `world`
     row slabs (K timed steps, max over ranks), then the same grid on rank 0's GPU alone
     (`speedup_vs_1gpu` = the ratio of the two step times, both measured in this run)."""
-    from soillib_amd import _abi, silt
-    import torch
     if G % world:
         return {"skipped": "%d rows do not split into %d equal slabs" % (G, world)}
     S = G // world
     if weak_runner.G > S:
         return {"skipped": "ghost depth %d exceeds the %d rows of a slab" % (weak_runner.G, S)}
-    dist = weak_runner.dist
-    # the weak run's planes go back to the allocator first
-    weak_runner.P.clear()
-    weak_runner.stage.clear()
-    weak_runner.rng = weak_runner.rng_debris = None
-    torch.cuda.empty_cache()
-    runner = slab_runner(S, G, True, param, args.particles_div)
+    weak_runner.close()          # the weak run's planes go back to the device first
+    runner = slab_runner(S, G, True, param, args.particles_div, comm, pair)
     K = args.steps
     elapsed, phase, psteps = timed_steps(runner, ev, K, args.warmup, world)
     block = {
@@ -514,10 +510,7 @@ def strong_scaling_block(args, weak_runner, ev, rank, world, param, G):
         "halo": halo_report(runner),
         "gparticle_steps_per_s": psteps * world / elapsed / 1e9,
     }
-    runner.P.clear()
-    runner.stage.clear()
-    runner.rng = runner.rng_debris = None
-    torch.cuda.empty_cache()
+    runner.close()
     # the same grid on one GPU (rank 0; the others wait at the barrier)
     if rank == 0 and os.environ.get("SOIL_BENCH_NO_1GPU_REF") != "1":
         k1 = max(2, min(K, 4))
@@ -527,7 +520,7 @@ def strong_scaling_block(args, weak_runner, ev, rank, world, param, G):
                             "steps": k1, "warmup": 1}
         block["speedup_vs_1gpu"] = (e1 / k1) / (elapsed / K)
         del single
-    dist.barrier()
+    comm.barrier()
     return block
 
 

@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "soil_hip.h"
+#include "soil_slab.h"
 
 namespace silt {
 
@@ -272,6 +273,77 @@ inline F solve_uniform(const F flow, const F source, const F decay, silt::tensor
                            static_cast<int>(source.shape()[2]), detail::s2(scale).v, count, nullptr));
   return flux;
 }
+// ---- the sharded step (soil_slab.h): one slab_runner per rank / GPU -------------------------------
+//
+// The reference has no multi-GPU path; BASELINE configs[4] cuts the 16384^2 grid into row slabs.
+// A rank makes its device current (soil_set_device), builds a communicator — rccl(id, rank, world)
+// with the 128-byte id of rccl_unique_id() handed round by whatever launched the job (MPI_Bcast, a
+// file, ...) — and steps:
+//     soil::comm wire = soil::comm::rccl(id, rank, world);
+//     soil::slab_runner slab(cfg, param, wire);
+//     for (int s = 0; s < steps; ++s) slab.step();
+class comm {
+ public:
+  static std::array<uint8_t, 128> rccl_unique_id() {
+    std::array<uint8_t, 128> id{};
+    silt::check(soil_comm_rccl_unique_id(id.data()));
+    return id;
+  }
+  static comm rccl(const std::array<uint8_t, 128>& id, int rank, int world) {
+    soil_comm* c = nullptr;
+    silt::check(soil_comm_rccl_create(&c, id.data(), rank, world));
+    return comm(c, &soil_comm_rccl_destroy);
+  }
+  static comm self() {  // a world of one
+    soil_comm* c = nullptr;
+    silt::check(soil_comm_self_create(&c));
+    return comm(c, &soil_comm_self_destroy);
+  }
+  const soil_comm* get() const { return c_.get(); }
+  int rank() const { return c_->rank; }
+  int world() const { return c_->world; }
+ private:
+  comm(soil_comm* c, int (*drop)(soil_comm*)) : c_(c, [drop](soil_comm* q) { drop(q); }) {}
+  std::shared_ptr<soil_comm> c_;
+};
+
+class slab_runner {
+ public:
+  // rows_per_rank x W cells owned by every rank; N = H * W / particles_div particles per launch
+  static soil_slab_config config(int64_t rows_per_rank, int64_t W, int64_t particles_div = 8, uint64_t seed = 0) {
+    soil_slab_config c{};
+    c.rows_per_rank = rows_per_rank, c.W = W, c.particles_div = particles_div, c.seed = seed;
+    c.noise_seed = 3.0f, c.init = 1, c.trim = -1, c.pair = -1;
+    return c;
+  }
+  slab_runner(const soil_slab_config& cfg, const param_t& param, comm wire) : wire_(std::move(wire)) {
+    soil_slab* s = nullptr;
+    silt::check(soil_slab_create(&s, &cfg, &param, wire_.get(), nullptr));
+    s_.reset(s, [](soil_slab* q) { soil_slab_destroy(q); });
+  }
+  void step() { silt::check(soil_slab_step(s_.get(), nullptr, nullptr)); }
+  void sync() { silt::check(soil_slab_sync(s_.get())); }
+  soil_slab_info info() const {
+    soil_slab_info i{};
+    silt::check(soil_slab_get_info(s_.get(), &i));
+    return i;
+  }
+  // the owned rows of a plane ("layers", "height", "waterHeight", ...) copied to the host
+  std::vector<float> owned_rows(const char* name) {
+    float* p = nullptr;
+    int64_t rows = 0, ch = 0;
+    silt::check(soil_slab_plane(s_.get(), name, &p, &rows, &ch));
+    const soil_slab_info i = info();
+    sync();
+    std::vector<float> out(static_cast<size_t>((i.r1 - i.r0) * i.W * ch));
+    silt::check(soil_memcpy_d2h(out.data(), p + i.r0 * i.W * ch, out.size() * sizeof(float), nullptr));
+    return out;
+  }
+ private:
+  comm wire_;
+  std::shared_ptr<soil_slab> s_;
+};
+
 struct noise_param_t : soil_noise_param {
   noise_param_t() { soil_noise_param_default(this); }
 };

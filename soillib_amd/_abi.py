@@ -145,6 +145,97 @@ SIGNATURES = {
     "soil_noise_window": (cint, [vp, i64, i64, i64, C.POINTER(NoiseParam), vp]),
 }
 
+
+# ---- include/soil_slab.h ------------------------------------------------------------
+
+class Xfer(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("bytes", C.c_int64), ("peer", C.c_int32)]
+
+
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(Xfer), C.c_int32, C.POINTER(Xfer), C.c_int32,
+                          C.c_void_p)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+BARRIER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)
+SOIL_COMM_HOST_ORDERED = 1
+
+
+class Comm(C.Structure):
+    """soil_comm: the wire between the ranks of a slab world."""
+    _fields_ = [("ctx", C.c_void_p), ("rank", C.c_int32), ("world", C.c_int32), ("flags", C.c_int32),
+                ("exchange", EXCHANGE_FN), ("all_reduce_sum_f32", ALLREDUCE_FN), ("barrier", BARRIER_FN)]
+
+
+_PP = C.POINTER(ErosionPlanes)
+_DP = C.POINTER(Domain)
+_F3P = C.POINTER(C.c_float)
+_PARP = C.POINTER(Param)
+OPS_FIELDS = [
+    ("alloc", C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_void_p), C.c_int64)),
+    ("release", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)),
+    ("fill_f32", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_int64, C.c_int32)),
+    ("add_f32", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32)),
+    ("rng_seed", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_uint64, C.c_uint64)),
+    ("particles_fluvial", C.CFUNCTYPE(C.c_int, C.c_void_p, _PP, C.c_void_p, C.c_int64, C.c_void_p, _DP, _F3P, _PARP)),
+    ("particles_debris", C.CFUNCTYPE(C.c_int, C.c_void_p, _PP, C.c_void_p, C.c_int64, C.c_void_p, _DP, _F3P, _PARP)),
+    ("particles_pair", C.CFUNCTYPE(C.c_int, C.c_void_p, _PP, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, _DP, _F3P,
+                                   _PARP)),
+    ("cells", C.CFUNCTYPE(C.c_int, C.c_void_p, _PP, _DP, _F3P, _PARP)),
+    ("ghost_extent", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
+                                 C.POINTER(C.c_int32))),
+    ("noise_rows", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
+                               C.POINTER(NoiseParam))),
+    ("layers_from_bedrock", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64)),
+    ("to_host", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64)),
+    ("from_host", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64)),
+    ("fork", C.CFUNCTYPE(C.c_int, C.c_void_p)),
+    ("join", C.CFUNCTYPE(C.c_int, C.c_void_p)),
+    ("sync", C.CFUNCTYPE(C.c_int, C.c_void_p)),
+    ("stream", C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_int32)),
+]
+
+
+class SlabOps(C.Structure):
+    """soil_slab_ops: the compute back-end of a slab runner."""
+    _fields_ = [("ctx", C.c_void_p)] + OPS_FIELDS
+
+
+class SlabConfig(C.Structure):
+    _fields_ = [("rows_per_rank", C.c_int64), ("W", C.c_int64), ("particles_div", C.c_int64),
+                ("seed", C.c_uint64), ("scale", C.c_float * 3), ("noise_seed", C.c_float),
+                ("noise_rows", C.c_int64), ("init", C.c_int32), ("trim", C.c_int32), ("pair", C.c_int32),
+                ("halo_need", C.c_int32)]
+
+
+class SlabInfo(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in ("H", "W", "S", "G", "x0", "rows", "r0", "r1", "N")] + [
+        ("step_index", C.c_uint64), ("rank", C.c_int32), ("world", C.c_int32), ("trim", C.c_int32),
+        ("pair", C.c_int32), ("rows_flux", C.c_int64), ("rows_field", C.c_int64), ("rows_full", C.c_int64),
+        ("repeated_launches", C.c_int64), ("reach_hist", C.c_int32 * 4), ("n_reach", C.c_int32)]
+
+
+MARK_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int32)
+
+SLAB_SIGNATURES = {
+    "soil_comm_rccl_unique_id": (cint, [C.POINTER(C.c_uint8)]),
+    "soil_comm_rccl_create": (cint, [C.POINTER(C.POINTER(Comm)), C.POINTER(C.c_uint8), C.c_int32, C.c_int32]),
+    "soil_comm_rccl_destroy": (cint, [C.POINTER(Comm)]),
+    "soil_comm_rccl_info": (cint, [C.POINTER(Comm), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                   C.POINTER(C.c_int32)]),
+    "soil_comm_self_create": (cint, [C.POINTER(C.POINTER(Comm))]),
+    "soil_comm_self_destroy": (cint, [C.POINTER(Comm)]),
+    "soil_slab_create": (cint, [C.POINTER(vp), C.POINTER(SlabConfig), C.POINTER(Param), C.POINTER(Comm),
+                                C.POINTER(SlabOps)]),
+    "soil_slab_step": (cint, [vp, MARK_FN, vp]),
+    "soil_slab_plane": (cint, [vp, C.c_char_p, C.POINTER(vp), C.POINTER(i64), C.POINTER(i64)]),
+    "soil_slab_get_info": (cint, [vp, C.POINTER(SlabInfo)]),
+    "soil_slab_sync": (cint, [vp]),
+    "soil_slab_stream": (cint, [vp, C.c_int32, C.POINTER(vp)]),
+    "soil_slab_destroy": (cint, [vp]),
+    "soil_slab_ops_hip_create": (cint, [C.POINTER(C.POINTER(SlabOps))]),
+    "soil_slab_ops_hip_destroy": (cint, [C.POINTER(SlabOps)]),
+    "soil_slab_layout": (None, [C.c_int32, C.c_int32, i64, i64, C.POINTER(i64)]),
+}
+
 _lib = None
 
 
@@ -176,7 +267,7 @@ def lib():
                 "libsoil_hip.so is missing (%s): build it with `python -m soillib_amd.build`; "
                 "there is no CPU fallback" % LIB_PATH)
         _lib = C.CDLL(LIB_PATH)
-        for name, (res, args) in SIGNATURES.items():
+        for name, (res, args) in list(SIGNATURES.items()) + list(SLAB_SIGNATURES.items()):
             fn = getattr(_lib, name)
             fn.restype = res
             fn.argtypes = args

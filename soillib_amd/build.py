@@ -17,7 +17,7 @@ LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(HERE, "build")
 LIB = os.path.join(LIBDIR, "libsoil_hip.so")
 
-SOURCES = ["runtime.hip", "erosion_cells.hip", "erosion_particles.hip", "erosion_particles_tiled.hip", "erosion_step.hip", "graph.hip",
+SOURCES = ["runtime.hip", "erosion_cells.hip", "erosion_particles.hip", "erosion_particles_tiled.hip", "erosion_step.hip", "slab_runner.hip", "graph.hip",
            "stencil.hip", "path.hip", "noise.hip", "io_tiff.hip", "conditioning.hip"]
 
 # -ffp-contract=off / no fast-math: the numerical contract
@@ -39,6 +39,7 @@ def _deps_digest():
     h = hashlib.sha256()
     paths = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC))]
     paths.append(os.path.join(HERE, "..", "include", "soil_hip.h"))
+    paths.append(os.path.join(HERE, "..", "include", "soil_slab.h"))
     for p in paths:
         with open(p, "rb") as f:
             h.update(p.encode())
@@ -76,7 +77,7 @@ def build(force=False, verbose=False, variant=None, extra_flags=()):
 
     with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
         objs = list(ex.map(compile_one, SOURCES))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-lz"]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-lz", "-ldl"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))

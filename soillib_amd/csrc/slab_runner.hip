@@ -1,0 +1,928 @@
+// slab_runner.hip — the sharded erosion step (include/soil_slab.h): row slabs, deep halos trimmed to
+// the measured reach of the walks, RCCL on the runner's own streams.
+//
+// The reference has no multi-GPU path at all (one default-stream launch per kernel,
+// erosion.cu:209, :413); BASELINE.json configs[4] defines the job.  Three parts:
+//   1. SlabRunner — the host logic of one rank.  It only talks to the two function tables of
+//      soil_slab.h, so the same code runs on HIP + RCCL (the product), on HIP + an in-process wire
+//      (several slabs on one GPU: tests) and on the CPU oracle + gloo (tests without a GPU).
+//   2. HipOps     — soil_slab_ops over this library's kernels: a main and a communication stream.
+//   3. RcclComm   — soil_comm over librccl, resolved at run time (dlopen).
+//
+// Why deep halos: one __stepsize step moves a walker by at most sqrt(2) cells
+// (erosion_map.cu:61-76), so with G = ceil(sqrt(2) maxage) + 2 ghost rows per interior side every
+// walker born in the owned rows ends inside the slab; what travels between ranks are rows of planes,
+// nearest neighbours only, and how many rows is decided by measurement (soil_ghost_extent): see
+// step() below.  DESIGN.md 5 has the cost model next to the alternative (walkers handed over at the
+// slab edge).
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/soil_slab.h"
+#include "common.hpp"
+
+namespace soil {
+
+// ------------------------------------------------------------------------------------------------
+// 1. the runner
+// ------------------------------------------------------------------------------------------------
+
+namespace {
+
+struct Layout { int64_t x0, rows, r0, r1; };
+
+Layout slab_layout(int rank, int world, int64_t S, int64_t G) {
+  const int64_t H = world * S, o0 = rank * S, o1 = (rank + 1) * S;
+  const int64_t x0 = std::max<int64_t>(0, o0 - G), x1 = std::min<int64_t>(H, o1 + G);
+  return Layout{x0, x1 - x0, o0 - x0, o1 - x0};
+}
+
+enum Plane {
+  kLayers, kLayersNext, kHeight, kUplift, kRainfall, kWaterHeight, kWaterFlux, kMass, kMassFlux,
+  kVelocity, kVelocityFlux, kDebris, kDebrisFlux, kDebrisVelocity, kDebrisVelocityFlux, kPlanes
+};
+const char* const kPlaneName[kPlanes] = {
+    "layers", "layers_next", "height", "uplift", "rainfall", "waterHeight", "waterFlux", "mass",
+    "massFlux", "velocity", "velocityFlux", "debris", "debrisFlux", "debrisVelocity",
+    "debrisVelocityFlux"};
+const int kPlaneCh[kPlanes] = {2, 2, 1, 1, 1, 1, 1, 1, 1, 2, 2, 1, 1, 2, 2};
+const Plane kField[4] = {kLayers, kVelocity, kWaterHeight, kDebrisVelocity};  // what particles read
+const Plane kFluxFluvial[3] = {kWaterFlux, kMassFlux, kVelocityFlux};         // final after the fluvial launch
+const Plane kFluxDebris[2] = {kDebrisFlux, kDebrisVelocityFlux};              // final after the debris launch
+
+}  // namespace
+
+}  // namespace soil
+
+using soil::fail;
+
+// what soillib_amd/_abi.py mirrors with ctypes
+static_assert(sizeof(soil_xfer) == 24 && sizeof(soil_comm) == 48 && sizeof(soil_slab_ops) == 19 * 8 &&
+                  sizeof(soil_slab_config) == 72 && sizeof(soil_slab_info) == 152,
+              "soil_slab.h struct layout changed: update soillib_amd/_abi.py");
+
+struct soil_slab {
+  const soil_comm* comm = nullptr;
+  const soil_slab_ops* ops = nullptr;
+  soil_slab_ops* own_ops = nullptr;  // HIP back-end made by soil_slab_create
+  soil_param param{};
+  int rank = 0, world = 1;
+  int64_t S = 0, W = 0, H = 0, G = 0, N = 0;
+  soil::Layout lay{};
+  float scale[3] = {0, 0, 0};
+  uint64_t seed = 0, step_index = 0;
+  bool trim = false, pair = false, host_ordered = false;
+  int halo_need = 0;
+  float* P[soil::kPlanes] = {};
+  float* stage[soil::kPlanes][2] = {};  // [plane][0: from the neighbour above, 1: from below]
+  soil_rng *rng = nullptr, *rng_debris = nullptr;
+  float* remote0 = nullptr;
+  float* ints = nullptr;  // all_ints scratch (world * 2 floats)
+  int up = -1, down = -1;
+  int64_t gu = 0, gd = 0;  // my ghost rows above / below
+  std::vector<std::pair<int64_t, int64_t>> fresh_all;  // per rank: ghost rows (above, below) with fresh fields
+  std::vector<int> reach_hist;
+  int64_t fallbacks = 0, rows_flux = 0, rows_field = 0, rows_full = 0;
+
+  // ---- helpers --------------------------------------------------------------------------------
+  int64_t row_floats(int p) const { return W * soil::kPlaneCh[p]; }
+  float* rowp(int p, int64_t local_row) const { return P[p] + local_row * row_floats(p); }
+  int64_t peer_ghost(int peer) const {  // ghost rows `peer` holds on the side facing this rank
+    if (peer < 0) return 0;
+    const soil::Layout l = soil::slab_layout(peer, world, S, G);
+    return peer > rank ? l.r0 : l.rows - l.r1;
+  }
+  soil_domain domain(int64_t r0, int64_t r1) const { return soil_domain{H, W, lay.x0, lay.rows, r0, r1}; }
+  soil_erosion_planes planes() const {
+    soil_erosion_planes q{};
+    q.layers = P[soil::kLayers], q.layers_next = P[soil::kLayersNext], q.height = P[soil::kHeight];
+    q.uplift = P[soil::kUplift], q.rainfall = P[soil::kRainfall], q.waterHeight = P[soil::kWaterHeight];
+    q.waterFlux = P[soil::kWaterFlux], q.mass = P[soil::kMass], q.massFlux = P[soil::kMassFlux];
+    q.velocity = P[soil::kVelocity], q.velocityFlux = P[soil::kVelocityFlux], q.debris = P[soil::kDebris];
+    q.debrisFlux = P[soil::kDebrisFlux], q.debrisVelocity = P[soil::kDebrisVelocity];
+    q.debrisVelocityFlux = P[soil::kDebrisVelocityFlux];
+    return q;
+  }
+  void* stream(int lane) const { return ops->stream ? ops->stream(ops->ctx, lane) : nullptr; }
+
+#define SLAB_TRY(expr)                     \
+  do {                                     \
+    const int slab_rc_ = (expr);           \
+    if (slab_rc_ != SOIL_OK) return slab_rc_; \
+  } while (0)
+
+  // ---- the wire ---------------------------------------------------------------------------------
+  int exchange(const std::vector<soil_xfer>& sends, const std::vector<soil_xfer>& recvs, int lane) {
+    if (sends.empty() && recvs.empty()) return SOIL_OK;
+    if (host_ordered) SLAB_TRY(ops->sync(ops->ctx));
+    return comm->exchange(comm->ctx, sends.data(), static_cast<int32_t>(sends.size()), recvs.data(),
+                          static_cast<int32_t>(recvs.size()), stream(lane));
+  }
+  // every rank's k small non-negative ints, as out[rank * k + i]: one all-reduce of a zero-padded
+  // vector (any wire that can sum will do); blocks until the host has them
+  int all_ints(const int* mine, int k, std::vector<int>& out) {
+    const int64_t n = static_cast<int64_t>(world) * k;
+    std::vector<float> h(static_cast<size_t>(n), 0.0f);
+    for (int i = 0; i < k; ++i) h[static_cast<size_t>(rank) * k + i] = static_cast<float>(mine[i]);
+    SLAB_TRY(ops->from_host(ops->ctx, ints, h.data(), n * 4));
+    if (host_ordered) SLAB_TRY(ops->sync(ops->ctx));
+    SLAB_TRY(comm->all_reduce_sum_f32(comm->ctx, ints, n, stream(0)));
+    SLAB_TRY(ops->to_host(ops->ctx, h.data(), ints, n * 4));
+    out.resize(static_cast<size_t>(n));
+    for (int64_t i = 0; i < n; ++i) out[static_cast<size_t>(i)] = static_cast<int>(h[static_cast<size_t>(i)] + 0.5f);
+    return SOIL_OK;
+  }
+
+  struct Counts { int64_t send_up, send_down, recv_up, recv_down; };
+
+  // Ship the flux deposited into my ghost rows to their owners (rows nearest the boundary first),
+  // add what the neighbours deposited for me, clear what I shipped.
+  int flux_exchange(const soil::Plane* planes_, int n, const Counts* counts, int lane) {
+    Counts c = counts ? *counts : Counts{gu, gd, peer_ghost(up), peer_ghost(down)};
+    std::vector<soil_xfer> sends, recvs;
+    for (int i = 0; i < n; ++i) {
+      const int p = planes_[i];
+      const int64_t rb = row_floats(p) * 4;
+      if (up >= 0) {
+        if (c.send_up) sends.push_back({rowp(p, lay.r0 - c.send_up), c.send_up * rb, up});
+        if (c.recv_up) recvs.push_back({stage[p][0], c.recv_up * rb, up});
+      }
+      if (down >= 0) {
+        if (c.send_down) sends.push_back({rowp(p, lay.r1), c.send_down * rb, down});
+        if (c.recv_down) recvs.push_back({stage[p][1], c.recv_down * rb, down});
+      }
+    }
+    rows_flux += (c.send_up + c.send_down) * n;
+    rows_full += (gu + gd) * n;
+    SLAB_TRY(exchange(sends, recvs, lane));
+    for (int i = 0; i < n; ++i) {
+      const int p = planes_[i];
+      const int64_t rf = row_floats(p);
+      // the up neighbour's lower ghost rows are my first owned rows
+      if (up >= 0 && c.recv_up) SLAB_TRY(ops->add_f32(ops->ctx, rowp(p, lay.r0), stage[p][0], c.recv_up * rf, lane));
+      if (down >= 0 && c.recv_down)
+        SLAB_TRY(ops->add_f32(ops->ctx, rowp(p, lay.r1 - c.recv_down), stage[p][1], c.recv_down * rf, lane));
+      if (up >= 0 && c.send_up) SLAB_TRY(ops->fill_f32(ops->ctx, rowp(p, lay.r0 - c.send_up), 0.0f, c.send_up * rf, lane));
+      if (down >= 0 && c.send_down) SLAB_TRY(ops->fill_f32(ops->ctx, rowp(p, lay.r1), 0.0f, c.send_down * rf, lane));
+    }
+    return SOIL_OK;
+  }
+
+  // Refresh the ghost rows of the fields the next launches read.  need_*: rows I want from each
+  // neighbour, give_*: rows I owe them (nearest the boundary first).  `layers_plane`: which of the
+  // two layer buffers is the current one at this point of the step.
+  int field_exchange(int layers_plane, const Counts* counts, int lane) {
+    // Counts reused as (need_up, need_down, give_up, give_down)
+    Counts c = counts ? *counts : Counts{gu, gd, peer_ghost(up), peer_ghost(down)};
+    const int64_t need_up = c.send_up, need_down = c.send_down, give_up = c.recv_up, give_down = c.recv_down;
+    std::vector<soil_xfer> sends, recvs;
+    for (int i = 0; i < 4; ++i) {
+      const int p = soil::kField[i] == soil::kLayers ? layers_plane : soil::kField[i];
+      const int64_t rb = row_floats(p) * 4;
+      if (up >= 0) {
+        if (give_up) sends.push_back({rowp(p, lay.r0), give_up * rb, up});
+        if (need_up) recvs.push_back({rowp(p, lay.r0 - need_up), need_up * rb, up});
+      }
+      if (down >= 0) {
+        if (give_down) sends.push_back({rowp(p, lay.r1 - give_down), give_down * rb, down});
+        if (need_down) recvs.push_back({rowp(p, lay.r1), need_down * rb, down});
+      }
+    }
+    rows_field += (give_up + give_down) * 4;
+    rows_full += (peer_ghost(up) + peer_ghost(down)) * 4;
+    return exchange(sends, recvs, lane);
+  }
+
+  // ---- measured reach ---------------------------------------------------------------------------
+  // [rank] -> (rows above, rows below) its owned rows the deposits in `planes_` got to
+  int reach(const soil::Plane* planes_, int n, std::vector<int>& all) {
+    int32_t depth[2] = {0, 0};
+    for (int i = 0; i < n; ++i)
+      SLAB_TRY(ops->ghost_extent(ops->ctx, P[planes_[i]], lay.rows, row_floats(planes_[i]), lay.r0, lay.r1, depth));
+    const int mine[2] = {depth[0], depth[1]};
+    return all_ints(mine, 2, all);
+  }
+  // Did a launch, on any rank, get within a row of ghost rows that were not refreshed?  (The cell
+  // record of ghost row d is made of rows d - 1 .. d + 1.)  The same answer on every rank.
+  bool too_deep(const std::vector<int>& r) const {
+    for (int k = 0; k < world; ++k) {
+      const soil::Layout l = soil::slab_layout(k, world, S, G);
+      const int64_t f_up = fresh_all[static_cast<size_t>(k)].first, f_down = fresh_all[static_cast<size_t>(k)].second;
+      const int64_t u = r[static_cast<size_t>(2 * k)], d = r[static_cast<size_t>(2 * k + 1)];
+      if ((u >= f_up && f_up < l.r0) || (d >= f_down && f_down < l.rows - l.r1)) return true;
+    }
+    return false;
+  }
+  void fresh_everything() {
+    fresh_all.clear();
+    for (int k = 0; k < world; ++k) {
+      const soil::Layout l = soil::slab_layout(k, world, S, G);
+      fresh_all.emplace_back(l.r0, l.rows - l.r1);
+    }
+  }
+  // The prediction was too small: fetch the whole ghost zones of the fields as they stand (the cell
+  // phase of this step has not touched them yet).
+  int refresh_all() {
+    ++fallbacks;
+    SLAB_TRY(field_exchange(soil::kLayers, nullptr, 0));
+    fresh_everything();
+    return SOIL_OK;
+  }
+  // Ghost rows to refresh for the next step: as deep as the walks of the last steps got anywhere, a
+  // tenth more and ten rows on top (the reach moves by a row or two from step to step); everything
+  // while there is no history.
+  void predict_need(int64_t& nu, int64_t& nd) const {
+    if (reach_hist.empty()) {
+      nu = gu, nd = gd;
+      return;
+    }
+    int64_t want = static_cast<int64_t>(1.1 * *std::max_element(reach_hist.begin(), reach_hist.end())) + 10;
+    if (halo_need > 0) want = halo_need;
+    nu = std::min(gu, want), nd = std::min(gd, want);
+  }
+  Counts counts_of(const std::vector<int>& r) const {
+    return Counts{r[static_cast<size_t>(2 * rank)], r[static_cast<size_t>(2 * rank + 1)],
+                  up >= 0 ? r[static_cast<size_t>(2 * up + 1)] : 0, down >= 0 ? r[static_cast<size_t>(2 * down)] : 0};
+  }
+  void note_reach(const std::vector<int>& a, const std::vector<int>& b) {
+    int m = 0;
+    for (int v : a) m = std::max(m, v);
+    for (int v : b) m = std::max(m, v);
+    reach_hist.push_back(m);
+    if (reach_hist.size() > 4) reach_hist.erase(reach_hist.begin());
+  }
+  int zero_planes(const soil::Plane* planes_, int n) {
+    for (int i = 0; i < n; ++i) SLAB_TRY(ops->fill_f32(ops->ctx, P[planes_[i]], 0.0f, lay.rows * row_floats(planes_[i]), 0));
+    return SOIL_OK;
+  }
+
+  // ---- one step ----------------------------------------------------------------------------------
+  //   1 fluvial particles            -
+  //   2 debris particles             overlapped: flux halo-accumulate of the fluvial planes
+  //   3 flux halo, debris planes     exposed (the bands below need it)
+  //   4 cell phase, bands next to    -
+  //     the neighbours
+  //   5 cell phase, interior rows    overlapped: field halo of the NEW layers, velocity,
+  //                                  waterHeight, debrisVelocity -> the neighbours' ghost rows
+  // With `pair` the two launches run overlapped on the back-end's own streams instead and all five
+  // flux planes travel in step 3.
+  int step(soil_slab_mark_fn mark, void* mctx) {
+    auto mk = [&](int i) { if (mark) mark(mctx, i); };
+    const soil_erosion_planes pl = planes();
+    const soil_domain dom = domain(lay.r0, lay.r1);
+    const uint64_t off = step_index * static_cast<uint64_t>(N);
+    SLAB_TRY(ops->rng_seed(ops->ctx, rng, N, seed, off));
+    SLAB_TRY(ops->fill_f32(ops->ctx, remote0, 0.0f, 8, 0));
+    bool early = false;  // the fluvial planes' halo went out before the debris launch ended
+    Counts cf{}, cd{};
+    std::vector<int> rf, rd;
+    mk(0);
+    const bool paired = pair && ops->particles_pair && rng_debris;
+    if (paired) {
+      // the debris launch draws from a tensor of its own, seeded where the fluvial launch leaves
+      // the shared one in the sequential order
+      SLAB_TRY(ops->rng_seed(ops->ctx, rng_debris, N, seed, off + 2));
+      SLAB_TRY(ops->particles_pair(ops->ctx, &pl, rng, rng_debris, N, remote0, &dom, scale, &param));
+      if (trim) {
+        SLAB_TRY(reach(soil::kFluxFluvial, 3, rf));
+        SLAB_TRY(reach(soil::kFluxDebris, 2, rd));
+        if (too_deep(rf) || too_deep(rd)) {  // rare: both launches again, on complete fields
+          SLAB_TRY(refresh_all());
+          SLAB_TRY(zero_planes(soil::kFluxFluvial, 3));
+          SLAB_TRY(zero_planes(soil::kFluxDebris, 2));
+          SLAB_TRY(ops->fill_f32(ops->ctx, remote0, 0.0f, 8, 0));
+          SLAB_TRY(ops->rng_seed(ops->ctx, rng, N, seed, off));
+          SLAB_TRY(ops->rng_seed(ops->ctx, rng_debris, N, seed, off + 2));
+          SLAB_TRY(ops->particles_pair(ops->ctx, &pl, rng, rng_debris, N, remote0, &dom, scale, &param));
+          SLAB_TRY(reach(soil::kFluxFluvial, 3, rf));
+          SLAB_TRY(reach(soil::kFluxDebris, 2, rd));
+        }
+        cf = counts_of(rf), cd = counts_of(rd);
+        note_reach(rf, rd);
+      }
+      mk(1);
+    } else {
+      SLAB_TRY(ops->particles_fluvial(ops->ctx, &pl, rng, N, remote0, &dom, scale, &param));
+      if (trim) {
+        SLAB_TRY(reach(soil::kFluxFluvial, 3, rf));
+        if (too_deep(rf)) {  // rare: repeat the launch on complete fields
+          SLAB_TRY(refresh_all());
+          SLAB_TRY(zero_planes(soil::kFluxFluvial, 3));
+          SLAB_TRY(ops->fill_f32(ops->ctx, remote0, 0.0f, 8, 0));
+          SLAB_TRY(ops->rng_seed(ops->ctx, rng, N, seed, off));
+          SLAB_TRY(ops->particles_fluvial(ops->ctx, &pl, rng, N, remote0, &dom, scale, &param));
+          SLAB_TRY(reach(soil::kFluxFluvial, 3, rf));
+        }
+        cf = counts_of(rf);
+      }
+      mk(1);
+      if (world > 1) {
+        // the fluvial flux is final: its halo travels, and is added, while the debris launch runs
+        SLAB_TRY(ops->fork(ops->ctx));
+        SLAB_TRY(flux_exchange(soil::kFluxFluvial, 3, trim ? &cf : nullptr, 1));
+        early = true;
+      }
+      SLAB_TRY(ops->particles_debris(ops->ctx, &pl, rng, N, remote0, &dom, scale, &param));
+      if (trim) {
+        SLAB_TRY(reach(soil::kFluxDebris, 2, rd));
+        if (too_deep(rd)) {
+          SLAB_TRY(refresh_all());
+          SLAB_TRY(zero_planes(soil::kFluxDebris, 2));
+          // the NaN walkers' debris deposits are entries 4..6 of remote0; the launch draws where
+          // the fluvial one left the streams (two draws per particle on)
+          SLAB_TRY(ops->fill_f32(ops->ctx, remote0 + 4, 0.0f, 4, 0));
+          SLAB_TRY(ops->rng_seed(ops->ctx, rng, N, seed, off + 2));
+          SLAB_TRY(ops->particles_debris(ops->ctx, &pl, rng, N, remote0, &dom, scale, &param));
+          SLAB_TRY(reach(soil::kFluxDebris, 2, rd));
+        }
+        cd = counts_of(rd);
+        note_reach(rf, rd);
+      }
+    }
+    mk(2);
+    if (world == 1) {
+      SLAB_TRY(ops->cells(ops->ctx, &pl, &dom, scale, &param));
+    } else {
+      // NaN walkers of the other ranks -> global cell (0,0) (8 floats, latency only)
+      if (host_ordered) SLAB_TRY(ops->sync(ops->ctx));
+      SLAB_TRY(comm->all_reduce_sum_f32(comm->ctx, remote0, 8, stream(0)));
+      if (rank == 0) {
+        SLAB_TRY(ops->add_f32(ops->ctx, P[soil::kWaterFlux], remote0 + 0, 1, 0));
+        SLAB_TRY(ops->add_f32(ops->ctx, P[soil::kMassFlux], remote0 + 1, 1, 0));
+        SLAB_TRY(ops->add_f32(ops->ctx, P[soil::kVelocityFlux], remote0 + 2, 2, 0));
+        SLAB_TRY(ops->add_f32(ops->ctx, P[soil::kDebrisFlux], remote0 + 4, 1, 0));
+        SLAB_TRY(ops->add_f32(ops->ctx, P[soil::kDebrisVelocityFlux], remote0 + 5, 2, 0));
+      }
+      // rows whose flux is complete without the neighbours' contribution
+      const int64_t i0 = std::min(lay.r1, lay.r0 + (up >= 0 ? peer_ghost(up) : 0));
+      const int64_t i1 = std::max(i0, lay.r1 - (down >= 0 ? peer_ghost(down) : 0));
+      // 1. the rest of the flux halo (exposed: the bands below need it)
+      if (early) {
+        SLAB_TRY(flux_exchange(soil::kFluxDebris, 2, trim ? &cd : nullptr, 0));
+      } else {
+        SLAB_TRY(flux_exchange(soil::kFluxFluvial, 3, trim ? &cf : nullptr, 0));
+        SLAB_TRY(flux_exchange(soil::kFluxDebris, 2, trim ? &cd : nullptr, 0));
+      }
+      SLAB_TRY(ops->join(ops->ctx));  // ... and the part that travelled early
+      mk(4);                          // 2 -> 4: flux halo not hidden by the debris launch
+      // 2. the bands next to the neighbours first: they are what the neighbours' ghost rows get
+      if (i0 > lay.r0) {
+        const soil_domain b = domain(lay.r0, i0);
+        SLAB_TRY(ops->cells(ops->ctx, &pl, &b, scale, &param));
+      }
+      if (lay.r1 > i1) {
+        const soil_domain b = domain(i1, lay.r1);
+        SLAB_TRY(ops->cells(ops->ctx, &pl, &b, scale, &param));
+      }
+      // 3. the field halo travels while the interior rows are computed (they are G rows away from
+      //    anything the exchange reads or writes)
+      Counts fc{};
+      const Counts* fcp = nullptr;
+      if (trim) {  // as deep as next step's walks are expected to get; everybody says what it wants
+        int64_t nu, nd;
+        predict_need(nu, nd);
+        const int mine[2] = {static_cast<int>(nu), static_cast<int>(nd)};
+        std::vector<int> wants;
+        SLAB_TRY(all_ints(mine, 2, wants));
+        fc = Counts{nu, nd, up >= 0 ? wants[static_cast<size_t>(2 * up + 1)] : 0,
+                    down >= 0 ? wants[static_cast<size_t>(2 * down)] : 0};
+        fcp = &fc;
+        fresh_all.clear();
+        for (int k = 0; k < world; ++k) fresh_all.emplace_back(wants[static_cast<size_t>(2 * k)], wants[static_cast<size_t>(2 * k + 1)]);
+      }
+      SLAB_TRY(ops->fork(ops->ctx));
+      SLAB_TRY(field_exchange(soil::kLayersNext, fcp, 1));
+      if (i1 > i0) {
+        const soil_domain b = domain(i0, i1);
+        SLAB_TRY(ops->cells(ops->ctx, &pl, &b, scale, &param));
+      }
+      mk(5);  // 5 -> 3: field halo not hidden by the interior rows
+      SLAB_TRY(ops->join(ops->ctx));
+    }
+    mk(3);
+    std::swap(P[soil::kLayers], P[soil::kLayersNext]);
+    ++step_index;
+    return SOIL_OK;
+  }
+};
+
+namespace soil {
+
+// ------------------------------------------------------------------------------------------------
+// 2. the HIP back-end
+// ------------------------------------------------------------------------------------------------
+
+namespace {
+
+struct HipOps {
+  hipStream_t main = nullptr, comm = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  int32_t* depth_dev = nullptr;
+  int device = 0;
+};
+
+#define HIP_OPS(c) HipOps& o = *static_cast<HipOps*>(c)
+
+int hip_alloc(void*, void** out, int64_t bytes) {
+  SOIL_HIP(hipMalloc(out, static_cast<size_t>(bytes > 0 ? bytes : 4)));
+  SOIL_HIP(hipMemset(*out, 0, static_cast<size_t>(bytes > 0 ? bytes : 4)));
+  return SOIL_OK;
+}
+int hip_release(void*, void* p) {
+  if (p) SOIL_HIP(hipFree(p));
+  return SOIL_OK;
+}
+int hip_fill(void* c, float* dst, float v, int64_t n, int32_t lane) {
+  HIP_OPS(c);
+  return soil_set_f32(dst, v, n, lane ? o.comm : o.main);
+}
+int hip_add(void* c, float* dst, const float* src, int64_t n, int32_t lane) {
+  HIP_OPS(c);
+  return soil_add_f32(dst, src, n, lane ? o.comm : o.main);
+}
+int hip_seed(void* c, soil_rng* rng, int64_t N, uint64_t seed, uint64_t offset) {
+  HIP_OPS(c);
+  return soil_rng_seed(rng, N, seed, offset, o.main);
+}
+int hip_fluvial(void* c, const soil_erosion_planes* p, soil_rng* rng, int64_t N, float* remote0,
+                const soil_domain* dom, const float scale[3], const soil_param* param) {
+  HIP_OPS(c);
+  return soil_particles_fluvial_slab(p->waterFlux, p->massFlux, p->velocityFlux, nullptr, rng, N, p->layers,
+                                     p->rainfall, p->waterHeight, p->velocity, nullptr, remote0, dom, scale,
+                                     param, o.main);
+}
+int hip_debris(void* c, const soil_erosion_planes* p, soil_rng* rng, int64_t N, float* remote0,
+               const soil_domain* dom, const float scale[3], const soil_param* param) {
+  HIP_OPS(c);
+  return soil_particles_debris_slab(p->debrisFlux, p->debrisVelocityFlux, nullptr, rng, N, p->layers,
+                                    p->debrisVelocity, nullptr, remote0, dom, scale, param, o.main);
+}
+int hip_pair(void* c, const soil_erosion_planes* p, soil_rng* rf, soil_rng* rd, int64_t N, float* remote0,
+             const soil_domain* dom, const float scale[3], const soil_param* param) {
+  HIP_OPS(c);
+  return soil_particles_pair_slab(p, rf, rd, N, remote0, dom, scale, param, o.main);
+}
+int hip_cells(void* c, const soil_erosion_planes* p, const soil_domain* dom, const float scale[3],
+              const soil_param* param) {
+  HIP_OPS(c);
+  if (dom->r1 <= dom->r0) return SOIL_OK;
+  return soil_erode_cells_fused(p, dom, scale, param, o.main);
+}
+int hip_extent(void* c, const float* plane, int64_t rows, int64_t row_floats, int64_t r0, int64_t r1,
+               int32_t depth[2]) {
+  HIP_OPS(c);
+  SOIL_HIP(hipMemsetAsync(o.depth_dev, 0, 8, o.main));
+  if (int rc = soil_ghost_extent(o.depth_dev, plane, rows, row_floats, r0, r1, o.main); rc != SOIL_OK) return rc;
+  int32_t h[2] = {0, 0};
+  SOIL_HIP(hipMemcpyAsync(h, o.depth_dev, 8, hipMemcpyDeviceToHost, o.main));
+  SOIL_HIP(hipStreamSynchronize(o.main));
+  depth[0] = std::max(depth[0], h[0]);
+  depth[1] = std::max(depth[1], h[1]);
+  return SOIL_OK;
+}
+int hip_noise(void* c, float* out, int64_t rows, int64_t W, int64_t x0, const soil_noise_param* p) {
+  HIP_OPS(c);
+  return soil_noise_window(out, rows, W, x0, p, o.main);
+}
+int hip_layers(void* c, float* layers, const float* bed, int64_t n) {
+  HIP_OPS(c);
+  return soil_layers_from_planes(layers, bed, nullptr, n, o.main);
+}
+int hip_to_host(void* c, void* dst, const void* src, int64_t bytes) {
+  HIP_OPS(c);
+  SOIL_HIP(hipMemcpyAsync(dst, src, static_cast<size_t>(bytes), hipMemcpyDeviceToHost, o.main));
+  SOIL_HIP(hipStreamSynchronize(o.main));
+  return SOIL_OK;
+}
+int hip_from_host(void* c, void* dst, const void* src, int64_t bytes) {
+  HIP_OPS(c);
+  SOIL_HIP(hipMemcpyAsync(dst, src, static_cast<size_t>(bytes), hipMemcpyHostToDevice, o.main));
+  SOIL_HIP(hipStreamSynchronize(o.main));  // `src` is the caller's stack
+  return SOIL_OK;
+}
+int hip_fork(void* c) {
+  HIP_OPS(c);
+  SOIL_HIP(hipEventRecord(o.ev_fork, o.main));
+  SOIL_HIP(hipStreamWaitEvent(o.comm, o.ev_fork, 0));
+  return SOIL_OK;
+}
+int hip_join(void* c) {
+  HIP_OPS(c);
+  SOIL_HIP(hipEventRecord(o.ev_join, o.comm));
+  SOIL_HIP(hipStreamWaitEvent(o.main, o.ev_join, 0));
+  return SOIL_OK;
+}
+int hip_sync(void* c) {
+  HIP_OPS(c);
+  SOIL_HIP(hipStreamSynchronize(o.main));
+  SOIL_HIP(hipStreamSynchronize(o.comm));
+  return SOIL_OK;
+}
+void* hip_stream(void* c, int32_t lane) {
+  HIP_OPS(c);
+  return lane ? o.comm : o.main;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// 3. RCCL
+// ------------------------------------------------------------------------------------------------
+
+namespace {
+
+// The few entry points of rccl.h this file needs, bound at run time.  (ncclUniqueId is 128 bytes,
+// ncclComm_t an opaque pointer; ncclInt8 = 0, ncclFloat32 = 7, ncclSum = 0 — nccl.h's enums.)
+struct Id128 { char bytes[128]; };
+struct Rccl {
+  void* lib = nullptr;
+  int (*GetUniqueId)(void*) = nullptr;
+  int (*CommInitRank)(void**, int, /* ncclUniqueId by value */ Id128, int) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  int (*Send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*CommCount)(void*, int*) = nullptr;
+  int (*CommUserRank)(void*, int*) = nullptr;
+  int (*CommCuDevice)(void*, int*) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+};
+
+Rccl g_rccl;
+
+int rccl_load() {
+  if (g_rccl.lib) return SOIL_OK;
+  void* h = nullptr;
+  if (const char* e = std::getenv("SOIL_RCCL_LIB")) h = dlopen(e, RTLD_NOW | RTLD_GLOBAL);
+  // a copy the process has loaded already (PyTorch's) before one of our own choosing: two RCCLs
+  // in one process would each bring their idea of the HIP runtime
+  for (const char* name : {"librccl.so", "librccl.so.1"})
+    if (!h) h = dlopen(name, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
+  for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+    if (!h) h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+  if (!h) return fail(SOIL_ERR_INVALID_ARGUMENT, std::string("librccl not found (set SOIL_RCCL_LIB): ") + dlerror());
+  auto sym = [&](const char* n) { return dlsym(h, n); };
+#define RCCL_BIND(field, name)                                                       \
+  g_rccl.field = reinterpret_cast<decltype(g_rccl.field)>(sym(name));              \
+  if (!g_rccl.field) return fail(SOIL_ERR_INVALID_ARGUMENT, std::string("librccl lacks ") + name)
+  RCCL_BIND(GetUniqueId, "ncclGetUniqueId");
+  RCCL_BIND(CommInitRank, "ncclCommInitRank");
+  RCCL_BIND(CommDestroy, "ncclCommDestroy");
+  RCCL_BIND(GroupStart, "ncclGroupStart");
+  RCCL_BIND(GroupEnd, "ncclGroupEnd");
+  RCCL_BIND(Send, "ncclSend");
+  RCCL_BIND(Recv, "ncclRecv");
+  RCCL_BIND(AllReduce, "ncclAllReduce");
+  RCCL_BIND(CommCount, "ncclCommCount");
+  RCCL_BIND(CommUserRank, "ncclCommUserRank");
+  RCCL_BIND(CommCuDevice, "ncclCommCuDevice");
+  RCCL_BIND(GetErrorString, "ncclGetErrorString");
+#undef RCCL_BIND
+  g_rccl.lib = h;
+  return SOIL_OK;
+}
+
+int rccl_fail(int e, const char* what) {
+  return fail(SOIL_ERR_HIP, std::string("RCCL error ") + std::to_string(e) + " (" +
+                                (g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "?") + ") from " + what);
+}
+#define SOIL_RCCL(expr)                                  \
+  do {                                                   \
+    const int rccl_e_ = (expr);                          \
+    if (rccl_e_ != 0) return rccl_fail(rccl_e_, #expr);  \
+  } while (0)
+
+struct RcclCtx {
+  void* comm = nullptr;
+  float* scratch = nullptr;  // barrier
+};
+
+int rccl_exchange(void* c, const soil_xfer* sends, int32_t ns, const soil_xfer* recvs, int32_t nr, void* stream) {
+  RcclCtx& r = *static_cast<RcclCtx*>(c);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  SOIL_RCCL(g_rccl.GroupStart());
+  for (int i = 0; i < nr; ++i)
+    SOIL_RCCL(g_rccl.Recv(recvs[i].ptr, static_cast<size_t>(recvs[i].bytes), 0 /* ncclInt8 */, recvs[i].peer, r.comm, st));
+  for (int i = 0; i < ns; ++i)
+    SOIL_RCCL(g_rccl.Send(sends[i].ptr, static_cast<size_t>(sends[i].bytes), 0, sends[i].peer, r.comm, st));
+  SOIL_RCCL(g_rccl.GroupEnd());
+  return SOIL_OK;
+}
+int rccl_all_reduce(void* c, float* buf, int64_t n, void* stream) {
+  RcclCtx& r = *static_cast<RcclCtx*>(c);
+  SOIL_RCCL(g_rccl.AllReduce(buf, buf, static_cast<size_t>(n), 7 /* ncclFloat32 */, 0 /* ncclSum */, r.comm,
+                             static_cast<hipStream_t>(stream)));
+  return SOIL_OK;
+}
+int rccl_barrier(void* c) {
+  RcclCtx& r = *static_cast<RcclCtx*>(c);
+  SOIL_RCCL(g_rccl.AllReduce(r.scratch, r.scratch, 1, 7, 0, r.comm, nullptr));
+  SOIL_HIP(hipStreamSynchronize(nullptr));
+  return SOIL_OK;
+}
+
+// a world of one: exchanges with oneself are device copies
+int self_exchange(void*, const soil_xfer* sends, int32_t ns, const soil_xfer* recvs, int32_t nr, void* stream) {
+  SOIL_REQUIRE(ns == nr, "self comm: sends and receives must pair up");
+  for (int i = 0; i < ns; ++i) {
+    SOIL_REQUIRE(sends[i].bytes == recvs[i].bytes && sends[i].peer == 0 && recvs[i].peer == 0,
+                 "self comm: mismatched transfer");
+    SOIL_HIP(hipMemcpyAsync(recvs[i].ptr, sends[i].ptr, static_cast<size_t>(sends[i].bytes), hipMemcpyDeviceToDevice,
+                            static_cast<hipStream_t>(stream)));
+  }
+  return SOIL_OK;
+}
+int self_all_reduce(void*, float*, int64_t, void*) { return SOIL_OK; }
+int self_barrier(void*) { return SOIL_OK; }
+
+}  // namespace
+
+}  // namespace soil
+
+using namespace soil;
+
+extern "C" {
+
+void soil_slab_layout(int32_t rank, int32_t world, int64_t S, int64_t G, int64_t out[4]) {
+  const Layout l = slab_layout(rank, world, S, G);
+  out[0] = l.x0, out[1] = l.rows, out[2] = l.r0, out[3] = l.r1;
+}
+
+int soil_slab_ops_hip_create(soil_slab_ops** out) {
+  SOIL_DEVICE();
+  SOIL_REQUIRE(out, "slab_ops_hip_create: null argument");
+  HipOps* o = new HipOps;
+  SOIL_HIP(hipGetDevice(&o->device));
+  SOIL_HIP(hipStreamCreateWithFlags(&o->main, hipStreamNonBlocking));
+  SOIL_HIP(hipStreamCreateWithFlags(&o->comm, hipStreamNonBlocking));
+  SOIL_HIP(hipEventCreateWithFlags(&o->ev_fork, hipEventDisableTiming));
+  SOIL_HIP(hipEventCreateWithFlags(&o->ev_join, hipEventDisableTiming));
+  SOIL_HIP(hipMalloc(reinterpret_cast<void**>(&o->depth_dev), 8));
+  soil_slab_ops* t = new soil_slab_ops{};
+  t->ctx = o;
+  t->alloc = hip_alloc, t->release = hip_release, t->fill_f32 = hip_fill, t->add_f32 = hip_add;
+  t->rng_seed = hip_seed, t->particles_fluvial = hip_fluvial, t->particles_debris = hip_debris;
+  t->particles_pair = hip_pair, t->cells = hip_cells, t->ghost_extent = hip_extent;
+  t->noise_rows = hip_noise, t->layers_from_bedrock = hip_layers, t->to_host = hip_to_host;
+  t->from_host = hip_from_host, t->fork = hip_fork, t->join = hip_join, t->sync = hip_sync;
+  t->stream = hip_stream;
+  *out = t;
+  return SOIL_OK;
+}
+
+int soil_slab_ops_hip_destroy(soil_slab_ops* ops) {
+  if (!ops) return SOIL_OK;
+  HipOps* o = static_cast<HipOps*>(ops->ctx);
+  if (o) {
+    (void)hipStreamSynchronize(o->main);
+    (void)hipStreamSynchronize(o->comm);
+    (void)hipFree(o->depth_dev);
+    (void)hipEventDestroy(o->ev_fork);
+    (void)hipEventDestroy(o->ev_join);
+    (void)hipStreamDestroy(o->main);
+    (void)hipStreamDestroy(o->comm);
+    delete o;
+  }
+  delete ops;
+  return SOIL_OK;
+}
+
+int soil_slab_create(soil_slab** out, const soil_slab_config* cfg, const soil_param* param,
+                     const soil_comm* comm, const soil_slab_ops* ops) {
+  SOIL_REQUIRE(out && cfg && param && comm, "slab_create: null argument");
+  SOIL_REQUIRE(cfg->rows_per_rank > 0 && cfg->W > 0 && cfg->particles_div > 0, "slab_create: empty slab");
+  SOIL_REQUIRE(comm->world >= 1 && comm->rank >= 0 && comm->rank < comm->world && comm->exchange &&
+                   comm->all_reduce_sum_f32 && comm->barrier,
+               "slab_create: incomplete communicator");
+  soil_slab* s = new soil_slab;
+  auto bail = [&](int rc) {
+    soil_slab_destroy(s);
+    return rc;
+  };
+  if (!ops) {
+    if (int rc = soil_slab_ops_hip_create(&s->own_ops); rc != SOIL_OK) {
+      delete s;
+      return rc;
+    }
+    ops = s->own_ops;
+  }
+  s->comm = comm, s->ops = ops, s->param = *param;
+  s->rank = comm->rank, s->world = comm->world;
+  s->host_ordered = (comm->flags & SOIL_COMM_HOST_ORDERED) != 0;
+  s->S = cfg->rows_per_rank, s->W = cfg->W, s->H = s->world * s->S;
+  s->G = soil_ghost_rows(param);
+  if (s->world > 1 && s->G > s->S)
+    return bail(fail(SOIL_ERR_INVALID_ARGUMENT, "ghost depth " + std::to_string(s->G) + " exceeds the " +
+                                                    std::to_string(s->S) + " rows a neighbour owns"));
+  s->lay = slab_layout(s->rank, s->world, s->S, s->G);
+  s->N = s->H * s->W / cfg->particles_div;
+  s->seed = cfg->seed;
+  const bool given = cfg->scale[0] != 0.0f || cfg->scale[1] != 0.0f || cfg->scale[2] != 0.0f;
+  s->scale[0] = given ? cfg->scale[0] : 20.0f / static_cast<float>(s->H);
+  s->scale[1] = given ? cfg->scale[1] : 20.0f / static_cast<float>(s->W);
+  s->scale[2] = given ? cfg->scale[2] : 4.0f;
+  auto env_is = [](const char* n, const char* v) {
+    const char* e = std::getenv(n);
+    return e && std::strcmp(e, v) == 0;
+  };
+  s->trim = cfg->trim >= 0 ? cfg->trim != 0 : (s->world > 1 && !env_is("SOIL_HALO_FULL", "1"));
+  if (s->world == 1 || !ops->ghost_extent) s->trim = false;
+  s->pair = cfg->pair >= 0 ? cfg->pair != 0 : env_is("SOIL_STEP_PAIR", "1");
+  s->halo_need = cfg->halo_need;
+  if (s->halo_need <= 0)
+    if (const char* e = std::getenv("SOIL_HALO_NEED")) s->halo_need = std::atoi(e);
+  s->up = s->rank > 0 ? s->rank - 1 : -1;
+  s->down = s->rank < s->world - 1 ? s->rank + 1 : -1;
+  s->gu = s->lay.r0, s->gd = s->lay.rows - s->lay.r1;
+  s->fresh_everything();
+  for (int p = 0; p < kPlanes; ++p) {
+    void* q = nullptr;
+    if (int rc = ops->alloc(ops->ctx, &q, s->lay.rows * s->row_floats(p) * 4); rc != SOIL_OK) return bail(rc);
+    s->P[p] = static_cast<float*>(q);
+  }
+  for (const Plane* list : {kFluxFluvial, kFluxDebris})
+    for (int i = 0; i < (list == kFluxFluvial ? 3 : 2); ++i) {
+      const int p = list[i];
+      for (int side = 0; side < 2; ++side) {
+        const int peer = side ? s->down : s->up;
+        if (peer < 0) continue;
+        void* q = nullptr;
+        if (int rc = ops->alloc(ops->ctx, &q, s->peer_ghost(peer) * s->row_floats(p) * 4); rc != SOIL_OK) return bail(rc);
+        s->stage[p][side] = static_cast<float*>(q);
+      }
+    }
+  void* q = nullptr;
+  if (int rc = ops->alloc(ops->ctx, &q, s->N * static_cast<int64_t>(sizeof(soil_rng))); rc != SOIL_OK) return bail(rc);
+  s->rng = static_cast<soil_rng*>(q);
+  if (ops->particles_pair) {
+    if (int rc = ops->alloc(ops->ctx, &q, s->N * static_cast<int64_t>(sizeof(soil_rng))); rc != SOIL_OK) return bail(rc);
+    s->rng_debris = static_cast<soil_rng*>(q);
+  }
+  if (int rc = ops->alloc(ops->ctx, &q, 8 * 4); rc != SOIL_OK) return bail(rc);
+  s->remote0 = static_cast<float*>(q);
+  if (int rc = ops->alloc(ops->ctx, &q, static_cast<int64_t>(s->world) * 2 * 4); rc != SOIL_OK) return bail(rc);
+  s->ints = static_cast<float*>(q);
+  if (cfg->init) {
+    if (int rc = ops->alloc(ops->ctx, &q, s->lay.rows * s->W * 4); rc != SOIL_OK) return bail(rc);
+    float* bed = static_cast<float*>(q);
+    soil_noise_param np;
+    soil_noise_param_default(&np);
+    np.seed = cfg->noise_seed;
+    np.ext[0] = static_cast<float>(cfg->noise_rows > 0 ? cfg->noise_rows : s->H);
+    np.ext[1] = static_cast<float>(s->W);
+    int rc = ops->noise_rows(ops->ctx, bed, s->lay.rows, s->W, s->lay.x0, &np);
+    if (rc == SOIL_OK) rc = ops->layers_from_bedrock(ops->ctx, s->P[kLayers], bed, s->lay.rows * s->W);
+    if (rc == SOIL_OK) rc = ops->fill_f32(ops->ctx, s->P[kRainfall], 1.0f, s->lay.rows * s->W, 0);
+    if (rc == SOIL_OK) rc = ops->sync(ops->ctx);
+    ops->release(ops->ctx, bed);
+    if (rc != SOIL_OK) return bail(rc);
+  }
+  *out = s;
+  return SOIL_OK;
+}
+
+int soil_slab_step(soil_slab* slab, soil_slab_mark_fn mark, void* mark_ctx) {
+  SOIL_REQUIRE(slab, "slab_step: null runner");
+  return slab->step(mark, mark_ctx);
+}
+
+int soil_slab_plane(soil_slab* slab, const char* name, float** data, int64_t* rows, int64_t* channels) {
+  SOIL_REQUIRE(slab && name && data, "slab_plane: null argument");
+  for (int p = 0; p < kPlanes; ++p)
+    if (std::strcmp(name, kPlaneName[p]) == 0) {
+      *data = slab->P[p];
+      if (rows) *rows = slab->lay.rows;
+      if (channels) *channels = kPlaneCh[p];
+      return SOIL_OK;
+    }
+  return fail(SOIL_ERR_INVALID_ARGUMENT, std::string("slab_plane: no plane called ") + name);
+}
+
+int soil_slab_get_info(const soil_slab* s, soil_slab_info* info) {
+  SOIL_REQUIRE(s && info, "slab_get_info: null argument");
+  *info = soil_slab_info{};
+  info->H = s->H, info->W = s->W, info->S = s->S, info->G = s->G;
+  info->x0 = s->lay.x0, info->rows = s->lay.rows, info->r0 = s->lay.r0, info->r1 = s->lay.r1;
+  info->N = s->N, info->step_index = s->step_index;
+  info->rank = s->rank, info->world = s->world, info->trim = s->trim, info->pair = s->pair;
+  info->rows_flux = s->rows_flux, info->rows_field = s->rows_field, info->rows_full = s->rows_full;
+  info->repeated_launches = s->fallbacks;
+  info->n_reach = static_cast<int32_t>(s->reach_hist.size());
+  for (int i = 0; i < info->n_reach && i < 4; ++i) info->reach_hist[i] = s->reach_hist[static_cast<size_t>(i)];
+  return SOIL_OK;
+}
+
+int soil_slab_sync(soil_slab* slab) {
+  SOIL_REQUIRE(slab, "slab_sync: null runner");
+  return slab->ops->sync(slab->ops->ctx);
+}
+
+int soil_slab_stream(soil_slab* slab, int32_t lane, void** stream) {
+  SOIL_REQUIRE(slab && stream, "slab_stream: null argument");
+  *stream = slab->stream(lane);
+  return SOIL_OK;
+}
+
+int soil_slab_destroy(soil_slab* s) {
+  if (!s) return SOIL_OK;
+  if (s->ops) {
+    if (s->ops->sync) (void)s->ops->sync(s->ops->ctx);
+    auto drop = [&](void* p) {
+      if (p) (void)s->ops->release(s->ops->ctx, p);
+    };
+    for (int p = 0; p < kPlanes; ++p) {
+      drop(s->P[p]);
+      drop(s->stage[p][0]);
+      drop(s->stage[p][1]);
+    }
+    drop(s->rng), drop(s->rng_debris), drop(s->remote0), drop(s->ints);
+  }
+  if (s->own_ops) soil_slab_ops_hip_destroy(s->own_ops);
+  delete s;
+  return SOIL_OK;
+}
+
+// ---- communicators --------------------------------------------------------------------------------
+
+int soil_comm_rccl_unique_id(uint8_t id[128]) {
+  SOIL_DEVICE();
+  SOIL_REQUIRE(id, "comm_rccl_unique_id: null argument");
+  if (int rc = rccl_load(); rc != SOIL_OK) return rc;
+  SOIL_RCCL(g_rccl.GetUniqueId(id));
+  return SOIL_OK;
+}
+
+int soil_comm_rccl_create(soil_comm** out, const uint8_t id[128], int32_t rank, int32_t world) {
+  SOIL_DEVICE();
+  SOIL_REQUIRE(out && id && world >= 1 && rank >= 0 && rank < world, "comm_rccl_create: bad argument");
+  if (int rc = rccl_load(); rc != SOIL_OK) return rc;
+  Id128 uid;
+  std::memcpy(uid.bytes, id, 128);
+  RcclCtx* r = new RcclCtx;
+  if (const int e = g_rccl.CommInitRank(&r->comm, world, uid, rank); e != 0) {
+    delete r;
+    return rccl_fail(e, "ncclCommInitRank");
+  }
+  SOIL_HIP(hipMalloc(reinterpret_cast<void**>(&r->scratch), 4));
+  SOIL_HIP(hipMemset(r->scratch, 0, 4));
+  soil_comm* c = new soil_comm{};
+  c->ctx = r, c->rank = rank, c->world = world, c->flags = 0;
+  c->exchange = rccl_exchange, c->all_reduce_sum_f32 = rccl_all_reduce, c->barrier = rccl_barrier;
+  *out = c;
+  return SOIL_OK;
+}
+
+int soil_comm_rccl_info(const soil_comm* comm, int32_t* count, int32_t* rank, int32_t* device) {
+  SOIL_REQUIRE(comm && comm->ctx && g_rccl.lib, "comm_rccl_info: not an RCCL communicator");
+  const RcclCtx& r = *static_cast<const RcclCtx*>(comm->ctx);
+  int v = 0;
+  if (count) {
+    SOIL_RCCL(g_rccl.CommCount(r.comm, &v));
+    *count = v;
+  }
+  if (rank) {
+    SOIL_RCCL(g_rccl.CommUserRank(r.comm, &v));
+    *rank = v;
+  }
+  if (device) {
+    SOIL_RCCL(g_rccl.CommCuDevice(r.comm, &v));
+    *device = v;
+  }
+  return SOIL_OK;
+}
+
+int soil_comm_rccl_destroy(soil_comm* comm) {
+  if (!comm) return SOIL_OK;
+  RcclCtx* r = static_cast<RcclCtx*>(comm->ctx);
+  if (r) {
+    (void)hipDeviceSynchronize();
+    if (r->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(r->comm);
+    (void)hipFree(r->scratch);
+    delete r;
+  }
+  delete comm;
+  return SOIL_OK;
+}
+
+int soil_comm_self_create(soil_comm** out) {
+  SOIL_REQUIRE(out, "comm_self_create: null argument");
+  soil_comm* c = new soil_comm{};
+  c->rank = 0, c->world = 1;
+  c->exchange = self_exchange, c->all_reduce_sum_f32 = self_all_reduce, c->barrier = self_barrier;
+  *out = c;
+  return SOIL_OK;
+}
+
+int soil_comm_self_destroy(soil_comm* comm) {
+  delete comm;
+  return SOIL_OK;
+}
+
+}  // extern "C"

@@ -1,46 +1,27 @@
-"""Row-slab sharding of the erosion step across the GPUs of one node.
+"""Row-slab sharding of the erosion step across the GPUs of one node — Python face of the
+library's slab runner (include/soil_slab.h, csrc/slab_runner.hip).
 
-One process per GPU (torch.distributed; backend "nccl" == RCCL over xGMI).
-Rank r owns global rows [r*S, (r+1)*S) of a (world*S, W) grid and holds G ghost
-rows on each interior side, G = soil_ghost_rows(param) = ceil(sqrt(2)*maxage)+2:
-one particle step moves at most sqrt(2) cells (erosion_map.cu:61-76), so no
-trajectory born in the owned rows can leave the slab.  That makes the sharded
-step EXACT (same trajectories, same deposits as the single-GPU run; only the
-fp32 summation order of the flux differs) with nearest-neighbour traffic only:
+One process per GPU.  Rank r owns global rows [r*S, (r+1)*S) of a (world*S, W) grid plus
+G = soil_ghost_rows(param) = ceil(sqrt(2)*maxage)+2 ghost rows per interior side: one particle
+step moves at most sqrt(2) cells (erosion_map.cu:61-76), so no trajectory born in the owned
+rows can leave the slab and the sharded step is EXACT (same trajectories, same deposits as the
+single-GPU run; only the fp32 summation order of the flux differs).  The step — exchange
+schedule, halos trimmed to the measured reach of the walks, repeat-launch fallback, RCCL
+send/recv groups on the runner's own HIP streams — is C++ inside libsoil_hip.so; what is left
+here is construction:
 
-  per step                         exchanged with each neighbour
-  1 fluvial particles              -
-  2 debris particles               overlapped: flux halo-accumulate of the fluvial planes
-                                   (G rows x 4 floats -> added by the owner)
-  3 flux halo of the debris planes G rows x 3 floats (exposed)
-  4 cell phase, bands next to the  -
-    neighbours
-  5 cell phase, interior rows      overlapped: field halo — G rows of layers, velocity,
-                                   waterHeight, debrisVelocity -> neighbour's ghost rows
-
-How much of the G rows really travels is decided by measurement, not by the bound: after each
-particle launch a rank looks how deep into its ghost rows the deposits got (`ghost_extent`; at
-the acceptance parameters ~190 of the 365 rows for water, none for debris) and ships exactly
-those rows of flux; the field halo is refreshed as deep as the walks of the last steps reached,
-plus a margin, and a launch whose deposits get within a row of the refreshed depth is REPEATED
-after the missing rows have been fetched (they are still unchanged at the neighbour's: the cell
-phase has not run yet), so the step stays exact whatever the prediction was.  The reach numbers
-of all ranks travel in two small all-reduces per step.
-
-Every rank replays all world*N particle streams (two Philox draws each) and
-traces the ones whose spawn row it owns (soil_particles_*_slab), so the set of
-trajectories is identical to a single-GPU run of the global grid.  Even the
-reference's NaN walkers, whose one deposit belongs
-to global cell (0,0), are reproduced: a rank that does not hold global row 0
-parks those deposits in an 8-float buffer that is all-reduced to the owner.
-
-The runner is written against a small `ops` interface so that the exchange and
-partition logic can be tested on CPU (gloo) with the oracle as the compute
-back-end (tests/test_parallel_gloo.py); the product back-end is HipOps — HIP
-kernels through the C ABI, torch only for allocation and communication.
+  SlabRunner      forwards to soil_slab_create / soil_slab_step / soil_slab_plane
+  RcclComm        the library's RCCL communicator (soil_comm_rccl_*); the 128-byte id travels
+                  through torch.distributed's store (gloo), which is all torch is used for
+  CallbackComm    a soil_comm made of Python callables: gloo on staged host buffers (several
+                  ranks sharing one GPU, or no GPU at all) and the in-process wire of the tests
+  CallbackOps     a soil_slab_ops made of Python callables: the CPU tests plug the oracle in
+                  here, so that world-size-2/3 gloo runs exercise the library's own host logic
 """
 import ctypes as C
 import os
+
+from . import _abi
 
 FIELD_PLANES = ("layers", "velocity", "waterHeight", "debrisVelocity")
 FLUX_FLUVIAL = ("waterFlux", "massFlux", "velocityFlux")      # final after the fluvial launch
@@ -55,504 +36,408 @@ PLANE_CHANNELS = {
 
 def slab_layout(rank, world, S, G):
     """Rows a rank holds: (x0, rows, r0, r1) — global row of local row 0, local
-    row count, owned local row range."""
-    H = world * S
-    o0, o1 = rank * S, (rank + 1) * S
-    x0 = max(0, o0 - G)
-    x1 = min(H, o1 + G)
-    return x0, x1 - x0, o0 - x0, o1 - x0
+    row count, owned local row range (soil_slab_layout)."""
+    out = (C.c_int64 * 4)()
+    _abi.lib().soil_slab_layout(rank, world, S, G, out)
+    return tuple(int(v) for v in out)
 
 
-class HipOps:
-    """Product back-end: torch CUDA tensors for storage, HIP kernels via the C ABI."""
+# ---- the wire -------------------------------------------------------------------------
 
-    def __init__(self, local_rank):
-        import torch
-        from . import _abi
-        self.torch, self.abi, self.lib = torch, _abi, _abi.lib()
-        torch.cuda.set_device(local_rank)
-        _abi.check(self.lib.soil_set_device(local_rank))
-        self.device = torch.device("cuda", local_rank)
-        self.main = torch.cuda.current_stream()
-        self.comm = torch.cuda.Stream()
+class SelfComm:
+    """A world of one (soil_comm_self_create)."""
 
-    def alloc(self, shape, kind="f32"):
-        t = self.torch
-        if kind == "rng":
-            return t.zeros((shape[0], 2), dtype=t.int64, device=self.device)
-        return t.zeros(tuple(shape), dtype=t.float32, device=self.device)
+    def __init__(self):
+        self.rank, self.world = 0, 1
+        self._c = C.POINTER(_abi.Comm)()
+        _abi.check(_abi.lib().soil_comm_self_create(C.byref(self._c)))
 
-    def _stream(self):
-        return C.c_void_p(self.torch.cuda.current_stream().cuda_stream)
-
-    @staticmethod
-    def _p(t):
-        return C.c_void_p(t.data_ptr())
-
-    def seed(self, rng, seed, offset):
-        self.abi.check(self.lib.soil_rng_seed(self._p(rng), rng.shape[0], seed, offset,
-                                              self._stream()))
-
-    def fill(self, t, value):
-        self.abi.check(self.lib.soil_set_f32(self._p(t), float(value), t.numel(), self._stream()))
-
-    def zero(self, t):
-        self.fill(t, 0.0)
-
-    def add(self, dst, src):
-        self.abi.check(self.lib.soil_add_f32(self._p(dst), self._p(src), dst.numel(),
-                                             self._stream()))
-
-    def copy(self, dst, src):
-        self.abi.check(self.lib.soil_memcpy_d2d(self._p(dst), self._p(src),
-                                                dst.numel() * dst.element_size(), self._stream()))
-
-    def noise_rows(self, out, H, W, x0, seed):
-        """Bedrock rows [x0, x0+rows) of the global soil.noise heightmap."""
-        from . import _abi
-        p = _abi.NoiseParam()
-        self.lib.soil_noise_param_default(C.byref(p))
-        p.seed = seed
-        p.ext[0], p.ext[1] = float(H), float(W)
-        # noise is a pure function of the global cell index: generate the whole
-        # columns x rows window by offsetting the row origin
-        self.abi.check(self.lib.soil_noise_window(self._p(out), out.shape[0], W, x0, C.byref(p),
-                                                  self._stream()))
-
-    def layers_from_bedrock(self, layers, bed):
-        self.abi.check(self.lib.soil_layers_from_planes(self._p(layers), self._p(bed), None,
-                                                        bed.numel(), self._stream()))
-
-    def particles_fluvial(self, P, rng, N, dom, scale, param, remote0):
-        self.abi.check(self.lib.soil_particles_fluvial_slab(
-            self._p(P["waterFlux"]), self._p(P["massFlux"]), self._p(P["velocityFlux"]), None,
-            self._p(rng), N, self._p(P["layers"]), self._p(P["rainfall"]),
-            self._p(P["waterHeight"]), self._p(P["velocity"]), None, self._p(remote0),
-            C.byref(dom), self.abi.vec(scale, 3), param._ref(), self._stream()))
-
-    def particles_debris(self, P, rng, N, dom, scale, param, remote0):
-        self.abi.check(self.lib.soil_particles_debris_slab(
-            self._p(P["debrisFlux"]), self._p(P["debrisVelocityFlux"]), None, self._p(rng), N,
-            self._p(P["layers"]), self._p(P["debrisVelocity"]), None, self._p(remote0),
-            C.byref(dom), self.abi.vec(scale, 3), param._ref(), self._stream()))
-
-    def particles_pair(self, P, rng, rng_debris, N, dom, scale, param, remote0):
-        """Both launches overlapped (soil_particles_pair_slab)."""
-        planes = self.abi.ErosionPlanes()
-        for name in self.abi._PLANES:
-            setattr(planes, name, P[name].data_ptr())
-        self.abi.check(self.lib.soil_particles_pair_slab(
-            C.byref(planes), self._p(rng), self._p(rng_debris), N, self._p(remote0), C.byref(dom),
-            self.abi.vec(scale, 3), param._ref(), self._stream()))
-
-    def ghost_extent(self, planes, r0, r1):
-        """(rows above, rows below) the owned local rows [r0, r1) that hold a deposit in any of
-        `planes` — soil_ghost_extent; synchronises the current stream (two ints come back)."""
-        t = self.torch
-        if not hasattr(self, "_extent"):
-            self._extent = t.zeros(2, dtype=t.int32, device=self.device)
-        self._extent.zero_()
-        for p in planes:
-            self.abi.check(self.lib.soil_ghost_extent(
-                self._p(self._extent), self._p(p), p.shape[0], p.numel() // p.shape[0], r0, r1,
-                self._stream()))
-        up, down = self._extent.tolist()
-        return int(up), int(down)
-
-    def add_cell0(self, P, remote0):
-        """Global cell (0,0) += the all-reduced deposits of the other ranks' NaN walkers."""
-        for plane, lo, n in (("waterFlux", 0, 1), ("massFlux", 1, 1), ("velocityFlux", 2, 2),
-                             ("debrisFlux", 4, 1), ("debrisVelocityFlux", 5, 2)):
-            self.abi.check(self.lib.soil_add_f32(self._p(P[plane]),
-                                                 C.c_void_p(remote0.data_ptr() + 4 * lo), n,
-                                                 self._stream()))
-
-    def cells(self, P, dom, r0, r1, scale, param):
-        if r1 <= r0:
-            return
-        planes = self.abi.ErosionPlanes()
-        for name in self.abi._PLANES:
-            setattr(planes, name, P[name].data_ptr())
-        d = self.abi.Domain(dom.H, dom.W, dom.x0, dom.rows, r0, r1)
-        self.abi.check(self.lib.soil_erode_cells_fused(C.byref(planes), C.byref(d),
-                                                       self.abi.vec(scale, 3), param._ref(),
-                                                       self._stream()))
-
-    # -- stream plumbing for overlap ---------------------------------------
-    def fork_comm(self):
-        """Make the communication stream wait for everything queued so far."""
-        self.comm.wait_stream(self.torch.cuda.current_stream())
-        return self.torch.cuda.stream(self.comm)
-
-    def join_comm(self):
-        self.torch.cuda.current_stream().wait_stream(self.comm)
-
-    def sync(self):
-        self.torch.cuda.synchronize()
-
-
-class SlabRunner:
-    """The sharded erosion model; `step()` advances the global grid by one step."""
-
-    def __init__(self, rows_per_rank, W, param, particles_div=8, seed=0, ops=None, scale=None,
-                 noise_seed=3.0, init=True, comm=None, rank=None, world=None, noise_rows=None):
-        """`comm` is a torch.distributed-like module (P2POp, isend, irecv,
-        batch_isend_irecv, all_reduce, barrier); the default is torch.distributed
-        itself.  Tests inject an in-process stand-in to drive several slabs on one GPU.
-        `noise_rows`: the row extent the initial noise heightmap is normalised by (default:
-        the global height, i.e. the same landscape stretched over more rows as the world
-        grows; weak-scaling runs pass `rows_per_rank` to keep the terrain statistics per cell)."""
-        if comm is None:
-            import torch.distributed as dist
-        else:
-            dist = comm
-        self.dist = dist
-        self.rank = int(os.environ.get("RANK", "0")) if rank is None else int(rank)
-        self.world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else int(world)
-        # SOIL_DEVICE / SOIL_DIST_BACKEND: which GPU and which torch.distributed backend, when
-        # they are not LOCAL_RANK and RCCL (several ranks sharing one GPU over gloo: tests)
-        local_rank = int(os.environ.get("SOIL_DEVICE", os.environ.get("LOCAL_RANK", "0")))
-        if ops is None:
-            ops = HipOps(local_rank)
-        self.ops = ops
-        if comm is None and not dist.is_initialized():
-            backend = os.environ.get("SOIL_DIST_BACKEND") or (
-                "nccl" if isinstance(ops, HipOps) else "gloo")
-            kw = {}
-            if backend == "nccl":
-                kw["device_id"] = ops.device
-            dist.init_process_group(backend=backend, **kw)
-        # RCCL orders its transfers with the stream they are issued on; gloo moving device
-        # tensors (tests: several ranks on one GPU) does not, so the host waits for the
-        # device before every exchange there
-        self._host_ordered = (comm is None and isinstance(ops, HipOps)
-                              and dist.get_backend() != "nccl")
-        self.S, self.W, self.param = int(rows_per_rank), int(W), param
-        self.H = self.world * self.S
-        self.scale = list(scale) if scale is not None else [20.0 / self.H, 20.0 / self.W, 4.0]
-        self.G = int(ops.ghost_rows(param)) if hasattr(ops, "ghost_rows") else self._ghost(param)
-        if self.world > 1 and self.G > self.S:
-            raise ValueError("ghost depth %d exceeds the %d rows a neighbour owns" %
-                             (self.G, self.S))
-        self.x0, self.rows, self.r0, self.r1 = slab_layout(self.rank, self.world, self.S, self.G)
-        self.N = self.H * self.W // int(particles_div)   # particles of the GLOBAL grid
-        self.seed = int(seed)
-        self.step_index = 0
-        self.dom = self._domain(self.r0, self.r1)
-        self.P = {name: ops.alloc((self.rows, self.W, ch) if ch > 1 else (self.rows, self.W))
-                  for name, ch in PLANE_CHANNELS.items()}
-        self.rng = ops.alloc((self.N,), "rng")
-        self.rng_debris = ops.alloc((self.N,), "rng") if hasattr(ops, "particles_pair") else None
-        self.serial_particles = os.environ.get("SOIL_STEP_PAIR") != "1"   # overlap is opt-in
-        self.remote0 = ops.alloc((8,))
-        self.up = self.rank - 1 if self.rank > 0 else None
-        self.down = self.rank + 1 if self.rank < self.world - 1 else None
-        # staging buffers for the flux halo-accumulate (one per plane and side)
-        self.gu, self.gd = self.r0, self.rows - self.r1      # ghost rows above / below
-        # measured-reach trimming of the halos (module docstring); SOIL_HALO_FULL=1: always G rows
-        self.trim = (self.world > 1 and hasattr(ops, "ghost_extent")
-                     and os.environ.get("SOIL_HALO_FULL") != "1")
-        self.fresh_up, self.fresh_down = self.gu, self.gd   # ghost rows whose fields are up to date
-        self.reach_hist = []     # max reach over all ranks, last steps (the same on every rank)
-        self.fallbacks = 0       # launches repeated because the refreshed depth was too small
-        self.halo_rows = {"flux": 0, "field": 0, "full": 0}  # rows shipped so far vs the bound
-        self._ints = None
-        # (ghost rows above, below) whose fields every rank holds up to date: all of them at first
-        self._fresh_all = [(slab_layout(r, self.world, self.S, self.G)[2],
-                            slab_layout(r, self.world, self.S, self.G)[1] -
-                            slab_layout(r, self.world, self.S, self.G)[3]) for r in range(self.world)]
-        self.stage = {}
-        for name in FLUX_PLANES:
-            ch = PLANE_CHANNELS[name]
-            tail = (self.W, ch) if ch > 1 else (self.W,)
-            self.stage[name] = (ops.alloc((self._peer_ghost(self.up),) + tail) if self.up is not None else None,
-                                ops.alloc((self._peer_ghost(self.down),) + tail) if self.down is not None else None)
-        if init:
-            bed = ops.alloc((self.rows, self.W))
-            ops.noise_rows(bed, self.H if noise_rows is None else int(noise_rows), self.W, self.x0,
-                           noise_seed)
-            ops.layers_from_bedrock(self.P["layers"], bed)
-            self.fill(self.P["rainfall"], 1.0)
-
-    # -- helpers -------------------------------------------------------------
-    def _ghost(self, param):
-        from . import _abi
-        return _abi.lib().soil_ghost_rows(param._ref())
-
-    def _domain(self, r0, r1):
-        from . import _abi
-        return _abi.Domain(self.H, self.W, self.x0, self.rows, r0, r1)
-
-    def _peer_ghost(self, peer):
-        """Ghost rows the neighbour `peer` holds on the side facing this rank."""
-        if peer is None:
-            return 0
-        x0, rows, r0, r1 = slab_layout(peer, self.world, self.S, self.G)
-        return r0 if peer > self.rank else rows - r1
-
-    def fill(self, t, value):
-        self.ops.fill(t, value)
-
-    # -- halo exchanges --------------------------------------------------------
-    def _exchange(self, sends, recvs):
-        """sends/recvs: lists of (tensor_view, peer).  One batched group per call."""
-        dist = self.dist
-        ops_ = [dist.P2POp(dist.isend, t, peer) for t, peer in sends] + \
-               [dist.P2POp(dist.irecv, t, peer) for t, peer in recvs]
-        if not ops_:
-            return []
-        if self._host_ordered:      # see __init__: the backend does not follow the stream
-            self.ops.sync()
-        return dist.batch_isend_irecv(ops_)
-
-    def _all_ints(self, values):
-        """Every rank's list of small non-negative ints, as [rank][i] (one all-reduce of a
-        zero-padded vector: works with any communicator that can sum)."""
-        k = len(values)
-        if self._ints is None or self._ints.shape[0] != self.world * k:
-            self._ints = self.ops.alloc((self.world * k,))
-        t = self._ints
-        self.ops.zero(t)
-        t[self.rank * k:(self.rank + 1) * k] = self._as_tensor(values, t)
-        if self._host_ordered:
-            self.ops.sync()
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
-        flat = [int(round(v)) for v in t.tolist()]
-        return [flat[r * k:(r + 1) * k] for r in range(self.world)]
-
-    @staticmethod
-    def _as_tensor(values, like):
-        import torch
-        return torch.tensor([float(v) for v in values], dtype=like.dtype, device=like.device)
-
-    def flux_exchange_start(self, planes=FLUX_PLANES, counts=None):
-        """Ship the flux deposited into my ghost rows to their owners.  counts = (send_up,
-        send_down, recv_up, recv_down) rows, nearest the boundary first; default: all of them."""
-        if counts is None:
-            counts = (self.gu, self.gd, self._peer_ghost(self.up), self._peer_ghost(self.down))
-        send_up, send_down, recv_up, recv_down = counts
-        sends, recvs = [], []
-        for name in planes:
-            t = self.P[name]
-            su, sd = self.stage[name]
-            if self.up is not None:
-                if send_up:
-                    sends.append((t[self.r0 - send_up:self.r0], self.up))
-                if recv_up:
-                    recvs.append((su[0:recv_up], self.up))
-            if self.down is not None:
-                if send_down:
-                    sends.append((t[self.r1:self.r1 + send_down], self.down))
-                if recv_down:
-                    recvs.append((sd[0:recv_down], self.down))
-        self.halo_rows["flux"] += (send_up + send_down) * len(planes)
-        self.halo_rows["full"] += (self.gu + self.gd) * len(planes)
-        return self._exchange(sends, recvs), counts
-
-    def flux_exchange_finish(self, started, planes=FLUX_PLANES):
-        reqs, (send_up, send_down, recv_up, recv_down) = started
-        for r in reqs:
-            r.wait()
-        for name in planes:
-            t = self.P[name]
-            su, sd = self.stage[name]
-            if su is not None and recv_up:   # the up neighbour's lower ghost rows = my first owned rows
-                self.ops.add(t[self.r0:self.r0 + recv_up], su[0:recv_up])
-            if sd is not None and recv_down:
-                self.ops.add(t[self.r1 - recv_down:self.r1], sd[0:recv_down])
-            if self.up is not None and send_up:
-                self.ops.zero(t[self.r0 - send_up:self.r0])
-            if self.down is not None and send_down:
-                self.ops.zero(t[self.r1:self.r1 + send_down])
-
-    def field_exchange(self, layers_key="layers", counts=None):
-        """Refresh the ghost rows of the fields the next step's particles read.  counts =
-        (need_up, need_down, give_up, give_down): rows I want from / owe to each neighbour,
-        nearest the boundary first; default: the whole ghost zones."""
-        if counts is None:
-            counts = (self.gu, self.gd, self._peer_ghost(self.up), self._peer_ghost(self.down))
-        need_up, need_down, give_up, give_down = counts
-        sends, recvs = [], []
-        for name in FIELD_PLANES:
-            t = self.P[layers_key if name == "layers" else name]
-            if self.up is not None:
-                if give_up:
-                    sends.append((t[self.r0:self.r0 + give_up], self.up))
-                if need_up:
-                    recvs.append((t[self.r0 - need_up:self.r0], self.up))
-            if self.down is not None:
-                if give_down:
-                    sends.append((t[self.r1 - give_down:self.r1], self.down))
-                if need_down:
-                    recvs.append((t[self.r1:self.r1 + need_down], self.down))
-        self.halo_rows["field"] += (give_up + give_down) * len(FIELD_PLANES)
-        self.halo_rows["full"] += (self._peer_ghost(self.up) + self._peer_ghost(self.down)) * len(FIELD_PLANES)
-        for r in self._exchange(sends, recvs):
-            r.wait()
-        self.fresh_up, self.fresh_down = need_up, need_down
-
-    # -- measured reach ----------------------------------------------------------
-    def _reach(self, planes):
-        """[rank] -> (rows above, rows below) its owned rows this launch's deposits got to."""
-        up, down = self.ops.ghost_extent([self.P[n] for n in planes], self.r0, self.r1)
-        return self._all_ints([up, down])
-
-    def _too_deep(self, reach):
-        """Did a launch, on any rank, get within a row of ghost rows that were not refreshed?
-        (The cell record of ghost row d is made of rows d - 1 .. d + 1.)  The answer is the same
-        on every rank: everybody knows everybody's reach and refreshed depth."""
-        for r, (up, down) in enumerate(reach):
-            f_up, f_down = self._fresh_all[r]
-            x0, rows, r0, r1 = slab_layout(r, self.world, self.S, self.G)
-            if (up >= f_up and f_up < r0) or (down >= f_down and f_down < rows - r1):
-                return True
-        return False
-
-    def _refresh_all(self):
-        """The prediction was too small: fetch the whole ghost zones of the fields as they stand
-        (the cell phase of this step has not touched them yet)."""
-        self.fallbacks += 1
-        self.field_exchange("layers")
-        self._fresh_all = [(slab_layout(r, self.world, self.S, self.G)[2],
-                            slab_layout(r, self.world, self.S, self.G)[1] -
-                            slab_layout(r, self.world, self.S, self.G)[3]) for r in range(self.world)]
-
-    def _predict_need(self):
-        """Ghost rows to refresh for the next step: as deep as the walks of the last steps got
-        anywhere, a tenth more and ten rows on top (the reach moves by a row or two from step to step);
-        everything while there is no history."""
-        if not self.reach_hist:
-            return self.gu, self.gd
-        want = int(1.1 * max(self.reach_hist)) + 10
-        if os.environ.get("SOIL_HALO_NEED"):    # tests: a prediction that is too small on purpose
-            want = int(os.environ["SOIL_HALO_NEED"])
-        return min(self.gu, want), min(self.gd, want)
-
-    # -- one step ---------------------------------------------------------------
-    def step(self, ev=None):
-        ops, P = self.ops, self.P
-        trim = self.trim
-        ops.seed(self.rng, self.seed, self.step_index * self.N)
-        ops.zero(self.remote0)
-        early = ()          # flux planes whose halo is exchanged before the debris launch ends
-        counts_f = counts_d = None
-        if ev: ev.record(0)
-        if hasattr(ops, "particles_pair") and not self.serial_particles and not trim:
-            # the debris launch draws from a tensor of its own, seeded where the fluvial
-            # launch leaves the shared one in the sequential order
-            ops.seed(self.rng_debris, self.seed, self.step_index * self.N + 2)
-            ops.particles_pair(P, self.rng, self.rng_debris, self.N, self.dom, self.scale,
-                               self.param, self.remote0)
-            if ev: ev.record(1)
-        else:
-            ops.particles_fluvial(P, self.rng, self.N, self.dom, self.scale, self.param,
-                                  self.remote0)
-            if trim:
-                reach_f = self._reach(FLUX_FLUVIAL)
-                if self._too_deep(reach_f):      # rare: repeat the launch on complete fields
-                    self._refresh_all()
-                    for name in FLUX_FLUVIAL:
-                        ops.zero(P[name])
-                    ops.zero(self.remote0)
-                    ops.seed(self.rng, self.seed, self.step_index * self.N)
-                    ops.particles_fluvial(P, self.rng, self.N, self.dom, self.scale, self.param,
-                                          self.remote0)
-                    reach_f = self._reach(FLUX_FLUVIAL)
-                me = reach_f[self.rank]
-                counts_f = (me[0], me[1],
-                            reach_f[self.up][1] if self.up is not None else 0,
-                            reach_f[self.down][0] if self.down is not None else 0)
-            if ev: ev.record(1)
-            if self.world > 1:
-                # the fluvial flux is final: its halo travels, and is added, while the
-                # debris launch runs
-                with ops.fork_comm():
-                    self.flux_exchange_finish(self.flux_exchange_start(FLUX_FLUVIAL, counts_f),
-                                              FLUX_FLUVIAL)
-                early = FLUX_FLUVIAL
-            ops.particles_debris(P, self.rng, self.N, self.dom, self.scale, self.param,
-                                 self.remote0)
-            if trim:
-                reach_d = self._reach(FLUX_DEBRIS)
-                if self._too_deep(reach_d):
-                    self._refresh_all()
-                    for name in FLUX_DEBRIS:
-                        ops.zero(P[name])
-                    # the NaN walkers' debris deposits are entries 4..6 of remote0; the launch
-                    # draws where the fluvial one left the streams (two draws per particle on)
-                    ops.zero(self.remote0[4:8])
-                    ops.seed(self.rng, self.seed, self.step_index * self.N + 2)
-                    ops.particles_debris(P, self.rng, self.N, self.dom, self.scale, self.param,
-                                         self.remote0)
-                    reach_d = self._reach(FLUX_DEBRIS)
-                me = reach_d[self.rank]
-                counts_d = (me[0], me[1],
-                            reach_d[self.up][1] if self.up is not None else 0,
-                            reach_d[self.down][0] if self.down is not None else 0)
-                self.reach_hist = (self.reach_hist + [max(max(a, b) for a, b in reach_f + reach_d)])[-4:]
-        if ev: ev.record(2)
-        if self.world == 1:
-            ops.cells(P, self.dom, self.r0, self.r1, self.scale, self.param)
-        else:
-            # NaN walkers of the other ranks -> global cell (0,0) (8 floats, latency only)
-            if self._host_ordered:
-                ops.sync()
-            self.dist.all_reduce(self.remote0)
-            if self.rank == 0:
-                ops.add_cell0(P, self.remote0)
-            # rows whose flux is complete without the neighbours' contribution
-            i0 = min(self.r1, self.r0 + (self._peer_ghost(self.up) if self.up is not None else 0))
-            i1 = max(i0, self.r1 - (self._peer_ghost(self.down) if self.down is not None else 0))
-            # 1. the rest of the flux halo (exposed: the bands below need it)
-            late = tuple(n for n in FLUX_PLANES if n not in early)
-            self.flux_exchange_finish(self.flux_exchange_start(late, counts_d if trim else None), late)
-            ops.join_comm()                      # ... and the part that travelled early
-            if ev: ev.record(4)                  # 2 -> 4: flux halo not hidden by the debris launch
-            # 2. the bands next to the neighbours first: they are what the neighbours' ghost
-            #    rows get
-            ops.cells(P, self.dom, self.r0, i0, self.scale, self.param)
-            ops.cells(P, self.dom, i1, self.r1, self.scale, self.param)
-            # 3. the field halo travels while the interior rows are computed (they are
-            #    G rows away from anything the exchange reads or writes)
-            counts = None
-            if trim:     # as deep as next step's walks are expected to get; everybody says what it wants
-                need = self._predict_need()
-                wants = self._all_ints(list(need))
-                counts = (need[0], need[1],
-                          wants[self.up][1] if self.up is not None else 0,
-                          wants[self.down][0] if self.down is not None else 0)
-                self._fresh_all = [tuple(w) for w in wants]
-            with ops.fork_comm():
-                self.field_exchange("layers_next", counts)
-            ops.cells(P, self.dom, i0, i1, self.scale, self.param)
-            if ev: ev.record(5)                  # 5 -> 3: field halo not hidden by the interior rows
-            ops.join_comm()
-        if ev: ev.record(3)
-        P["layers"], P["layers_next"] = P["layers_next"], P["layers"]
-        self.step_index += 1
-
-    # -- bench plumbing ----------------------------------------------------------
-    def sync(self):
-        self.ops.sync()
+    def c_comm(self):
+        return self._c
 
     def barrier(self):
-        if self.world > 1:
-            self.dist.barrier()
+        pass
 
-    def shutdown(self):
-        """Tear the process group down (only when it is torch.distributed itself)."""
-        d = self.dist
-        if hasattr(d, "is_initialized") and d.is_initialized():
-            self.sync()
-            d.barrier()
-            d.destroy_process_group()
+    def max_over_ranks(self, value):
+        return float(value)
+
+    def describe(self):
+        return {"backend": "self", "world_size": 1}
+
+    def close(self):
+        if self._c:
+            _abi.lib().soil_comm_self_destroy(self._c)
+            self._c = None
+
+
+def _dist_env():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+
+
+def _init_gloo():
+    """torch.distributed over gloo: the bootstrap channel (ids, timings), never the data path of a
+    GPU run."""
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29671"), ("RANK", "0"),
+                     ("WORLD_SIZE", "1")):
+            os.environ.setdefault(k, v)
+        dist.init_process_group(backend="gloo")
+    return dist
+
+
+class RcclComm:
+    """RCCL communicator owned by libsoil_hip.so (soil_comm_rccl_create).  Rank 0 makes the id,
+    torch.distributed (gloo) broadcasts its 128 bytes."""
+
+    def __init__(self):
+        import torch
+        dist = self.dist = _init_gloo()
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        lib = _abi.lib()
+        uid = (C.c_uint8 * 128)()
+        if self.rank == 0:
+            _abi.check(lib.soil_comm_rccl_unique_id(uid))
+        t = torch.tensor(list(uid), dtype=torch.uint8)
+        dist.broadcast(t, 0)
+        uid = (C.c_uint8 * 128)(*t.tolist())
+        self._c = C.POINTER(_abi.Comm)()
+        _abi.check(lib.soil_comm_rccl_create(C.byref(self._c), uid, self.rank, self.world))
+
+    def c_comm(self):
+        return self._c
+
+    def barrier(self):
+        self.dist.barrier()
 
     def max_over_ranks(self, value):
         import torch
-        t = torch.tensor([float(value)], dtype=torch.float64,
-                         device=getattr(self.ops, "device", "cpu"))
+        t = torch.tensor([float(value)], dtype=torch.float64)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
+
+    def describe(self):
+        n, r, d = C.c_int32(), C.c_int32(), C.c_int32()
+        _abi.check(_abi.lib().soil_comm_rccl_info(self._c, C.byref(n), C.byref(r), C.byref(d)))
+        return {"backend": "rccl (libsoil_hip: ncclSend/ncclRecv groups)", "world_size": int(n.value),
+                "rank": int(r.value), "device": int(d.value)}
+
+    def close(self):
+        if self._c:
+            _abi.lib().soil_comm_rccl_destroy(self._c)
+            self._c = None
+        if self.dist.is_initialized():
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+class CallbackComm:
+    """soil_comm whose three entry points are Python callables (SOIL_COMM_HOST_ORDERED: the runner
+    synchronises its back-end before every call and the call blocks until the data have landed).
+
+    impl.exchange(sends, recvs)   lists of (address, bytes, peer)
+    impl.all_reduce(address, n)   in-place float32 sum over the ranks
+    impl.barrier()
+    """
+
+    def __init__(self, rank, world, impl):
+        self.rank, self.world, self.impl = int(rank), int(world), impl
+        self.error = None
+
+        def guard(fn):
+            def run(*a):
+                try:
+                    fn(*a)
+                    return 0
+                except BaseException as e:      # an exception cannot cross the C frames
+                    self.error = e
+                    return _abi.SOIL_ERR_HIP
+            return run
+
+        def xfers(p, n):
+            return [(int(p[i].ptr or 0), int(p[i].bytes), int(p[i].peer)) for i in range(n)]
+
+        self._ex = _abi.EXCHANGE_FN(guard(lambda ctx, s, ns, r, nr, st: impl.exchange(xfers(s, ns), xfers(r, nr))))
+        self._ar = _abi.ALLREDUCE_FN(guard(lambda ctx, buf, n, st: impl.all_reduce(int(buf), int(n))))
+        self._ba = _abi.BARRIER_FN(guard(lambda ctx: impl.barrier()))
+        self._comm = _abi.Comm(None, self.rank, self.world, _abi.SOIL_COMM_HOST_ORDERED, self._ex, self._ar,
+                               self._ba)
+
+    def c_comm(self):
+        return C.pointer(self._comm)
+
+    def barrier(self):
+        self.impl.barrier()
+
+    def max_over_ranks(self, value):
+        return self.impl.max_over_ranks(value)
+
+    def describe(self):
+        return {"backend": type(self.impl).__name__, "world_size": self.world}
+
+    def close(self):
+        if hasattr(self.impl, "close"):
+            self.impl.close()
+
+
+class GlooWire:
+    """torch.distributed (gloo) as the wire of a CallbackComm.  `device` memory is staged through
+    host buffers (soil_memcpy_d2h / h2d) — functional only, tens of MB/s: several ranks sharing one
+    GPU in tests; with `device=False` the addresses are host memory (CPU back-end)."""
+
+    def __init__(self, device):
+        self.dist = _init_gloo()
+        self.device = device
+
+    def _view(self, addr, nbytes):
+        import numpy as np
+        return np.ctypeslib.as_array((C.c_uint8 * nbytes).from_address(addr))
+
+    def _to_host(self, addr, nbytes):
+        import numpy as np
+        if not self.device:
+            return self._view(addr, nbytes)
+        h = np.empty(nbytes, np.uint8)
+        _abi.check(_abi.lib().soil_memcpy_d2h(h.ctypes.data, C.c_void_p(addr), nbytes, None))
+        return h
+
+    def exchange(self, sends, recvs):
+        import numpy as np
+        import torch
+        dist = self.dist
+        keep, ops = [], []
+        for addr, n, peer in sends:
+            t = torch.from_numpy(np.ascontiguousarray(self._to_host(addr, n)))
+            keep.append(t)
+            ops.append(dist.P2POp(dist.isend, t, peer))
+        landed = []
+        for addr, n, peer in recvs:
+            t = torch.empty(n, dtype=torch.uint8)
+            landed.append((addr, n, t))
+            ops.append(dist.P2POp(dist.irecv, t, peer))
+        for r in dist.batch_isend_irecv(ops) if ops else ():
+            r.wait()
+        for addr, n, t in landed:
+            if self.device:
+                _abi.check(_abi.lib().soil_memcpy_h2d(C.c_void_p(addr), t.numpy().ctypes.data, n, None))
+            else:
+                self._view(addr, n)[:] = t.numpy()
+
+    def all_reduce(self, addr, n):
+        import numpy as np
+        import torch
+        h = self._to_host(addr, 4 * n).view(np.float32)
+        t = torch.from_numpy(np.ascontiguousarray(h).copy())
+        self.dist.all_reduce(t)
+        if self.device:
+            _abi.check(_abi.lib().soil_memcpy_h2d(C.c_void_p(addr), t.numpy().ctypes.data, 4 * n, None))
+        else:
+            self._view(addr, 4 * n).view(np.float32)[:] = t.numpy()
+
+    def barrier(self):
+        self.dist.barrier()
+
+    def max_over_ranks(self, value):
+        import torch
+        t = torch.tensor([float(value)], dtype=torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def close(self):
+        if self.dist.is_initialized():
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+def default_comm(device=True):
+    """The communicator of a job launched by torch.distributed.run: RCCL in the library; gloo on
+    staged buffers when SOIL_DIST_BACKEND=gloo (ranks that share a GPU) or without a device."""
+    rank, world = _dist_env()
+    backend = os.environ.get("SOIL_DIST_BACKEND") or ("nccl" if device else "gloo")
+    if backend == "gloo":
+        wire = GlooWire(device)
+        return CallbackComm(wire.dist.get_rank(), wire.dist.get_world_size(), wire)
+    if world == 1 and os.environ.get("SOIL_RCCL_WORLD1") != "1":
+        return SelfComm()
+    return RcclComm()
+
+
+# ---- the compute back-end ---------------------------------------------------------------
+
+class CallbackOps:
+    """soil_slab_ops whose entries are methods of a Python object (tests/parallel_worker.py: the
+    oracle on host memory).  Methods take raw addresses and the ctypes structs of _abi."""
+
+    def __init__(self, backend):
+        self.backend = backend
+        self.error = None
+        self._keep = []
+        fields = {}
+
+        def wrap(name, proto):
+            fn = getattr(backend, name, None)
+            if fn is None:
+                return proto()          # NULL entry
+            if name == "stream":
+                cb = proto(lambda ctx, lane: None)
+            else:
+                def run(ctx, *a, _fn=fn):
+                    try:
+                        _fn(*a)
+                        return 0
+                    except BaseException as e:
+                        self.error = e
+                        return _abi.SOIL_ERR_HIP
+                cb = proto(run)
+            self._keep.append(cb)
+            return cb
+        for name, proto in _abi.OPS_FIELDS:
+            fields[name] = wrap(name, proto)
+        self._ops = _abi.SlabOps(None, *[fields[n] for n, _ in _abi.OPS_FIELDS])
+
+    def c_ops(self):
+        return C.pointer(self._ops)
+
+
+# ---- the runner -----------------------------------------------------------------------------
+
+class SlabRunner:
+    """The sharded erosion model; `step()` advances the global grid by one step
+    (soil_slab_step)."""
+
+    def __init__(self, rows_per_rank, W, param, particles_div=8, seed=0, ops=None, scale=None,
+                 noise_seed=3.0, init=True, comm=None, noise_rows=None, trim=None, pair=None,
+                 halo_need=0, device=None):
+        """comm: SelfComm / RcclComm / CallbackComm (default: default_comm()); ops: CallbackOps or
+        None for the HIP back-end on device `device` (default: SOIL_DEVICE or LOCAL_RANK)."""
+        lib = self.lib = _abi.lib()
+        self.cb_ops = ops
+        if ops is None:
+            if device is None:
+                device = int(os.environ.get("SOIL_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+            _abi.check(lib.soil_set_device(int(device)))
+        self.comm = comm if comm is not None else default_comm(device=ops is None)
+        self.param = param
+        cfg = _abi.SlabConfig()
+        cfg.rows_per_rank, cfg.W, cfg.particles_div, cfg.seed = int(rows_per_rank), int(W), int(particles_div), int(seed)
+        if scale is not None:
+            cfg.scale[0], cfg.scale[1], cfg.scale[2] = [float(v) for v in scale]
+        cfg.noise_seed = float(noise_seed)
+        cfg.noise_rows = int(noise_rows or 0)
+        cfg.init = 1 if init else 0
+        cfg.trim = -1 if trim is None else int(bool(trim))
+        cfg.pair = -1 if pair is None else int(bool(pair))
+        cfg.halo_need = int(halo_need)
+        self._h = C.c_void_p()
+        pref = param._ref() if hasattr(param, "_ref") else C.byref(param)
+        self._check(lib.soil_slab_create(C.byref(self._h), C.byref(cfg), pref, self.comm.c_comm(),
+                                         ops.c_ops() if ops is not None else None))
+        i = self.info()
+        self.rank, self.world = i.rank, i.world
+        self.S, self.W, self.H, self.G, self.N = i.S, i.W, i.H, i.G, i.N
+        self.x0, self.rows, self.r0, self.r1 = i.x0, i.rows, i.r0, i.r1
+        self.trim, self.pair = bool(i.trim), bool(i.pair)
+        self.scale = list(scale) if scale is not None else [20.0 / self.H, 20.0 / self.W, 4.0]
+        self._mark = None
+
+    def _check(self, rc):
+        if rc != 0:
+            for src in (self.cb_ops, self.comm):
+                err = getattr(src, "error", None)
+                if err is not None:
+                    src.error = None
+                    raise err
+        _abi.check(rc)
+
+    def info(self):
+        i = _abi.SlabInfo()
+        _abi.check(self.lib.soil_slab_get_info(self._h, C.byref(i)))
+        return i
+
+    def step(self, ev=None):
+        """One step of the global grid.  `ev`: an object with record(i) — bench.py's HIP events —
+        called at the marks of soil_slab_step on the runner's main stream."""
+        if ev is not None:
+            if self._mark is None or self._mark[0] is not ev:
+                self._mark = (ev, _abi.MARK_FN(lambda ctx, i: ev.record(int(i), self.stream())))
+            self._check(self.lib.soil_slab_step(self._h, self._mark[1], None))
+        else:
+            self._check(self.lib.soil_slab_step(self._h, _abi.MARK_FN(), None))
+
+    def stream(self, lane=0):
+        """The runner's main (lane 0) / communication (1) HIP stream as a c_void_p."""
+        st = C.c_void_p()
+        _abi.check(self.lib.soil_slab_stream(self._h, lane, C.byref(st)))
+        return st
+
+    def plane_ptr(self, name):
+        p, rows, ch = C.c_void_p(), C.c_int64(), C.c_int64()
+        _abi.check(self.lib.soil_slab_plane(self._h, name.encode(), C.byref(p), C.byref(rows), C.byref(ch)))
+        return p, int(rows.value), int(ch.value)
+
+    def plane(self, name, owned=False):
+        """A plane of the slab as a numpy array (a copy for the HIP back-end, a view of the
+        back-end's memory otherwise): local rows incl. ghost rows, or the owned rows only."""
+        import numpy as np
+        p, rows, ch = self.plane_ptr(name)
+        shape = (rows, self.W, ch) if ch > 1 else (rows, self.W)
+        n = rows * self.W * ch
+        if self.cb_ops is None:
+            self.sync()
+            a = np.empty(shape, np.float32)
+            _abi.check(self.lib.soil_memcpy_d2h(a.ctypes.data, p, 4 * n, None))
+        else:
+            a = np.ctypeslib.as_array((C.c_float * n).from_address(p.value)).reshape(shape)
+        return a[self.r0:self.r1] if owned else a
+
+    def set_plane(self, name, array):
+        import numpy as np
+        p, rows, ch = self.plane_ptr(name)
+        a = np.ascontiguousarray(array, np.float32)
+        assert a.size == rows * self.W * ch, (a.shape, rows, self.W, ch)
+        if self.cb_ops is None:
+            _abi.check(self.lib.soil_memcpy_h2d(p, a.ctypes.data, 4 * a.size, None))
+            _abi.check(self.lib.soil_device_synchronize())
+        else:
+            C.memmove(p.value, a.ctypes.data, 4 * a.size)
+
+    @property
+    def halo_rows(self):
+        i = self.info()
+        return {"flux": int(i.rows_flux), "field": int(i.rows_field), "full": int(i.rows_full)}
+
+    @property
+    def fallbacks(self):
+        return int(self.info().repeated_launches)
+
+    @property
+    def reach_hist(self):
+        i = self.info()
+        return [int(i.reach_hist[k]) for k in range(i.n_reach)]
+
+    @property
+    def step_index(self):
+        return int(self.info().step_index)
+
+    # -- bench plumbing ----------------------------------------------------------
+    def sync(self):
+        self._check(self.lib.soil_slab_sync(self._h))
+
+    def barrier(self):
+        self.comm.barrier()
+
+    def max_over_ranks(self, value):
+        return self.comm.max_over_ranks(value)
+
+    def close(self):
+        if self._h:
+            self.lib.soil_slab_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def shutdown(self):
+        """Free the slab and tear the communicator down."""
+        self.close()
+        self.comm.close()
 
 
 # ---- flow accumulation: replicas, realisations sharded ------------------------------

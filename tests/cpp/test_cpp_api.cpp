@@ -74,6 +74,28 @@ int main() {
     EXPECT(st == 0.0);                             // the flux planes are left zeroed
     std::printf("ERODE3 %llu %.9e %.9e\n", static_cast<unsigned long long>(steps), sh_, sd);
   }
+  // the sharded step through the C ABI: a world of one (one-rank wire, then a one-rank RCCL
+  // communicator made by the library) must walk the walks of soil::erode on the same grid
+  {
+    const int S = 96;
+    soil::param_t sp;
+    sp.maxage = 64; sp.timeStep = 1000.0f; sp.critSlopeBedrock = 0.57f; sp.suspensionRateFluvial = 0.0008f;
+    double sums[2] = {0, 0};
+    for (int which = 0; which < 2; ++which) {
+      soil::comm wire = which == 0 ? soil::comm::self() : soil::comm::rccl(soil::comm::rccl_unique_id(), 0, 1);
+      soil::slab_runner slab(soil::slab_runner::config(S, S), sp, wire);
+      uint64_t before = 0, after = 0;
+      check(soil_particle_steps(&before, 1, nullptr));
+      for (int s = 0; s < 3; ++s) slab.step();
+      slab.sync();
+      check(soil_particle_steps(&after, 1, nullptr));
+      EXPECT(slab.info().step_index == 3 && slab.info().world == 1 && slab.info().rows == S);
+      EXPECT(after > 0);
+      for (float v : slab.owned_rows("height")) sums[which] += v;
+      std::printf("SLAB%d %llu %.9e\n", which, static_cast<unsigned long long>(after), sums[which]);
+    }
+    EXPECT(std::fabs(sums[0] - sums[1]) <= 1e-6 * std::fabs(sums[0]));
+  }
   std::printf("CPP_API_OK\n");
   return 0;
 }

@@ -21,9 +21,8 @@ def main():
     for _ in range(steps):
         r.step()
     r.sync()
-    own = slice(r.r0, r.r1)
     np.savez(os.path.join(out_dir, "rank%d.npz" % r.rank),
-             **{k: r.P[k][own].cpu().numpy() for k in ("layers", "waterHeight", "velocity", "debris")})
+             **{k: r.plane(k, owned=True) for k in ("layers", "waterHeight", "velocity", "debris")})
     assert r.max_over_ranks(float(r.rank)) == r.world - 1
     r.shutdown()
 

@@ -9,8 +9,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
-    text = open(os.path.join(ROOT, "include", "soil_hip.h")).read()
+def declared_symbols(header="soil_hip.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(soil_[a-z0-9_]+)\s*\(", text)))
 
@@ -34,6 +34,10 @@ def test_library_exports_every_declared_symbol():
     assert set(declared_symbols()) == set(_abi.SIGNATURES), \
         set(declared_symbols()) ^ set(_abi.SIGNATURES)
     assert lib.soil_abi_version() == 1
+    # include/soil_slab.h: the sharded step (slab runner, communicators)
+    slab = declared_symbols("soil_slab.h")
+    assert not [s for s in slab if not hasattr(lib, s)]
+    assert set(slab) == set(_abi.SLAB_SIGNATURES), set(slab) ^ set(_abi.SLAB_SIGNATURES)
 
 
 def test_struct_layouts_match_the_header():
@@ -43,6 +47,9 @@ def test_struct_layouts_match_the_header():
     assert ctypes.sizeof(_abi.Domain) == 48
     assert ctypes.sizeof(_abi.ErosionPlanes) == 15 * 8
     assert ctypes.sizeof(_abi.NoiseParam) == 28
+    assert ctypes.sizeof(_abi.Xfer) == 24 and ctypes.sizeof(_abi.Comm) == 48
+    assert ctypes.sizeof(_abi.SlabOps) == 8 * 19 and ctypes.sizeof(_abi.SlabConfig) == 72
+    assert ctypes.sizeof(_abi.SlabInfo) == 9 * 8 + 8 + 16 + 4 * 8 + 16 + 8
     from oracle import pyoracle
     assert ctypes.sizeof(pyoracle.Param) == 112
 

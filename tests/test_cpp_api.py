@@ -65,6 +65,12 @@ def test_cpp_mirror_on_gpu(tmp_path):
     d = np.nansum(data.discharge.cpu().numpy().astype(np.float64))
     assert abs(h - float(line[2])) <= 1e-6 * abs(h) + 1e-6         # fp32 deposits, summation order
     assert abs(d - float(line[3])) <= 1e-4 * abs(d)
+    # the slab runner (soil::slab_runner over soil_slab_*): the same grid, parameters and seed as
+    # the three soil::erode steps above, hence the same walks and the same terrain
+    for tag in ("SLAB0", "SLAB1"):
+        sl = [l for l in out.stdout.splitlines() if l.startswith(tag)][0].split()
+        assert int(sl[1]) == int(line[1])
+        assert abs(float(sl[2]) - float(line[2])) <= 1e-6 * abs(h) + 1e-6
 
 
 def test_cpp_io_roundtrip(tmp_path):

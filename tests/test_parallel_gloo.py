@@ -1,9 +1,10 @@
-"""Multi-process (gloo, CPU) test of the row-slab sharding logic.
+"""Multi-process (gloo, CPU) test of the library's slab runner (soil_slab_step,
+csrc/slab_runner.hip).
 
-world_size 2 and 3 jobs run soillib_amd.parallel.SlabRunner with the oracle as
-compute back-end (tests/parallel_worker.py); the owned rows of all ranks,
-stitched together, must equal a single-domain oracle run of the same global
-grid: same trajectories and deposits, fp32 flux summation order aside.
+world_size 2 and 3 jobs drive the C++ runner with the oracle plugged in as compute back-end
+(soil_slab_ops) and gloo as the wire (soil_comm) — tests/parallel_worker.py; the owned rows of
+all ranks, stitched together, must equal a single-domain oracle run of the same global grid:
+same trajectories and deposits, fp32 flux summation order aside.
 """
 import os
 import socket
@@ -51,12 +52,14 @@ def _single_domain(oracle, H, W, steps, maxage):
     return st
 
 
-@pytest.mark.parametrize("world,S,W,maxage,steps,need", [
-    (2, 24, 32, 8, 2, None), (3, 16, 24, 6, 2, None),
-    (2, 80, 48, 48, 4, None),      # deep ghost zone (70 rows): the measured reach trims both halos
-    (3, 72, 40, 48, 3, "2"),       # a refresh depth that is too small: launches are repeated
+@pytest.mark.parametrize("world,S,W,maxage,steps,need,pair", [
+    (2, 24, 32, 8, 2, None, False), (3, 16, 24, 6, 2, None, False),
+    (2, 80, 48, 48, 4, None, False),   # deep ghost zone (70 rows): the measured reach trims both halos
+    (3, 72, 40, 48, 3, "2", False),    # a refresh depth that is too small: launches are repeated
+    (2, 80, 48, 48, 3, None, True),    # both launches as one call (soil_particles_pair_slab's slot), trimmed
+    (3, 72, 40, 48, 3, "2", True),     # ... and repeated together
 ])
-def test_slab_runner_matches_single_domain(oracle, tmp_path, world, S, W, maxage, steps, need):
+def test_slab_runner_matches_single_domain(oracle, tmp_path, world, S, W, maxage, steps, need, pair):
     port = _free_port()
     procs = []
     for rank in range(world):
@@ -67,8 +70,8 @@ def test_slab_runner_matches_single_domain(oracle, tmp_path, world, S, W, maxage
             env["SOIL_HALO_NEED"] = need
         procs.append(subprocess.Popen(
             [sys.executable, os.path.join(ROOT, "tests", "parallel_worker.py"), str(tmp_path),
-             str(S), str(W), str(steps), str(maxage)], env=env, stdout=subprocess.PIPE,
-            stderr=subprocess.STDOUT))
+             str(S), str(W), str(steps), str(maxage)] + (["pair"] if pair else []), env=env,
+            stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     outs = [p.communicate(timeout=600)[0].decode() for p in procs]
     for p, out in zip(procs, outs):
         assert p.returncode == 0, out[-3000:]

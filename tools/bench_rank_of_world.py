@@ -22,28 +22,20 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
 
 
-class NullComm:
-    class ReduceOp:
-        SUM, MAX = "sum", "max"
+class NullWire:
+    """impl of parallel.CallbackComm that moves nothing"""
 
-    class P2POp:
-        def __init__(self, op, tensor, peer):
-            self.op, self.tensor, self.peer = op, tensor, peer
+    def exchange(self, sends, recvs):
+        pass
 
-    isend, irecv = "isend", "irecv"
-
-    class _Req:
-        def wait(self):
-            pass
-
-    def batch_isend_irecv(self, ops):
-        return [self._Req() for _ in ops]
-
-    def all_reduce(self, t, op="sum"):
+    def all_reduce(self, addr, n):
         pass
 
     def barrier(self):
         pass
+
+    def max_over_ranks(self, value):
+        return value
 
 
 def main():
@@ -54,13 +46,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     args = ap.parse_args()
     from soillib_amd import soil
-    from soillib_amd.parallel import SlabRunner
+    from soillib_amd.parallel import CallbackComm, SlabRunner
     from util import script_param
     base = None
     for world in [int(w) for w in args.worlds.split(",")]:
         param = script_param(soil.param_t())
         r = SlabRunner(rows_per_rank=args.size, W=args.size, param=param, particles_div=8, seed=0,
-                       comm=NullComm(), rank=world // 2, world=world,
+                       comm=CallbackComm(world // 2, world, NullWire()),
                        scale=[20.0 / args.size, 20.0 / args.size, 4.0], noise_rows=args.size)
         for _ in range(args.warmup):
             r.step()
@@ -76,6 +68,7 @@ def main():
         print("world %d rank %d: rows %d (+%d ghost), N %d: %.2f ms/step, %.2f G particle steps, "
               "compute-side efficiency %.3f" % (world, r.rank, args.size, r.rows - args.size, r.N,
                                                 ms, steps / 1e9, base / ms), flush=True)
+        r.close()
         del r
         from soillib_amd import silt
         silt.empty_cache()
