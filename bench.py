@@ -241,6 +241,11 @@ class _Single:
         from soillib_amd import _abi, silt, soil
         from soillib_amd.erosion import ErosionModel
         self.abi, self.lib, self.serial = _abi, _abi.lib(), serial
+        # a chain of steps does not re-zero the flux planes between steps: the particle launches'
+        # first rounds overwrite them (soil_erode_step_ex's lazy flags, what soil_erode runs with);
+        # SOIL_BENCH_EAGER_FLUX=1: the reference's set(track.*, 0) semantics after every step
+        self.lazy = not serial and os.environ.get("SOIL_BENCH_EAGER_FLUX") != "1"
+        self.dirty = False
         self.H, self.W = H, W
         scale = (20.0 / H, 20.0 / W, 4.0)
         self.model = model = ErosionModel(H, W, scale, param, H * W // particles_div, seed=0)
@@ -262,10 +267,11 @@ class _Single:
             if ev: ev.record(1)
             model.particles_debris()
         else:                     # both launches overlapped on two streams
-            model.particles_pair()
+            model.particles_pair(overwrite=self.dirty)
             if ev: ev.record(1)
         if ev: ev.record(2)
-        model.cells_fused()
+        model.cells_fused(keep_flux=self.lazy)
+        self.dirty = self.lazy
         if ev: ev.record(3)
         model.swap_layers()
         model.step_index += 1

@@ -277,6 +277,12 @@ typedef struct soil_erosion_planes {
  * HBM-roofline kernel: 112 algorithmic bytes per cell. */
 int soil_erode_cells_fused(const soil_erosion_planes* planes, const soil_domain* dom,
                            const float scale[3], const soil_param* param, void* stream);
+/* The same with flags.  SOIL_CELLS_KEEP_FLUX: the five flux planes are read and left as they are
+ * (84 bytes per cell instead of 112); whoever adds to them next must overwrite them first —
+ * SOIL_FLUX_OVERWRITE of the particle launches does. */
+#define SOIL_CELLS_KEEP_FLUX 1
+int soil_erode_cells_fused_ex(const soil_erosion_planes* planes, const soil_domain* dom,
+                              const float scale[3], const soil_param* param, int flags, void* stream);
 
 /* Particle halves of transport_fluvial / transport_debris alone (no
  * normalise), on a slab: __transport_fluvial erosion.cu:29-141,
@@ -316,6 +322,17 @@ int soil_particles_pair_slab(const soil_erosion_planes* planes, soil_rng* rng_fl
                              soil_rng* rng_debris, int64_t N, float* remote0,
                              const soil_domain* dom, const float scale[3], const soil_param* param,
                              void* stream);
+/* The same with flags.  SOIL_FLUX_OVERWRITE: the flux planes hold stale values on entry (the cell
+ * phase ran with SOIL_CELLS_KEEP_FLUX) and hold exactly this call's deposits on return.  The tiled
+ * launch shape gets there without a clearing pass: the first round of each launch, whose tiles
+ * partition the plane, flushes its LDS accumulators with plain stores — zeros included — instead
+ * of read-modify-writes; where that cannot be done (an empty tile, a tile shared by several
+ * work-groups, the small-N launch shapes) the planes are cleared first. */
+#define SOIL_FLUX_OVERWRITE 1
+int soil_particles_pair_slab_ex(const soil_erosion_planes* planes, soil_rng* rng_fluvial,
+                                soil_rng* rng_debris, int64_t N, float* remote0,
+                                const soil_domain* dom, const float scale[3],
+                                const soil_param* param, int flags, void* stream);
 /* ------------------------------------------------ erosion: whole steps */
 
 /* One whole erosion step on one device: re-seed the particle streams at
@@ -333,6 +350,16 @@ int soil_particles_pair_slab(const soil_erosion_planes* planes, soil_rng* rng_fl
 int soil_erode_step(const soil_erosion_planes* planes, soil_rng* rng, int64_t N, uint64_t seed,
                     uint64_t step_index, int64_t H, int64_t W, const float scale[3],
                     const soil_param* param, void* stream);
+/* A step inside a chain of steps.  The reference zeroes its track planes between steps
+ * (example/dem_process.py: silt.set(track.*, 0)) — 28 bytes of stores per cell that nobody reads.
+ * SOIL_STEP_FLUX_OUT_DIRTY: this step leaves the five flux planes holding its accumulated flux
+ * (SOIL_CELLS_KEEP_FLUX); SOIL_STEP_FLUX_IN_DIRTY: the previous step did so, this step's particle
+ * launches overwrite them (SOIL_FLUX_OVERWRITE).  flags == 0 is soil_erode_step. */
+#define SOIL_STEP_FLUX_IN_DIRTY 1
+#define SOIL_STEP_FLUX_OUT_DIRTY 2
+int soil_erode_step_ex(const soil_erosion_planes* planes, soil_rng* rng, int64_t N, uint64_t seed,
+                       uint64_t step_index, int64_t H, int64_t W, const float scale[3],
+                       const soil_param* param, int flags, void* stream);
 
 /* The containers of the legacy API (example/erosion_gpu.py:44-71): model_t, the `data` and the
  * `track` buffers.  All float32 device planes of H*W cells ((H,W,2) for the momenta). */

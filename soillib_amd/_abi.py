@@ -18,6 +18,9 @@ SOIL_ERR_HIP = -3
 SOIL_ERR_OUT_OF_MEMORY = -4
 
 D4, D8 = 0, 1
+SOIL_CELLS_KEEP_FLUX = 1
+SOIL_FLUX_OVERWRITE = 1
+SOIL_STEP_FLUX_IN_DIRTY, SOIL_STEP_FLUX_OUT_DIRTY = 1, 2
 
 _PARAM_FLOATS = (
     "lrate", "timeStep", "exitSlope", "uplift", "rainfall", "gravity", "evapRate",
@@ -111,6 +114,12 @@ SIGNATURES = {
                                    [C.POINTER(Domain), F3, C.POINTER(Param), vp]),
     "soil_particles_pair_slab": (cint, [C.POINTER(ErosionPlanes), vp, vp, i64, vp,
                                         C.POINTER(Domain), F3, C.POINTER(Param), vp]),
+    "soil_particles_pair_slab_ex": (cint, [C.POINTER(ErosionPlanes), vp, vp, i64, vp,
+                                           C.POINTER(Domain), F3, C.POINTER(Param), cint, vp]),
+    "soil_erode_cells_fused_ex": (cint, [C.POINTER(ErosionPlanes), C.POINTER(Domain), F3,
+                                         C.POINTER(Param), cint, vp]),
+    "soil_erode_step_ex": (cint, [C.POINTER(ErosionPlanes), vp, i64, u64, u64, i64, i64, F3,
+                                  C.POINTER(Param), cint, vp]),
     "soil_erode_step": (cint, [C.POINTER(ErosionPlanes), vp, i64, u64, u64, i64, i64, F3,
                                C.POINTER(Param), vp]),
     "soil_erode": (cint, [C.POINTER(ErodeModel), i64, i64, i64, u64, u64, cint, F3, C.POINTER(Param),

@@ -311,7 +311,9 @@ __device__ __forceinline__ CellResult fused_cell(const Nbhd& nb, float uplift, f
 // DIRECT: every lane stores its own 32 bytes of a two-channel plane (round 1's stores) instead of
 // swapping them through LDS into 1 KiB-contiguous instructions — kept for A/B inside bench.py
 // (SOIL_CELLS_VARIANT=4)
-template <bool XCD_REMAP, bool NT, int BLOCK = kBlock, bool DIRECT = false>
+// REZERO = false: the five flux planes are left as they are (SOIL_CELLS_KEEP_FLUX: the next particle
+// launch overwrites them, soil_erode_step's lazy mode) — 84 instead of 112 bytes per cell.
+template <bool XCD_REMAP, bool NT, int BLOCK = kBlock, bool DIRECT = false, bool REZERO = true>
 __global__ void __launch_bounds__(BLOCK)
     k_erode_cells_fused(Planes P, Dom d, Scale3 s, Param p, int64_t groups_per_row,
                         int64_t total_groups) {
@@ -396,8 +398,10 @@ __global__ void __launch_bounds__(BLOCK)
       Row4 z2;
 #pragma unroll
       for (int k = 0; k < kVec; ++k) z2.v[k] = make_float2(0.0f, 0.0f);
-      store_row4<NT>(P.velocityFlux + n0, z2);
-      store_row4<NT>(P.debrisVelocityFlux + n0, z2);
+      if (REZERO) {
+        store_row4<NT>(P.velocityFlux + n0, z2);
+        store_row4<NT>(P.debrisVelocityFlux + n0, z2);
+      }
     }
   } else {
     // A lane's four cells of a two-channel plane are 32 contiguous bytes: stored as they are, every
@@ -414,7 +418,7 @@ __global__ void __launch_bounds__(BLOCK)
     pair(P.layers_next, o_layers);
     pair(P.velocity, o_vel);
     pair(P.debrisVelocity, o_dvel);
-    {  // re-zero the two-channel flux planes (zeros need no swapping: lane i takes the i-th and the
+    if (REZERO) {  // re-zero the two-channel flux planes (zeros need no swapping: lane i takes the i-th and the
        // (64 + i)-th 16 bytes of the wave's stretch — every lane of the wave, its idle ones included)
       const int n_real = 2 * __popcll(__ballot(active));
       v4f* zv = reinterpret_cast<v4f*>(P.velocityFlux + wave_n0);
@@ -435,11 +439,12 @@ __global__ void __launch_bounds__(BLOCK)
   store4<NT>(P.waterHeight + n0, o_wh);
   store4<NT>(P.mass + n0, o_m);
   store4<NT>(P.debris + n0, o_d);
-  // re-zero the scalar flux planes for the next step's atomics
-  const float z[kVec] = {0.0f, 0.0f, 0.0f, 0.0f};
-  store4<NT>(P.waterFlux + n0, z);
-  store4<NT>(P.massFlux + n0, z);
-  store4<NT>(P.debrisFlux + n0, z);
+  if (REZERO) {  // re-zero the scalar flux planes for the next step's atomics
+    const float z[kVec] = {0.0f, 0.0f, 0.0f, 0.0f};
+    store4<NT>(P.waterFlux + n0, z);
+    store4<NT>(P.massFlux + n0, z);
+    store4<NT>(P.debrisFlux + n0, z);
+  }
 }
 
 // Experiment (SOIL_CELLS_WARM=<stride in KiB>): one word of every `stride` bytes of every plane's
@@ -469,7 +474,7 @@ __global__ void __launch_bounds__(256)
 
 // scalar path for W % 4 != 0 (ragged widths): one thread per cell
 __global__ void __launch_bounds__(kBlock)
-    k_erode_cells_fused_scalar(Planes P, Dom d, Scale3 s, Param p) {
+    k_erode_cells_fused_scalar(Planes P, Dom d, Scale3 s, Param p, bool rezero) {
   const int64_t t = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
   if (t >= (d.r1 - d.r0) * d.W) return;
   const int64_t lx = d.r0 + t / d.W, y = t % d.W;
@@ -484,6 +489,7 @@ __global__ void __launch_bounds__(kBlock)
   P.velocity[n] = r.fl.velocity;
   P.debris[n] = r.db.mass;
   P.debrisVelocity[n] = r.db.velocity;
+  if (!rezero) return;
   P.waterFlux[n] = 0.0f;
   P.massFlux[n] = 0.0f;
   P.debrisFlux[n] = 0.0f;
@@ -644,6 +650,11 @@ int soil_albedo_discharge(float* albedo, const float* discharge, int64_t n,
 
 int soil_erode_cells_fused(const soil_erosion_planes* pl, const soil_domain* dom,
                            const float scale[3], const soil_param* param, void* stream) {
+  return soil_erode_cells_fused_ex(pl, dom, scale, param, 0, stream);
+}
+
+int soil_erode_cells_fused_ex(const soil_erosion_planes* pl, const soil_domain* dom,
+                              const float scale[3], const soil_param* param, int flags, void* stream) {
   SOIL_DEVICE();
   SOIL_REQUIRE(pl && dom && scale && param, "erode_cells_fused: null argument");
   SOIL_REQUIRE(pl->layers && pl->layers_next && pl->uplift && pl->rainfall && pl->waterHeight &&
@@ -711,7 +722,12 @@ int soil_erode_cells_fused(const soil_erosion_planes* pl, const soil_domain* dom
       if (int rc2 = workspace_get(8, 256, &sink); rc2 != SOIL_OK) return rc2;
       k_touch_pages<<<static_cast<unsigned>(8 * ((pages + 255) / 256)), 256, 0, st>>>(t, stride, static_cast<uint32_t*>(sink));
     }
-    if (variant == 1 && (total % 512) == 0 && ((total / 512) % 8) == 0)
+    const bool keep = (flags & SOIL_CELLS_KEEP_FLUX) != 0;
+    if (keep && remap)
+      k_erode_cells_fused<true, false, kBlock, false, false><<<nblk, kBlock, 0, st>>>(P, d, s3(scale), *param, groups_per_row, total);
+    else if (keep)
+      k_erode_cells_fused<false, false, kBlock, false, false><<<nblk, kBlock, 0, st>>>(P, d, s3(scale), *param, groups_per_row, total);
+    else if (variant == 1 && (total % 512) == 0 && ((total / 512) % 8) == 0)
       k_erode_cells_fused<true, false, 512><<<static_cast<unsigned>(total / 512), 512, 0, st>>>(P, d, s3(scale), *param, groups_per_row, total);
     else if (variant == 3 && (total % 128) == 0 && ((total / 128) % 8) == 0)
       k_erode_cells_fused<true, false, 128><<<static_cast<unsigned>(total / 128), 128, 0, st>>>(P, d, s3(scale), *param, groups_per_row, total);
@@ -726,8 +742,8 @@ int soil_erode_cells_fused(const soil_erosion_planes* pl, const soil_domain* dom
     else
       k_erode_cells_fused<false, false><<<nblk, kBlock, 0, st>>>(P, d, s3(scale), *param, groups_per_row, total);
   } else {
-    k_erode_cells_fused_scalar<<<blocks_for(cells, kBlock), kBlock, 0, st>>>(P, d, s3(scale),
-                                                                              *param);
+    k_erode_cells_fused_scalar<<<blocks_for(cells, kBlock), kBlock, 0, st>>>(
+        P, d, s3(scale), *param, (flags & SOIL_CELLS_KEEP_FLUX) == 0);
   }
   SOIL_LAUNCH_CHECK();
   return SOIL_OK;

@@ -639,6 +639,13 @@ int soil_particles_pair_slab(const soil_erosion_planes* planes, soil_rng* rng_fl
                              soil_rng* rng_debris, int64_t N, float* remote0,
                              const soil_domain* dom, const float scale[3], const soil_param* param,
                              void* stream) {
+  return soil_particles_pair_slab_ex(planes, rng_fluvial, rng_debris, N, remote0, dom, scale, param, 0, stream);
+}
+
+int soil_particles_pair_slab_ex(const soil_erosion_planes* planes, soil_rng* rng_fluvial,
+                                soil_rng* rng_debris, int64_t N, float* remote0,
+                                const soil_domain* dom, const float scale[3], const soil_param* param,
+                                int flags, void* stream) {
   SOIL_DEVICE();
   SOIL_REQUIRE(planes && dom && scale && param, "particles_pair_slab: null argument");
   const soil_erosion_planes& P = *planes;
@@ -650,11 +657,23 @@ int soil_particles_pair_slab(const soil_erosion_planes* planes, soil_rng* rng_fl
   const Dom d = to_dom(dom);
   int rc = check_domain(d);
   if (rc != SOIL_OK) return rc;
-  if (N <= 0) return SOIL_OK;
-  const Scale3 s = s3p(scale);
   hipStream_t st = as_stream(stream);
+  const bool overwrite = (flags & SOIL_FLUX_OVERWRITE) != 0;
+  auto clear_flux = [&]() -> int {  // what a launch that cannot store its first round does instead
+    const size_t b = sizeof(float) * static_cast<size_t>(d.rows) * static_cast<size_t>(d.W);
+    SOIL_HIP(hipMemsetAsync(P.waterFlux, 0, b, st));
+    SOIL_HIP(hipMemsetAsync(P.massFlux, 0, b, st));
+    SOIL_HIP(hipMemsetAsync(P.velocityFlux, 0, 2 * b, st));
+    SOIL_HIP(hipMemsetAsync(P.debrisFlux, 0, b, st));
+    SOIL_HIP(hipMemsetAsync(P.debrisVelocityFlux, 0, 2 * b, st));
+    return SOIL_OK;
+  };
+  if (N <= 0) return overwrite ? clear_flux() : SOIL_OK;
+  const Scale3 s = s3p(scale);
   if (use_tiled(N, d))
-    return launch_pair_tiled(P, rng_fluvial, rng_debris, N, remote0, d, s, *param, st);
+    return launch_pair_tiled(P, rng_fluvial, rng_debris, N, remote0, d, s, *param, st, overwrite);
+  if (overwrite)
+    if (int rc2 = clear_flux(); rc2 != SOIL_OK) return rc2;
   rc = launch_particles_fluvial(P.waterFlux, P.massFlux, P.velocityFlux, nullptr, rng_fluvial, N,
                                 P.layers, P.rainfall, P.waterHeight, P.velocity, nullptr, remote0, d,
                                 s, *param, st);

@@ -538,6 +538,7 @@ struct TiledHostWord {  // pinned, device-mapped
   uint32_t blocks;  // work-groups the round needs (entries of the block list)
   unsigned long long steps;
   uint32_t seq;     // written last: the number of the k_queue_prepare launch that filled the word
+  uint32_t whole;   // 1: one work-group per tile and no tile empty (the round's flush may store, see `store_all`)
 };
 
 #ifdef SOIL_PROF
@@ -685,9 +686,13 @@ __global__ void __launch_bounds__(1024)
     if (!cut && t > 0) block_list[pos] = make_uint4(static_cast<uint32_t>(i), start[i * kNB], t, 0u);
   }
   if (!cut) {  // the common case on large grids: one work-group per non-empty tile
-    if (tid == 0) publish(static_cast<uint32_t>(tiles) - hist[255]);
+    if (tid == 0) {
+      host->whole = hist[255] == 0 ? 1u : 0u;
+      publish(static_cast<uint32_t>(tiles) - hist[255]);
+    }
     return;
   }
+  if (tid == 0) host->whole = 0u;
   __syncthreads();
   auto groups = [&](int64_t pos) {
     const uint32_t t = tile_order[pos];
@@ -834,10 +839,14 @@ __global__ void __launch_bounds__(1024)
   };
   PREP_AT(2);  // start, order, jobs of uncut queues
   if (!cut) {  // the common case on large grids: one work-group per non-empty tile
-    if (tid == 0) publish(static_cast<uint32_t>(tiles) - hist[255]);
+    if (tid == 0) {
+      host->whole = hist[255] == 0 ? 1u : 0u;
+      publish(static_cast<uint32_t>(tiles) - hist[255]);
+    }
     PREP_AT(4);
     return;
   }
+  if (tid == 0) host->whole = 0u;
   __syncthreads();
   // queues cut into chunks: position p of the ordered list gets ceil(queue / cap) work-groups.
   // The divisions run with one position per thread (strided); the scan takes the counts from LDS
@@ -1119,7 +1128,7 @@ __global__ void __launch_bounds__(NT, round_waves_per_simd(KIND, TR, TC, NT, ALB
                   float* __restrict__ remote0, unsigned long long* __restrict__ steps, Dom d,
                   Scale3 s, Param param, int tiles_w, int off_r, int off_c, int steps_per_round,
                   TileShape ts_next,
-                  int tiles_w_next, int agg_min, int agg_groups, int retries) {
+                  int tiles_w_next, int agg_min, int agg_groups, int retries, int store_all) {
   constexpr int kCells = TR * TC, kBlock = NT, kPer = (kCells + NT - 1) / NT;
   PROF_DECL;
   // this work-group's share of its tile's queue (k_queue_prepare's block list)
@@ -1404,6 +1413,22 @@ __global__ void __launch_bounds__(NT, round_waves_per_simd(KIND, TR, TC, NT, ALB
       ax[j] = ok ? s_v[2 * c] : 0.0f;
       ay[j] = ok ? s_v[2 * c + 1] : 0.0f;
     }
+    if (store_all) {
+      // The first round of a launch that was told to OVERWRITE the flux planes (soil_erode_step's
+      // lazy mode: the cell phase did not re-zero them): every tile has exactly one work-group, the
+      // tiles partition the plane, so plain stores of the tile's accumulators — zeros included —
+      // leave the planes holding this round's deposits and nothing else, without a read.
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int c = tid + (j0 + j) * kBlock;
+        const int lx = row0 + c / TC, y = col0 + c % TC;
+        if (!(c < kCells && lx >= 0 && y >= 0 && lx < static_cast<int>(d.rows) && y < k.W)) continue;
+        flux0[l[j]] = a0[j];
+        if (KIND == FLUVIAL) flux1[l[j]] = a1[j];
+        fluxV[l[j]] = make_float2(ax[j], ay[j]);
+      }
+      continue;
+    }
     if (shared_tile) {  // uniform per work-group
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
@@ -1625,6 +1650,10 @@ struct TiledRun {
   unsigned long long steps_before = 0;
   bool timed = false, done = false;
   bool ready = false, skip_pack = false;  // setup() done; p4 filled by k_tiled_pack_pair
+  // The flux planes hold stale values on entry (the cell phase left them as they were): the launch
+  // must leave them holding its deposits only.  Round 0 stores instead of adding where it can (one
+  // work-group per tile, none empty, no colour planes); otherwise the planes are cleared first.
+  bool overwrite = false;
   int resident_groups[2] = {512, 512};  // work-groups of a round kernel the chip holds at once (early, late shape)
 
   int shape_of(uint64_t r) const { return r >= static_cast<uint64_t>(switch_round) ? shape_late : shape_early; }
@@ -1887,6 +1916,17 @@ struct TiledRun {
                    h[h.size() / 2], h[h.size() * 9 / 10], h[h.size() * 99 / 100], h.back(),
                    static_cast<unsigned long long>(batches), timed ? rate * 1e-9 : 0.0);
     }
+    int store_all = 0;
+    if (overwrite && round == 0) {
+      if (host->whole == 1u && live > 0 && !fluxA && deposit == 0) {
+        store_all = 1;
+      } else {  // cannot: clear the planes the launch adds to
+        const size_t cells_b = sizeof(float) * static_cast<size_t>(d.rows) * static_cast<size_t>(d.W);
+        SOIL_HIP(hipMemsetAsync(flux0, 0, cells_b, st));
+        if (flux1) SOIL_HIP(hipMemsetAsync(flux1, 0, cells_b, st));
+        SOIL_HIP(hipMemsetAsync(fluxV, 0, 2 * cells_b, st));
+      }
+    }
     // every live particle advances >= 1 step per round: maxage + 2 rounds always suffice
     if (live == 0 || round >= p.maxage + 2) return finish_steps();
     if (round > 0 && (static_cast<int64_t>(live) <= tail || rate < finish_rate)) {
@@ -1905,7 +1945,7 @@ struct TiledRun {
                             reinterpret_cast<float2*>(fluxV), fluxA, static_cast<const float4*>(p4),
                             remote0, steps_run, d, s, p, tiles_w, ts_cur.off_r, ts_cur.off_c,
                             steps_per_round, ts_of(sh_next, round + 1),
-                            tiles_w_of(sh_next, round + 1), agg_min, agg_groups, retries);
+                            tiles_w_of(sh_next, round + 1), agg_min, agg_groups, retries, store_all);
     else
       launch_round<KIND, 1>(sh, blocks, st, next, dest, rank, count_next,
                             static_cast<const PRec*>(cur), static_cast<const uint32_t*>(order),
@@ -1913,7 +1953,7 @@ struct TiledRun {
                             reinterpret_cast<float2*>(fluxV), fluxA, static_cast<const float4*>(p4),
                             remote0, steps_run, d, s, p, tiles_w, ts_cur.off_r, ts_cur.off_c,
                             steps_per_round, ts_of(sh_next, round + 1),
-                            tiles_w_of(sh_next, round + 1), agg_min, agg_groups, retries);
+                            tiles_w_of(sh_next, round + 1), agg_min, agg_groups, retries, store_all);
     SOIL_LAUNCH_CHECK();
     SOIL_HIP(hipEventRecord(ev1, st));
     timed = true;
@@ -1955,7 +1995,7 @@ static int run_tiled(float* flux0, float* flux1, float* fluxV, float* fluxA,
 // Both launches of a step, overlapped: two internal streams forked from `st` and joined
 // back into it; the host alternates between the two runs' decisions.
 int launch_pair_tiled(const soil_erosion_planes& P, soil_rng* rng_fluvial, soil_rng* rng_debris, int64_t N,
-                      float* remote0, const Dom& d, Scale3 s, const Param& p, hipStream_t st) {
+                      float* remote0, const Dom& d, Scale3 s, const Param& p, hipStream_t st, bool overwrite) {
   // forked streams and their events, one set per (thread, device)
   struct Fork {
     hipStream_t sA = nullptr, sB = nullptr;
@@ -1993,6 +2033,7 @@ int launch_pair_tiled(const soil_erosion_planes& P, soil_rng* rng_fluvial, soil_
   const uint64_t delay = delay_env > 0 ? static_cast<uint64_t>(delay_env) : 2;
   // Whatever happens in between, `st` is joined with both streams before this returns: rounds may
   // still be in flight on the workspace the next call reuses.
+  A.overwrite = B.overwrite = overwrite;
   auto run = [&]() -> int {
     if (int rc = A.setup(); rc != SOIL_OK) return rc;
     if (int rc = B.setup(); rc != SOIL_OK) return rc;

@@ -60,6 +60,12 @@ int soil_ghost_extent(int32_t* depth, const float* plane, int64_t rows, int64_t 
 int soil_erode_step(const soil_erosion_planes* planes, soil_rng* rng, int64_t N, uint64_t seed,
                     uint64_t step_index, int64_t H, int64_t W, const float scale[3],
                     const soil_param* param, void* stream) {
+  return soil_erode_step_ex(planes, rng, N, seed, step_index, H, W, scale, param, 0, stream);
+}
+
+int soil_erode_step_ex(const soil_erosion_planes* planes, soil_rng* rng, int64_t N, uint64_t seed,
+                       uint64_t step_index, int64_t H, int64_t W, const float scale[3],
+                       const soil_param* param, int flags, void* stream) {
   SOIL_DEVICE();
   SOIL_REQUIRE(planes && rng && scale && param, "erode_step: null argument");
   SOIL_REQUIRE(H > 0 && W > 0 && N > 0, "erode_step: empty grid or no particles");
@@ -75,7 +81,17 @@ int soil_erode_step(const soil_erosion_planes* planes, soil_rng* rng, int64_t N,
   // read on every call (one getenv per step): a host may switch it between steps
   const char* pair_env = std::getenv("SOIL_STEP_PAIR");
   const bool sequential = pair_env && pair_env[0] == '0';
+  // Lazy flux planes (SOIL_STEP_FLUX_IN_DIRTY / _OUT_DIRTY): a chain of steps need not write 28 bytes
+  // of zeros per cell and step — the first round of the next step's particle launches overwrites
+  // the planes (SOIL_FLUX_OVERWRITE) — only the last step of a chain re-zeroes them.
+  const bool in_dirty = (flags & SOIL_STEP_FLUX_IN_DIRTY) != 0, out_dirty = (flags & SOIL_STEP_FLUX_OUT_DIRTY) != 0;
+  const int cell_flags = out_dirty ? SOIL_CELLS_KEEP_FLUX : 0;
   if (sequential) {  // one launch after the other on the caller's streams (diagnostics: phase timings)
+    if (in_dirty) {
+      const size_t b = sizeof(float) * static_cast<size_t>(H) * static_cast<size_t>(W);
+      for (float* t : {P.waterFlux, P.massFlux, P.debrisFlux}) SOIL_HIP(hipMemsetAsync(t, 0, b, as_stream(stream)));
+      for (float* t : {P.velocityFlux, P.debrisVelocityFlux}) SOIL_HIP(hipMemsetAsync(t, 0, 2 * b, as_stream(stream)));
+    }
     if (int rc = soil_rng_seed(rng, N, seed, offset, stream); rc != SOIL_OK) return rc;
     if (int rc = soil_particles_fluvial_slab(P.waterFlux, P.massFlux, P.velocityFlux, nullptr, rng, N,
                                              P.layers, P.rainfall, P.waterHeight, P.velocity, nullptr,
@@ -87,7 +103,7 @@ int soil_erode_step(const soil_erosion_planes* planes, soil_rng* rng, int64_t N,
                                             stream);
         rc != SOIL_OK)
       return rc;
-    return soil_erode_cells_fused(planes, &dom, scale, param, stream);
+    return soil_erode_cells_fused_ex(planes, &dom, scale, param, cell_flags, stream);
   }
   // The two launches do not depend on each other (they add to different flux planes and read the
   // same fields), so they run overlapped: the sparse late rounds and the finishing launch of
@@ -100,10 +116,11 @@ int soil_erode_step(const soil_erosion_planes* planes, soil_rng* rng, int64_t N,
   soil_rng* rng_fluvial = static_cast<soil_rng*>(scratch);
   if (int rc = soil_rng_seed(rng_fluvial, N, seed, offset, stream); rc != SOIL_OK) return rc;
   if (int rc = soil_rng_seed(rng, N, seed, offset + 2, stream); rc != SOIL_OK) return rc;
-  if (int rc = soil_particles_pair_slab(planes, rng_fluvial, rng, N, nullptr, &dom, scale, param, stream);
+  if (int rc = soil_particles_pair_slab_ex(planes, rng_fluvial, rng, N, nullptr, &dom, scale, param,
+                                           in_dirty ? SOIL_FLUX_OVERWRITE : 0, stream);
       rc != SOIL_OK)
     return rc;
-  return soil_erode_cells_fused(planes, &dom, scale, param, stream);
+  return soil_erode_cells_fused_ex(planes, &dom, scale, param, cell_flags, stream);
 }
 
 int soil_erode(const soil_erode_model* model, int64_t H, int64_t W, int64_t N, uint64_t seed,
@@ -152,8 +169,11 @@ int soil_erode(const soil_erode_model* model, int64_t H, int64_t W, int64_t N, u
   for (int s = 0; s < steps; ++s) {
     P.layers = layers;
     P.layers_next = layers_next;
-    if (int rc = soil_erode_step(&P, rng, N, seed, first_step + static_cast<uint64_t>(s), H, W, scale,
-                                 param, stream);
+    // the track planes were zeroed above and are left zeroed by the last step; in between nobody
+    // looks at them
+    const int flags = (s > 0 ? SOIL_STEP_FLUX_IN_DIRTY : 0) | (s + 1 < steps ? SOIL_STEP_FLUX_OUT_DIRTY : 0);
+    if (int rc = soil_erode_step_ex(&P, rng, N, seed, first_step + static_cast<uint64_t>(s), H, W, scale,
+                                    param, flags, stream);
         rc != SOIL_OK)
       return rc;
     float* t = layers;

@@ -62,8 +62,9 @@ int launch_debris_tiled(float* massFlux, float* velocityFlux, float* albedoFlux,
                         const float* albedoSource, float* remote0, const Dom& d, Scale3 s,
                         const Param& p, hipStream_t st);
 // both launches of a step overlapped on two internal streams forked from / joined into `st`
+// (`overwrite`: the flux planes hold stale values — SOIL_FLUX_OVERWRITE, soil_hip.h)
 int launch_pair_tiled(const soil_erosion_planes& P, soil_rng* rng_fluvial, soil_rng* rng_debris,
                       int64_t N, float* remote0, const Dom& d, Scale3 s, const Param& p,
-                      hipStream_t st);
+                      hipStream_t st, bool overwrite);
 
 }  // namespace soil

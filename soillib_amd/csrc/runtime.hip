@@ -91,6 +91,7 @@ int step_counter(unsigned long long** out) {
   if (!c) {
     SOIL_HIP(hipMalloc(&c, sizeof(unsigned long long)));
     SOIL_HIP(hipMemset(c, 0, sizeof(unsigned long long)));
+    SOIL_HIP(hipDeviceSynchronize());  // once: callers add to it from non-blocking streams
   }
   *out = c;
   return SOIL_OK;

@@ -428,9 +428,12 @@ struct HipOps {
 
 #define HIP_OPS(c) HipOps& o = *static_cast<HipOps*>(c)
 
-int hip_alloc(void*, void** out, int64_t bytes) {
+int hip_alloc(void* c, void** out, int64_t bytes) {
+  HIP_OPS(c);
   SOIL_HIP(hipMalloc(out, static_cast<size_t>(bytes > 0 ? bytes : 4)));
-  SOIL_HIP(hipMemset(*out, 0, static_cast<size_t>(bytes > 0 ? bytes : 4)));
+  // cleared ON THE MAIN LANE: a hipMemset would run on the null stream, which the two (non-blocking)
+  // lanes are not ordered with — it could land after the first kernels that fill the block
+  SOIL_HIP(hipMemsetAsync(*out, 0, static_cast<size_t>(bytes > 0 ? bytes : 4), o.main));
   return SOIL_OK;
 }
 int hip_release(void*, void* p) {

@@ -74,15 +74,18 @@ class ErosionModel:
     def seed_step(self):
         silt.seed(self.rng, self.seed, self.step_index * self.N)
 
-    def particles_pair(self):
+    def particles_pair(self, overwrite=False):
         """Both particle launches of the step, overlapped (soil_particles_pair_slab).  The
         debris launch draws from its own tensor, seeded where the fluvial launch leaves
-        the shared one in the sequential order (two draws per particle further)."""
+        the shared one in the sequential order (two draws per particle further).
+        `overwrite`: the flux planes were left as they were by cells_fused(keep_flux=True)
+        (SOIL_FLUX_OVERWRITE: the launches' first rounds store instead of adding)."""
         silt.seed(self.rng_debris, self.seed, self.step_index * self.N + 2)
         planes = self._planes()
-        _abi.check(_abi.lib().soil_particles_pair_slab(
+        _abi.check(_abi.lib().soil_particles_pair_slab_ex(
             C.byref(planes), self.rng.c_ptr, self.rng_debris.c_ptr, self.N, None,
-            C.byref(self.dom), self._scale(), self.param._ref(), _abi.stream()))
+            C.byref(self.dom), self._scale(), self.param._ref(),
+            _abi.SOIL_FLUX_OVERWRITE if overwrite else 0, _abi.stream()))
 
     def particles_fluvial(self):
         L = _abi.lib()
@@ -99,14 +102,17 @@ class ErosionModel:
             self.layers.c_ptr, self.debrisVelocity.c_ptr, None, None, C.byref(self.dom),
             self._scale(), self.param._ref(), _abi.stream()))
 
-    def cells_fused(self, r0=None, r1=None):
-        """Fused cell phase on local rows [r0, r1) (default: the owned rows)."""
+    def cells_fused(self, r0=None, r1=None, keep_flux=False):
+        """Fused cell phase on local rows [r0, r1) (default: the owned rows).  `keep_flux`: the
+        flux planes are not re-zeroed (SOIL_CELLS_KEEP_FLUX) — the next particles_pair must then
+        be told to overwrite them."""
         d = self.dom
         dom = _abi.Domain(d.H, d.W, d.x0, d.rows, d.r0 if r0 is None else r0,
                           d.r1 if r1 is None else r1)
         planes = self._planes()
-        _abi.check(_abi.lib().soil_erode_cells_fused(C.byref(planes), C.byref(dom), self._scale(),
-                                                     self.param._ref(), _abi.stream()))
+        _abi.check(_abi.lib().soil_erode_cells_fused_ex(
+            C.byref(planes), C.byref(dom), self._scale(), self.param._ref(),
+            _abi.SOIL_CELLS_KEEP_FLUX if keep_flux else 0, _abi.stream()))
 
     def swap_layers(self):
         self.layers, self.layers_next = self.layers_next, self.layers

@@ -1092,7 +1092,98 @@ def test_contended_deposits_conserve_what_the_walkers_carry(hip, oracle, monkeyp
         assert np.isfinite(got).all() and np.isfinite(want).all()
         # the funnel really is contended: one cell holds a large share of everything deposited
         if k == "wf":
-            assert want.max() > 0.01 * want.sum()
+            assert want.max() > 100 * np.median(want[want > 0])
         ref = np.abs(want).sum()
         assert abs(got.sum() - want.sum()) <= 2e-6 * ref, (k, got.sum(), want.sum())
         _flux_close(got.astype(np.float32), want.astype(np.float32), "contended flux " + k)
+
+
+# ---------------------------------------------------------- lazy flux planes
+
+@pytest.mark.parametrize("S,maxage,mode", [(256, 64, 0), (512, 96, 0), (64, 32, 0), (256, 64, 1), (1024, 128, 0)])
+def test_steps_without_rezeroing_the_flux_planes(hip, S, maxage, mode):
+    """soil_erode_step_ex's lazy mode (what soil_erode and bench.py run): the cell phase leaves the
+    flux planes as they are (SOIL_CELLS_KEEP_FLUX) and the next step's particle launches overwrite
+    them (SOIL_FLUX_OVERWRITE) — by plain stores in their first round where every tile has exactly
+    one work-group, by a clearing pass otherwise (small grids with empty or split tiles, the small-N
+    launch shapes).  Every step must leave the same fields as the re-zeroing step does: the flux a
+    cell receives is summed in the same order either way (0 + a == a), so the comparison is exact
+    up to the order of the atomic adds of the late rounds (same tolerance as pair vs sequential)."""
+    from soillib_amd import _abi, silt, soil
+    from soillib_amd.erosion import ErosionModel
+    pp = script_param(soil.param_t())
+    pp.maxage = maxage
+    scale = (20.0 / S, 20.0 / S, 4.0)
+    npar = soil.noise_t()
+    npar.seed = 3.0
+    npar.ext = [S, S]
+    bed = soil.noise(silt.shape(S, S), npar, host=silt.gpu)
+
+    def make():
+        m = ErosionModel(S, S, scale, pp, S * S // 8, seed=0)
+        _abi.check(hip.soil_layers_from_planes(m.layers.c_ptr, bed.c_ptr, None, bed.elem(), None))
+        silt.set(m.rainfall, 1.0)
+        return m
+    a, b = make(), make()
+    assert hip.soil_set_particle_mode(mode) == 0
+    try:
+        dirty = False
+        for step in range(4):
+            a.seed_step()                     # eager: the reference's set(track.*, 0) after every step
+            a.particles_pair()
+            a.cells_fused()
+            a.swap_layers()
+            a.step_index += 1
+            b.seed_step()                     # lazy
+            b.particles_pair(overwrite=dirty)
+            last = step == 3
+            b.cells_fused(keep_flux=not last)
+            dirty = not last
+            b.swap_layers()
+            b.step_index += 1
+            for name in ("layers", "height", "waterHeight", "mass", "velocity", "debris", "debrisVelocity"):
+                x, y = to_np(getattr(a, name)), to_np(getattr(b, name))
+                tol = dict(rtol=1e-4, atol=1e-5 * (np.nanmax(np.abs(x)) + 1e-30))
+                _close_but_for_stray_walks(y, x, tol["rtol"], tol["atol"], 0.0 if step == 0 else 2e-3,
+                                           "step %d %s" % (step, name))
+        for name in ("waterFlux", "massFlux", "velocityFlux", "debrisFlux", "debrisVelocityFlux"):
+            assert not to_np(getattr(b, name)).any(), name + ": the last step of a chain re-zeroes"
+    finally:
+        hip.soil_set_particle_mode(0)
+
+
+def test_erode_chain_leaves_the_track_planes_zeroed(hip):
+    """soil_erode (the legacy composite) runs its steps lazily inside and hands the track planes
+    back zeroed; its terrain equals a chain of plain soil_erode_step calls."""
+    import soillib as soil
+    from soillib_amd import silt
+    S = 192
+    q = soil.noise_t()
+    q.seed = 3.0
+    q.ext = [S, S]
+    planes = lambda *dims: silt.tensor(silt.float32, silt.shape(*dims), silt.gpu)
+
+    def run(chunks):
+        model = soil.map_t(silt.shape(S, S), [20.0 / S, 20.0 / S, 4.0])
+        model.height = soil.noise(silt.shape(S, S), q, host=silt.gpu)
+        model.sediment, model.uplift, model.rainfall = planes(S, S), planes(S, S), planes(S, S)
+        silt.set(model.sediment, 0.0)
+        silt.set(model.uplift, 0.0)
+        silt.set(model.rainfall, 1.0)
+        data, track = soil.data_t(silt.shape(S, S)), soil.data_t(silt.shape(S, S))
+        for d in (data, track):
+            d.discharge, d.mass, d.debris = planes(S, S), planes(S, S), planes(S, S)
+            d.momentum, d.debris_momentum = planes(S, S, 2), planes(S, S, 2)
+            for t in (d.discharge, d.mass, d.debris, d.momentum, d.debris_momentum):
+                silt.set(t, 0.0)
+        p = soil.param_t()
+        p.samples, p.maxage, p.timeStep = S * S // 8, 64, 1000.0
+        for n in chunks:
+            soil.erode(model, data, track, p, n)
+        for t in (track.discharge, track.mass, track.debris, track.momentum, track.debris_momentum):
+            assert not t.cpu().numpy().any()
+        return model.height.cpu().numpy(), data.discharge.cpu().numpy()
+    h4, d4 = run([4])            # one chain of four (steps 2..4 start from dirty planes)
+    h1, d1 = run([1, 1, 1, 1])   # four chains of one (every step eager)
+    _close_but_for_stray_walks(h4, h1, 1e-4, 1e-6, 2e-3, "height")
+    _close_but_for_stray_walks(d4, d1, 1e-4, 1e-5 * np.nanmax(np.abs(d1)), 2e-3, "discharge")
