@@ -37,6 +37,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 CELL_BYTES = 112               # fused floor, SURVEY.md §8d / DESIGN.md §Roofline
+CELL_BYTES_LAZY = 84           # ... without the 28 B/cell re-zero of the flux planes (lazy chain of steps)
 
 
 def script_param(soil):
@@ -421,14 +422,19 @@ def main():
     ms_step = elapsed / K * 1e3
     cells_rank = S * W
     t_cells = (phase[2] - phase[3] - phase[4]) / K * 1e-3
-    achieved = CELL_BYTES * cells_rank / t_cells / 1e9
+    # bytes the fused kernel has to move as launched: 112 per cell with the flux planes re-zeroed in
+    # the same pass (SURVEY.md 8d's fused floor), 84 when the chain of steps leaves that to the
+    # particle launches' first rounds (soil_erode_step_ex: 28 B/cell of zero stores never written)
+    lazy = bool(getattr(runner, "lazy", False))
+    cell_bytes = CELL_BYTES_LAZY if lazy else CELL_BYTES
+    achieved = cell_bytes * cells_rank / t_cells / 1e9
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic_fused_cells.json")
     if os.path.exists(tpath):
         try:
             t = json.load(open(tpath))
-            if list(t.get("grid", [])) == [S, W]:   # measured for this launch size only
-                traffic = t.get("hbm_bytes_per_launch")
+            if list(t.get("grid", [])) == [S, W] and bool(t.get("lazy_flux", False)) == lazy:
+                traffic = t.get("hbm_bytes_per_launch")   # measured for this launch size and mode only
         except Exception:
             traffic = None
     # the kernel that carries the step is bound by VALU issue, not HBM: its measured share of busy
@@ -477,7 +483,13 @@ def main():
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic,
                      "stream_probe": probe,
-                     "algorithmic_bytes_per_launch": CELL_BYTES * cells_rank,
+                     "algorithmic_bytes_per_launch": cell_bytes * cells_rank,
+                     "algorithmic_bytes_per_cell": cell_bytes,
+                     "flux_planes": ("left to the next step's particle launches (their first rounds "
+                                     "store instead of adding): 84 B/cell, the 28 B/cell re-zero of "
+                                     "SURVEY 8d's 112-B floor is never written") if lazy else
+                                    "re-zeroed by this kernel: SURVEY 8d's 112-B fused floor",
+                     "vs_survey_floor_112B_per_cell": CELL_BYTES * cells_rank / t_cells / 1e9 / HBM_PEAK_GBS,
                      "avg_launch_ms": t_cells * 1e3},
     }
     out["roofline_particles"] = proof

@@ -1061,7 +1061,10 @@ static void orc_blur_pass(float* out, const float* in, int64_t H, int64_t W, int
           if (ny > W - 1) ny = W - 1;
           const float Z = sqrtf(2.0f * 3.14159265f) * sigma;                          /* :47 */
           const float kernel = orc_expf(-0.5f * ((float)k / sigma) * ((float)k / sigma)) / Z; /* :48 */
-          val += in[C * (nx * W + ny) + c] * kernel; /* :49-50 */
+          /* `val += src * kernel`, :49-50, as nvcc compiles it: its default -fmad=true contracts the
+           * statement into one fused multiply-add (this file is built with -ffp-contract=off, so the
+           * fma is written out) */
+          val = fmaf(in[C * (nx * W + ny) + c], kernel, val);
         }
         out[C * (x * W + y) + c] = val; /* :54 */
       }

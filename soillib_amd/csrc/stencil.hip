@@ -339,16 +339,20 @@ struct BlurWeights {
 };
 
 // __blur<T>, filter.cu:24-70: 33 taps along one axis, index clamped to the edge,
-// accumulated in the order k = -16..16 (:35-54).  Two launch shapes, both on the
+// accumulated in the order k = -16..16 (:35-54).  `val += src * kernel` (:50) is stated as the fused
+// multiply-add nvcc makes of it (its default -fmad=true contracts the statement; this build and the
+// oracle compile with contraction off, so the fma is written out on both sides): one rounding per
+// tap, as on the reference's hardware, and half the instructions.  Two launch shapes, both on the
 // plane seen as an (H, W*C) matrix of floats:
 //
 //  * along axis 0 (rows): a thread owns one float column of a 32-row band, reads the
 //    64 rows it needs (coalesced across the wave) into registers and produces its 32
 //    outputs from them — no LDS, 33 taps from registers;
 //  * along axis 1 (the contiguous one): a work-group stages a 1024-float row segment
-//    plus its 16-cell aprons in LDS (clamped per cell, channels interleaved), every
-//    thread then produces 4 outputs 256 floats apart (coalesced stores) from 33
-//    conflict-free LDS reads each.
+//    plus its 16-cell aprons in LDS (clamped per cell, channels interleaved); a thread
+//    pulls the 4 + 32 C consecutive floats its four consecutive outputs need into
+//    registers with 16-byte LDS reads (9 or 17 instead of 132 four-byte ones) and
+//    stores its outputs as one 16-byte word.
 //
 // The one-thread-per-output form it replaces issued 33 global loads per output
 // (1.4-1.6 ms per pass at 8192^2, 4.5 % of the HBM roofline).
@@ -373,7 +377,7 @@ __global__ void __launch_bounds__(kSBlock)
     if (x0 + r >= H) break;
     float val = 0.0f;  // :35
 #pragma unroll
-    for (int k = 0; k < 33; ++k) val += v[r + k] * bw.w[k];  // :49-50
+    for (int k = 0; k < 33; ++k) val = __builtin_fmaf(v[r + k], bw.w[k], val);  // :49-50
     out[(x0 + r) * WC + col] = val;                           // :54
   }
 }
@@ -382,7 +386,7 @@ template <int C>
 __global__ void __launch_bounds__(kSBlock)
     k_blur_cols(float* __restrict__ out, const float* __restrict__ in, int64_t W, BlurWeights bw) {
   constexpr int kSeg = 4 * kSBlock;  // output floats per work-group
-  __shared__ float seg[kSeg + 32 * C];
+  __shared__ __attribute__((aligned(16))) float seg[kSeg + 32 * C];
   const int64_t WC = W * C;
   const int64_t row = blockIdx.x;
   const int64_t f0 = static_cast<int64_t>(blockIdx.y) * kSeg;  // first output float of the segment
@@ -397,14 +401,30 @@ __global__ void __launch_bounds__(kSBlock)
     seg[i] = src[y * C + c];
   }
   __syncthreads();
+  // outputs f0 + 4 t .. + 3 of thread t read LDS floats 4 t .. 4 t + 3 + 32 C
+  constexpr int kWin = 4 + 32 * C;
+  const int i0 = 4 * static_cast<int>(threadIdx.x);
+  if (f0 + i0 >= WC) return;
+  float w[kWin];
+#pragma unroll
+  for (int q = 0; q < kWin / 4; ++q) {
+    const float4 t4 = *reinterpret_cast<const float4*>(&seg[i0 + 4 * q]);
+    w[4 * q] = t4.x, w[4 * q + 1] = t4.y, w[4 * q + 2] = t4.z, w[4 * q + 3] = t4.w;
+  }
+  float val[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const int i = threadIdx.x + j * kSBlock;
-    if (f0 + i >= WC) break;
-    float val = 0.0f;  // :35
+    val[j] = 0.0f;  // :35
 #pragma unroll
-    for (int k = 0; k < 33; ++k) val += seg[i + k * C] * bw.w[k];  // :49-50
-    out[row * WC + f0 + i] = val;                                   // :54
+    for (int k = 0; k < 33; ++k) val[j] = __builtin_fmaf(w[j + k * C], bw.w[k], val[j]);  // :49-50
+  }
+  float* dst = out + row * WC + f0 + i0;  // :54
+  if (f0 + i0 + 3 < WC && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
+    *reinterpret_cast<float4*>(dst) = make_float4(val[0], val[1], val[2], val[3]);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (f0 + i0 + j < WC) dst[j] = val[j];
   }
 }
 

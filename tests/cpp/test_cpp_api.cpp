@@ -91,7 +91,10 @@ int main() {
       check(soil_particle_steps(&after, 1, nullptr));
       EXPECT(slab.info().step_index == 3 && slab.info().world == 1 && slab.info().rows == S);
       EXPECT(after > 0);
-      for (float v : slab.owned_rows("height")) sums[which] += v;
+      {  // bedrock = channel 0 of the layer plane: what soil::erode hands back as model.height
+        const std::vector<float> lay = slab.owned_rows("layers");
+        for (size_t i = 0; i < lay.size(); i += 2) sums[which] += lay[i];
+      }
       std::printf("SLAB%d %llu %.9e\n", which, static_cast<unsigned long long>(after), sums[which]);
     }
     EXPECT(std::fabs(sums[0] - sums[1]) <= 1e-6 * std::fabs(sums[0]));
