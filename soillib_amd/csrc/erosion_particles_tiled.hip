@@ -1827,6 +1827,14 @@ struct TiledRun {
                                                  reinterpret_cast<const uint4*>(count), tiles, lanes, slots,
                                                  steps_run, host_dev, ++*seq_ctr);
     SOIL_LAUNCH_CHECK();
+    // The slot sort of the round this scan belongs to does not wait for the host: it needs the scan's
+    // offsets and the slots the last round filled (n_src), nothing the host decides.  Queued here, it
+    // runs while the host is still waiting for the scan's word (a launch gap and a small kernel off
+    // the critical path of every round: the chain of rounds is what bounds small grids); should the
+    // host then choose the finishing launch instead, it was a few microseconds of idle chip.
+    k_tiled_scatter<<<blocks_for(n_src, 256), 256, 0, st>>>(
+        order, start, dest, rank, n_src, count_next, static_cast<int64_t>(b_cnt / sizeof(uint32_t)));
+    SOIL_LAUNCH_CHECK();
     return SOIL_OK;
   }
 
@@ -1936,8 +1944,6 @@ struct TiledRun {
       return finish_steps();
     }
     SOIL_HIP(hipEventRecord(ev0, st));
-    k_tiled_scatter<<<blocks_for(n_src, 256), 256, 0, st>>>(
-        order, start, dest, rank, n_src, count_next, static_cast<int64_t>(b_cnt / sizeof(uint32_t)));
     if (deposit == 1)
       launch_round<KIND, 0>(sh, blocks, st, next, dest, rank, count_next,
                             static_cast<const PRec*>(cur), static_cast<const uint32_t*>(order),
