@@ -80,6 +80,57 @@ struct alignas(16) PRec {  // parked particle, 64 bytes
 };
 static_assert(sizeof(PRec) == 64, "PRec must be one 64-byte line");
 
+struct TiledHostWord {  // pinned, device-mapped
+  uint32_t live;    // particles queued for the round
+  uint32_t blocks;  // work-groups the round needs (entries of the block list)
+  unsigned long long steps;
+  uint32_t seq;     // written last: the number of the k_queue_prepare launch that filled the word
+  uint32_t whole;   // 1: one work-group per tile and no tile empty (the round's flush may store, see `store_all`)
+  uint32_t mode;    // TiledCtl::mode after this scan
+  uint32_t stop_round;  // the round at which mode left 0 (valid when mode != 0)
+};
+
+// What the DEVICE decides between two rounds, and what the kernels of the following rounds look at
+// before they do anything.  The host queues rounds ahead of the words it has seen (TiledRun::advance);
+// whether such a round still has work is settled here: the scan of round r counts the queues, decides
+// "another round" / "the finishing launch takes over" / "nothing left" — by the number of live
+// particles and by the rate of the round just done (steps per second between two scans, the
+// constant-rate realtime counter) — and every scan, slot sort and round kernel queued behind a
+// decision to stop returns at once.
+struct TiledCtl {
+  uint32_t mode;    // 0: rounds go on, 1: the finishing launch takes over, 2: nothing left
+  uint32_t blocks;  // work-groups of the round the last scan prepared
+  uint32_t slots;   // record slots the round before (or the spawn) filled: what the slot sort and the finishing launch look at
+  uint32_t live;    // particles the last scan queued
+  unsigned long long steps_prev, t_prev;  // step counter and realtime clock at the last scan
+  uint32_t stop_round, pad;
+};
+struct ScanRule {  // when the rounds stop (TiledRun::setup)
+  uint32_t round, tail, max_round;
+  float ticks_per_step_max;  // a round slower than this many realtime ticks per particle step hands over
+};
+__device__ __forceinline__ unsigned long long realtime_ticks() { return wall_clock64(); }
+// thread 0 of a scan: the decision for round `rule.round`, given its `total` queued particles
+__device__ __forceinline__ uint32_t scan_decide(TiledCtl* ctl, const ScanRule& rule, uint32_t total,
+                                                unsigned long long steps_now) {
+  const unsigned long long now = realtime_ticks();
+  uint32_t mode = 0;
+  if (total == 0) {
+    mode = 2;
+  } else if (rule.round > 0) {
+    const unsigned long long ds = steps_now - ctl->steps_prev, dt = now - ctl->t_prev;
+    const bool slow = static_cast<float>(dt) > rule.ticks_per_step_max * static_cast<float>(ds);
+    if (total <= rule.tail || slow || rule.round >= rule.max_round) mode = 1;
+  }
+  ctl->slots = ctl->live;  // what the round before left in the record array
+  ctl->live = total;
+  ctl->steps_prev = steps_now;
+  ctl->t_prev = now;
+  ctl->mode = mode;
+  if (mode != 0) ctl->stop_round = rule.round;
+  return mode;
+}
+
 // float -> cell coordinate, 32-bit flavour of cell_of (positions are < 2^31)
 __device__ __forceinline__ int cell32(float f) { return (f != f) ? 0 : static_cast<int>(f); }
 
@@ -388,8 +439,9 @@ __global__ void __launch_bounds__(256)
                   uint32_t* __restrict__ count, soil_rng* __restrict__ rng, int64_t N, const float4* __restrict__ p4,
                   const float* __restrict__ waterSource, const float* __restrict__ albedoSource,
                   Dom d, Scale3 s, Param param,
-                  int tiles_w, TileShape ts, int steps_per_round) {
+                  int tiles_w, TileShape ts, int steps_per_round, TiledCtl* __restrict__ ctl) {
   const int64_t n = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (n == 0) ctl->live = static_cast<uint32_t>(N);  // the spawn fills slots 0 .. N-1 (scan 0 turns it into `slots`)
   if (n >= N) return;
   PRec r;
   uint32_t tile = kNoTile;
@@ -508,7 +560,9 @@ __device__ __forceinline__ uint32_t wave_append(uint32_t* counter, bool pred) {
 __global__ void __launch_bounds__(256)
     k_tiled_scatter(uint32_t* __restrict__ order, const uint32_t* __restrict__ start,
                     const uint32_t* __restrict__ dest, const uint32_t* __restrict__ rank,
-                    int64_t n_src, uint32_t* __restrict__ clear, int64_t n_clear) {
+                    const TiledCtl* __restrict__ ctl, uint32_t* __restrict__ clear, int64_t n_clear) {
+  if (ctl->mode != 0) return;  // the scan before decided that no round follows
+  const int64_t n_src = ctl->slots;
   const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
   // the section counters of the round that follows, zeroed on the side (saves a fill
   // launch per round)
@@ -532,14 +586,6 @@ __global__ void __launch_bounds__(256)
 //  * the queue total and the launch's step counter go straight into pinned host
 //    memory (a device-to-host copy is a 23 us blit kernel each on this stack).
 static_assert(kNB == 4, "k_queue_prepare moves the sections of a tile as one uint4");
-
-struct TiledHostWord {  // pinned, device-mapped
-  uint32_t live;    // particles queued for the round
-  uint32_t blocks;  // work-groups the round needs (entries of the block list)
-  unsigned long long steps;
-  uint32_t seq;     // written last: the number of the k_queue_prepare launch that filled the word
-  uint32_t whole;   // 1: one work-group per tile and no tile empty (the round's flush may store, see `store_all`)
-};
 
 #ifdef SOIL_PROF
 __device__ unsigned long long soil_prof_prepare[8];  // cycles between the stamps of k_queue_prepare, summed
@@ -591,14 +637,29 @@ __global__ void __launch_bounds__(1024)
                     uint4* __restrict__ block_list, const uint4* __restrict__ count4,
                     int64_t tiles, int lanes, int slots,
                     const unsigned long long* __restrict__ steps_run, TiledHostWord* host,
-                    uint32_t seq) {
+                    uint32_t seq, TiledCtl* __restrict__ ctl, ScanRule rule) {
   // the host spins on host->seq (TiledRun::wait_word): everything it reads is stored, and
   // fenced out to system scope, before the number
   auto publish = [&](uint32_t blocks) {
+    ctl->blocks = blocks;
     host->blocks = blocks;
+    // words of later scans overwrite this one while the host may still be reading it: the verdict
+    // is a single word, and what goes with it is out before it
+    host->stop_round = ctl->stop_round;
+    __threadfence_system();
+    __atomic_store_n(&host->mode, ctl->mode, __ATOMIC_RELEASE);
     __threadfence_system();
     __atomic_store_n(&host->seq, seq, __ATOMIC_RELEASE);
   };
+  if (ctl->mode != 0) {  // an earlier scan ended the rounds: only the word the host waits for
+    if (threadIdx.x == 0) {
+      host->live = ctl->live;
+      host->steps = *steps_run;
+      host->whole = 0u;
+      publish(0u);
+    }
+    return;
+  }
   // Global traffic is coalesced (thread t takes tiles t, t + 1024, ...); the scan wants
   // each thread on a run of consecutive tiles, so the per-tile totals go through LDS.
   __shared__ uint32_t tot[kPanel];
@@ -666,6 +727,7 @@ __global__ void __launch_bounds__(1024)
     start[tiles * kNB] = carry;  // particles queued in total
     host->live = carry;
     host->steps = *steps_run;
+    scan_decide(ctl, rule, carry, *steps_run);
     const uint32_t share = (s_batches + slots - 1) / slots;
     s_cap = (share > 0 ? share : 1u) * static_cast<uint32_t>(lanes);  // chunk capacity
     carry = 0;
@@ -740,7 +802,22 @@ __device__ __forceinline__ int pad16(int i) { return i + (i >> 4); }
 __global__ void __launch_bounds__(1024)
     k_queue_prepare(uint32_t* __restrict__ start, uint4* __restrict__ block_list,
                     const uint4* __restrict__ count4, int tiles, int lanes, int slots,
-                    const unsigned long long* __restrict__ steps_run, TiledHostWord* host, uint32_t seq) {
+                    const unsigned long long* __restrict__ steps_run, TiledHostWord* host, uint32_t seq,
+                    TiledCtl* __restrict__ ctl, ScanRule rule) {
+  if (ctl->mode != 0) {  // an earlier scan ended the rounds: only the word the host waits for
+    if (threadIdx.x == 0) {
+      host->live = ctl->live;
+      host->steps = *steps_run;
+      host->whole = 0u;
+      host->blocks = 0u;
+      host->stop_round = ctl->stop_round;
+      __threadfence_system();
+      __atomic_store_n(&host->mode, ctl->mode, __ATOMIC_RELEASE);
+      __threadfence_system();
+      __atomic_store_n(&host->seq, seq, __ATOMIC_RELEASE);
+    }
+    return;
+  }
   constexpr int kRun = kPanel / 1024;  // tiles per thread
   __shared__ uint32_t pre[kPanel + kPanel / 16 + 2];  // totals, then their exclusive prefix (padded)
   // tiles, longest queue first (uint16: kPanel / 2 words), and behind them the per-position group
@@ -814,6 +891,7 @@ __global__ void __launch_bounds__(1024)
     start[static_cast<int64_t>(tiles) * kNB] = total;  // particles queued in all
     host->live = total;
     host->steps = *steps_run;
+    scan_decide(ctl, rule, total, *steps_run);
     const uint32_t share = (s_batches + slots - 1) / slots;
     s_cap = (share > 0 ? share : 1u) * static_cast<uint32_t>(lanes);  // chunk capacity, see above
   }
@@ -833,7 +911,13 @@ __global__ void __launch_bounds__(1024)
     if (!cut && t > 0) block_list[pos] = make_uint4(static_cast<uint32_t>(i), r, t, 0u);
   }
   auto publish = [&](uint32_t blocks) {  // everything the host reads is stored and fenced first
+    ctl->blocks = blocks;
     host->blocks = blocks;
+    // words of later scans overwrite this one while the host may still be reading it: the verdict
+    // is a single word, and what goes with it is out before it
+    host->stop_round = ctl->stop_round;
+    __threadfence_system();
+    __atomic_store_n(&host->mode, ctl->mode, __ATOMIC_RELEASE);
     __threadfence_system();
     __atomic_store_n(&host->seq, seq, __ATOMIC_RELEASE);
   };
@@ -1128,8 +1212,11 @@ __global__ void __launch_bounds__(NT, round_waves_per_simd(KIND, TR, TC, NT, ALB
                   float* __restrict__ remote0, unsigned long long* __restrict__ steps, Dom d,
                   Scale3 s, Param param, int tiles_w, int off_r, int off_c, int steps_per_round,
                   TileShape ts_next,
-                  int tiles_w_next, int agg_min, int agg_groups, int retries, int store_all) {
+                  int tiles_w_next, int agg_min, int agg_groups, int retries, int store_all,
+                  const TiledCtl* __restrict__ ctl) {
   constexpr int kCells = TR * TC, kBlock = NT, kPer = (kCells + NT - 1) / NT;
+  // queued ahead of the scan's verdict: no round at all, or fewer work-groups than the launch has
+  if (ctl->mode != 0 || blockIdx.x >= ctl->blocks) return;
   PROF_DECL;
   // this work-group's share of its tile's queue (k_queue_prepare's block list)
   const uint4 job = block_list[blockIdx.x];
@@ -1477,13 +1564,13 @@ __global__ void __launch_bounds__(NT, round_waves_per_simd(KIND, TR, TC, NT, ALB
 
 template <int KIND>
 __global__ void __launch_bounds__(256)
-    k_tiled_finish(const PRec* __restrict__ recs, const uint32_t* __restrict__ dest, int64_t n,
-                   float* __restrict__ flux0,
+    k_tiled_finish(const PRec* __restrict__ recs, const uint32_t* __restrict__ dest,
+                   const TiledCtl* __restrict__ ctl, float* __restrict__ flux0,
                    float* __restrict__ flux1, float* __restrict__ fluxV, float* __restrict__ fluxA,
                    const float4* __restrict__ p4, float* __restrict__ remote0,
                    unsigned long long* __restrict__ steps, Dom d, Scale3 s, Param param) {
   const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
-  if (i >= n) return;
+  if (ctl->mode != 1 || i >= static_cast<int64_t>(ctl->slots)) return;
   if (dest[i] == kNoTile) return;
   PRec r = recs[i];
   uint32_t nsteps = 0;
@@ -1642,13 +1729,18 @@ struct TiledRun {
   unsigned long long *steps_global = nullptr, *steps_run = nullptr;
   size_t b_cnt = 0;
   TiledHostWord *host = nullptr, *host_dev = nullptr;  // the same pinned word, host / device view
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  // progress
-  uint64_t round = 0;
+  TiledCtl* ctl = nullptr;      // the device's own state of the chain of rounds
+  // progress.  The host runs ahead of the device: `scans` scans (each with its slot sort) and `rounds`
+  // round kernels are queued, `seen` scan words have been read; round r is only ever queued behind
+  // scan r, and what a queued round finds to do is the device's decision (TiledCtl).
+  uint64_t round = 0;           // = rounds (kept under its old name: the pair driver reads it)
+  uint64_t scans = 0, seen = 0;
+  int depth = 2;                // rounds queued beyond the last word seen (SOIL_TILED_AHEAD)
   uint32_t* seq_ctr = nullptr;  // number of the last k_queue_prepare launch (TiledHostWord::seq)
-  int64_t n_src = 0;
-  unsigned long long steps_before = 0;
-  bool timed = false, done = false;
+  uint32_t seq_first = 0;       // ... of this run's scan 0
+  int64_t live_known = 0;       // an upper bound of the record slots in use: the last live count seen
+  double ticks_per_second = 1.0e8;
+  bool done = false;
   bool ready = false, skip_pack = false;  // setup() done; p4 filled by k_tiled_pack_pair
   // The flux planes hold stale values on entry (the cell phase left them as they were): the launch
   // must leave them holding its deposits only.  Round 0 stores instead of adding where it can (one
@@ -1660,6 +1752,8 @@ struct TiledRun {
   // the tile grid of round r: shifted by half a tile on odd rounds (TileShape)
   bool stagger = true;
   int agg_min = 48, agg_groups = 4, retries = 2;
+  PRec* recs_of(uint64_t r) const { return (r & 1) ? next : cur; }               // records round r reads
+  uint32_t* count_of(uint64_t r) const { return (r & 1) ? count_next : count; }   // section counts round r's scan reads
   TileShape ts_of(int sh, uint64_t r) const {
     const bool odd = stagger && (r & 1);
     return TileShape{Shapes<KIND>::v[sh].tr, __builtin_ctz(Shapes<KIND>::v[sh].tc),
@@ -1783,14 +1877,15 @@ struct TiledRun {
     tile_order = reinterpret_cast<uint32_t*>(w);  w += b_cnt;
     block_list = reinterpret_cast<uint4*>(w);     w += b_blk;
     steps_run = reinterpret_cast<unsigned long long*>(w);
+    ctl = reinterpret_cast<TiledCtl*>(w + 64);
     rc = step_counter(&steps_global);
     if (rc != SOIL_OK) return rc;
     // pinned word + events, one set per (thread, device, kind): a host thread that moves on to
     // another device (soil_set_device) must not poll a word or record events of the first one
     struct HostSide {
       TiledHostWord *host = nullptr, *host_dev = nullptr;
-      hipEvent_t ev0 = nullptr, ev1 = nullptr;
       uint32_t seq = 0;  // numbers the launches that fill `host`, across runs
+      double ticks_per_second = 1.0e8;
     };
     static thread_local std::map<int, HostSide> t_side;
     int dev = 0;
@@ -1800,59 +1895,73 @@ struct TiledRun {
       SOIL_HIP(hipHostMalloc(reinterpret_cast<void**>(&hs.host), sizeof(TiledHostWord), hipHostMallocMapped | hipHostMallocCoherent));
       SOIL_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&hs.host_dev), hs.host, 0));
       hs.host->seq = 0;
-      SOIL_HIP(hipEventCreate(&hs.ev0));
-      SOIL_HIP(hipEventCreate(&hs.ev1));
+      int khz = 0;  // rate of the realtime counter the scans time the rounds with
+      if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) == hipSuccess && khz > 0)
+        hs.ticks_per_second = 1.0e3 * khz;
+      else
+        (void)hipGetLastError();
     }
     host = hs.host;
     host_dev = hs.host_dev;
     seq_ctr = &hs.seq;
-    ev0 = hs.ev0;
-    ev1 = hs.ev1;
+    ticks_per_second = hs.ticks_per_second;
+    depth = verbose ? 0 : env_int("SOIL_TILED_AHEAD", 2);
+    if (std::getenv("SOIL_TILED_AHEAD") && std::atoi(std::getenv("SOIL_TILED_AHEAD")) == 0) depth = 0;
     ready = true;
     return SOIL_OK;
   }
 
-  // scan of the queues the next round starts from + what the host needs to decide
+  // Scan of the queues round `scans` starts from — with the device's decision whether that round
+  // takes place at all (scan_decide) and the word for the host — and the slot sort of that round.
+  // Neither waits for the host: the sort needs the scan's offsets and the slots the round before
+  // filled, both on the device.
   int queue_scan() {
-    const int64_t tiles = tiles_of(shape_of(round), round);
-    const int lanes = Shapes<KIND>::v[shape_of(round)].nt;
-    const int slots = resident_groups[round >= static_cast<uint64_t>(switch_round) ? 1 : 0];
+    const uint64_t r = scans;
+    const int64_t tiles = tiles_of(shape_of(r), r);
+    const int lanes = Shapes<KIND>::v[shape_of(r)].nt;
+    const int slots = resident_groups[r >= static_cast<uint64_t>(switch_round) ? 1 : 0];
+    // every live particle advances >= 1 step per round: maxage + 2 rounds always suffice
+    const uint64_t max_round = p.maxage + 2;
+    ScanRule rule;
+    rule.round = static_cast<uint32_t>(r);
+    rule.tail = static_cast<uint32_t>(tail);
+    rule.max_round = max_round > 0xffffffffull ? 0xffffffffu : static_cast<uint32_t>(max_round);
+    rule.ticks_per_step_max = static_cast<float>(ticks_per_second / finish_rate);
     // SOIL_TILED_PANELS=1: the many-tiles variant whatever the grid (tests)
     const bool panels = tiles > kPanel || std::getenv("SOIL_TILED_PANELS") != nullptr;
+    const uint4* cnt4 = reinterpret_cast<const uint4*>(count_of(r));
     if (!panels)
-      k_queue_prepare<<<1, 1024, 0, st>>>(start, block_list, reinterpret_cast<const uint4*>(count),
-                                          static_cast<int>(tiles), lanes, slots, steps_run, host_dev, ++*seq_ctr);
+      k_queue_prepare<<<1, 1024, 0, st>>>(start, block_list, cnt4, static_cast<int>(tiles), lanes, slots,
+                                          steps_run, host_dev, ++*seq_ctr, ctl, rule);
     else
-      k_queue_prepare_panels<<<1, 1024, 0, st>>>(start, tile_order, block_list,
-                                                 reinterpret_cast<const uint4*>(count), tiles, lanes, slots,
-                                                 steps_run, host_dev, ++*seq_ctr);
+      k_queue_prepare_panels<<<1, 1024, 0, st>>>(start, tile_order, block_list, cnt4, tiles, lanes, slots,
+                                                 steps_run, host_dev, ++*seq_ctr, ctl, rule);
     SOIL_LAUNCH_CHECK();
-    // The slot sort of the round this scan belongs to does not wait for the host: it needs the scan's
-    // offsets and the slots the last round filled (n_src), nothing the host decides.  Queued here, it
-    // runs while the host is still waiting for the scan's word (a launch gap and a small kernel off
-    // the critical path of every round: the chain of rounds is what bounds small grids); should the
-    // host then choose the finishing launch instead, it was a few microseconds of idle chip.
-    k_tiled_scatter<<<blocks_for(n_src, 256), 256, 0, st>>>(
-        order, start, dest, rank, n_src, count_next, static_cast<int64_t>(b_cnt / sizeof(uint32_t)));
+    if (r == 0) seq_first = *seq_ctr;
+    k_tiled_scatter<<<blocks_for(live_known, 256), 256, 0, st>>>(
+        order, start, dest, rank, ctl, count_of(r + 1), static_cast<int64_t>(b_cnt / sizeof(uint32_t)));
     SOIL_LAUNCH_CHECK();
+    ++scans;
     return SOIL_OK;
   }
 
-  // Wait for the word of the last queue_scan.  Polling the pinned word sees it a few
-  // microseconds after the kernel stored it; hipStreamSynchronize adds the runtime's
-  // completion handling on top — per round, 25 rounds per step.  Falls back to the
-  // runtime's wait (and its error reporting) when the word does not show up soon.
+  // Wait for the word of scan `seen`.  Polling the pinned word sees it a few microseconds after the
+  // kernel stored it; hipStreamSynchronize adds the runtime's completion handling on top.  Falls back
+  // to the runtime's wait (and its error reporting) when the word does not show up soon.  Words of
+  // later scans may have overwritten it by then: they carry the same verdict or a later one, and
+  // sequence numbers only grow.
   int wait_word() {
+    const uint32_t want = seq_first + static_cast<uint32_t>(seen);
+    auto arrived = [&]() { return static_cast<int32_t>(__atomic_load_n(&host->seq, __ATOMIC_ACQUIRE) - want) >= 0; };
     const auto t0 = std::chrono::steady_clock::now();
     for (uint32_t spins = 0;; ++spins) {
-      if (__atomic_load_n(&host->seq, __ATOMIC_ACQUIRE) == *seq_ctr) return SOIL_OK;
+      if (arrived()) return SOIL_OK;
       if ((spins & 1023u) == 1023u &&
           std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20))
         break;
     }
     SOIL_HIP(hipStreamSynchronize(st));
-    if (__atomic_load_n(&host->seq, __ATOMIC_ACQUIRE) != *seq_ctr)
-      return fail(SOIL_ERR_HIP, "tiled transport: the queue word of the round never arrived");
+    if (!arrived()) return fail(SOIL_ERR_HIP, "tiled transport: the queue word of the round never arrived");
     return SOIL_OK;
   }
 
@@ -1865,13 +1974,15 @@ struct TiledRun {
           p4, reinterpret_cast<const float2*>(layers), reinterpret_cast<const float2*>(velocity),
           waterHeight, d, s, p, lo, hi + 1);
     SOIL_HIP(hipMemsetAsync(count, 0, b_cnt, st));
-    SOIL_HIP(hipMemsetAsync(steps_run, 0, sizeof(unsigned long long), st));
+    // the step counter of the run and, behind it, the device's control block: mode 0, the N spawn
+    // slots as what "the round before" left
+    SOIL_HIP(hipMemsetAsync(steps_run, 0, 64 + sizeof(TiledCtl), st));
     k_tiled_spawn<KIND><<<blocks_for(N, 256), 256, 0, st>>>(
         cur, dest, rank, count, rng, N, p4, waterSource, albedoSource, d, s, p, tiles_w_of(shape_of(0), 0),
-        ts_of(shape_of(0), 0), steps_per_round);
+        ts_of(shape_of(0), 0), steps_per_round, ctl);
     SOIL_LAUNCH_CHECK();
-    n_src = N;  // slots of `cur` to look at (spawn output, then survivor slots)
-    round = 0;
+    live_known = N;  // slots of the record array to look at (spawn output, then survivor slots)
+    round = scans = seen = 0;
     return queue_scan();
   }
 
@@ -1882,29 +1993,54 @@ struct TiledRun {
     return SOIL_OK;
   }
 
+  // round kernel `round` (behind its scan) and the scan of the round after it
+  int queue_round(int store_all) {
+    const uint64_t r = round;
+    const int sh = shape_of(r), sh_next = shape_of(r + 1);
+    const int64_t tiles = tiles_of(sh, r);
+    const int tiles_w = tiles_w_of(sh, r);
+    const TileShape ts_cur = ts_of(sh, r);
+    // as many work-groups as a round can have (a tile each, plus the chunks long queues are cut into);
+    // those beyond the scan's count return at once
+    const int slots = resident_groups[r >= static_cast<uint64_t>(switch_round) ? 1 : 0];
+    const unsigned grid = static_cast<unsigned>(std::min<int64_t>(tiles + slots, std::max<int64_t>(live_known, 1)));
+    PRec* in = recs_of(r);
+    PRec* out = recs_of(r + 1);
+    if (deposit == 1)
+      launch_round<KIND, 0>(sh, grid, st, out, dest, rank, count_of(r + 1),
+                            static_cast<const PRec*>(in), static_cast<const uint32_t*>(order),
+                            static_cast<const uint4*>(block_list), flux0, flux1,
+                            reinterpret_cast<float2*>(fluxV), fluxA, static_cast<const float4*>(p4),
+                            remote0, steps_run, d, s, p, tiles_w, ts_cur.off_r, ts_cur.off_c,
+                            steps_per_round, ts_of(sh_next, r + 1),
+                            tiles_w_of(sh_next, r + 1), agg_min, agg_groups, retries, store_all,
+                            static_cast<const TiledCtl*>(ctl));
+    else
+      launch_round<KIND, 1>(sh, grid, st, out, dest, rank, count_of(r + 1),
+                            static_cast<const PRec*>(in), static_cast<const uint32_t*>(order),
+                            static_cast<const uint4*>(block_list), flux0, flux1,
+                            reinterpret_cast<float2*>(fluxV), fluxA, static_cast<const float4*>(p4),
+                            remote0, steps_run, d, s, p, tiles_w, ts_cur.off_r, ts_cur.off_c,
+                            steps_per_round, ts_of(sh_next, r + 1),
+                            tiles_w_of(sh_next, r + 1), agg_min, agg_groups, retries, store_all,
+                            static_cast<const TiledCtl*>(ctl));
+    SOIL_LAUNCH_CHECK();
+    ++round;
+    return queue_scan();
+  }
+
+  // One look at the device's progress: wait for the next scan's word; if the rounds go on, make sure
+  // the round it belongs to is queued and queue `depth` rounds beyond it; if the device has stopped
+  // them, queue the finishing launch for the records the last executed round left.
   int advance() {
     if (done) return SOIL_OK;
     if (int rc = wait_word(); rc != SOIL_OK) return rc;
-    const uint32_t live = host->live;  // particles queued for this round
-    const unsigned blocks = host->blocks;
-    const unsigned long long steps_now = host->steps;
-    const int sh = shape_of(round), sh_next = shape_of(round + 1);
-    const int64_t tiles = tiles_of(sh, round);
-    const int tiles_w = tiles_w_of(sh, round);
-    const TileShape ts_cur = ts_of(sh, round);
-    double rate = 1e30;  // steps per second of the round just done
-    if (timed) {
-      float ms = 0.0f;
-      // ev1 precedes the kernel whose word just arrived; should the runtime not have
-      // noticed yet, this round simply goes without a rate
-      if (hipEventElapsedTime(&ms, ev0, ev1) != hipSuccess) {
-        (void)hipGetLastError();
-        ms = 0.0f;
-      }
-      if (ms > 0.0f) rate = static_cast<double>(steps_now - steps_before) / (ms * 1e-3);
-    }
-    steps_before = steps_now;
-    if (verbose) {  // queue-length statistics of the round (diagnostics only)
+    const uint64_t r = seen++;  // the word of scan r (or of a later one carrying the same verdict)
+    const uint32_t mode = __atomic_load_n(&host->mode, __ATOMIC_ACQUIRE);
+    if (mode == 0) live_known = std::min<int64_t>(live_known, static_cast<int64_t>(host->live));
+    if (verbose) {  // queue-length statistics of the round (diagnostics only; depth 0: the word is scan r's)
+      const int sh = shape_of(r);
+      const int64_t tiles = tiles_of(sh, r);
       std::vector<uint32_t> pre(static_cast<size_t>(tiles * kNB + 1)), h(static_cast<size_t>(tiles));
       SOIL_HIP(hipMemcpy(pre.data(), start, sizeof(uint32_t) * pre.size(), hipMemcpyDeviceToHost));
       for (int64_t t = 0; t < tiles; ++t) h[t] = pre[(t + 1) * kNB] - pre[t * kNB];
@@ -1917,16 +2053,16 @@ struct TiledRun {
         sparse += c > 0 && c < static_cast<uint32_t>(lanes) / 4;
       }
       std::fprintf(stderr,
-                   "[tiled kind %d] round %llu: %u live; tiles %lld empty %llu sparse(<1/4) %llu "
-                   "median %u p90 %u p99 %u max %u batches %llu; last round %.2f G steps/s\n",
-                   KIND, static_cast<unsigned long long>(round), live, static_cast<long long>(tiles),
+                   "[tiled kind %d] round %llu: %u live (mode %u); tiles %lld empty %llu sparse(<1/4) %llu "
+                   "median %u p90 %u p99 %u max %u batches %llu; %llu steps so far\n",
+                   KIND, static_cast<unsigned long long>(r), host->live, mode, static_cast<long long>(tiles),
                    static_cast<unsigned long long>(empty), static_cast<unsigned long long>(sparse),
                    h[h.size() / 2], h[h.size() * 9 / 10], h[h.size() * 99 / 100], h.back(),
-                   static_cast<unsigned long long>(batches), timed ? rate * 1e-9 : 0.0);
+                   static_cast<unsigned long long>(batches), static_cast<unsigned long long>(host->steps));
     }
     int store_all = 0;
-    if (overwrite && round == 0) {
-      if (host->whole == 1u && live > 0 && !fluxA && deposit == 0) {
+    if (overwrite && r == 0) {  // round 0 is never queued ahead of its word in this mode (round == 0 here)
+      if (mode == 0 && host->whole == 1u && !fluxA && deposit == 0) {
         store_all = 1;
       } else {  // cannot: clear the planes the launch adds to
         const size_t cells_b = sizeof(float) * static_cast<size_t>(d.rows) * static_cast<size_t>(d.W);
@@ -1935,39 +2071,20 @@ struct TiledRun {
         SOIL_HIP(hipMemsetAsync(fluxV, 0, 2 * cells_b, st));
       }
     }
-    // every live particle advances >= 1 step per round: maxage + 2 rounds always suffice
-    if (live == 0 || round >= p.maxage + 2) return finish_steps();
-    if (round > 0 && (static_cast<int64_t>(live) <= tail || rate < finish_rate)) {
-      k_tiled_finish<KIND><<<blocks_for(n_src, 256), 256, 0, st>>>(
-          cur, dest, n_src, flux0, flux1, fluxV, fluxA, p4, remote0, steps_run, d, s, p);
-      SOIL_LAUNCH_CHECK();
+    if (mode != 0) {
+      if (mode == 1) {  // the records round `stop_round` would have read, and the slots in use among them
+        const uint64_t stop = host->stop_round;
+        k_tiled_finish<KIND><<<blocks_for(live_known, 256), 256, 0, st>>>(
+            recs_of(stop), dest, ctl, flux0, flux1, fluxV, fluxA, p4, remote0, steps_run, d, s, p);
+        SOIL_LAUNCH_CHECK();
+      }
       return finish_steps();
     }
-    SOIL_HIP(hipEventRecord(ev0, st));
-    if (deposit == 1)
-      launch_round<KIND, 0>(sh, blocks, st, next, dest, rank, count_next,
-                            static_cast<const PRec*>(cur), static_cast<const uint32_t*>(order),
-                            static_cast<const uint4*>(block_list), flux0, flux1,
-                            reinterpret_cast<float2*>(fluxV), fluxA, static_cast<const float4*>(p4),
-                            remote0, steps_run, d, s, p, tiles_w, ts_cur.off_r, ts_cur.off_c,
-                            steps_per_round, ts_of(sh_next, round + 1),
-                            tiles_w_of(sh_next, round + 1), agg_min, agg_groups, retries, store_all);
-    else
-      launch_round<KIND, 1>(sh, blocks, st, next, dest, rank, count_next,
-                            static_cast<const PRec*>(cur), static_cast<const uint32_t*>(order),
-                            static_cast<const uint4*>(block_list), flux0, flux1,
-                            reinterpret_cast<float2*>(fluxV), fluxA, static_cast<const float4*>(p4),
-                            remote0, steps_run, d, s, p, tiles_w, ts_cur.off_r, ts_cur.off_c,
-                            steps_per_round, ts_of(sh_next, round + 1),
-                            tiles_w_of(sh_next, round + 1), agg_min, agg_groups, retries, store_all);
-    SOIL_LAUNCH_CHECK();
-    SOIL_HIP(hipEventRecord(ev1, st));
-    timed = true;
-    n_src = live;
-    std::swap(cur, next);
-    std::swap(count, count_next);
-    ++round;
-    return queue_scan();
+    if (round == r)
+      if (int rc = queue_round(store_all); rc != SOIL_OK) return rc;
+    while (round < seen + static_cast<uint64_t>(depth) && round < p.maxage + 3)
+      if (int rc = queue_round(0); rc != SOIL_OK) return rc;
+    return SOIL_OK;
   }
 };
 
@@ -2036,7 +2153,9 @@ int launch_pair_tiled(const soil_erosion_planes& P, soil_rng* rng_fluvial, soil_
   // (2) 37.2 (6) 37.3 (8): small grids are bound by the latency of each launch's chain of rounds, and two
   // chains interleave; at 8192^2 either launch fills the chip by itself.
   static const int delay_env = env_int("SOIL_PAIR_DELAY", 0);
-  const uint64_t delay = delay_env > 0 ? static_cast<uint64_t>(delay_env) : 2;
+  // (round 3, with rounds queued ahead of the host: counted in scans the host has seen; 1024^2 1.59 / 1.62 /
+  // 1.67 ms per step at 1 / 2 / 3, 2048^2 3.98 / 3.86 / 3.75, 4096^2 10.28 / 10.36 / 10.48)
+  const uint64_t delay = delay_env > 0 ? static_cast<uint64_t>(delay_env) : (N <= 300000 ? 1 : 2);
   // Whatever happens in between, `st` is joined with both streams before this returns: rounds may
   // still be in flight on the workspace the next call reuses.
   A.overwrite = B.overwrite = overwrite;
@@ -2058,7 +2177,7 @@ int launch_pair_tiled(const soil_erosion_planes& P, soil_rng* rng_fluvial, soil_
     if (int rc = A.begin(); rc != SOIL_OK) return rc;
     bool b_started = false;
     while (!A.done || !B.done) {
-      if (!b_started && (A.done || A.round >= delay)) {
+      if (!b_started && (A.done || A.seen >= delay)) {  // `delay` scans of the fluvial launch seen
         if (int rc = B.begin(); rc != SOIL_OK) return rc;
         b_started = true;
       }
