@@ -1,8 +1,8 @@
 #!/bin/bash
 # Collects everything profiles/<name>/ holds, on the GPU box:
-#   gpurun --timeout 2400 -- 'tools/profile_final.sh r02_final'
-# then, back in the container:  python tools/profile_post.py r02_final
-name=${1:-r02_final}
+#   gpurun --timeout 2400 -- 'tools/profile_final.sh r03_final'
+# then, back in the container:  python tools/profile_post.py r03_final
+name=${1:-r03_final}
 out=/root/repo/gpurun_out/$name; rm -rf $out; mkdir -p $out
 cd /tmp; export TMPDIR=/tmp
 python /root/repo/bench.py --steps 10 --warmup 2 2>/dev/null | tail -1 > $out/bench_line.json
@@ -13,6 +13,12 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o s -- pytho
 pmc() { rocprofv3 --kernel-trace --pmc $2 --output-format csv -d $out/$1 -o p -- python /root/repo/bench.py --steps $3 --warmup 1 --no-cpu-baseline --sequential-particles > /dev/null 2>&1; }
 pmc fetch "FETCH_SIZE" 2
 pmc write "WRITE_SIZE" 2
+# the default step (both launches overlapped, flux planes left to the next step's first rounds): the
+# traffic of the 84-byte flavour of the fused cell kernel and of the storing first round
+pmcd() { rocprofv3 --kernel-trace --pmc $2 --output-format csv -d $out/$1 -o p -- python /root/repo/bench.py --steps $3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1; }
+pmcd fetch_lazy "FETCH_SIZE" 3
+pmcd write_lazy "WRITE_SIZE" 3
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_default -o s -- python /root/repo/bench.py --steps 10 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
 pmc valu "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_TRANS_F32" 1
 pmc lds "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_INSTS_SALU SQ_INSTS_BRANCH" 1
 pmc mix "SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT GRBM_GUI_ACTIVE" 1
@@ -25,4 +31,5 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $out/accumulate -o s -- 
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/stencils_fetch -o p -- python /root/repo/tools/bench_stencils.py > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/stencils_write -o p -- python /root/repo/tools/bench_stencils.py > /dev/null 2>&1
 python /root/repo/bench.py --size 1024 --steps 10000 --warmup 10 --no-cpu-baseline 2>/dev/null | tail -1 > $out/bench_c2_1024x10000.json
+# drop the raw per-dispatch tables of the big passes once summarised? (kept: they fit the 64 MiB budget)
 find $out -name "*.csv" | head -40; du -sh $out

@@ -9,7 +9,7 @@ import shutil
 import sys
 
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
-name = sys.argv[1] if len(sys.argv) > 1 else "r01_final"
+name = sys.argv[1] if len(sys.argv) > 1 else "r03_final"
 src = os.path.join(ROOT, "gpurun_out", name)
 dst = os.path.join(ROOT, "profiles", name)
 os.makedirs(dst, exist_ok=True)
@@ -43,6 +43,10 @@ def load(d):
 for f in os.listdir(os.path.join(src, "stats")):
     if f.endswith("kernel_stats.csv"):
         shutil.copy(os.path.join(src, "stats", f), os.path.join(dst, "kernel_stats.csv"))
+if os.path.isdir(os.path.join(src, "stats_default")):      # the default step: launches overlapped, lazy flux planes
+    for f in os.listdir(os.path.join(src, "stats_default")):
+        if f.endswith("kernel_stats.csv"):
+            shutil.copy(os.path.join(src, "stats_default", f), os.path.join(dst, "kernel_stats_default_step.csv"))
 for f in ("bench_line.json", "bench_line_sequential.json", "bench_c2_1024x10000.json"):
     if os.path.exists(os.path.join(src, f)) and os.path.getsize(os.path.join(src, f)) > 2:
         shutil.copy(os.path.join(src, f), os.path.join(dst, f))
@@ -58,13 +62,30 @@ for d, key in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
         per[k][key + "_KB_avg"] = sum(v) / len(v)
         per[k]["launches_" + key.split("_")[0].lower()] = len(v)
 json.dump(per, open(os.path.join(dst, "pmc_fetch_write_per_kernel.json"), "w"), indent=1)
+# the default step's flavour of the fused cell kernel (flux planes not re-zeroed: 84 B/cell) and its
+# storing first rounds come from the passes over the default bench
+lazy_per = collections.defaultdict(dict)
+if os.path.isdir(os.path.join(src, "fetch_lazy")):
+    for d, key in (("fetch_lazy", "FETCH_SIZE"), ("write_lazy", "WRITE_SIZE")):
+        acc = collections.defaultdict(list)
+        for c in load(d):
+            if key in c:
+                acc[c["name"]].append(c[key])
+        for k, v in acc.items():
+            lazy_per[k][key + "_KB_avg"] = sum(v) / len(v)
+            lazy_per[k]["launches_" + key.split("_")[0].lower()] = len(v)
+    json.dump(lazy_per, open(os.path.join(dst, "pmc_fetch_write_per_kernel_default_step.json"), "w"), indent=1)
+lazy_cells = next((v for k, v in lazy_per.items() if "k_erode_cells_fused" in k and k.rstrip(">").endswith("false")
+                   and "FETCH_SIZE_KB_avg" in v and "WRITE_SIZE_KB_avg" in v), None)
 cells = next((v for k, v in per.items() if "k_erode_cells_fused" in k), None)
 if cells:
     bench = json.load(open(os.path.join(dst, "bench_line.json")))
+    if lazy_cells and bench["roofline"].get("algorithmic_bytes_per_cell") == 84:
+        cells = dict(lazy_cells, lazy=True)
     fetch = cells["FETCH_SIZE_KB_avg"] * 1024 * 2      # gfx950: FETCH_SIZE counts half the bytes
     write = cells["WRITE_SIZE_KB_avg"] * 1024
     json.dump({
-        "kernel": "k_erode_cells_fused", "grid": bench["config"]["grid"],
+        "kernel": "k_erode_cells_fused", "grid": bench["config"]["grid"], "lazy_flux": bool(cells.get("lazy")),
         "hbm_bytes_per_launch": fetch + write, "fetch_bytes": fetch, "write_bytes": write,
         "source": "profiles/%s/pmc_fetch_write_per_kernel.json (rocprofv3 --pmc FETCH_SIZE and --pmc "
                   "WRITE_SIZE in separate passes of `python bench.py --steps 2 --warmup 1`)" % name,
@@ -123,6 +144,15 @@ COST = {"SQ_INSTS_VALU_ADD_F32": 2.0, "SQ_INSTS_VALU_MUL_F32": 2.0, "SQ_INSTS_VA
         "SQ_INSTS_VALU_TRANS_F32": 8.0, "SQ_INSTS_VALU_CVT": 4.0,
         "SQ_INSTS_VALU_INT32": 3.0,   # v_add/sub_u32 and shifts right 2, the rest 4
         "other": 3.5}                 # moves and logic 2; compares, selects, min/max, DPP, readlane 4
+# ... and the two classes the counters do not resolve are priced from the opcodes that are in the
+# stepping loop (tools/isa_mix.py compiles the kernel and reads the loop off the ISA)
+isa = None
+try:
+    import subprocess
+    isa = json.loads(subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "isa_mix.py")]))
+    json.dump(isa, open(os.path.join(dst, "isa_round_loop.json"), "w"), indent=1)
+except Exception as e:          # no hipcc here: keep round 2's assumption
+    print("isa_mix failed, 'other' stays at 3.5 cycles:", e)
 roof = {}
 mix_ok = os.path.isdir(os.path.join(src, "mix"))
 mix = load("mix") if mix_ok else []
@@ -134,11 +164,16 @@ for kind, label in ((0, "fluvial_rounds"), (1, "debris_rounds")):
     n = sum(r["SQ_INSTS_VALU"] for r in rows)
     typed = {k: sum(r.get(k, 0.0) for r in rows) for k in COST if k != "other"}
     other = n - sum(typed.values())
-    issue = sum(typed[k] * COST[k] for k in typed) + other * COST["other"]
+    cost = dict(COST)
+    if isa and label in isa:
+        cost["other"] = isa[label]["other_issue_cycles"]
+        cost["SQ_INSTS_VALU_INT32"] = isa[label]["int32_issue_cycles"]
+    issue = sum(typed[k] * cost[k] for k in typed) + other * cost["other"]
     cycles = sum(1024 * r["GRBM_GUI_ACTIVE"] / 8 for r in rows)
     roof[label] = {"valu_issue_share": round(issue / cycles, 3), "launches": len(rows),
                    "time_ms": round(sum(r["dur_us"] for r in rows) / 1e3, 3), "valu_instructions": n,
                    "issue_cycles_per_instruction": round(issue / n, 2),
+                   "issue_cost_cycles": cost,
                    "wall_simd_cycles_per_instruction": round(cycles / n, 2),
                    "mix": {k.replace("SQ_INSTS_VALU_", ""): round(v / n, 3) for k, v in typed.items()} | {
                        "other": round(other / n, 3)}}
@@ -149,7 +184,9 @@ if roof:
         "achieved": sum(v["valu_issue_share"] * v["time_ms"] for v in roof.values()) / tot_t,
         "peak": 1.0, "unit": "share of SIMD cycles taken by the issue of vector instructions",
         "per_kind": roof,
-        "issue_cost_cycles": COST,
+        "issue_cost_cycles": "per kind above: ADD/MUL/FMA 2, TRANS 8, CVT 4 (tools/microbench/valu_issue*.hip); INT32 and "
+                             "the unclassified rest priced by the opcodes in the stepping loop's ISA "
+                             "(profiles/%s/isa_round_loop.json, tools/isa_mix.py)" % name,
         "source": "profiles/%s: rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F32 "
                   "SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT GRBM_GUI_ACTIVE on `python bench.py --steps 1 --warmup 1` "
                   "(gpurun_out/%s/mix), priced with the wave64 issue cycles per opcode class measured by "
