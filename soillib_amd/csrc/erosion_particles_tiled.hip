@@ -103,7 +103,11 @@ struct TiledCtl {
   uint32_t slots;   // record slots the round before (or the spawn) filled: what the slot sort and the finishing launch look at
   uint32_t live;    // particles the last scan queued
   unsigned long long steps_prev, t_prev;  // step counter and realtime clock at the last scan
-  uint32_t stop_round, pad;
+  uint32_t stop_round;
+  uint32_t done;        // work-groups of the running round that have finished (its last one scans)
+  // blocks of round r in slot r & 1: the scan at the tail of round r writes the other slot, which no
+  // work-group of round r reads — stragglers beyond the round's count may still be arriving then
+  uint32_t blocks_of[2];
 };
 struct ScanRule {  // when the rounds stop (TiledRun::setup)
   uint32_t round, tail, max_round;
@@ -632,16 +636,73 @@ __device__ __forceinline__ uint32_t block_scan_1024(uint32_t v, uint32_t* wsum) 
   return v + before;
 }
 
-__global__ void __launch_bounds__(1024)
-    k_queue_prepare_panels(uint32_t* __restrict__ start, uint32_t* __restrict__ tile_order,
-                    uint4* __restrict__ block_list, const uint4* __restrict__ count4,
-                    int64_t tiles, int lanes, int slots,
-                    const unsigned long long* __restrict__ steps_run, TiledHostWord* host,
-                    uint32_t seq, TiledCtl* __restrict__ ctl, ScanRule rule) {
+// inclusive prefix sum over the NT threads of a work-group (two barriers; `wsum`: NT / 64 words of LDS)
+template <int NT>
+__device__ __forceinline__ uint32_t block_scan_nt(uint32_t v, uint32_t* wsum) {
+  const int wave = static_cast<int>(threadIdx.x >> 6), lane = static_cast<int>(threadIdx.x & 63u);
+  v = wave_scan(v);
+  __syncthreads();  // wsum may still be read from the previous call
+  if (lane == 63) wsum[wave] = v;
+  __syncthreads();
+  uint32_t before = 0;
+#pragma unroll
+  for (int w = 0; w < NT / 64; ++w) before += (w < wave) ? wsum[w] : 0u;
+  return v + before;
+}
+
+// What a scan is asked to do, by value: it runs as a kernel of its own once per launch (the queues
+// the spawn filled) and at the tail of every round kernel (QueueScan of the round that follows).
+struct QueueScan {
+  uint32_t* start;       // out: kNB offsets per tile (+ the total)
+  uint32_t* tile_order;  // scratch: tiles, longest queue first
+  uint4* block_list;     // out: the work-groups of the round
+  const uint4* count4;   // in: section counts per tile
+  int64_t tiles;
+  int lanes, slots;
+  const unsigned long long* steps_run;
+  TiledHostWord* host;
+  uint32_t seq;
+  TiledCtl* ctl;
+  ScanRule rule;
+};
+constexpr int scan_lds_words(int nt) { return 16 * nt + 256 + 256 + 8 + 16; }
+
+// The scan with its panels in LDS scratch handed in by the caller (scan_lds_words(NT) words): any
+// number of tiles, NT threads, all of which must call it.  Global traffic is coalesced (thread t
+// takes tiles t, t + NT, ...); the scan wants each thread on a run of consecutive tiles, so the
+// per-tile totals go through LDS.
+template <int NT>
+__device__ void queue_scan_dev(const QueueScan& q, uint32_t* lds) {
+  constexpr int kP = 16 * NT, kRun = 16;  // tiles per panel, consecutive tiles per thread within it
+  uint32_t* tot = lds;
+  uint32_t* hist = lds + kP;
+  uint32_t* base = hist + 256;
+  uint32_t* misc = base + 256;  // 0 carry, 1 batches, 2 longest, 3 chunk capacity, 4 the panel's total
+  uint32_t* wsum = misc + 8;
+  uint32_t* start = q.start;
+  uint32_t* tile_order = q.tile_order;
+  uint4* block_list = q.block_list;
+  const uint4* count4 = q.count4;
+  const int64_t tiles = q.tiles;
+  const int lanes = q.lanes, slots = q.slots;
+  TiledHostWord* host = q.host;
+  TiledCtl* ctl = q.ctl;
+  const int tid = threadIdx.x;
+  // the section counts of a tile, read where the atomics that made them were carried out (device
+  // scope: past this XCD's L2 — at the tail of a round kernel other XCDs are still adding to them
+  // until the last ticket is drawn)
+  auto counts_of = [&](int64_t i) {
+    const uint32_t* c = reinterpret_cast<const uint32_t*>(count4 + i);
+    return make_uint4(__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                      __hip_atomic_load(c + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                      __hip_atomic_load(c + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                      __hip_atomic_load(c + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  };
   // the host spins on host->seq (TiledRun::wait_word): everything it reads is stored, and
   // fenced out to system scope, before the number
   auto publish = [&](uint32_t blocks) {
     ctl->blocks = blocks;
+    ctl->blocks_of[q.rule.round & 1u] = blocks;
     host->blocks = blocks;
     // words of later scans overwrite this one while the host may still be reading it: the verdict
     // is a single word, and what goes with it is out before it
@@ -649,38 +710,22 @@ __global__ void __launch_bounds__(1024)
     __threadfence_system();
     __atomic_store_n(&host->mode, ctl->mode, __ATOMIC_RELEASE);
     __threadfence_system();
-    __atomic_store_n(&host->seq, seq, __ATOMIC_RELEASE);
+    __atomic_store_n(&host->seq, q.seq, __ATOMIC_RELEASE);
   };
-  if (ctl->mode != 0) {  // an earlier scan ended the rounds: only the word the host waits for
-    if (threadIdx.x == 0) {
-      host->live = ctl->live;
-      host->steps = *steps_run;
-      host->whole = 0u;
-      publish(0u);
-    }
-    return;
-  }
-  // Global traffic is coalesced (thread t takes tiles t, t + 1024, ...); the scan wants
-  // each thread on a run of consecutive tiles, so the per-tile totals go through LDS.
-  __shared__ uint32_t tot[kPanel];
-  __shared__ uint32_t part[1024];
-  __shared__ uint32_t hist[256], base[256];
-  __shared__ uint32_t carry, s_batches, s_longest, s_cap, wsum[16];
-  const int tid = threadIdx.x;
-  constexpr int kRun = kPanel / 1024;  // consecutive tiles per thread within a panel
   // bucket 255: empty tiles; 254..0: 1-15, 16-31, ... particles (longest first)
   auto bucket = [](uint32_t c) { return c == 0 ? 255u : 254u - (c >> 4 > 254u ? 254u : c >> 4); };
-  if (tid < 256) hist[tid] = 0;
-  if (tid == 0) carry = s_batches = s_longest = 0;
+  __syncthreads();  // the caller may have used the scratch for something else
+  for (int i = tid; i < 256; i += NT) hist[i] = 0;
+  if (tid == 0) misc[0] = misc[1] = misc[2] = 0;
   __syncthreads();
   uint4* out = reinterpret_cast<uint4*>(start);
   uint32_t my_batches = 0, my_longest = 0;
-  for (int64_t p0 = 0; p0 < tiles; p0 += kPanel) {
-    const int n = static_cast<int>(tiles - p0 < kPanel ? tiles - p0 : kPanel);
-    for (int i = tid; i < kPanel; i += 1024) {
+  for (int64_t p0 = 0; p0 < tiles; p0 += kP) {
+    const int n = static_cast<int>(tiles - p0 < kP ? tiles - p0 : kP);
+    for (int i = tid; i < kP; i += NT) {
       uint32_t t = 0;
       if (i < n) {
-        const uint4 c = count4[p0 + i];
+        const uint4 c = counts_of(p0 + i);
         t = c.x + c.y + c.z + c.w;
         atomicAdd(&hist[bucket(t)], 1u);
         my_batches += (t + lanes - 1) / lanes;
@@ -692,9 +737,9 @@ __global__ void __launch_bounds__(1024)
     uint32_t sum = 0;
 #pragma unroll
     for (int j = 0; j < kRun; ++j) sum += tot[tid * kRun + j];
-    const uint32_t incl = block_scan_1024(sum, wsum);
-    if (tid == 1023) part[1023] = incl;  // the panel's total
-    uint32_t run = carry + incl - sum;
+    const uint32_t incl = block_scan_nt<NT>(sum, wsum);
+    if (tid == NT - 1) misc[4] = incl;  // the panel's total
+    uint32_t run = misc[0] + incl - sum;
 #pragma unroll
     for (int j = 0; j < kRun; ++j) {  // tot[] becomes the exclusive prefix
       const uint32_t t = tot[tid * kRun + j];
@@ -702,17 +747,27 @@ __global__ void __launch_bounds__(1024)
       run += t;
     }
     __syncthreads();
-    for (int i = tid; i < n; i += 1024) {
-      const uint4 c = count4[p0 + i];
+    for (int i = tid; i < n; i += NT) {
+      const uint4 c = counts_of(p0 + i);
       const uint32_t r = tot[i];
       out[p0 + i] = make_uint4(r, r + c.x, r + c.x + c.y, r + c.x + c.y + c.z);
     }
     __syncthreads();
-    if (tid == 1023) carry += part[1023];
+    if (tid == NT - 1) misc[0] += misc[4];
     __syncthreads();
   }
-  atomicAdd(&s_batches, my_batches);
-  atomicMax(&s_longest, my_longest);
+  {  // one atomic per wave on the two scalars
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      my_batches += __shfl_xor(my_batches, off, 64);
+      const uint32_t o = __shfl_xor(my_longest, off, 64);
+      my_longest = o > my_longest ? o : my_longest;
+    }
+    if ((tid & 63) == 0) {
+      atomicAdd(&misc[1], my_batches);
+      atomicMax(&misc[2], my_longest);
+    }
+  }
   __syncthreads();
   // The block list: walking the tiles longest queue first, every non-empty tile gets a
   // work-group.  A work-group serves its queue in batches of `lanes` particles, so a
@@ -724,24 +779,28 @@ __global__ void __launch_bounds__(1024)
   // ~40 batches and nothing is cut; on 1024^2 .. 2048^2 it is 1-3 and the handful
   // of channel tiles would otherwise be the critical path of the whole round.
   if (tid == 0) {
-    start[tiles * kNB] = carry;  // particles queued in total
-    host->live = carry;
-    host->steps = *steps_run;
-    scan_decide(ctl, rule, carry, *steps_run);
-    const uint32_t share = (s_batches + slots - 1) / slots;
-    s_cap = (share > 0 ? share : 1u) * static_cast<uint32_t>(lanes);  // chunk capacity
-    carry = 0;
+    const uint32_t total = misc[0];
+    start[tiles * kNB] = total;  // particles queued in total
+    host->live = total;
+    host->steps = *q.steps_run;
+    scan_decide(ctl, q.rule, total, *q.steps_run);
+    const uint32_t share = (misc[1] + slots - 1) / slots;
+    misc[3] = (share > 0 ? share : 1u) * static_cast<uint32_t>(lanes);  // chunk capacity
+    misc[0] = 0;
   }
   {  // first slot of every bucket: exclusive scan of the histogram
-    const uint32_t h = tid < 256 ? hist[tid] : 0u;
-    const uint32_t incl = block_scan_1024(h, wsum);
+    uint32_t h = 0, h2 = 0;  // NT >= 256 except for ... every shape has NT >= 512
+    if (tid < 256) h = hist[tid];
+    const uint32_t incl = block_scan_nt<NT>(h, wsum);
     if (tid < 256) base[tid] = incl - h;
+    (void)h2;
   }
   __syncthreads();
-  const uint32_t chunk_cap = s_cap;
-  const bool cut = s_longest > chunk_cap;  // some queue needs more than one work-group
-  for (int64_t i = tid; i < tiles; i += 1024) {
-    const uint4 c = count4[i];
+  const uint32_t chunk_cap = misc[3];
+  const bool cut = misc[2] > chunk_cap;  // some queue needs more than one work-group
+  const uint32_t empty = hist[255];
+  for (int64_t i = tid; i < tiles; i += NT) {
+    const uint4 c = counts_of(i);
     const uint32_t t = c.x + c.y + c.z + c.w;
     const uint32_t pos = atomicAdd(&base[bucket(t)], 1u);
     tile_order[pos] = static_cast<uint32_t>(i);
@@ -749,8 +808,8 @@ __global__ void __launch_bounds__(1024)
   }
   if (!cut) {  // the common case on large grids: one work-group per non-empty tile
     if (tid == 0) {
-      host->whole = hist[255] == 0 ? 1u : 0u;
-      publish(static_cast<uint32_t>(tiles) - hist[255]);
+      host->whole = empty == 0 ? 1u : 0u;
+      publish(static_cast<uint32_t>(tiles) - empty);
     }
     return;
   }
@@ -761,16 +820,16 @@ __global__ void __launch_bounds__(1024)
     const uint32_t c = start[(t + 1) * kNB] - start[t * kNB];
     return (c + chunk_cap - 1) / chunk_cap;
   };
-  for (int64_t p0 = 0; p0 < tiles; p0 += kPanel) {
-    const int n = static_cast<int>(tiles - p0 < kPanel ? tiles - p0 : kPanel);
-    for (int i = tid; i < kPanel; i += 1024) tot[i] = i < n ? groups(p0 + i) : 0u;
+  for (int64_t p0 = 0; p0 < tiles; p0 += kP) {
+    const int n = static_cast<int>(tiles - p0 < kP ? tiles - p0 : kP);
+    for (int i = tid; i < kP; i += NT) tot[i] = i < n ? groups(p0 + i) : 0u;
     __syncthreads();
     uint32_t sum = 0;
 #pragma unroll
     for (int j = 0; j < kRun; ++j) sum += tot[tid * kRun + j];
-    const uint32_t incl = block_scan_1024(sum, wsum);
-    if (tid == 1023) part[1023] = incl;  // the panel's total
-    uint32_t run = carry + incl - sum;
+    const uint32_t incl = block_scan_nt<NT>(sum, wsum);
+    if (tid == NT - 1) misc[4] = incl;  // the panel's total
+    uint32_t run = misc[0] + incl - sum;
 #pragma unroll
     for (int j = 0; j < kRun; ++j) {
       const int i = tid * kRun + j;
@@ -778,208 +837,39 @@ __global__ void __launch_bounds__(1024)
       if (i < n) {
         const uint32_t tile = tile_order[p0 + i];
         const uint32_t q_first = start[tile * kNB], c = start[(tile + 1) * kNB] - q_first;
-        for (uint32_t q = 0; q < g; ++q) block_list[run + q] = queue_share(tile, q_first, c, g, q);
+        for (uint32_t k = 0; k < g; ++k) block_list[run + k] = queue_share(tile, q_first, c, g, k);
       }
       run += g;
     }
     __syncthreads();
-    if (tid == 1023) carry += part[1023];
+    if (tid == NT - 1) misc[0] += misc[4];
     __syncthreads();
   }
-  if (tid == 0) publish(carry);
+  if (tid == 0) publish(misc[0]);
 }
 
-// The same for up to kPanel tiles (every grid up to 8192^2 with 64-row tiles), with everything
-// between the one load of the counts and the stores of the results kept in registers and LDS.  The
-// scan above goes to global memory and back four times (counts three times, its own `start` and
-// `tile_order` once more when queues are cut); a round waits for this kernel, and on small grids
-// those round trips were most of it (20 us per launch at 1024^2, 25 launches per step).
-// Thread t owns tiles t, t + 1024, ... (coalesced loads and stores, counts in registers); the
-// scan runs over LDS with a pad word every 16 so that a thread's run of 16 consecutive tiles and
-// the strided accesses are both free of bank conflicts.
-__device__ __forceinline__ int pad16(int i) { return i + (i >> 4); }
+// the word the host waits for when the scan it belongs to does not take place (the rounds were
+// stopped by an earlier scan); one thread
+__device__ __forceinline__ void scan_skipped(const QueueScan& q) {
+  q.host->live = q.ctl->live;
+  q.host->steps = *q.steps_run;
+  q.host->whole = 0u;
+  q.host->blocks = 0u;
+  q.host->stop_round = q.ctl->stop_round;
+  __threadfence_system();
+  __atomic_store_n(&q.host->mode, q.ctl->mode, __ATOMIC_RELEASE);
+  __threadfence_system();
+  __atomic_store_n(&q.host->seq, q.seq, __ATOMIC_RELEASE);
+}
 
-__global__ void __launch_bounds__(1024)
-    k_queue_prepare(uint32_t* __restrict__ start, uint4* __restrict__ block_list,
-                    const uint4* __restrict__ count4, int tiles, int lanes, int slots,
-                    const unsigned long long* __restrict__ steps_run, TiledHostWord* host, uint32_t seq,
-                    TiledCtl* __restrict__ ctl, ScanRule rule) {
-  if (ctl->mode != 0) {  // an earlier scan ended the rounds: only the word the host waits for
-    if (threadIdx.x == 0) {
-      host->live = ctl->live;
-      host->steps = *steps_run;
-      host->whole = 0u;
-      host->blocks = 0u;
-      host->stop_round = ctl->stop_round;
-      __threadfence_system();
-      __atomic_store_n(&host->mode, ctl->mode, __ATOMIC_RELEASE);
-      __threadfence_system();
-      __atomic_store_n(&host->seq, seq, __ATOMIC_RELEASE);
-    }
+// the scan as a kernel of its own: the queues the spawn filled
+__global__ void __launch_bounds__(1024) k_queue_scan(QueueScan q) {
+  __shared__ uint32_t lds[scan_lds_words(1024)];
+  if (q.ctl->mode != 0) {
+    if (threadIdx.x == 0) scan_skipped(q);
     return;
   }
-  constexpr int kRun = kPanel / 1024;  // tiles per thread
-  __shared__ uint32_t pre[kPanel + kPanel / 16 + 2];  // totals, then their exclusive prefix (padded)
-  // tiles, longest queue first (uint16: kPanel / 2 words), and behind them the per-position group
-  // counts of the cut path (padded like pre[])
-  __shared__ uint16_t ord[kPanel + (kPanel + kPanel / 16 + 2)];
-  __shared__ uint32_t hist[256], base[256];
-  __shared__ uint32_t s_batches, s_longest, s_cap, s_total, s_published, wsum[16];
-  const int tid = threadIdx.x;
-  PREP_DECL;
-  // bucket 255: empty tiles; 254..0: 1-15, 16-31, ... particles (longest first)
-  auto bucket = [](uint32_t c) { return c == 0 ? 255u : 254u - (c >> 4 > 254u ? 254u : c >> 4); };
-  if (tid < 256) hist[tid] = 0;
-  if (tid == 0) s_batches = s_longest = 0;
-  __syncthreads();
-  uint4 c[kRun];
-  uint32_t my_batches = 0, my_longest = 0;
-#pragma unroll
-  for (int m = 0; m < kRun; ++m) {
-    const int i = tid + 1024 * m;
-    c[m] = make_uint4(0u, 0u, 0u, 0u);
-    if (i < tiles) c[m] = count4[i];
-    const uint32_t t = c[m].x + c[m].y + c[m].z + c[m].w;
-    pre[pad16(i)] = t;
-    if (i < tiles) {
-      atomicAdd(&hist[bucket(t)], 1u);
-      my_batches += (t + lanes - 1) / lanes;
-      my_longest = t > my_longest ? t : my_longest;
-    }
-  }
-  {  // one atomic per wave on the two scalars (1024 same-address LDS atomics cost microseconds)
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      my_batches += __shfl_xor(my_batches, off, 64);
-      const uint32_t o = __shfl_xor(my_longest, off, 64);
-      my_longest = o > my_longest ? o : my_longest;
-    }
-    if ((tid & 63) == 0) {
-      atomicAdd(&s_batches, my_batches);
-      atomicMax(&s_longest, my_longest);
-    }
-  }
-  __syncthreads();
-  PREP_AT(0);  // counts loaded
-  {  // exclusive prefix of the totals, in place
-    uint32_t run[kRun], sum = 0;
-#pragma unroll
-    for (int j = 0; j < kRun; ++j) {
-      run[j] = pre[pad16(tid * kRun + j)];
-      sum += run[j];
-    }
-    const uint32_t incl = block_scan_1024(sum, wsum);
-    uint32_t at = incl - sum;
-#pragma unroll
-    for (int j = 0; j < kRun; ++j) {
-      pre[pad16(tid * kRun + j)] = at;
-      at += run[j];
-    }
-    if (tid == 1023) {
-      s_total = incl;
-      pre[pad16(kPanel)] = incl;  // entry `tiles` is the grand total (below kPanel the scan put it there)
-    }
-  }
-  {  // first slot of every bucket: exclusive scan of the histogram (the barriers of the scan
-     // also publish pre[])
-    const uint32_t h = tid < 256 ? hist[tid] : 0u;
-    const uint32_t incl = block_scan_1024(h, wsum);
-    if (tid < 256) base[tid] = incl - h;
-  }
-  if (tid == 0) {
-    const uint32_t total = s_total;
-    start[static_cast<int64_t>(tiles) * kNB] = total;  // particles queued in all
-    host->live = total;
-    host->steps = *steps_run;
-    scan_decide(ctl, rule, total, *steps_run);
-    const uint32_t share = (s_batches + slots - 1) / slots;
-    s_cap = (share > 0 ? share : 1u) * static_cast<uint32_t>(lanes);  // chunk capacity, see above
-  }
-  __syncthreads();
-  PREP_AT(1);  // scans, host word's first fields
-  const uint32_t chunk_cap = s_cap;
-  const bool cut = s_longest > chunk_cap;  // some queue needs more than one work-group
-  uint4* out = reinterpret_cast<uint4*>(start);
-#pragma unroll
-  for (int m = 0; m < kRun; ++m) {
-    const int i = tid + 1024 * m;
-    if (i >= tiles) break;
-    const uint32_t r = pre[pad16(i)], t = c[m].x + c[m].y + c[m].z + c[m].w;
-    out[i] = make_uint4(r, r + c[m].x, r + c[m].x + c[m].y, r + c[m].x + c[m].y + c[m].z);
-    const uint32_t pos = atomicAdd(&base[bucket(t)], 1u);
-    ord[pos] = static_cast<uint16_t>(i);
-    if (!cut && t > 0) block_list[pos] = make_uint4(static_cast<uint32_t>(i), r, t, 0u);
-  }
-  auto publish = [&](uint32_t blocks) {  // everything the host reads is stored and fenced first
-    ctl->blocks = blocks;
-    host->blocks = blocks;
-    // words of later scans overwrite this one while the host may still be reading it: the verdict
-    // is a single word, and what goes with it is out before it
-    host->stop_round = ctl->stop_round;
-    __threadfence_system();
-    __atomic_store_n(&host->mode, ctl->mode, __ATOMIC_RELEASE);
-    __threadfence_system();
-    __atomic_store_n(&host->seq, seq, __ATOMIC_RELEASE);
-  };
-  PREP_AT(2);  // start, order, jobs of uncut queues
-  if (!cut) {  // the common case on large grids: one work-group per non-empty tile
-    if (tid == 0) {
-      host->whole = hist[255] == 0 ? 1u : 0u;
-      publish(static_cast<uint32_t>(tiles) - hist[255]);
-    }
-    PREP_AT(4);
-    return;
-  }
-  if (tid == 0) host->whole = 0u;
-  __syncthreads();
-  // queues cut into chunks: position p of the ordered list gets ceil(queue / cap) work-groups.
-  // The divisions run with one position per thread (strided); the scan takes the counts from LDS
-  // (`grp`, padded like `pre`) in runs of 16 per thread, which costs it additions only.
-  // (a round has at most tiles + slots work-groups: counts and their prefix fit 16 bits)
-  uint16_t* grp = ord + kPanel;
-#pragma unroll
-  for (int m = 0; m < kRun; ++m) {
-    const int pos = tid + 1024 * m;
-    uint32_t gq = 0;
-    if (pos < tiles) {
-      const int tile = ord[pos];
-      const uint32_t cnt = pre[pad16(tile + 1)] - pre[pad16(tile)];
-      gq = (cnt + chunk_cap - 1) / chunk_cap;
-    }
-    grp[pad16(pos)] = static_cast<uint16_t>(gq);
-  }
-  __syncthreads();
-  uint32_t incl;
-  {
-    uint32_t run[kRun], sum = 0;
-#pragma unroll
-    for (int j = 0; j < kRun; ++j) {
-      run[j] = grp[pad16(tid * kRun + j)];
-      sum += run[j];
-    }
-    incl = block_scan_1024(sum, wsum);
-    uint32_t at = incl - sum;
-#pragma unroll
-    for (int j = 0; j < kRun; ++j) {
-      grp[pad16(tid * kRun + j)] = static_cast<uint16_t>(at);
-      at += run[j];
-    }
-  }
-  __syncthreads();
-#pragma unroll
-  for (int m = 0; m < kRun; ++m) {
-    const int pos = tid + 1024 * m;
-    if (pos >= tiles) break;
-    const uint32_t tile = ord[pos];
-    const uint32_t q_first = pre[pad16(tile)], cnt = pre[pad16(tile + 1)] - q_first;
-    const uint32_t gq = (cnt + chunk_cap - 1) / chunk_cap, at = grp[pad16(pos)];
-    for (uint32_t q = 0; q < gq; ++q) block_list[at + q] = queue_share(tile, q_first, cnt, gq, q);
-  }
-  if (tid == 1023) s_published = incl;
-  __syncthreads();
-  PREP_AT(3);  // jobs of cut queues
-  if (tid == 0) publish(s_published);
-  PREP_AT(4);  // published
+  queue_scan_dev<1024>(q, lds);
 }
 
 // ---- one round: advance the particles of one tile against LDS ---------------------
@@ -1204,8 +1094,8 @@ __device__ __forceinline__ uint32_t opaque(uint32_t x) {
 template <int KIND, int DEP, int TR, int TC, int NT, bool ALB>
 __global__ void __launch_bounds__(NT, round_waves_per_simd(KIND, TR, TC, NT, ALB))
     k_tiled_round(PRec* __restrict__ out, uint32_t* __restrict__ dest, uint32_t* __restrict__ rank,
-                  uint32_t* __restrict__ count_next, const PRec* __restrict__ in,
-                  const uint32_t* __restrict__ order, const uint4* __restrict__ block_list,
+                  uint32_t* count_next, const PRec* __restrict__ in,
+                  const uint32_t* __restrict__ order, const uint4* block_list,
                   float* __restrict__ flux0,
                   float* __restrict__ flux1, float2* __restrict__ fluxV,
                   float* __restrict__ fluxA, const float4* __restrict__ p4,
@@ -1213,29 +1103,43 @@ __global__ void __launch_bounds__(NT, round_waves_per_simd(KIND, TR, TC, NT, ALB
                   Scale3 s, Param param, int tiles_w, int off_r, int off_c, int steps_per_round,
                   TileShape ts_next,
                   int tiles_w_next, int agg_min, int agg_groups, int retries, int store_all,
-                  const TiledCtl* __restrict__ ctl) {
+                  TiledCtl* __restrict__ ctl, uint32_t round, QueueScan next) {
   constexpr int kCells = TR * TC, kBlock = NT, kPer = (kCells + NT - 1) / NT;
-  // queued ahead of the scan's verdict: no round at all, or fewer work-groups than the launch has
-  if (ctl->mode != 0 || blockIdx.x >= ctl->blocks) return;
+  // Queued ahead of the scan's verdict: no round at all (the word the host waits for at the end of
+  // this round still goes out), or fewer work-groups than the launch has.
+  if (ctl->mode != 0) {
+    if (blockIdx.x == 0 && threadIdx.x == 0 && next.host) scan_skipped(next);
+    return;
+  }
+  const uint32_t n_groups = ctl->blocks_of[round & 1u];
+  if (blockIdx.x >= n_groups) return;
   PROF_DECL;
-  // this work-group's share of its tile's queue (k_queue_prepare's block list)
+  // this work-group's share of its tile's queue (the scan's block list)
   const uint4 job = block_list[blockIdx.x];
   const int tile = static_cast<int>(job.x);
   const uint32_t first = job.y, cnt = job.z;
-  if (cnt == 0) return;
   const bool shared_tile = job.w != 0;  // other work-groups deposit into the same cells
   // local row, column of the tile's first cell (negative on the rim of a shifted grid)
   const int row0 = (tile / tiles_w) * TR - off_r, col0 = (tile % tiles_w) * TC - off_c;
+  const int tid = threadIdx.x;
 
   // flux accumulators as separate planes: lane addresses c map to 32 distinct
   // banks (an AoS float4 would put every lane of a deposit on 8 banks)
   // fluvial: water | mass interleaved (an 8-byte word per cell: CasDeposit's pairs); debris: mass
-  __shared__ __attribute__((aligned(8))) float s_a[KIND == FLUVIAL ? 2 * kCells : kCells];
-  __shared__ __attribute__((aligned(8))) float s_v[2 * kCells];  // velocity flux x | y interleaved
-  __shared__ float s_c0[ALB ? kCells : 1], s_c1[ALB ? kCells : 1], s_c2[ALB ? kCells : 1];  // colour
+  // one block of LDS: the accumulators, and — for the work-group that finishes the round — the
+  // scratch of the scan of the round that follows (queue_scan_dev)
   constexpr int kA = (KIND == FLUVIAL) ? 2 : 1;  // floats of s_a per cell
-  __shared__ uint32_t s_next, s_out, s_steps;
-  const int tid = threadIdx.x;
+  constexpr int kAcc = kA * kCells + 2 * kCells + (ALB ? 3 * kCells : 0);
+  constexpr int kWords = kAcc > scan_lds_words(NT) ? kAcc : scan_lds_words(NT);
+  __shared__ __attribute__((aligned(16))) float s_mem[kWords];
+  float* const s_a = s_mem;                                  // water | mass (fluvial), mass (debris)
+  float* const s_v = s_mem + kA * kCells;                    // velocity flux x | y interleaved
+  float* const s_c0 = s_v + 2 * kCells;                      // colour (ALB)
+  float* const s_c1 = s_c0 + (ALB ? kCells : 0);
+  float* const s_c2 = s_c1 + (ALB ? kCells : 0);
+  __shared__ uint32_t s_next, s_out, s_steps, s_last;
+  do {  // the round's work proper (a chunk of a cut queue may be empty)
+  if (cnt == 0) break;
   if (tid == 0) {
     s_next = kBlock;  // the first kBlock queue entries go to the lanes directly, see below
     s_out = 0;
@@ -1558,6 +1462,27 @@ __global__ void __launch_bounds__(NT, round_waves_per_simd(KIND, TR, TC, NT, ALB
     }
   }
   PROF_FLUSH(KIND);  // [9]: flush of the tile's flux
+  } while (false);
+
+  // The work-group that finishes last scans the queues of the round that follows: no launch of its
+  // own for the scan (it used to wait for a CU with 139 KiB of free LDS behind the other launch's
+  // round kernel: 0.24 ms per scan in the overlapped step), no launch gap on either side of it.
+  // No fences: a device-scope release / acquire writes back and invalidates the L2 of the XCD (the
+  // eight L2s are not coherent with each other) — per work-group that cost 20 % of the launch.  None
+  // is needed: all the scan reads of this round are the section counts, and those are only ever
+  // touched by device-scope atomics, which are carried out at the memory side; every one of them is
+  // a returning atomic whose answer this work-group has stored by now (barrier above), so it is
+  // done before the ticket is drawn; the scan reads the counts with device-scope loads.  Everything
+  // else the round writes (records, ranks, flux) is for later kernels.
+  if (!next.host) return;  // uniform: the scan is a launch of its own (SOIL_TILED_TAILSCAN=2)
+  __syncthreads();
+  if (tid == 0)
+    s_last = __hip_atomic_fetch_add(&ctl->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n_groups - 1u ? 1u : 0u;
+  __syncthreads();
+  if (s_last != 0u) {
+    if (tid == 0) __hip_atomic_store(&ctl->done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    queue_scan_dev<NT>(next, reinterpret_cast<uint32_t*>(s_mem));
+  }
 }
 
 // ---- the last launch: walk the remaining particles to the end against HBM ----------
@@ -1736,6 +1661,7 @@ struct TiledRun {
   uint64_t round = 0;           // = rounds (kept under its old name: the pair driver reads it)
   uint64_t scans = 0, seen = 0;
   int depth = 2;                // rounds queued beyond the last word seen (SOIL_TILED_AHEAD)
+  bool tail_scan = true;        // the scan of a round at the tail of the round kernel before it (SOIL_TILED_TAILSCAN=2: a launch of its own)
   uint32_t* seq_ctr = nullptr;  // number of the last k_queue_prepare launch (TiledHostWord::seq)
   uint32_t seq_first = 0;       // ... of this run's scan 0
   int64_t live_known = 0;       // an upper bound of the record slots in use: the last live count seen
@@ -1905,43 +1831,45 @@ struct TiledRun {
     host_dev = hs.host_dev;
     seq_ctr = &hs.seq;
     ticks_per_second = hs.ticks_per_second;
+    tail_scan = env_int("SOIL_TILED_TAILSCAN", 1) == 1;
     depth = verbose ? 0 : env_int("SOIL_TILED_AHEAD", 2);
     if (std::getenv("SOIL_TILED_AHEAD") && std::atoi(std::getenv("SOIL_TILED_AHEAD")) == 0) depth = 0;
     ready = true;
     return SOIL_OK;
   }
 
-  // Scan of the queues round `scans` starts from — with the device's decision whether that round
-  // takes place at all (scan_decide) and the word for the host — and the slot sort of that round.
-  // Neither waits for the host: the sort needs the scan's offsets and the slots the round before
-  // filled, both on the device.
-  int queue_scan() {
-    const uint64_t r = scans;
-    const int64_t tiles = tiles_of(shape_of(r), r);
-    const int lanes = Shapes<KIND>::v[shape_of(r)].nt;
-    const int slots = resident_groups[r >= static_cast<uint64_t>(switch_round) ? 1 : 0];
+  // What the scan of the queues round r starts from is asked to do (QueueScan): offsets, dispatch
+  // order and work-group list of that round, the device's decision whether the round takes place at
+  // all (scan_decide) and the word for the host.
+  QueueScan make_scan(uint64_t r) {
+    QueueScan q;
+    q.start = start;
+    q.tile_order = tile_order;
+    q.block_list = block_list;
+    q.count4 = reinterpret_cast<const uint4*>(count_of(r));
+    q.tiles = tiles_of(shape_of(r), r);
+    q.lanes = Shapes<KIND>::v[shape_of(r)].nt;
+    q.slots = resident_groups[r >= static_cast<uint64_t>(switch_round) ? 1 : 0];
+    q.steps_run = steps_run;
+    q.host = host_dev;
+    q.seq = ++*seq_ctr;
+    q.ctl = ctl;
     // every live particle advances >= 1 step per round: maxage + 2 rounds always suffice
     const uint64_t max_round = p.maxage + 2;
-    ScanRule rule;
-    rule.round = static_cast<uint32_t>(r);
-    rule.tail = static_cast<uint32_t>(tail);
-    rule.max_round = max_round > 0xffffffffull ? 0xffffffffu : static_cast<uint32_t>(max_round);
-    rule.ticks_per_step_max = static_cast<float>(ticks_per_second / finish_rate);
-    // SOIL_TILED_PANELS=1: the many-tiles variant whatever the grid (tests)
-    const bool panels = tiles > kPanel || std::getenv("SOIL_TILED_PANELS") != nullptr;
-    const uint4* cnt4 = reinterpret_cast<const uint4*>(count_of(r));
-    if (!panels)
-      k_queue_prepare<<<1, 1024, 0, st>>>(start, block_list, cnt4, static_cast<int>(tiles), lanes, slots,
-                                          steps_run, host_dev, ++*seq_ctr, ctl, rule);
-    else
-      k_queue_prepare_panels<<<1, 1024, 0, st>>>(start, tile_order, block_list, cnt4, tiles, lanes, slots,
-                                                 steps_run, host_dev, ++*seq_ctr, ctl, rule);
+    q.rule.round = static_cast<uint32_t>(r);
+    q.rule.tail = static_cast<uint32_t>(tail);
+    q.rule.max_round = max_round > 0xffffffffull ? 0xffffffffu : static_cast<uint32_t>(max_round);
+    q.rule.ticks_per_step_max = static_cast<float>(ticks_per_second / finish_rate);
+    return q;
+  }
+  // the scan of round 0 (the queues the spawn filled) is a kernel of its own; every later one runs at
+  // the tail of the round kernel before it
+  int queue_scan() {
+    const QueueScan q = make_scan(0);
+    seq_first = q.seq;
+    k_queue_scan<<<1, 1024, 0, st>>>(q);
     SOIL_LAUNCH_CHECK();
-    if (r == 0) seq_first = *seq_ctr;
-    k_tiled_scatter<<<blocks_for(live_known, 256), 256, 0, st>>>(
-        order, start, dest, rank, ctl, count_of(r + 1), static_cast<int64_t>(b_cnt / sizeof(uint32_t)));
-    SOIL_LAUNCH_CHECK();
-    ++scans;
+    scans = 1;
     return SOIL_OK;
   }
 
@@ -1993,19 +1921,30 @@ struct TiledRun {
     return SOIL_OK;
   }
 
-  // round kernel `round` (behind its scan) and the scan of the round after it
-  int queue_round(int store_all) {
+  // Round `round`: the slot sort (it needs the scan's offsets and the slots the round before filled,
+  // both on the device) and the round kernel, whose last work-group scans the queues of the round
+  // after it.  Queued ahead of the host's look at the scan's word: what the round finds to do is
+  // the device's decision.
+  // `slots_bound`: an upper bound of the record slots the round before filled (what the slot sort has
+  // to look at): the live count of the last word seen BEFORE the word of this round's own scan
+  int queue_round(int store_all, int64_t slots_bound) {
     const uint64_t r = round;
     const int sh = shape_of(r), sh_next = shape_of(r + 1);
     const int64_t tiles = tiles_of(sh, r);
     const int tiles_w = tiles_w_of(sh, r);
     const TileShape ts_cur = ts_of(sh, r);
+    k_tiled_scatter<<<blocks_for(std::max<int64_t>(slots_bound, 1), 256), 256, 0, st>>>(
+        order, start, dest, rank, ctl, count_of(r + 1), static_cast<int64_t>(b_cnt / sizeof(uint32_t)));
+    SOIL_LAUNCH_CHECK();
     // as many work-groups as a round can have (a tile each, plus the chunks long queues are cut into);
     // those beyond the scan's count return at once
     const int slots = resident_groups[r >= static_cast<uint64_t>(switch_round) ? 1 : 0];
     const unsigned grid = static_cast<unsigned>(std::min<int64_t>(tiles + slots, std::max<int64_t>(live_known, 1)));
     PRec* in = recs_of(r);
     PRec* out = recs_of(r + 1);
+    QueueScan next_scan = make_scan(r + 1);
+    const QueueScan standalone = next_scan;
+    if (!tail_scan) next_scan.host = nullptr;  // the round kernel leaves the scan to a launch of its own
     if (deposit == 1)
       launch_round<KIND, 0>(sh, grid, st, out, dest, rank, count_of(r + 1),
                             static_cast<const PRec*>(in), static_cast<const uint32_t*>(order),
@@ -2014,7 +1953,7 @@ struct TiledRun {
                             remote0, steps_run, d, s, p, tiles_w, ts_cur.off_r, ts_cur.off_c,
                             steps_per_round, ts_of(sh_next, r + 1),
                             tiles_w_of(sh_next, r + 1), agg_min, agg_groups, retries, store_all,
-                            static_cast<const TiledCtl*>(ctl));
+                            ctl, static_cast<uint32_t>(r), next_scan);
     else
       launch_round<KIND, 1>(sh, grid, st, out, dest, rank, count_of(r + 1),
                             static_cast<const PRec*>(in), static_cast<const uint32_t*>(order),
@@ -2023,10 +1962,15 @@ struct TiledRun {
                             remote0, steps_run, d, s, p, tiles_w, ts_cur.off_r, ts_cur.off_c,
                             steps_per_round, ts_of(sh_next, r + 1),
                             tiles_w_of(sh_next, r + 1), agg_min, agg_groups, retries, store_all,
-                            static_cast<const TiledCtl*>(ctl));
+                            ctl, static_cast<uint32_t>(r), next_scan);
     SOIL_LAUNCH_CHECK();
+    if (!tail_scan) {
+      k_queue_scan<<<1, 1024, 0, st>>>(standalone);
+      SOIL_LAUNCH_CHECK();
+    }
     ++round;
-    return queue_scan();
+    ++scans;
+    return SOIL_OK;
   }
 
   // One look at the device's progress: wait for the next scan's word; if the rounds go on, make sure
@@ -2037,6 +1981,7 @@ struct TiledRun {
     if (int rc = wait_word(); rc != SOIL_OK) return rc;
     const uint64_t r = seen++;  // the word of scan r (or of a later one carrying the same verdict)
     const uint32_t mode = __atomic_load_n(&host->mode, __ATOMIC_ACQUIRE);
+    const int64_t slots_before = live_known;  // >= the slots round r's sort and the finishing launch look at
     if (mode == 0) live_known = std::min<int64_t>(live_known, static_cast<int64_t>(host->live));
     if (verbose) {  // queue-length statistics of the round (diagnostics only; depth 0: the word is scan r's)
       const int sh = shape_of(r);
@@ -2074,16 +2019,16 @@ struct TiledRun {
     if (mode != 0) {
       if (mode == 1) {  // the records round `stop_round` would have read, and the slots in use among them
         const uint64_t stop = host->stop_round;
-        k_tiled_finish<KIND><<<blocks_for(live_known, 256), 256, 0, st>>>(
+        k_tiled_finish<KIND><<<blocks_for(std::max<int64_t>(slots_before, 1), 256), 256, 0, st>>>(
             recs_of(stop), dest, ctl, flux0, flux1, fluxV, fluxA, p4, remote0, steps_run, d, s, p);
         SOIL_LAUNCH_CHECK();
       }
       return finish_steps();
     }
     if (round == r)
-      if (int rc = queue_round(store_all); rc != SOIL_OK) return rc;
+      if (int rc = queue_round(store_all, slots_before); rc != SOIL_OK) return rc;
     while (round < seen + static_cast<uint64_t>(depth) && round < p.maxage + 3)
-      if (int rc = queue_round(0); rc != SOIL_OK) return rc;
+      if (int rc = queue_round(0, live_known); rc != SOIL_OK) return rc;
     return SOIL_OK;
   }
 };
@@ -2153,6 +2098,16 @@ int launch_pair_tiled(const soil_erosion_planes& P, soil_rng* rng_fluvial, soil_
   // (2) 37.2 (6) 37.3 (8): small grids are bound by the latency of each launch's chain of rounds, and two
   // chains interleave; at 8192^2 either launch fills the chip by itself.
   static const int delay_env = env_int("SOIL_PAIR_DELAY", 0);
+  // Overlapped or one after the other (SOIL_PAIR_MODE=1 / 3; default: by size).  Where either launch
+  // fills the chip by itself, mixing their work-groups loses: a CU's LDS holds two fluvial tiles or
+  // three debris ones, a fluvial and a debris one leave 28 KiB unused and no third.  Measured on one
+  // box (ms per step, overlapped | debris after fluvial; both share the one pack pass): 1024^2 1.59 | 2.10,
+  // 2048^2 3.98 | 4.44, 4096^2 10.37 | 10.48, 8192^2 38.1 | 36.5.  (Round 2's overlapped 8192^2 step was
+  // as fast as the serial one by accident: its scan kernels asked for 139 KiB of LDS and so waited
+  // for an empty CU, which made the two launches take turns round by round.  Stream priorities do
+  // not change the mix: 38.4 | 38.1 with the fluvial stream at the highest priority.)
+  const int pair_mode = env_int("SOIL_PAIR_MODE", 0);
+  const bool serial_pair = pair_mode == 3 || (pair_mode != 1 && N >= 4000000);
   // (round 3, with rounds queued ahead of the host: counted in scans the host has seen; 1024^2 1.59 / 1.62 /
   // 1.67 ms per step at 1 / 2 / 3, 2048^2 3.98 / 3.86 / 3.75, 4096^2 10.28 / 10.36 / 10.48)
   const uint64_t delay = delay_env > 0 ? static_cast<uint64_t>(delay_env) : (N <= 300000 ? 1 : 2);
@@ -2177,7 +2132,7 @@ int launch_pair_tiled(const soil_erosion_planes& P, soil_rng* rng_fluvial, soil_
     if (int rc = A.begin(); rc != SOIL_OK) return rc;
     bool b_started = false;
     while (!A.done || !B.done) {
-      if (!b_started && (A.done || A.seen >= delay)) {  // `delay` scans of the fluvial launch seen
+      if (!b_started && (A.done || (!serial_pair && A.seen >= delay))) {  // `delay` scans of the fluvial launch seen
         if (int rc = B.begin(); rc != SOIL_OK) return rc;
         b_started = true;
       }

@@ -1,0 +1,12 @@
+(timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | grep -v "^  File\|^Extension" | tail -25)
+run() { python bench.py "$@" --no-cpu-baseline 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('$LABEL', round(d['ms_per_step'],4), {k:round(v,3) for k,v in d['phases_ms'].items()})"; }
+for i in 1 2; do
+LABEL="1024" run --size 1024 --steps 3000 --warmup 50
+LABEL="2048" run --size 2048 --steps 300 --warmup 20
+LABEL="4096" run --size 4096 --steps 60 --warmup 5
+LABEL="8192" run --steps 10 --warmup 3
+LABEL="8192 seq" run --steps 10 --warmup 3 --sequential-particles
+done

@@ -113,8 +113,10 @@ summary = {
             "x cycles), lds_bank_conflict likewise",
 }
 for kind, label in ((0, "fluvial_rounds"), (1, "debris_rounds")):
-    ra = [c for c in valu if "k_tiled_round<%d" % kind in c["name"]]
-    rb = [c for c in lds if "k_tiled_round<%d" % kind in c["name"]]
+    # (round kernels queued ahead of the device's decision to stop return at once: not launches of a round)
+    skipped = {c["id"] for c in valu if "k_tiled_round<%d" % kind in c["name"] and c.get("SQ_INSTS_VALU", 0) < 1e4}
+    ra = [c for c in valu if "k_tiled_round<%d" % kind in c["name"] and c.get("SQ_INSTS_VALU", 0) >= 1e4]
+    rb = [c for c in lds if "k_tiled_round<%d" % kind in c["name"] and c.get("SQ_INSTS_LDS", 0) > 0]
     ra, rb = ra[len(ra) // 2:], rb[len(rb) // 2:]
     rows = []
     for i, (a, b) in enumerate(zip(ra, rb)):
@@ -157,7 +159,7 @@ roof = {}
 mix_ok = os.path.isdir(os.path.join(src, "mix"))
 mix = load("mix") if mix_ok else []
 for kind, label in ((0, "fluvial_rounds"), (1, "debris_rounds")):
-    rows = [c for c in mix if "k_tiled_round<%d" % kind in c["name"]]
+    rows = [c for c in mix if "k_tiled_round<%d" % kind in c["name"] and c.get("SQ_INSTS_VALU", 0) >= 1e4]
     rows = rows[len(rows) // 2:]
     if not rows:
         continue
