@@ -2105,7 +2105,8 @@ int launch_pair_tiled(const soil_erosion_planes& P, soil_rng* rng_fluvial, soil_
   // 2048^2 3.98 | 4.44, 4096^2 10.37 | 10.48, 8192^2 38.1 | 36.5.  (Round 2's overlapped 8192^2 step was
   // as fast as the serial one by accident: its scan kernels asked for 139 KiB of LDS and so waited
   // for an empty CU, which made the two launches take turns round by round.  Stream priorities do
-  // not change the mix: 38.4 | 38.1 with the fluvial stream at the highest priority.)
+  // not change the mix: 38.4 | 38.1 with the fluvial stream at the highest priority; neither does a
+  // scan kernel of its own padded to 160 KiB of LDS so that it waits for a drained CU: 37.4-37.7.)
   const int pair_mode = env_int("SOIL_PAIR_MODE", 0);
   const bool serial_pair = pair_mode == 3 || (pair_mode != 1 && N >= 4000000);
   // (round 3, with rounds queued ahead of the host: counted in scans the host has seen; 1024^2 1.59 / 1.62 /
