@@ -105,6 +105,7 @@ struct TiledCtl {
   unsigned long long steps_prev, t_prev;  // step counter and realtime clock at the last scan
   uint32_t stop_round;
   uint32_t done;        // work-groups of the running round that have finished (its last one scans)
+  uint32_t started;     // ... that have started (the last one to start opens the gate of the other launch, PairGate)
   // blocks of round r in slot r & 1: the scan at the tail of round r writes the other slot, which no
   // work-group of round r reads — stragglers beyond the round's count may still be arriving then
   uint32_t blocks_of[2];
@@ -872,6 +873,32 @@ __global__ void __launch_bounds__(1024) k_queue_scan(QueueScan q) {
   queue_scan_dev<1024>(q, lds);
 }
 
+// ---- taking turns: the two launches of a step on a grid either of them fills by itself -------------
+//
+// Mixed freely, the two round kernels waste LDS (a CU holds two fluvial tiles or three debris ones,
+// one of each leaves 28 KiB unused); run one after the other, each leaves the chip half empty at the
+// end of every round (the last generation of work-groups, the slot sort, the scan).  So they take
+// turns: a launch's round may begin once the other launch is NOT in the dense part of a round — its
+// work-groups all handed out (what is still running is the tail), or between two rounds, or done —
+// and the work-groups of the new round fill the slots the other's tail leaves.  `dense[k]` is launch
+// k's state; a one-thread gate kernel in front of every round kernel waits (device-scope loads,
+// s_sleep, bounded: after 50 ms it lets the round through) while the other's is set and sets its
+// own; the last work-group of a round to START clears it.  Both gates waiting at once means neither
+// launch is in a round: both flags are clear and both pass.
+struct PairGate {
+  uint32_t dense[2];
+};
+__global__ void k_pair_gate(PairGate* gate, int me, const TiledCtl* __restrict__ ctl,
+                            unsigned long long ticks_max) {
+  if (ctl->mode != 0) return;  // no round follows
+  const unsigned long long t0 = realtime_ticks();
+  while (__hip_atomic_load(&gate->dense[1 - me], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+    __builtin_amdgcn_s_sleep(32);
+    if (realtime_ticks() - t0 > ticks_max) break;
+  }
+  __hip_atomic_store(&gate->dense[me], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // ---- one round: advance the particles of one tile against LDS ---------------------
 
 // Float adds on LDS words by compare-and-swap, split in two halves so that the
@@ -1103,7 +1130,7 @@ __global__ void __launch_bounds__(NT, round_waves_per_simd(KIND, TR, TC, NT, ALB
                   Scale3 s, Param param, int tiles_w, int off_r, int off_c, int steps_per_round,
                   TileShape ts_next,
                   int tiles_w_next, int agg_min, int agg_groups, int retries, int store_all,
-                  TiledCtl* __restrict__ ctl, uint32_t round, QueueScan next) {
+                  TiledCtl* __restrict__ ctl, uint32_t round, QueueScan next, uint32_t* my_dense) {
   constexpr int kCells = TR * TC, kBlock = NT, kPer = (kCells + NT - 1) / NT;
   // Queued ahead of the scan's verdict: no round at all (the word the host waits for at the end of
   // this round still goes out), or fewer work-groups than the launch has.
@@ -1113,6 +1140,12 @@ __global__ void __launch_bounds__(NT, round_waves_per_simd(KIND, TR, TC, NT, ALB
   }
   const uint32_t n_groups = ctl->blocks_of[round & 1u];
   if (blockIdx.x >= n_groups) return;
+  // taking turns with the other launch of the step (PairGate): the last work-group of the round to
+  // start — every one has been handed out, what follows is the round's tail — lets the other's next
+  // round in
+  if (my_dense && threadIdx.x == 0 &&
+      __hip_atomic_fetch_add(&ctl->started, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n_groups - 1u)
+    __hip_atomic_store(my_dense, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   PROF_DECL;
   // this work-group's share of its tile's queue (the scan's block list)
   const uint4 job = block_list[blockIdx.x];
@@ -1480,7 +1513,10 @@ __global__ void __launch_bounds__(NT, round_waves_per_simd(KIND, TR, TC, NT, ALB
     s_last = __hip_atomic_fetch_add(&ctl->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n_groups - 1u ? 1u : 0u;
   __syncthreads();
   if (s_last != 0u) {
-    if (tid == 0) __hip_atomic_store(&ctl->done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) {
+      __hip_atomic_store(&ctl->done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&ctl->started, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     queue_scan_dev<NT>(next, reinterpret_cast<uint32_t*>(s_mem));
   }
 }
@@ -1662,6 +1698,7 @@ struct TiledRun {
   uint64_t scans = 0, seen = 0;
   int depth = 2;                // rounds queued beyond the last word seen (SOIL_TILED_AHEAD)
   bool tail_scan = true;        // the scan of a round at the tail of the round kernel before it (SOIL_TILED_TAILSCAN=2: a launch of its own)
+  PairGate* gate = nullptr;     // taking turns with the other launch of the step (launch_pair_tiled); me = KIND
   uint32_t* seq_ctr = nullptr;  // number of the last k_queue_prepare launch (TiledHostWord::seq)
   uint32_t seq_first = 0;       // ... of this run's scan 0
   int64_t live_known = 0;       // an upper bound of the record slots in use: the last live count seen
@@ -1942,6 +1979,12 @@ struct TiledRun {
     const unsigned grid = static_cast<unsigned>(std::min<int64_t>(tiles + slots, std::max<int64_t>(live_known, 1)));
     PRec* in = recs_of(r);
     PRec* out = recs_of(r + 1);
+    uint32_t* my_dense = nullptr;
+    if (gate && tail_scan) {  // (the `started` ticket is reset by the tail scan's work-group)
+      k_pair_gate<<<1, 1, 0, st>>>(gate, KIND, ctl, static_cast<unsigned long long>(0.05 * ticks_per_second));
+      SOIL_LAUNCH_CHECK();
+      my_dense = &gate->dense[KIND];
+    }
     QueueScan next_scan = make_scan(r + 1);
     const QueueScan standalone = next_scan;
     if (!tail_scan) next_scan.host = nullptr;  // the round kernel leaves the scan to a launch of its own
@@ -1953,7 +1996,7 @@ struct TiledRun {
                             remote0, steps_run, d, s, p, tiles_w, ts_cur.off_r, ts_cur.off_c,
                             steps_per_round, ts_of(sh_next, r + 1),
                             tiles_w_of(sh_next, r + 1), agg_min, agg_groups, retries, store_all,
-                            ctl, static_cast<uint32_t>(r), next_scan);
+                            ctl, static_cast<uint32_t>(r), next_scan, my_dense);
     else
       launch_round<KIND, 1>(sh, grid, st, out, dest, rank, count_of(r + 1),
                             static_cast<const PRec*>(in), static_cast<const uint32_t*>(order),
@@ -1962,7 +2005,7 @@ struct TiledRun {
                             remote0, steps_run, d, s, p, tiles_w, ts_cur.off_r, ts_cur.off_c,
                             steps_per_round, ts_of(sh_next, r + 1),
                             tiles_w_of(sh_next, r + 1), agg_min, agg_groups, retries, store_all,
-                            ctl, static_cast<uint32_t>(r), next_scan);
+                            ctl, static_cast<uint32_t>(r), next_scan, my_dense);
     SOIL_LAUNCH_CHECK();
     if (!tail_scan) {
       k_queue_scan<<<1, 1024, 0, st>>>(standalone);
@@ -2098,17 +2141,26 @@ int launch_pair_tiled(const soil_erosion_planes& P, soil_rng* rng_fluvial, soil_
   // (2) 37.2 (6) 37.3 (8): small grids are bound by the latency of each launch's chain of rounds, and two
   // chains interleave; at 8192^2 either launch fills the chip by itself.
   static const int delay_env = env_int("SOIL_PAIR_DELAY", 0);
-  // Overlapped or one after the other (SOIL_PAIR_MODE=1 / 3; default: by size).  Where either launch
-  // fills the chip by itself, mixing their work-groups loses: a CU's LDS holds two fluvial tiles or
-  // three debris ones, a fluvial and a debris one leave 28 KiB unused and no third.  Measured on one
-  // box (ms per step, overlapped | debris after fluvial; both share the one pack pass): 1024^2 1.59 | 2.10,
-  // 2048^2 3.98 | 4.44, 4096^2 10.37 | 10.48, 8192^2 38.1 | 36.5.  (Round 2's overlapped 8192^2 step was
-  // as fast as the serial one by accident: its scan kernels asked for 139 KiB of LDS and so waited
-  // for an empty CU, which made the two launches take turns round by round.  Stream priorities do
-  // not change the mix: 38.4 | 38.1 with the fluvial stream at the highest priority; neither does a
-  // scan kernel of its own padded to 160 KiB of LDS so that it waits for a drained CU: 37.4-37.7.)
+  // How the two launches share the chip (SOIL_PAIR_MODE; default: by size).  1: overlapped freely;
+  // 2: overlapped, taking turns round by round behind the device-side gate (PairGate); 3: the debris
+  // launch after the fluvial one.  All three share the one pack pass.  Mixing the two round kernels
+  // freely loses where either fills the chip by itself (a CU's LDS holds two fluvial tiles or three
+  // debris ones; one of each leaves 28 KiB unused and no third); one after the other, every round
+  // ends with the chip half empty.  Measured on one box, ms per step, 1 | 2 | 3: 1024^2 1.58 | 1.63 | 2.10,
+  // 2048^2 3.98 | 3.90 | 4.44, 4096^2 10.89 | 10.20 | 10.59, 8192^2 38.27 | 35.94 | 36.86.  (Round 2's
+  // overlapped 8192^2 step took turns by accident: its scan kernels asked for 139 KiB of LDS and so
+  // waited for a CU the other launch's round had drained.  Stream priorities do not change the mix
+  // of mode 1 (38.4 with the fluvial stream at the highest priority); opening the gate 128 / 256 / 512
+  // work-groups before the round's last one has started: 35.66 / 36.25 / 38.21 against 35.66.)
   const int pair_mode = env_int("SOIL_PAIR_MODE", 0);
-  const bool serial_pair = pair_mode == 3 || (pair_mode != 1 && N >= 4000000);
+  const bool turns = pair_mode == 2 || (pair_mode == 0 && N >= 500000);
+  const bool serial_pair = pair_mode == 3;
+  if (turns) {
+    void* g = nullptr;
+    if (int rc = workspace_get(9, 256, &g); rc != SOIL_OK) return rc;
+    SOIL_HIP(hipMemsetAsync(g, 0, sizeof(PairGate), sA));  // sA and sB both wait for `fork`; B starts after A's first scans
+    A.gate = B.gate = static_cast<PairGate*>(g);
+  }
   // (round 3, with rounds queued ahead of the host: counted in scans the host has seen; 1024^2 1.59 / 1.62 /
   // 1.67 ms per step at 1 / 2 / 3, 2048^2 3.98 / 3.86 / 3.75, 4096^2 10.28 / 10.36 / 10.48)
   const uint64_t delay = delay_env > 0 ? static_cast<uint64_t>(delay_env) : (N <= 300000 ? 1 : 2);

@@ -1193,3 +1193,49 @@ def test_erode_chain_leaves_the_track_planes_zeroed(hip):
     h1, d1 = run([1, 1, 1, 1])   # four chains of one (every step eager)
     _close_but_for_stray_walks(h4, h1, 1e-4, 1e-6, 2e-3, "height")
     _close_but_for_stray_walks(d4, d1, 1e-4, 1e-5 * np.nanmax(np.abs(d1)), 2e-3, "discharge")
+
+
+@pytest.mark.parametrize("mode", ["1", "2", "3"])
+def test_pair_modes_walk_the_same_walks(hip, monkeypatch, mode):
+    """SOIL_PAIR_MODE: the two launches of a step overlapped freely (1), taking turns round by round
+    behind the device-side gate (2: what grids of 4 M particles and more get), one after the other (3)
+    — the same walks and the same fields as two separate launches."""
+    from soillib_amd import _abi, silt, soil
+    from soillib_amd.erosion import ErosionModel
+    monkeypatch.setenv("SOIL_PAIR_MODE", mode)
+    S = 512
+    pp = script_param(soil.param_t())
+    pp.maxage = 96
+    scale = (20.0 / S, 20.0 / S, 4.0)
+    npar = soil.noise_t()
+    npar.seed = 3.0
+    npar.ext = [S, S]
+    bed = soil.noise(silt.shape(S, S), npar, host=silt.gpu)
+
+    def make():
+        m = ErosionModel(S, S, scale, pp, S * S // 8, seed=0)
+        _abi.check(hip.soil_layers_from_planes(m.layers.c_ptr, bed.c_ptr, None, bed.elem(), None))
+        silt.set(m.rainfall, 1.0)
+        return m
+    a, b = make(), make()
+    for step in range(3):
+        soil.particle_steps(reset=True)
+        a.seed_step()
+        a.particles_pair()
+        sa = soil.particle_steps(reset=True)
+        a.cells_fused()
+        a.swap_layers()
+        a.step_index += 1
+        b.seed_step()
+        b.particles_fluvial()
+        b.particles_debris()
+        sb = soil.particle_steps(reset=True)
+        b.cells_fused()
+        b.swap_layers()
+        b.step_index += 1
+        if step == 0:
+            assert sa == sb
+        for name in ("layers", "waterHeight", "velocity", "debris", "debrisVelocity"):
+            x, y = to_np(getattr(a, name)), to_np(getattr(b, name))
+            _close_but_for_stray_walks(x, y, 1e-4, 1e-5 * (np.nanmax(np.abs(y)) + 1e-30),
+                                       0.0 if step == 0 else 2e-3, "step %d %s" % (step, name))
