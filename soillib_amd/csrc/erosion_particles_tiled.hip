@@ -326,8 +326,14 @@ __device__ __forceinline__ StepGeom step_geom(const PRec& r, const StepConst& k)
 // ... and the second half: the speed update, the attenuations, the move (:125-137 / :331-347)
 template <int KIND>
 __device__ __forceinline__ bool step_apply(PRec& r, const float4 q, const StepConst& k, const StepGeom& g) {
-  if (!g.alive) return false;
-  if (KIND == DEBRIS || !g.ok) return advance_slow<KIND>(r, q, k, g.v_norm);
+  // A lane whose walk has just ended (v_norm < eps, :121-122 / :326-327) computes on regardless: its
+  // record is dropped by the caller, nothing here touches memory, and a branch around the rest costs
+  // every iteration of every wave three scalar instructions.  It takes the fast path whatever its
+  // operands look like (its results are not used).
+  if (KIND == DEBRIS || (!g.ok && g.alive)) {
+    (void)advance_slow<KIND>(r, q, k, g.v_norm);
+    return g.alive;
+  }
   const float ax = q.x + k.fx, ay = q.y + k.fy;                 // :126
   const float w0 = quot(1.0f, g.rd), w1 = quot0(g.dL, g.rd);    // :127
   r.spx = w0 * r.spx + w1 * ax;
@@ -337,7 +343,7 @@ __device__ __forceinline__ bool step_apply(PRec& r, const float4 q, const StepCo
   r.a2 = r.a2 * att_exp(-g.dL * q.z);     // att_v :136
   r.px += g.v_step * g.ux;                // :137
   r.py += g.v_step * g.uy;
-  return true;
+  return g.alive;
 }
 template <int KIND>
 __device__ __forceinline__ bool advance(PRec& r, const float4 q, const StepConst& k) {
@@ -1275,6 +1281,7 @@ __global__ void __launch_bounds__(NT, round_waves_per_simd(KIND, TR, TC, NT, ALB
     // arithmetic (`runm`: lanes still stepping), the per-lane predicate comes back from the mask
     // (inverse ballot: free): the ballot of a combined predicate costs a v_cndmask + v_cmp pair.
     uint64_t runm = __builtin_amdgcn_ballot_w64(have);
+    uint32_t ended = 0u;
     for (;;) {
 #ifdef SOIL_PROF
       ++pt_iters;
@@ -1284,10 +1291,10 @@ __global__ void __launch_bounds__(NT, round_waves_per_simd(KIND, TR, TC, NT, ALB
       const uint64_t stepm = __builtin_amdgcn_ballot_w64(dr <= r_span) & __builtin_amdgcn_ballot_w64(dc <= c_span) &
                              __builtin_amdgcn_ballot_w64(r.iter < limit) & runm;
       runm = stepm;
-      if (stepm == 0) break;
-      // a queue longer than the work-group: once enough lanes of the wave are free they take new
-      // particles (enough: leaving the loop and coming back costs about as much as two iterations)
-      if (more && __popcll(~stepm) >= kRefillLanes) break;
+      // Nobody left to step — or, with a queue longer than the work-group (`more`), enough lanes of
+      // the wave free to take new particles (enough: leaving the loop and coming back costs about as
+      // much as two iterations): one population count against a bound that is 0 unless `more`.
+      if (__popcll(stepm) <= (more ? 64 - kRefillLanes : 0)) break;
       PROF_AT(2);  // head
       CasDeposit<kFluxPlanes + (ALB ? 3 : 0), (KIND == FLUVIAL) ? 2 : 1> dep;
       uint32_t lost_bits = 0;
@@ -1334,7 +1341,9 @@ __global__ void __launch_bounds__(NT, round_waves_per_simd(KIND, TR, TC, NT, ALB
         const StepGeom geom = step_geom<KIND>(r, k);             // needs neither q nor LDS
         if (KIND == FLUVIAL && deposit) dep.swap_all();          // the swaps' round trip hides under step_apply
         v_norm = geom.v_norm;
-        if (!step_apply<KIND>(r, q, k, geom)) have = false;      // :121-122 / :326-327: the walk is over
+        // :121-122 / :326-327: a walk that is over shows in `ended` (a value, not a lane mask merged
+        // through the branches of the iteration: `have` stays what it was when the loop began)
+        ended |= step_apply<KIND>(r, q, k, geom) ? 0u : 1u;
         if (deposit) lost_bits = dep.lost_bits();                // the swaps' answers, only now
         PROF_AT(4);  // the step's arithmetic
       }
@@ -1343,6 +1352,7 @@ __global__ void __launch_bounds__(NT, round_waves_per_simd(KIND, TR, TC, NT, ALB
       PROF_AT(5);  // deposit finished
     }
     const bool run = __builtin_amdgcn_inverse_ballot_w64(runm);
+    have = have && opaque(ended) == 0u;
 
     // ---- once per particle and round: what stopped it?
     if (have && !run) {
