@@ -1339,6 +1339,8 @@ __global__ void __launch_bounds__(NT, round_waves_per_simd(KIND, TR, TC, NT, ALB
         }
         PROF_AT(3);  // gather issued, deposit begun
         const StepGeom geom = step_geom<KIND>(r, k);             // needs neither q nor LDS
+        // (round 3: swapping right behind the load, as the debris launch does, times the same — 24.07-24.14 ms
+        // either way at 8192^2)
         if (KIND == FLUVIAL && deposit) dep.swap_all();          // the swaps' round trip hides under step_apply
         v_norm = geom.v_norm;
         // :121-122 / :326-327: a walk that is over shows in `ended` (a value, not a lane mask merged
