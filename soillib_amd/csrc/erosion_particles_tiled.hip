@@ -465,7 +465,11 @@ __global__ void __launch_bounds__(256)
     const int64_t cx = cell_of(pos.x), cy = cell_of(pos.y);
     const int64_t ind = cx * d.W + cy;
     const int64_t l = ind - d.x0 * d.W;
-    const float4 q = p4[l];
+    // one record of 16 bytes at a random cell: a streaming load (no line of 128 bytes pulled into L2
+    // for the 16 that are used)
+    typedef float v4f_ __attribute__((ext_vector_type(4)));
+    const v4f_ qv = __builtin_nontemporal_load(reinterpret_cast<const v4f_*>(p4 + l));
+    const float4 q = make_float4(qv.x, qv.y, qv.z, qv.w);
     float spx, spy;
     if (KIND == FLUVIAL) {
       spx = q.x + param.force[0];  // :77
@@ -489,7 +493,7 @@ __global__ void __launch_bounds__(256)
         r.a0 = 1.0f;                                  // att_w
         r.a1 = 1.0f;                                  // att_m
         r.a2 = 1.0f;                                  // att_v
-        r.s0 = Q * param.rainfall * waterSource[l];   // source_w :89
+        r.s0 = Q * param.rainfall * __builtin_nontemporal_load(waterSource + l);   // source_w :89
         r.s1 = Q * ks * q.w;                          // source_m :88
         r.svx = Q * q.x;                              // :90
         r.svy = Q * q.y;
