@@ -17,6 +17,8 @@
 // slab edge).
 #include <dlfcn.h>
 
+#include <mutex>
+
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
@@ -559,8 +561,10 @@ struct Rccl {
 };
 
 Rccl g_rccl;
+std::mutex g_rccl_mutex;
 
 int rccl_load() {
+  std::lock_guard<std::mutex> lock(g_rccl_mutex);  // several host threads may make their communicators at once
   if (g_rccl.lib) return SOIL_OK;
   void* h = nullptr;
   if (const char* e = std::getenv("SOIL_RCCL_LIB")) h = dlopen(e, RTLD_NOW | RTLD_GLOBAL);
@@ -873,8 +877,12 @@ int soil_comm_rccl_create(soil_comm** out, const uint8_t id[128], int32_t rank, 
     delete r;
     return rccl_fail(e, "ncclCommInitRank");
   }
-  SOIL_HIP(hipMalloc(reinterpret_cast<void**>(&r->scratch), 4));
-  SOIL_HIP(hipMemset(r->scratch, 0, 4));
+  if (hipMalloc(reinterpret_cast<void**>(&r->scratch), 4) != hipSuccess || hipMemset(r->scratch, 0, 4) != hipSuccess) {
+    (void)hipGetLastError();
+    (void)g_rccl.CommDestroy(r->comm);
+    delete r;
+    return fail(SOIL_ERR_OUT_OF_MEMORY, "comm_rccl_create: no device memory for the barrier word");
+  }
   soil_comm* c = new soil_comm{};
   c->ctx = r, c->rank = rank, c->world = world, c->flags = 0;
   c->exchange = rccl_exchange, c->all_reduce_sum_f32 = rccl_all_reduce, c->barrier = rccl_barrier;
