@@ -2179,7 +2179,9 @@ int launch_pair_tiled(const soil_erosion_planes& P, soil_rng* rng_fluvial, soil_
   }
   // (round 3, with rounds queued ahead of the host: counted in scans the host has seen; 1024^2 1.59 / 1.62 /
   // 1.67 ms per step at 1 / 2 / 3, 2048^2 3.98 / 3.86 / 3.75, 4096^2 10.28 / 10.36 / 10.48)
-  const uint64_t delay = delay_env > 0 ? static_cast<uint64_t>(delay_env) : (N <= 300000 ? 1 : 2);
+  // (taking turns the debris launch begins at once — its spawn beside the fluvial one's, its rounds behind
+  // the gate: 8192^2 34.72 / 34.78 / 34.88 / 34.95 / 35.18 ms per step at 0 / 1 / 2 / 3 / 5, 2048^2 3.75 at 0, 3.79 at 1)
+  const uint64_t delay = delay_env > 0 ? static_cast<uint64_t>(delay_env) : (turns ? 0 : (N <= 300000 ? 1 : 2));
   // Whatever happens in between, `st` is joined with both streams before this returns: rounds may
   // still be in flight on the workspace the next call reuses.
   A.overwrite = B.overwrite = overwrite;
