@@ -431,6 +431,48 @@ static bool use_tiled(int64_t N, const Dom& d) {
   return g_particle_mode == 0 && N >= 45000;
 }
 
+bool use_tiled_launch(int64_t N, const Dom& d) { return use_tiled(N, d); }
+
+// The slab launches on explicit streams (particles_common.hpp, Streams): the tiled shape takes uniform
+// streams as they are; the small-N shapes read a tensor, which is seeded here when the streams are
+// uniform (the caller hands one over for that).
+static int materialise(const Streams& st, int64_t N, hipStream_t s) {
+  if (!st.uniform) return SOIL_OK;
+  if (!st.rng) return fail(SOIL_ERR_INVALID_ARGUMENT, "uniform streams on a small launch need a tensor to seed");
+  return soil_rng_seed(st.rng, N, st.seed, st.offset, s);
+}
+int particles_fluvial_streams(const soil_erosion_planes& P, Streams rng, int64_t N, float* remote0,
+                              const Dom& d, Scale3 s, const Param& p, hipStream_t st) {
+  if (N <= 0) return SOIL_OK;
+  if (use_tiled(N, d))
+    return launch_fluvial_tiled(P.waterFlux, P.massFlux, P.velocityFlux, nullptr, rng, N, P.layers, P.rainfall,
+                                P.waterHeight, P.velocity, nullptr, remote0, d, s, p, st);
+  if (int rc = materialise(rng, N, st); rc != SOIL_OK) return rc;
+  return soil_particles_fluvial_slab(P.waterFlux, P.massFlux, P.velocityFlux, nullptr, rng.rng, N, P.layers,
+                                     P.rainfall, P.waterHeight, P.velocity, nullptr, remote0,
+                                     reinterpret_cast<const soil_domain*>(&d), &s.x, &p, st);
+}
+int particles_debris_streams(const soil_erosion_planes& P, Streams rng, int64_t N, float* remote0,
+                             const Dom& d, Scale3 s, const Param& p, hipStream_t st) {
+  if (N <= 0) return SOIL_OK;
+  if (use_tiled(N, d))
+    return launch_debris_tiled(P.debrisFlux, P.debrisVelocityFlux, nullptr, rng, N, P.layers, P.debrisVelocity,
+                               nullptr, remote0, d, s, p, st);
+  if (int rc = materialise(rng, N, st); rc != SOIL_OK) return rc;
+  return soil_particles_debris_slab(P.debrisFlux, P.debrisVelocityFlux, nullptr, rng.rng, N, P.layers,
+                                    P.debrisVelocity, nullptr, remote0, reinterpret_cast<const soil_domain*>(&d),
+                                    &s.x, &p, st);
+}
+int particles_pair_streams(const soil_erosion_planes& P, Streams rf, Streams rd, int64_t N, float* remote0,
+                           const Dom& d, Scale3 s, const Param& p, hipStream_t st) {
+  if (N <= 0) return SOIL_OK;
+  if (use_tiled(N, d)) return launch_pair_tiled(P, rf, rd, N, remote0, d, s, p, st, false);
+  if (int rc = materialise(rf, N, st); rc != SOIL_OK) return rc;
+  if (int rc = materialise(rd, N, st); rc != SOIL_OK) return rc;
+  return soil_particles_pair_slab(&P, rf.rng, rd.rng, N, remote0, reinterpret_cast<const soil_domain*>(&d), &s.x,
+                                  &p, st);
+}
+
 // Shared staging: pack the fields, bucket the spawn points.  Returns device
 // pointers into the per-device workspace (valid until the next staged call).
 struct Staged {
@@ -482,7 +524,7 @@ static int launch_particles_fluvial(float* waterFlux, float* massFlux, float* ve
                                     Scale3 s, const Param& p, hipStream_t st) {
   if (N <= 0) return SOIL_OK;
   if (use_tiled(N, d))
-    return launch_fluvial_tiled(waterFlux, massFlux, velocityFlux, albedoFlux, rng, N, layers,
+    return launch_fluvial_tiled(waterFlux, massFlux, velocityFlux, albedoFlux, streams_of(rng), N, layers,
                                 waterSource, waterHeight, velocity, albedoSource, remote0, d, s, p,
                                 st);
   unsigned long long* steps = nullptr;
@@ -511,7 +553,7 @@ static int launch_particles_debris(float* massFlux, float* velocityFlux, float* 
                                    hipStream_t st) {
   if (N <= 0) return SOIL_OK;
   if (use_tiled(N, d))
-    return launch_debris_tiled(massFlux, velocityFlux, albedoFlux, rng, N, layers, velocity,
+    return launch_debris_tiled(massFlux, velocityFlux, albedoFlux, streams_of(rng), N, layers, velocity,
                                albedoSource, remote0, d, s, p, st);
   unsigned long long* steps = nullptr;
   if (int rc = step_counter(&steps); rc != SOIL_OK) return rc;
@@ -671,7 +713,7 @@ int soil_particles_pair_slab_ex(const soil_erosion_planes* planes, soil_rng* rng
   if (N <= 0) return overwrite ? clear_flux() : SOIL_OK;
   const Scale3 s = s3p(scale);
   if (use_tiled(N, d))
-    return launch_pair_tiled(P, rng_fluvial, rng_debris, N, remote0, d, s, *param, st, overwrite);
+    return launch_pair_tiled(P, streams_of(rng_fluvial), streams_of(rng_debris), N, remote0, d, s, *param, st, overwrite);
   if (overwrite)
     if (int rc2 = clear_flux(); rc2 != SOIL_OK) return rc2;
   rc = launch_particles_fluvial(P.waterFlux, P.massFlux, P.velocityFlux, nullptr, rng_fluvial, N,

@@ -447,17 +447,18 @@ __global__ void __launch_bounds__(256)
 template <int KIND>
 __global__ void __launch_bounds__(256)
     k_tiled_spawn(PRec* __restrict__ recs, uint32_t* __restrict__ dest, uint32_t* __restrict__ rank,
-                  uint32_t* __restrict__ count, soil_rng* __restrict__ rng, int64_t N, const float4* __restrict__ p4,
+                  uint32_t* __restrict__ count, Streams rng, int64_t N, const float4* __restrict__ p4,
                   const float* __restrict__ waterSource, const float* __restrict__ albedoSource,
                   Dom d, Scale3 s, Param param,
                   int tiles_w, TileShape ts, int steps_per_round, TiledCtl* __restrict__ ctl) {
   const int64_t n = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
   if (n == 0) ctl->live = static_cast<uint32_t>(N);  // the spawn fills slots 0 .. N-1 (scan 0 turns it into `slots`)
   if (n >= N) return;
+  const bool in_range = true;
   PRec r;
   uint32_t tile = kNoTile;
-  const float2 pos = spawn_position(rng, n, d);
-  if (owns_spawn(d, pos.x)) {
+  const float2 pos = in_range ? spawn_position(rng, n, d) : make_float2(-1.0f, -1.0f);
+  if (in_range && owns_spawn(d, pos.x)) {
     const float A = s.x * s.y;
     const float Pr = 1.0f / (A * static_cast<float>(d.H * d.W));
     const float Q = 1.0f / (Pr * static_cast<float>(N));
@@ -514,9 +515,16 @@ __global__ void __launch_bounds__(256)
       tile = queue_key(static_cast<int>(d.x0), pos.x, pos.y, spx, spy,
                        param.maxage > 0x7fffffffull ? 0x7fffffffu : static_cast<uint32_t>(param.maxage),
                        tiles_w, ts, steps_per_round);
-      rank[n] = atomicAdd(&count[tile], 1u);  // its place in that queue section
-      recs[n] = r;
     }
+  }
+  // (Handing record slots only to the walkers that are made — so that a slab owning an eighth of the
+  // streams sorts an eighth of the slots — was tried with uniform streams: one counter for the whole
+  // launch, drawn from once per wave, is a million same-address atomics at 67 M streams: 61 instead
+  // of 39 ms per step for a rank of an 8-GPU world.  The slots stay one per stream.)
+  const bool made = tile != kNoTile;
+  if (made) {
+    rank[n] = atomicAdd(&count[tile], 1u);  // its place in that queue section
+    recs[n] = r;
   }
   dest[n] = tile;
 }
@@ -1684,7 +1692,7 @@ struct TiledRun {
   float *flux0, *flux1, *fluxV;
   float* fluxA = nullptr;                // colour flux (vec3), optional
   const float* albedoSource = nullptr;   // colour of the cell a particle starts on
-  soil_rng* rng;
+  Streams rng;
   int64_t N;
   const float *layers, *waterSource, *waterHeight, *velocity;
   float* remote0;
@@ -2094,7 +2102,7 @@ struct TiledRun {
 
 template <int KIND>
 static TiledRun<KIND> make_run(float* flux0, float* flux1, float* fluxV, float* fluxA,
-                               const float* albedoSource, soil_rng* rng, int64_t N,
+                               const float* albedoSource, Streams rng, int64_t N,
                                const float* layers, const float* waterSource,
                                const float* waterHeight, const float* velocity, float* remote0,
                                const Dom& d, Scale3 s, const Param& p, hipStream_t st) {
@@ -2108,7 +2116,7 @@ static TiledRun<KIND> make_run(float* flux0, float* flux1, float* fluxV, float* 
 
 template <int KIND>
 static int run_tiled(float* flux0, float* flux1, float* fluxV, float* fluxA,
-                     const float* albedoSource, soil_rng* rng, int64_t N, const float* layers, const float* waterSource, const float* waterHeight,
+                     const float* albedoSource, Streams rng, int64_t N, const float* layers, const float* waterSource, const float* waterHeight,
                      const float* velocity, float* remote0, const Dom& d, Scale3 s, const Param& p,
                      hipStream_t st) {
   TiledRun<KIND> r = make_run<KIND>(flux0, flux1, fluxV, fluxA, albedoSource, rng, N, layers,
@@ -2121,7 +2129,7 @@ static int run_tiled(float* flux0, float* flux1, float* fluxV, float* fluxA,
 
 // Both launches of a step, overlapped: two internal streams forked from `st` and joined
 // back into it; the host alternates between the two runs' decisions.
-int launch_pair_tiled(const soil_erosion_planes& P, soil_rng* rng_fluvial, soil_rng* rng_debris, int64_t N,
+int launch_pair_tiled(const soil_erosion_planes& P, Streams rng_fluvial, Streams rng_debris, int64_t N,
                       float* remote0, const Dom& d, Scale3 s, const Param& p, hipStream_t st, bool overwrite) {
   // forked streams and their events, one set per (thread, device)
   struct Fork {
@@ -2228,7 +2236,7 @@ int launch_pair_tiled(const soil_erosion_planes& P, soil_rng* rng_fluvial, soil_
 }
 
 int launch_fluvial_tiled(float* waterFlux, float* massFlux, float* velocityFlux, float* albedoFlux,
-                         soil_rng* rng, int64_t N, const float* layers, const float* waterSource,
+                         Streams rng, int64_t N, const float* layers, const float* waterSource,
                          const float* waterHeight, const float* velocity,
                          const float* albedoSource, float* remote0, const Dom& d, Scale3 s,
                          const Param& p, hipStream_t st) {
@@ -2236,7 +2244,7 @@ int launch_fluvial_tiled(float* waterFlux, float* massFlux, float* velocityFlux,
                             layers, waterSource, waterHeight, velocity, remote0, d, s, p, st);
 }
 
-int launch_debris_tiled(float* massFlux, float* velocityFlux, float* albedoFlux, soil_rng* rng,
+int launch_debris_tiled(float* massFlux, float* velocityFlux, float* albedoFlux, Streams rng,
                         int64_t N, const float* layers, const float* velocity,
                         const float* albedoSource, float* remote0, const Dom& d, Scale3 s,
                         const Param& p, hipStream_t st) {

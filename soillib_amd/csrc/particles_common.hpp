@@ -46,6 +46,32 @@ __device__ __forceinline__ float2 spawn_position(soil_rng* __restrict__ rng, int
   return make_float2(x, y);
 }
 
+// Where a launch's streams of draws come from.  The reference keeps one generator state per particle
+// (silt::rng = curandState, erosion.cu:57); a launch reads every state, draws, and writes it back.
+// `uniform`: every stream's state is {seed, offset} — a tensor that was seeded for this very launch
+// and is seeded again before the next, which is what the library's own step drivers do.  Nothing is
+// read or written then, and only the particles this slab owns get a record slot: the replay of the
+// other ranks' streams (7 of 8 on an 8-GPU run) costs one Philox draw per stream and no memory
+// traffic, where the tensor form moves 36 bytes per stream (csrc/slab_runner.hip, HipOps).
+struct Streams {
+  soil_rng* rng;
+  bool uniform;
+  uint64_t seed, offset;
+};
+inline Streams streams_of(soil_rng* rng) { return Streams{rng, false, 0, 0}; }
+// spawn position of particle n from the two first draws of its stream (see spawn_position)
+__device__ __forceinline__ float2 spawn_position(const Streams& st, int64_t n, const Dom& d) {
+  if (!st.uniform) return spawn_position(st.rng, n, d);
+  const float u1 = rng_uniform_at(st.seed, static_cast<uint64_t>(n), st.offset);
+  const float x = 0.5f + u1 * static_cast<float>(d.H - 1);
+  float y = 0.0f;
+  if (owns_spawn(d, x))
+    y = 0.5f + rng_uniform_at(st.seed, static_cast<uint64_t>(n), st.offset + 1) * static_cast<float>(d.W - 1);
+  return make_float2(x, y);
+}
+// the launch shape a launch of N particles on domain d gets (erosion_particles.hip)
+bool use_tiled_launch(int64_t N, const Dom& d);
+
 // exclusive scan of per-tile counts, start[tiles] = total (one 1024-thread group;
 // defined in erosion_particles.hip)
 __global__ void __launch_bounds__(1024)
@@ -53,18 +79,25 @@ __global__ void __launch_bounds__(1024)
 
 // tiled launch shape (erosion_particles_tiled.hip)
 int launch_fluvial_tiled(float* waterFlux, float* massFlux, float* velocityFlux, float* albedoFlux,
-                         soil_rng* rng, int64_t N, const float* layers, const float* waterSource,
+                         Streams rng, int64_t N, const float* layers, const float* waterSource,
                          const float* waterHeight, const float* velocity,
                          const float* albedoSource, float* remote0, const Dom& d, Scale3 s,
                          const Param& p, hipStream_t st);
-int launch_debris_tiled(float* massFlux, float* velocityFlux, float* albedoFlux, soil_rng* rng,
+int launch_debris_tiled(float* massFlux, float* velocityFlux, float* albedoFlux, Streams rng,
                         int64_t N, const float* layers, const float* velocity,
                         const float* albedoSource, float* remote0, const Dom& d, Scale3 s,
                         const Param& p, hipStream_t st);
 // both launches of a step overlapped on two internal streams forked from / joined into `st`
 // (`overwrite`: the flux planes hold stale values — SOIL_FLUX_OVERWRITE, soil_hip.h)
-int launch_pair_tiled(const soil_erosion_planes& P, soil_rng* rng_fluvial, soil_rng* rng_debris,
+int launch_pair_tiled(const soil_erosion_planes& P, Streams rng_fluvial, Streams rng_debris,
                       int64_t N, float* remote0, const Dom& d, Scale3 s, const Param& p,
                       hipStream_t st, bool overwrite);
+// the slab entry points of soil_hip.h on explicit streams (the slab runner's HIP back-end)
+int particles_fluvial_streams(const soil_erosion_planes& P, Streams rng, int64_t N, float* remote0,
+                              const Dom& d, Scale3 s, const Param& p, hipStream_t st);
+int particles_debris_streams(const soil_erosion_planes& P, Streams rng, int64_t N, float* remote0,
+                             const Dom& d, Scale3 s, const Param& p, hipStream_t st);
+int particles_pair_streams(const soil_erosion_planes& P, Streams rng_fluvial, Streams rng_debris, int64_t N,
+                           float* remote0, const Dom& d, Scale3 s, const Param& p, hipStream_t st);
 
 }  // namespace soil

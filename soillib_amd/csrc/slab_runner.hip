@@ -25,8 +25,11 @@
 #include <string>
 #include <vector>
 
+#include <map>
+
 #include "../../include/soil_slab.h"
 #include "common.hpp"
+#include "particles_common.hpp"
 
 namespace soil {
 
@@ -426,6 +429,24 @@ struct HipOps {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int32_t* depth_dev = nullptr;
   int device = 0;
+  // The runner seeds a stream tensor right before every launch that draws from it, so the state
+  // of every stream is known without the tensor: {seed, offset}, two draws further after a launch.
+  // `rng_seed` only notes it down here; the launches take it as uniform streams (particles_common.hpp:
+  // nothing read or written per stream, record slots only for the particles this slab owns — the
+  // replay of the other ranks' streams was 36 bytes of traffic per stream, 7 of 8 streams on 8 GPUs).
+  // SOIL_SLAB_UNIFORM=0: seed and read the tensors as the stand-alone entry points do.
+  struct Noted { uint64_t seed, offset; };
+  std::map<const soil_rng*, Noted> noted;
+  bool uniform = true;
+  Streams streams(soil_rng* rng) const {
+    const auto it = noted.find(rng);
+    if (!uniform || it == noted.end()) return streams_of(rng);
+    return Streams{rng, true, it->second.seed, it->second.offset};
+  }
+  void drew(soil_rng* rng) {  // a launch took its two draws per stream
+    const auto it = noted.find(rng);
+    if (it != noted.end()) it->second.offset += 2;
+  }
 };
 
 #define HIP_OPS(c) HipOps& o = *static_cast<HipOps*>(c)
@@ -452,25 +473,42 @@ int hip_add(void* c, float* dst, const float* src, int64_t n, int32_t lane) {
 }
 int hip_seed(void* c, soil_rng* rng, int64_t N, uint64_t seed, uint64_t offset) {
   HIP_OPS(c);
+  if (o.uniform) {
+    o.noted[rng] = HipOps::Noted{seed, offset};
+    return SOIL_OK;
+  }
   return soil_rng_seed(rng, N, seed, offset, o.main);
 }
 int hip_fluvial(void* c, const soil_erosion_planes* p, soil_rng* rng, int64_t N, float* remote0,
                 const soil_domain* dom, const float scale[3], const soil_param* param) {
   HIP_OPS(c);
-  return soil_particles_fluvial_slab(p->waterFlux, p->massFlux, p->velocityFlux, nullptr, rng, N, p->layers,
-                                     p->rainfall, p->waterHeight, p->velocity, nullptr, remote0, dom, scale,
-                                     param, o.main);
+  const Dom d = to_dom(dom);
+  if (int rc = check_domain(d); rc != SOIL_OK) return rc;
+  const int rc = particles_fluvial_streams(*p, o.streams(rng), N, remote0, d, Scale3{scale[0], scale[1], scale[2]},
+                                           *param, o.main);
+  o.drew(rng);
+  return rc;
 }
 int hip_debris(void* c, const soil_erosion_planes* p, soil_rng* rng, int64_t N, float* remote0,
                const soil_domain* dom, const float scale[3], const soil_param* param) {
   HIP_OPS(c);
-  return soil_particles_debris_slab(p->debrisFlux, p->debrisVelocityFlux, nullptr, rng, N, p->layers,
-                                    p->debrisVelocity, nullptr, remote0, dom, scale, param, o.main);
+  const Dom d = to_dom(dom);
+  if (int rc = check_domain(d); rc != SOIL_OK) return rc;
+  const int rc = particles_debris_streams(*p, o.streams(rng), N, remote0, d, Scale3{scale[0], scale[1], scale[2]},
+                                          *param, o.main);
+  o.drew(rng);
+  return rc;
 }
 int hip_pair(void* c, const soil_erosion_planes* p, soil_rng* rf, soil_rng* rd, int64_t N, float* remote0,
              const soil_domain* dom, const float scale[3], const soil_param* param) {
   HIP_OPS(c);
-  return soil_particles_pair_slab(p, rf, rd, N, remote0, dom, scale, param, o.main);
+  const Dom d = to_dom(dom);
+  if (int rc = check_domain(d); rc != SOIL_OK) return rc;
+  const int rc = particles_pair_streams(*p, o.streams(rf), o.streams(rd), N, remote0, d,
+                                        Scale3{scale[0], scale[1], scale[2]}, *param, o.main);
+  o.drew(rf);
+  o.drew(rd);
+  return rc;
 }
 int hip_cells(void* c, const soil_erosion_planes* p, const soil_domain* dom, const float scale[3],
               const soil_param* param) {
@@ -666,6 +704,7 @@ int soil_slab_ops_hip_create(soil_slab_ops** out) {
   SOIL_DEVICE();
   SOIL_REQUIRE(out, "slab_ops_hip_create: null argument");
   HipOps* o = new HipOps;
+  if (const char* e = std::getenv("SOIL_SLAB_UNIFORM")) o->uniform = e[0] != '0';
   SOIL_HIP(hipGetDevice(&o->device));
   SOIL_HIP(hipStreamCreateWithFlags(&o->main, hipStreamNonBlocking));
   SOIL_HIP(hipStreamCreateWithFlags(&o->comm, hipStreamNonBlocking));
