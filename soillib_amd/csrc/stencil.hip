@@ -347,16 +347,20 @@ struct BlurWeights {
 //
 //  * along axis 0 (rows): a thread owns one float column of a 32-row band, reads the
 //    64 rows it needs (coalesced across the wave) into registers and produces its 32
-//    outputs from them — no LDS, 33 taps from registers;
-//  * along axis 1 (the contiguous one): a work-group stages a 1024-float row segment
-//    plus its 16-cell aprons in LDS (clamped per cell, channels interleaved); a thread
-//    pulls the 4 + 32 C consecutive floats its four consecutive outputs need into
-//    registers with 16-byte LDS reads (9 or 17 instead of 132 four-byte ones) and
-//    stores its outputs as one 16-byte word.
+//    outputs from them — no LDS, 33 taps from registers.  (Bands of 2 .. 8 such chunks, the next
+//    chunk's 32 new rows on their way while one is computed, read less — and took as long or
+//    longer: 116 / 117 / 125 us at 8192^2 for 1 / 2 / 8 chunks.)
+//  * along axis 1 (the contiguous one): a work-group stages 1024-float segments of kBlurRows
+//    rows plus their 16-cell aprons in LDS (clamped per cell, channels interleaved) — all of a
+//    thread's 16-byte loads issued before the first is used: with one row per work-group the pass
+//    had 8 MiB in flight chip-wide and ran at 2.6 TB/s (now 5.9); a thread then pulls the 4 + 32 C
+//    consecutive floats its four consecutive outputs need into registers with 16-byte LDS reads
+//    (9 or 17 instead of 132 four-byte ones) and stores its outputs as one 16-byte word.
 //
 // The one-thread-per-output form it replaces issued 33 global loads per output
 // (1.4-1.6 ms per pass at 8192^2, 4.5 % of the HBM roofline).
 constexpr int kBlurBand = 32;  // output rows per thread of the axis-0 pass
+constexpr int kBlurRows = 8;   // rows per work-group of the axis-1 pass
 
 __global__ void __launch_bounds__(kSBlock)
     k_blur_rows(float* __restrict__ out, const float* __restrict__ in, int64_t H, int64_t WC,
@@ -382,51 +386,98 @@ __global__ void __launch_bounds__(kSBlock)
   }
 }
 
-template <int C>
-__global__ void __launch_bounds__(kSBlock)
-    k_blur_cols(float* __restrict__ out, const float* __restrict__ in, int64_t W, BlurWeights bw) {
-  constexpr int kSeg = 4 * kSBlock;  // output floats per work-group
-  __shared__ __attribute__((aligned(16))) float seg[kSeg + 32 * C];
+// WIDE (decided per work-group from launch constants only, so that the compiler keeps the two
+// forms apart instead of merging them into four-byte accesses with selected addresses): rows are
+// 16-byte aligned and the whole segment lies inside the row.
+template <int C, bool WIDE>
+__device__ __forceinline__ void blur_cols_group(float (*seg)[4 * kSBlock + 32 * C],
+                                                float* __restrict__ out,
+                                                const float* __restrict__ in, int64_t H, int64_t W,
+                                                int64_t row0, int64_t f0, const BlurWeights& bw) {
+  constexpr int kSeg = 4 * kSBlock;
   const int64_t WC = W * C;
-  const int64_t row = blockIdx.x;
-  const int64_t f0 = static_cast<int64_t>(blockIdx.y) * kSeg;  // first output float of the segment
-  const float* src = in + row * WC;
-  // LDS float i holds row float f0 - 16*C + i, its cell clamped into the row (:39-43)
-  for (int i = threadIdx.x; i < kSeg + 32 * C; i += kSBlock) {
-    const int64_t f = f0 - 16 * C + i;
+  const int i0 = 4 * static_cast<int>(threadIdx.x);
+  // LDS float i of a row holds row float f0 - 16*C + i, its cell clamped into the row (:39-43)
+  auto clamped = [&](const float* src, int64_t f) {
     const int64_t c = ((f % C) + C) % C;
     int64_t y = (f - c) / C;
     if (y < 0) y = 0;
     if (y > W - 1) y = W - 1;
-    seg[i] = src[y * C + c];
+    return src[y * C + c];
+  };
+  // (rows past the grid's last one restage the last row — no exits from these loops, so that
+  // `body` stays in registers: indexed behind a break it went through scratch memory, twice the
+  // cache traffic)
+  auto row_of = [&](int r) { return in + (row0 + r < H ? row0 + r : H - 1) * WC; };
+  float4 body[kBlurRows];
+#pragma unroll
+  for (int r = 0; r < kBlurRows; ++r) {
+    const float* src = row_of(r);
+    if constexpr (WIDE) {
+      body[r] = *reinterpret_cast<const float4*>(src + f0 + i0);
+    } else {
+      body[r] = make_float4(clamped(src, f0 + i0), clamped(src, f0 + i0 + 1),
+                            clamped(src, f0 + i0 + 2), clamped(src, f0 + i0 + 3));
+    }
   }
+  for (int a = threadIdx.x; a < 32 * C * kBlurRows; a += kSBlock) {
+    const int r = a / (32 * C), j = a % (32 * C);
+    const int i = j < 16 * C ? j : kSeg + j;
+    seg[r][i] = clamped(row_of(r), f0 - 16 * C + i);
+  }
+#pragma unroll
+  for (int r = 0; r < kBlurRows; ++r) *reinterpret_cast<float4*>(&seg[r][16 * C + i0]) = body[r];
   __syncthreads();
   // outputs f0 + 4 t .. + 3 of thread t read LDS floats 4 t .. 4 t + 3 + 32 C
   constexpr int kWin = 4 + 32 * C;
-  const int i0 = 4 * static_cast<int>(threadIdx.x);
-  if (f0 + i0 >= WC) return;
-  float w[kWin];
+  if (!WIDE && f0 + i0 >= WC) return;
+  for (int r = 0; r < kBlurRows; ++r) {
+    if (row0 + r >= H) break;
+    // Whole 16-byte reads, kept whole: left to itself the compiler takes the window apart into
+    // ds_read2_b32 pairs — at the 16-byte stride between lanes an 8-way bank conflict each.
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    float w[kWin];
+    f4 t4[kWin / 4];
 #pragma unroll
-  for (int q = 0; q < kWin / 4; ++q) {
-    const float4 t4 = *reinterpret_cast<const float4*>(&seg[i0 + 4 * q]);
-    w[4 * q] = t4.x, w[4 * q + 1] = t4.y, w[4 * q + 2] = t4.z, w[4 * q + 3] = t4.w;
-  }
-  float val[4];
+    for (int q = 0; q < kWin / 4; ++q) t4[q] = *reinterpret_cast<const f4*>(&seg[r][i0 + 4 * q]);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    val[j] = 0.0f;  // :35
+    for (int q = 0; q < kWin / 4; ++q) {
+      asm("" : "+v"(t4[q]));  // (all reads issued before the first is looked at)
+      w[4 * q] = t4[q].x, w[4 * q + 1] = t4[q].y, w[4 * q + 2] = t4[q].z, w[4 * q + 3] = t4[q].w;
+    }
+    float val[4];
 #pragma unroll
-    for (int k = 0; k < 33; ++k) val[j] = __builtin_fmaf(w[j + k * C], bw.w[k], val[j]);  // :49-50
-  }
-  float* dst = out + row * WC + f0 + i0;  // :54
-  if (f0 + i0 + 3 < WC && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
-    *reinterpret_cast<float4*>(dst) = make_float4(val[0], val[1], val[2], val[3]);
-  } else {
+    for (int j = 0; j < 4; ++j) {
+      val[j] = 0.0f;  // :35
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if (f0 + i0 + j < WC) dst[j] = val[j];
+      for (int k = 0; k < 33; ++k) val[j] = __builtin_fmaf(w[j + k * C], bw.w[k], val[j]);  // :49-50
+    }
+    float* dst = out + (row0 + r) * WC + f0 + i0;  // :54
+    if constexpr (WIDE) {
+      *reinterpret_cast<float4*>(dst) = make_float4(val[0], val[1], val[2], val[3]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (f0 + i0 + j < WC) dst[j] = val[j];
+    }
   }
 }
+
+template <int C>
+__global__ void __launch_bounds__(kSBlock)
+    k_blur_cols(float* __restrict__ out, const float* __restrict__ in, int64_t H, int64_t W,
+                int wide_rows, BlurWeights bw) {
+  constexpr int kSeg = 4 * kSBlock;    // output floats per row and work-group
+  constexpr int kLds = kSeg + 32 * C;  // LDS floats per row: the segment and its two aprons
+  __shared__ __attribute__((aligned(16))) float seg[kBlurRows][kLds];
+  // consecutive work-groups take consecutive segments of the same rows: what is in flight at a
+  // time is whole rows, not one 4 KiB column of many rows
+  const int64_t row0 = static_cast<int64_t>(blockIdx.y) * kBlurRows;
+  const int64_t f0 = static_cast<int64_t>(blockIdx.x) * kSeg;  // first output float of the segment
+  if (wide_rows && f0 + kSeg <= W * C) blur_cols_group<C, true>(seg, out, in, H, W, row0, f0, bw);
+  else blur_cols_group<C, false>(seg, out, in, H, W, row0, f0, bw);
+}
+
 
 // lerp5 gradient along one axis: the build's definition of silt's lerp5_t::grad
 // (un-vendored): 4th-order central difference when all five
@@ -717,12 +768,14 @@ int soil_gaussian_blur(float* tensor, float* scratch, int64_t H, int64_t W, int 
   const int64_t WC = W * C;
   hipStream_t st = as_stream(stream);
   const dim3 grid_rows(blocks_for(WC, kSBlock), static_cast<unsigned>((H + kBlurBand - 1) / kBlurBand));
-  SOIL_REQUIRE(grid_rows.y <= 65535u && WC <= 65535 * 4 * static_cast<int64_t>(kSBlock),
+  SOIL_REQUIRE(grid_rows.y <= 65535u && WC <= 65535 * 4 * static_cast<int64_t>(kSBlock) &&
+                   (H + kBlurRows - 1) / kBlurRows <= 65535,
                "gaussian_blur: grid too large for one launch");
   k_blur_rows<<<grid_rows, kSBlock, 0, st>>>(scratch, tensor, H, WC, bw);  // :81 / :86
-  const dim3 grid_cols(static_cast<unsigned>(H), blocks_for(WC, 4 * kSBlock));
-  if (C == 1) k_blur_cols<1><<<grid_cols, kSBlock, 0, st>>>(tensor, scratch, W, bw);  // :82 / :87
-  else k_blur_cols<2><<<grid_cols, kSBlock, 0, st>>>(tensor, scratch, W, bw);
+  const dim3 grid_cols(blocks_for(WC, 4 * kSBlock), static_cast<unsigned>((H + kBlurRows - 1) / kBlurRows));
+  const int wide_rows = (WC & 3) == 0 && ((reinterpret_cast<uintptr_t>(tensor) | reinterpret_cast<uintptr_t>(scratch)) & 15) == 0;
+  if (C == 1) k_blur_cols<1><<<grid_cols, kSBlock, 0, st>>>(tensor, scratch, H, W, wide_rows, bw);  // :82 / :87
+  else k_blur_cols<2><<<grid_cols, kSBlock, 0, st>>>(tensor, scratch, H, W, wide_rows, bw);
   SOIL_LAUNCH_CHECK();
   return SOIL_OK;
 }

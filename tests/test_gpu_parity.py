@@ -644,9 +644,11 @@ def test_window_kernels_across_seams(hip, oracle, H, W):
     assert_bit_equal(to_np(soil.normal(to_gpu(h), s3)), oracle.normal(h, s3), "normal")
 
 
-@pytest.mark.parametrize("H,W", [(70, 1500), (33, 1025), (300, 7)])
+@pytest.mark.parametrize("H,W", [(70, 1500), (33, 1025), (300, 7), (300, 1028), (131, 260), (64, 2048)])
 def test_gaussian_blur_across_tile_seams(hip, oracle, H, W):
-    """Grids wider than one 1024-float LDS segment and taller than one 32-row band."""
+    """Grids wider than one 1024-float LDS segment, taller than one 32-row band, row counts that
+    are no multiple of the 8 rows a work-group of the axis-1 pass takes, widths with and without
+    16-byte rows."""
     from soillib_amd import soil
     r = np.random.default_rng(H + W)
     for D in (1, 2):
