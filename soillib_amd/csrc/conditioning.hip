@@ -11,21 +11,33 @@
 // w is the least surface >= z without depressions; it is the greatest fixed
 // point below the start of
 //        w(c) <- max(z(c), min over the neighbours n of w(n))
-// started from w = z on cells next to an outlet and +inf elsewhere.  Only max
-// and min are involved, so the fixed point is reached exactly in fp32 whatever
-// the update order: the kernel relaxes 64x64 tiles in LDS until they stop
-// changing (chaotic Gauss-Seidel inside a tile, Jacobi across tiles per launch)
-// and the host repeats launches until no tile changed.
+// started from +inf (an outlet's neighbour comes down to z in the first step).  Only max and min
+// are involved, so the fixed point is reached exactly in fp32 whatever the update order: the
+// kernel settles 64x64 tiles in LDS (chaotic inside a tile, Jacobi across tiles per launch) and
+// the host repeats launches until no tile changed.
 //
 // Started from +inf, information has to travel from the grid's edge to its middle, one tile per
 // launch (39 launches at 4096^2).  The iteration reaches the same fixed point from ANY surface
-// that lies on or above it and equals z next to the outlets (it only ever lowers cells, never
-// below w; and w is the only fixed point: walk the cells in the order of their w).  So the start
-// is taken from the same problem on a 4x coarser grid — each coarse cell the maximum of its
-// 4x4 block, filled recursively: a fine cell can always follow the coarse path through its
-// block's neighbours without meeting anything higher than the blocks' maxima — and what is left
-// to settle is the inside of the lakes: 14 launches at 4096^2 (and 2-8 on each of the four small
-// levels), 10.7 -> 3.7 ms; 16x coarsening leaves 22, 128x128 tiles are slower per launch than they save.
+// that lies on or above it (it only ever lowers cells, never below w; and w is the only fixed
+// point: walk the cells in the order of their w).  So the start is taken from the same problem on
+// a 4x coarser grid — each coarse cell the maximum of its 4x4 block, filled recursively: a fine
+// cell can always follow the coarse path through its block's neighbours without meeting anything
+// higher than the blocks' maxima — and what is left is to bring every cell down from its block's
+// level and to re-level the lakes from their true spill points: 16 launches at 4096^2 (and 4-10 on
+// each of the three small levels); 16x coarsening leaves 22, 128x128 tiles cost more per launch
+// than they save.
+//
+// Inside a tile a step of the plain iteration moves information by one cell: a work-group spent
+// 100-300 us per launch whatever the number of tiles, 4.0 ms in all at 4096^2 (round 2).  Round 3:
+// whole lines at once.  Along a row (or column), going one way, cell j takes
+//        w'_j = max(z_j, min(w_j, w'_{j-1}))  =  clamp of its updated predecessor into [z_j, w_j],
+// and clamps compose to clamps — the chain is a prefix scan over (lo, hi) pairs, six DPP steps for
+// 64 cells (fill_line_pass).  Rows there and back, columns there and back, then one plain step
+// over all K neighbours (the diagonals; and what makes "nothing moved" the fixed point of the full
+// operator): a tile settles in 2-9 such rounds instead of up to 256 steps.  1024 threads per
+// tile (16 waves x 4 lines per direction); every tile writes its own "moved" mark (no clearing
+// pass between launches); the first launch of a level makes its start surface itself (no pass
+// over the level for it): 4.0 -> 1.7 ms at 4096^2, 8.1 -> 5.6 ms at 8192^2.
 #include <cstdio>
 #include <cstdlib>
 #include <utility>
@@ -37,21 +49,65 @@
 
 namespace soil {
 
+constexpr int kFC = 4;              // coarsening factor per level
 constexpr int kFT = 64;             // tile edge
 constexpr int kFH = kFT + 2;        // with its one-cell apron
 constexpr int kFBlock = 256;
-constexpr int kFPer = kFT * kFT / kFBlock;
+constexpr int kFRelax = 1024;  // threads of a relaxing work-group: 16 waves, 4 lines each per direction
+constexpr int kFCells = kFT * kFT / kFRelax;
+
+// One directional pass along a line of 64 cells (a row or a column of the tile), all 64 at once.
+// Going along the line, cell j takes  w'_j = max(z_j, min(w_j, w'_{j-1}))  — the clamp of its
+// updated predecessor into [z_j, w_j].  Clamps compose to clamps,
+//     (clamp into [l1,h1], then into [l2,h2]) = clamp into [clamp(l1; l2,h2), clamp(h1; l2,h2)],
+// so the whole chain is an inclusive prefix scan over (lo, hi) pairs: six cross-lane steps instead
+// of 64 dependent ones, med3 only (exact).  The steps are DPP moves (row_shr 1/2/4/8, row_bcast
+// 15/31): through ds_bpermute shuffles a pass was a chain of 24 LDS round trips and the kernel
+// slower than the cell-by-cell relaxation it replaces.  A lane without a source takes the identity
+// (-inf, +inf), which leaves its pair as it is.  `x_in`: the value in front of the line (apron).
+// The pass runs towards higher lanes; the caller reads the line backwards for the other direction.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void fill_scan_step(float& slo, float& shi) {
+  const float ninf = -__builtin_inff(), pinf = __builtin_inff();
+  const float plo = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
+      __builtin_bit_cast(int, ninf), __builtin_bit_cast(int, slo), CTRL, ROW_MASK, 0xf, false));
+  const float phi = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
+      __builtin_bit_cast(int, pinf), __builtin_bit_cast(int, shi), CTRL, ROW_MASK, 0xf, false));
+  // the earlier segment (p) first, then this one (s)
+  const float nlo = __builtin_amdgcn_fmed3f(plo, slo, shi), nhi = __builtin_amdgcn_fmed3f(phi, slo, shi);
+  slo = nlo;
+  shi = nhi;
+}
+__device__ __forceinline__ float fill_line_pass(float z, float w, float x_in) {
+  float slo = (z != z) ? -__builtin_inff() : z;  // cells outside the grid / NoData: w = -inf, held there
+  float shi = w;
+  fill_scan_step<0x111, 0xf>(slo, shi);  // row_shr:1
+  fill_scan_step<0x112, 0xf>(slo, shi);  // row_shr:2
+  fill_scan_step<0x114, 0xf>(slo, shi);  // row_shr:4
+  fill_scan_step<0x118, 0xf>(slo, shi);  // row_shr:8
+  fill_scan_step<0x142, 0xa>(slo, shi);  // row_bcast:15 into rows 1 and 3
+  fill_scan_step<0x143, 0xc>(slo, shi);  // row_bcast:31 into rows 2 and 3
+  return __builtin_amdgcn_fmed3f(x_in, slo, shi);
+}
+
+constexpr int kFZ = kFT + 1;  // row stride of the tile's z in LDS (column reads without conflicts)
 
 template <int K>
-__global__ void __launch_bounds__(kFBlock)
+__global__ void __launch_bounds__(kFRelax)
     k_fill_relax(float* __restrict__ w, const float* __restrict__ z, int64_t H, int64_t W,
                  int tiles_w, int tiles_h, int inner_max, int* __restrict__ changed,
                  const unsigned char* __restrict__ dirty_prev,
-                 unsigned char* __restrict__ dirty_next) {
+                 unsigned char* __restrict__ dirty_next, int first,
+                 const float* __restrict__ wc, int64_t Wc) {
   __shared__ float sw[kFH * kFH];
+  __shared__ float sz[kFT * kFZ];
   __shared__ int s_flag, s_any;
   const int tid = threadIdx.x;
-  {  // a tile can only move if it or one of its 8 neighbours moved in the previous launch
+  // `first`: the level's first launch — every tile takes part and makes its own start, the coarse
+  // level's surface of each cell's block (`wc`) or +inf on the coarsest level, never below z: a
+  // pass over the whole level for that (and one to mark every tile) is saved.  (Cells next to an
+  // outlet come down to z in the first relaxation step by themselves.)
+  if (!first) {  // a tile can only move if it or one of its 8 neighbours moved in the previous launch
     const int tx = blockIdx.x / tiles_w, ty = blockIdx.x % tiles_w;
     bool live = false;
     for (int dx = -1; dx <= 1; ++dx)
@@ -60,42 +116,112 @@ __global__ void __launch_bounds__(kFBlock)
         if (nx >= 0 && ny >= 0 && nx < tiles_h && ny < tiles_w)
           live = live || dirty_prev[nx * tiles_w + ny] != 0;
       }
-    if (!live) return;
+    if (!live) {
+      if (tid == 0) dirty_next[blockIdx.x] = 0;  // (every tile writes its mark: no clearing pass)
+      return;
+    }
   }
   const int64_t row0 = static_cast<int64_t>(blockIdx.x / tiles_w) * kFT;
   const int64_t col0 = static_cast<int64_t>(blockIdx.x % tiles_w) * kFT;
   const float ninf = -__builtin_inff();
   // tile + apron; off-grid and NaN cells are outlets: -inf
-  for (int i = tid; i < kFH * kFH; i += kFBlock) {
+  for (int i = tid; i < kFH * kFH; i += kFRelax) {
     const int64_t x = row0 + i / kFH - 1, y = col0 + i % kFH - 1;
     float v = ninf;
     if (x >= 0 && y >= 0 && x < H && y < W) {
-      v = w[x * W + y];
-      if (v != v) v = ninf;
+      if (first) {
+        const float zv = z[x * W + y];
+        v = wc ? fmaxf(zv, wc[(x / kFC) * Wc + y / kFC]) : __builtin_inff();  // (fmaxf: a NaN z gives wc)
+        if (zv != zv) v = ninf;
+      } else {
+        v = w[x * W + y];
+        if (v != v) v = ninf;
+      }
     }
     sw[i] = v;
   }
-  float zc[kFPer];
-  bool in[kFPer];
+  float zc[kFCells];
+  bool in[kFCells];
 #pragma unroll
-  for (int j = 0; j < kFPer; ++j) {
-    const int c = tid + j * kFBlock;
+  for (int j = 0; j < kFCells; ++j) {
+    const int c = tid + j * kFRelax;
     const int64_t x = row0 + c / kFT, y = col0 + c % kFT;
     in[j] = x < H && y < W;
     zc[j] = in[j] ? z[x * W + y] : 0.0f;
-    if (zc[j] != zc[j]) in[j] = false;  // NaN cells stay NaN and act as outlets
+    if (zc[j] != zc[j]) in[j] = false;  // NaN cells stay NaN (zc keeps it) and act as outlets
+    sz[(c / kFT) * kFZ + c % kFT] = in[j] ? zc[j] : __builtin_nanf("");
   }
   if (tid == 0) s_any = 0;
   __syncthreads();
+  const int lane = tid & 63, wave = tid >> 6;
+  constexpr int kLines = kFT / (kFRelax / 64);  // lines per wave and direction
   for (int it = 0; it < inner_max; ++it) {
     if (tid == 0) s_flag = 0;
     __syncthreads();
     bool moved = false;
+    // along the rows, there and back: a lake levels across the whole tile in one pass, not a cell
+    // per iteration.  (A wave owns its lines; the way back reads what the way there wrote.  Four
+    // lines at a time: their scans are independent chains the wave can interleave.)
+    constexpr int kTogether = 4;
+    for (int q0 = 0; q0 < kLines; q0 += kTogether) {
 #pragma unroll
-    for (int j = 0; j < kFPer; ++j) {
-      if (!in[j]) continue;
-      const int c = tid + j * kFBlock;
+      for (int back = 0; back < 2; ++back) {
+        const int col = back ? kFT - 1 - lane : lane;
+        float wv[kTogether], zv[kTogether], xin[kTogether];
+#pragma unroll
+        for (int u = 0; u < kTogether; ++u) {
+          const int r = wave * kLines + q0 + u;
+          wv[u] = sw[(r + 1) * kFH + col + 1];
+          zv[u] = sz[r * kFZ + col];
+          xin[u] = sw[(r + 1) * kFH + (back ? kFT + 1 : 0)];
+        }
+#pragma unroll
+        for (int u = 0; u < kTogether; ++u) {
+          if (__ballot(wv[u] > zv[u]) == 0) continue;  // no cell of the line stands above its z
+          const int r = wave * kLines + q0 + u;
+          const float v = fill_line_pass(zv[u], wv[u], xin[u]);
+          if (v < wv[u]) {
+            sw[(r + 1) * kFH + col + 1] = v;
+            moved = true;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // along the columns
+    for (int q0 = 0; q0 < kLines; q0 += kTogether) {
+#pragma unroll
+      for (int back = 0; back < 2; ++back) {
+        const int row = back ? kFT - 1 - lane : lane;
+        float wv[kTogether], zv[kTogether], xin[kTogether];
+#pragma unroll
+        for (int u = 0; u < kTogether; ++u) {
+          const int c = wave * kLines + q0 + u;
+          wv[u] = sw[(row + 1) * kFH + c + 1];
+          zv[u] = sz[row * kFZ + c];
+          xin[u] = sw[(back ? kFT + 1 : 0) * kFH + c + 1];
+        }
+#pragma unroll
+        for (int u = 0; u < kTogether; ++u) {
+          if (__ballot(wv[u] > zv[u]) == 0) continue;
+          const int c = wave * kLines + q0 + u;
+          const float v = fill_line_pass(zv[u], wv[u], xin[u]);
+          if (v < wv[u]) {
+            sw[(row + 1) * kFH + c + 1] = v;
+            moved = true;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // every neighbour, one step (the diagonals of D8; and what makes "nothing moved" the fixed
+    // point of the full operator)
+#pragma unroll
+    for (int j = 0; j < kFCells; ++j) {
+      const int c = tid + j * kFRelax;
       const int p = (c / kFT + 1) * kFH + (c % kFT + 1);
+      if (__ballot(in[j] && sw[p] > zc[j]) == 0) continue;  // nothing of these 64 cells can come down
+      if (!in[j]) continue;
       float m = fminf(fminf(sw[p - kFH], sw[p + kFH]), fminf(sw[p - 1], sw[p + 1]));
       if (K == 8)
         m = fminf(m, fminf(fminf(sw[p - kFH - 1], sw[p - kFH + 1]),
@@ -113,22 +239,21 @@ __global__ void __launch_bounds__(kFBlock)
     __syncthreads();
   }
   __syncthreads();
-  if (s_any) {
+  if (s_any || first) {
 #pragma unroll
-    for (int j = 0; j < kFPer; ++j) {
-      if (!in[j]) continue;
-      const int c = tid + j * kFBlock;
+    for (int j = 0; j < kFCells; ++j) {
+      const int c = tid + j * kFRelax;
       const int64_t x = row0 + c / kFT, y = col0 + c % kFT;
-      w[x * W + y] = sw[(c / kFT + 1) * kFH + (c % kFT + 1)];
+      if (in[j]) w[x * W + y] = sw[(c / kFT + 1) * kFH + (c % kFT + 1)];
+      else if (first && x < H && y < W) w[x * W + y] = zc[j];  // NaN cells stay NaN
     }
-    if (tid == 0) {
-      *changed = 1;
-      dirty_next[blockIdx.x] = 1;
-    }
+  }
+  if (tid == 0) {
+    if (s_any) *changed = 1;
+    dirty_next[blockIdx.x] = (s_any || first) ? 1 : 0;
   }
 }
 
-constexpr int kFC = 4;  // coarsening factor per level
 
 // block maxima (NaN cells skipped: leaving an outlet out only raises the start, which stays valid)
 __global__ void __launch_bounds__(kFBlock)
@@ -146,33 +271,6 @@ __global__ void __launch_bounds__(kFBlock)
   zc[n] = m;
 }
 
-// w = z where a neighbour is an outlet (or z is NaN); elsewhere the coarse level's surface of the
-// cell's block (`wc`, see the header) or +inf on the coarsest level
-template <int K>
-__global__ void __launch_bounds__(kFBlock)
-    k_fill_init(float* __restrict__ w, const float* __restrict__ z, int64_t H, int64_t W,
-                const float* __restrict__ wc, int64_t Wc) {
-  const int64_t n = static_cast<int64_t>(blockIdx.x) * kFBlock + threadIdx.x;
-  if (n >= H * W) return;
-  const int64_t x = n / W, y = n % W;
-  const float zv = z[n];
-  bool outlet = zv != zv;
-  const int dx[8] = {-1, 0, 0, 1, -1, -1, 1, 1}, dy[8] = {0, -1, 1, 0, -1, 1, -1, 1};
-#pragma unroll
-  for (int k = 0; k < K; ++k) {
-    const int64_t nx = x + dx[k], ny = y + dy[k];
-    if (nx < 0 || ny < 0 || nx >= H || ny >= W) {
-      outlet = true;
-    } else {
-      const float nv = z[nx * W + ny];
-      if (nv != nv) outlet = true;
-    }
-  }
-  float start = __builtin_inff();
-  if (wc) start = fmaxf(zv, wc[(x / kFC) * Wc + y / kFC]);  // >= zv anyway; the max guards -inf blocks
-  w[n] = outlet ? zv : start;
-}
-
 // one level: `out` = fill of `height` (H x W), started from the coarse surface `wc` (or +inf)
 template <int K>
 static int fill_level(float* out, const float* height, int64_t H, int64_t W, const float* wc,
@@ -181,17 +279,14 @@ static int fill_level(float* out, const float* height, int64_t H, int64_t W, con
   const int tiles_w = static_cast<int>((W + kFT - 1) / kFT);
   const int tiles_h = static_cast<int>((H + kFT - 1) / kFT);
   const size_t ntiles = static_cast<size_t>(tiles_w) * tiles_h;
-  SOIL_HIP(hipMemsetAsync(dirty_prev, 1, ntiles, st));  // first launch: every tile
-  k_fill_init<K><<<blocks_for(H * W, kFBlock), kFBlock, 0, st>>>(out, height, H, W, wc, Wc);
-  SOIL_LAUNCH_CHECK();
   // a launch moves information at least one tile further; H*W launches is a bound
   // no terrain reaches
   const int64_t max_launches = 4 * (static_cast<int64_t>(tiles_w) + tiles_h) * kFT + 16;
   // (a value below 1 or not a number would skip the launches and return the unrelaxed start)
   static const int per_check = [] {
     const char* e = std::getenv("SOIL_FILL_PER_CHECK");
-    const int v = e ? std::atoi(e) : 2;
-    return v >= 1 ? v : 2;
+    const int v = e ? std::atoi(e) : 3;
+    return v >= 1 ? v : 3;
   }();
   static const bool verbose = std::getenv("SOIL_FILL_VERBOSE") != nullptr;
   for (int64_t launch = 0; launch < max_launches; launch += per_check) {
@@ -199,9 +294,9 @@ static int fill_level(float* out, const float* height, int64_t H, int64_t W, con
     // several launches per look at the flag: a launch whose predecessor moved nothing costs a
     // few microseconds (every tile returns at once), a host round trip ~20
     for (int k = 0; k < per_check; ++k) {
-      SOIL_HIP(hipMemsetAsync(dirty_next, 0, ntiles, st));
-      k_fill_relax<K><<<static_cast<unsigned>(ntiles), kFBlock, 0, st>>>(
-          out, height, H, W, tiles_w, tiles_h, 4 * kFT, flag_dev, dirty_prev, dirty_next);
+      k_fill_relax<K><<<static_cast<unsigned>(ntiles), kFRelax, 0, st>>>(
+          out, height, H, W, tiles_w, tiles_h, 4 * kFT, flag_dev, dirty_prev, dirty_next,
+          launch + k == 0 ? 1 : 0, wc, Wc);
       std::swap(dirty_prev, dirty_next);
     }
     SOIL_LAUNCH_CHECK();

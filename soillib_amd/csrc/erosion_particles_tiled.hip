@@ -630,7 +630,6 @@ __device__ __forceinline__ uint4 queue_share(uint32_t tile, uint32_t q_first, ui
   return make_uint4(tile, q_first + off, cnt, groups > 1 ? 1u : 0u);
 }
 
-constexpr int kPanel = 16384;  // tiles per LDS panel of k_queue_prepare
 
 // inclusive prefix sum over the lanes of a wave / the 1024 threads of k_queue_prepare's
 // work-group (two barriers; `wsum`: 16 words of LDS)

@@ -414,7 +414,6 @@ int soil_random_weighted(int32_t* graph, const float* height, int64_t H, int64_t
   SOIL_REQUIRE(graph && height, "random_weighted: null tensor");
   SOIL_REQUIRE(H > 0 && W > 0 && H * W <= INT32_MAX,
                "random_weighted: grid must have 1..2^31-1 cells");
-  const unsigned nb = blocks_for(H * W, kGBlock);
   switch (edge) {
     case SOIL_D4: k_random_weighted<4><<<grid_rows(H, W, kGBlock), kGBlock, 0, as_stream(stream)>>>(graph, height, H, W, seed, offset, T); break;
     case SOIL_D8: k_random_weighted<8><<<grid_rows(H, W, kGBlock), kGBlock, 0, as_stream(stream)>>>(graph, height, H, W, seed, offset, T); break;
