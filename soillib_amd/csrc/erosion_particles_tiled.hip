@@ -2147,9 +2147,6 @@ int launch_pair_tiled(const soil_erosion_planes& P, Streams rng_fluvial, Streams
     SOIL_HIP(hipEventCreateWithFlags(&f.joinB, hipEventDisableTiming));
   }
   const hipStream_t sA = f.sA, sB = f.sB;
-  SOIL_HIP(hipEventRecord(f.fork, st));
-  SOIL_HIP(hipStreamWaitEvent(sA, f.fork, 0));
-  SOIL_HIP(hipStreamWaitEvent(sB, f.fork, 0));
   TiledRun<FLUVIAL> A = make_run<FLUVIAL>(P.waterFlux, P.massFlux, P.velocityFlux, nullptr, nullptr,
                                           rng_fluvial, N,
                                           P.layers, P.rainfall, P.waterHeight, P.velocity, remote0,
@@ -2181,7 +2178,7 @@ int launch_pair_tiled(const soil_erosion_planes& P, Streams rng_fluvial, Streams
   if (turns) {
     void* g = nullptr;
     if (int rc = workspace_get(9, 256, &g); rc != SOIL_OK) return rc;
-    SOIL_HIP(hipMemsetAsync(g, 0, sizeof(PairGate), sA));  // sA and sB both wait for `fork`; B starts after A's first scans
+    SOIL_HIP(hipMemsetAsync(g, 0, sizeof(PairGate), st));  // ahead of the fork
     A.gate = B.gate = static_cast<PairGate*>(g);
   }
   // (round 3, with rounds queued ahead of the host: counted in scans the host has seen; 1024^2 1.59 / 1.62 /
@@ -2199,14 +2196,19 @@ int launch_pair_tiled(const soil_erosion_planes& P, Streams rng_fluvial, Streams
     if (fused_pack) {
       const int64_t lo = stencil_lo(d), hi = stencil_hi(d);
       if (hi >= lo)
-        k_tiled_pack_pair<<<grid_rows(hi - lo + 1, d.W, 256), 256, 0, sA>>>(
+        k_tiled_pack_pair<<<grid_rows(hi - lo + 1, d.W, 256), 256, 0, st>>>(
             A.p4, B.p4, reinterpret_cast<const float2*>(P.layers), reinterpret_cast<const float2*>(P.velocity),
             P.waterHeight, reinterpret_cast<const float2*>(P.debrisVelocity), d, s, p, lo, hi + 1);
       SOIL_LAUNCH_CHECK();
-      SOIL_HIP(hipEventRecord(f.fork, sA));       // the debris launch reads its records from sB
-      SOIL_HIP(hipStreamWaitEvent(sB, f.fork, 0));
       A.skip_pack = B.skip_pack = true;
     }
+    // The fork, behind the one pack pass on the caller's stream.  (With the pass on the fluvial
+    // stream and the debris stream waiting for an event recorded there, the debris launch's first
+    // kernel started when the fluvial launch's round 0 ended, 3 ms late, on every step of the
+    // rocprof trace: the runtime resolved the wait with a later command of that stream.)
+    SOIL_HIP(hipEventRecord(f.fork, st));
+    SOIL_HIP(hipStreamWaitEvent(sA, f.fork, 0));
+    SOIL_HIP(hipStreamWaitEvent(sB, f.fork, 0));
     if (int rc = A.begin(); rc != SOIL_OK) return rc;
     bool b_started = false;
     while (!A.done || !B.done) {
