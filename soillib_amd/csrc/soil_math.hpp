@@ -160,15 +160,23 @@ __device__ __forceinline__ bool plain_num(float a) { return f2bits(a) == 0u || f
 // kernels' own sentinel) redoes the group with the written-out divisions.
 struct QuotWatch {
   uint32_t lo = 0xffffffffu, hi = 0u;
+  bool neg_zero = false;
   __device__ __forceinline__ float operator()(float q) {
     const uint32_t u = f2bits(q) & 0x7fffffffu;
     lo = min(lo, u - 1u);  // a zero wraps to the top: never the minimum
     hi = max(hi, u);
     return q;
   }
+  // For a quotient whose SIGN OF ZERO is seen by the caller (stored, not just compared): a
+  // numerator -0 (the difference (-0) - (+0), half of it, ...) has the IEEE quotient -0 over these
+  // positive denominators, the chain of quot() ends in +0.  Such a group is in doubt.
+  __device__ __forceinline__ float operator()(float q, float numerator) {
+    neg_zero = neg_zero || f2bits(numerator) == 0x80000000u;
+    return (*this)(q);
+  }
   __device__ __forceinline__ bool doubtful() const {
     constexpr uint32_t kLoBits = (127u - 60u) << 23, kHiBits = (127u + 90u) << 23;
-    return lo < kLoBits - 1u || hi > kHiBits;
+    return lo < kLoBits - 1u || hi > kHiBits || neg_zero;
   }
 };
 

@@ -104,6 +104,8 @@ __global__ void __launch_bounds__(kSBlock)
 struct DivWritten {
   __device__ __forceinline__ float operator()(float a, float b, const Recip&) const { return a / b; }
 };
+// (for quotients that are only compared with zero or squared — negslope: the sign of a zero
+// quotient is not seen; one that is stored goes through QuotWatch's two-argument form)
 struct DivShared {
   QuotWatch* watch;
   __device__ __forceinline__ float operator()(float a, float, const Recip& rb) const {
@@ -162,8 +164,9 @@ __global__ void __launch_bounds__(kWinBlock)
       QuotWatch watch;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        of[2 * k] = watch(quot(0.5f * (w.dn.v[k + 1] - w.up.v[k + 1]), rx));
-        of[2 * k + 1] = watch(quot(0.5f * (w.mid.v[k + 2] - w.mid.v[k]), ry));
+        const float ax = 0.5f * (w.dn.v[k + 1] - w.up.v[k + 1]), ay = 0.5f * (w.mid.v[k + 2] - w.mid.v[k]);
+        of[2 * k] = watch(quot(ax, rx), ax);  // (the sign of a zero gradient is stored: see QuotWatch)
+        of[2 * k + 1] = watch(quot(ay, ry), ay);
       }
       redo = watch.doubtful();
     }

@@ -628,6 +628,14 @@ def test_window_kernels_across_seams(hip, oracle, H, W):
     h[2, 1] = 3e-30                             # must hand to the written-out division
     if H > 40:
         h[40, 2] = np.inf
+    # signed zeros: (-0) - (+0) = -0 is a numerator whose IEEE quotient is -0; the shared-reciprocal
+    # chain would answer +0 (soil_math.hpp), so such groups must take the written-out division
+    h[10:13, 1:3] = 0.0
+    h[11, 1] = -0.0
+    h[10, 2] = -0.0
+    if W > 8:
+        h[20:25, 4:9] = -0.0
+        h[22, 6] = 0.0
     gh = to_gpu(h)
     sc = (0.4, 1.7)
     for edge in (D4, D8):
