@@ -460,13 +460,15 @@ int soil_multiflow(double* sum, const float* height, const float* source, int64_
 int soil_fill_depressions(float* out, const float* height, int64_t H, int64_t W, int edge,
                           void* stream);
 /* Scratch memory.  The reference allocates its scratch per call (graph.cu:539-550, :182-183;
- * path.cu:195; filter.cu:77); this library keeps one cached block per device and purpose
- * (accumulate, the particle launches of either kind, fill_depressions, soil_erode) and grows it
- * on demand.  Contract: calls that use the same block must not overlap in time — ONE host thread
- * per device drives the library (as in the reference: single host thread, GIL held throughout,
- * model.cpp), or several threads that serialise their calls.  A call that finds its block too
- * small synchronises the device before replacing it.
- * soil_workspace_release frees all cached blocks of the current device. */
+ * path.cu:195; filter.cu:77); this library keeps one cached block per host thread, device and
+ * purpose (accumulate, the particle launches of either kind, fill_depressions, soil_erode) and
+ * grows it on demand.  Several host threads may drive one device at the same time, each on its
+ * own stream: they share no scratch (nor streams, events or pinned words of the launches, which
+ * are per thread too).  Calls of ONE thread that use the same block must not overlap in time —
+ * they do not, since a thread's calls are ordered on the streams it passes.  A call that finds its
+ * block too small synchronises the device before replacing it.
+ * soil_workspace_release frees all cached blocks of the current device, of every thread: call it
+ * while no other thread is inside the library. */
 int soil_workspace_release(void);
 
 /* ---------------------------------------------------------------- stencils */

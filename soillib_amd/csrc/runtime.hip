@@ -4,6 +4,8 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <thread>
+#include <tuple>
 #include <utility>
 
 #include "common.hpp"
@@ -60,13 +62,17 @@ struct WsBlock {
   size_t bytes = 0;
 };
 static std::mutex g_ws_mutex;
-static std::map<std::pair<int, int>, WsBlock> g_ws;  // (device, slot) -> block
+// (host thread, device, slot) -> block.  A block per host thread: two threads driving one device
+// (each on its own stream) do not share scratch, so their calls may overlap in time; the streams,
+// events and pinned words of the launches are per thread as well (thread_local).
+using WsKey = std::tuple<std::thread::id, int, int>;
+static std::map<WsKey, WsBlock> g_ws;
 
 int workspace_get(int slot, size_t bytes, void** out) {
   int dev = 0;
   SOIL_HIP(hipGetDevice(&dev));
   std::lock_guard<std::mutex> lock(g_ws_mutex);
-  WsBlock& w = g_ws[{dev, slot}];
+  WsBlock& w = g_ws[WsKey{std::this_thread::get_id(), dev, slot}];
   if (w.bytes < bytes) {
     if (w.base) {
       SOIL_HIP(hipDeviceSynchronize());  // nobody may still be reading the old block
@@ -102,7 +108,7 @@ int workspace_release_all() {
   SOIL_HIP(hipGetDevice(&dev));
   std::lock_guard<std::mutex> lock(g_ws_mutex);
   for (auto it = g_ws.begin(); it != g_ws.end();) {
-    if (it->first.first == dev) {
+    if (std::get<1>(it->first) == dev) {
       if (it->second.base) {
         SOIL_HIP(hipDeviceSynchronize());
         SOIL_HIP(hipFree(it->second.base));

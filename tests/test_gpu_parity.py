@@ -1249,3 +1249,40 @@ def test_pair_modes_walk_the_same_walks(hip, monkeypatch, mode):
             x, y = to_np(getattr(a, name)), to_np(getattr(b, name))
             _close_but_for_stray_walks(x, y, 1e-4, 1e-5 * (np.nanmax(np.abs(y)) + 1e-30),
                                        0.0 if step == 0 else 2e-3, "step %d %s" % (step, name))
+
+
+def test_two_host_threads_share_a_device(hip, oracle):
+    """Two host threads step two models on one device at the same time (ctypes drops the GIL
+    inside a call): scratch, streams and pinned words are per thread, so each gets the result it
+    gets alone.  (With the per-device scratch of round 2 the second thread's spawn pass overwrote
+    the first one's queues.)"""
+    import threading
+    from soillib_amd import erosion, silt, soil
+    H = W = 1024
+    param = script_param(soil.param_t())
+    param.maxage = 128
+    dem = terrain(oracle, H, W)
+
+    def make():
+        m = erosion.ErosionModel(H, W, (20.0 / H, 20.0 / W, 4.0), param, H * W // 8, seed=3)
+        m.set_layers(to_gpu(dem))
+        silt.set(m.rainfall, 1.0)
+        return m
+
+    def run(m, out, key):
+        for _ in range(3):
+            m.step()
+        out[key] = to_np(m.layers)
+
+    alone = {}
+    run(make(), alone, "ref")
+    res = {}
+    models = [make(), make()]
+    threads = [threading.Thread(target=run, args=(m, res, i)) for i, m in enumerate(models)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for i in range(2):
+        # trajectories are the same bits; the flux sums (fp32 atomics) are a tolerance between runs
+        np.testing.assert_allclose(res[i], alone["ref"], rtol=2e-4, atol=1e-5)
