@@ -892,7 +892,8 @@ __global__ void __launch_bounds__(1024) k_queue_scan(QueueScan q) {
 
 // ---- taking turns: the two launches of a step on a grid either of them fills by itself -------------
 //
-// Mixed freely, the two round kernels waste LDS (a CU holds two fluvial tiles or three debris ones,
+// Mixed freely, the two round kernels wasted LDS (with the 68-row debris tiles this was measured
+// with, a CU held two fluvial tiles or three debris ones,
 // one of each leaves 28 KiB unused); run one after the other, each leaves the chip half empty at the
 // end of every round (the last generation of work-groups, the slot sort, the scan).  So they take
 // turns: a launch's round may begin once the other launch is NOT in the dense part of a round — its
@@ -1147,7 +1148,7 @@ __global__ void __launch_bounds__(NT, round_waves_per_simd(KIND, TR, TC, NT, ALB
                   Scale3 s, Param param, int tiles_w, int off_r, int off_c, int steps_per_round,
                   TileShape ts_next,
                   int tiles_w_next, int agg_min, int agg_groups, int retries, int store_all,
-                  TiledCtl* __restrict__ ctl, uint32_t round, QueueScan next, uint32_t* my_dense) {
+                  TiledCtl* __restrict__ ctl, uint32_t round, QueueScan next, uint32_t* my_dense, uint32_t gate_early) {
   constexpr int kCells = TR * TC, kBlock = NT, kPer = (kCells + NT - 1) / NT;
   // Queued ahead of the scan's verdict: no round at all (the word the host waits for at the end of
   // this round still goes out), or fewer work-groups than the launch has.
@@ -1161,7 +1162,8 @@ __global__ void __launch_bounds__(NT, round_waves_per_simd(KIND, TR, TC, NT, ALB
   // start — every one has been handed out, what follows is the round's tail — lets the other's next
   // round in
   if (my_dense && threadIdx.x == 0 &&
-      __hip_atomic_fetch_add(&ctl->started, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n_groups - 1u)
+      __hip_atomic_fetch_add(&ctl->started, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
+          n_groups - 1u - static_cast<uint32_t>((static_cast<uint64_t>(n_groups - 1u) * gate_early) / 100u))
     __hip_atomic_store(my_dense, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   PROF_DECL;
   // this work-group's share of its tile's queue (the scan's block list)
@@ -1627,15 +1629,19 @@ __global__ void k_fold_steps(unsigned long long* total, const unsigned long long
 //   DESIGN.md 3.2).  Also measured, and not kept: 3 x 52 rows x 512 lanes (fluvial 25.5), 4 x 52 x 384
 //   (debris 13.3), and small tiles for the sparse late rounds (32x32 x 64 lanes, 32x64 x 128: debris
 //   11.9-14.3 ms, fluvial 26.0-27.2 whatever the round they take over from).
+//   Round 3: debris on 104 rows x 768 lanes, two per CU like the fluvial tiles and the same
+//   79 872 B of LDS each (any mix of the two kernels fills a CU): with 40-step rounds 11.05 -> 10.78 ms
+//   per launch, the overlapped 8192^2 step 34.1-34.4 -> 33.9-34.0 ms on one box (fewer tile edges to
+//   park at; the walkers in flight are the same 1664 per CU as with three 68-row tiles).
 struct RoundShape { int tr, tc, nt; };
 constexpr int kShapeColour = 2;  // serves the launches that carry colour: 7 / 6 LDS planes, one work-group per CU
-constexpr int kShapeFull = 3;    // the LDS-filling tiles: fluvial 2 x 78 rows, debris 3 x 68 rows per CU
+constexpr int kShapeFull = 3;    // the LDS-filling tiles, two per CU of either kind: fluvial 78 rows, debris 104 rows, 768 lanes
 constexpr int kNumShapes = 4;
 template <int KIND>
 struct Shapes {
   static constexpr RoundShape v[kNumShapes] = {
       {64, 64, 512}, {64, 64, 768}, {64, 64, 1024},
-      KIND == FLUVIAL ? RoundShape{78, 64, 768} : RoundShape{68, 64, 512}};
+      KIND == FLUVIAL ? RoundShape{78, 64, 768} : RoundShape{104, 64, 768}};
 };
 
 template <int KIND, int DEP, int SH, bool ALB, typename... A>
@@ -1759,7 +1765,6 @@ struct TiledRun {
     // (fluvial walkers live out their 256 steps and stay on a 78-row tile longer than debris
     // walkers do: 8192^2, ms per launch at 24 / 28 / 32 / 36 / 40 / 48 / 64 steps: fluvial 27.6 26.5 24.9
     // 24.1 23.8 23.8 23.7, debris 11.6 11.1 10.9 10.95 11.0 11.05 11.3)
-    steps_per_round = env_kind("SOIL_TILED_STEPS", KIND, KIND == FLUVIAL ? 40 : 32);
     // the finishing launch pays ~4 L2 atomics per step (22.7 G/s), a round a fixed
     // cost that grows with the number of tiles: N/40 within [4096, 200000] is where
     // they cross for 512^2 .. 8192^2 grids with N = cells/8
@@ -1798,6 +1803,8 @@ struct TiledRun {
       shape_early = shape_late = kShapeColour;
       deposit = 0;  // compare-and-swap deposits
     }
+    // (debris on its 104-row tiles, round 3: 32 / 40 / 48 steps 11.05 / 10.78 / 10.77 ms per launch)
+    steps_per_round = env_kind("SOIL_TILED_STEPS", KIND, (KIND == FLUVIAL || shape_early == kShapeFull) ? 40 : 32);
     // A round is worth its fixed cost while it advances particles faster than the
     // finishing launch would (4 L2 atomics per step at 22.7 G/s = 5.7 G steps/s).
     // Particles that zig-zag along a tile edge get a handful of steps per round; on
@@ -2003,6 +2010,7 @@ struct TiledRun {
     PRec* in = recs_of(r);
     PRec* out = recs_of(r + 1);
     uint32_t* my_dense = nullptr;
+    static const uint32_t gate_early = static_cast<uint32_t>(std::min(100, std::max(0, env_int("SOIL_PAIR_EARLY", 20))));
     if (gate && tail_scan) {  // (the `started` ticket is reset by the tail scan's work-group)
       k_pair_gate<<<1, 1, 0, st>>>(gate, KIND, ctl, static_cast<unsigned long long>(0.05 * ticks_per_second));
       SOIL_LAUNCH_CHECK();
@@ -2019,7 +2027,7 @@ struct TiledRun {
                             remote0, steps_run, d, s, p, tiles_w, ts_cur.off_r, ts_cur.off_c,
                             steps_per_round, ts_of(sh_next, r + 1),
                             tiles_w_of(sh_next, r + 1), agg_min, agg_groups, retries, store_all,
-                            ctl, static_cast<uint32_t>(r), next_scan, my_dense);
+                            ctl, static_cast<uint32_t>(r), next_scan, my_dense, gate_early);
     else
       launch_round<KIND, 1>(sh, grid, st, out, dest, rank, count_of(r + 1),
                             static_cast<const PRec*>(in), static_cast<const uint32_t*>(order),
@@ -2028,7 +2036,7 @@ struct TiledRun {
                             remote0, steps_run, d, s, p, tiles_w, ts_cur.off_r, ts_cur.off_c,
                             steps_per_round, ts_of(sh_next, r + 1),
                             tiles_w_of(sh_next, r + 1), agg_min, agg_groups, retries, store_all,
-                            ctl, static_cast<uint32_t>(r), next_scan, my_dense);
+                            ctl, static_cast<uint32_t>(r), next_scan, my_dense, gate_early);
     SOIL_LAUNCH_CHECK();
     if (!tail_scan) {
       k_queue_scan<<<1, 1024, 0, st>>>(standalone);

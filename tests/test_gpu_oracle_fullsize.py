@@ -128,7 +128,7 @@ def test_4096x2048_default_launch_shapes(hip, oracle):
 
 
 def test_1024_with_the_lds_filling_tiles(hip, oracle, monkeypatch):
-    """The tile shape 8192^2 runs with by default (78 / 68 rows: not a power of two, queues
+    """The tile shape 8192^2 runs with by default (78 / 104 rows: not a power of two, queues
     longer than the work-group), forced onto the 1024^2 case."""
     monkeypatch.setenv("SOIL_TILED_SHAPE", "3")
     _run(hip, oracle, 1024, 1024, steps=2)

@@ -338,7 +338,7 @@ def _flux_close(got, want, what):
 @pytest.fixture(params=["direct", "staged", "tiled", "tiled-full", "tiled-panels"])
 def particle_mode(request, hip, monkeypatch):
     """The launch shapes of the particle kernels (soil_set_particle_mode).  "tiled-full": the tiled
-    shape with the LDS-filling tiles (78 / 68 rows) that large grids get by default;
+    shape with the LDS-filling tiles (78 / 104 rows) that large grids get by default;
     "tiled-panels": with the queue scan of grids of more than 16384 tiles."""
     if request.param == "tiled-full":
         monkeypatch.setenv("SOIL_TILED_SHAPE", "3")
