@@ -2211,9 +2211,10 @@ int launch_pair_tiled(const soil_erosion_planes& P, Streams rng_fluvial, Streams
       A.skip_pack = B.skip_pack = true;
     }
     // The fork, behind the one pack pass on the caller's stream.  (With the pass on the fluvial
-    // stream and the debris stream waiting for an event recorded there, the debris launch's first
-    // kernel started when the fluvial launch's round 0 ended, 3 ms late, on every step of the
-    // rocprof trace: the runtime resolved the wait with a later command of that stream.)
+    // stream and the debris stream waiting for a second event recorded there, the debris launch's
+    // first kernel started when the fluvial launch's round 0 ended, 3 ms late, on every step of the
+    // rocprof trace.  Why is not known: by itself such a wait resolves within 12 us of the kernel
+    // it stands behind, tools/microbench/event_wait.hip.)
     SOIL_HIP(hipEventRecord(f.fork, st));
     SOIL_HIP(hipStreamWaitEvent(sA, f.fork, 0));
     SOIL_HIP(hipStreamWaitEvent(sB, f.fork, 0));
