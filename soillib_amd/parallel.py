@@ -96,11 +96,17 @@ class RcclComm:
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         lib = _abi.lib()
         uid = (C.c_uint8 * 128)()
+        failed, why = 0, None
         if self.rank == 0:
-            _abi.check(lib.soil_comm_rccl_unique_id(uid))
-        t = torch.tensor(list(uid), dtype=torch.uint8)
+            try:
+                _abi.check(lib.soil_comm_rccl_unique_id(uid))
+            except Exception as e:      # noqa: BLE001  (the broadcast below must still take place)
+                failed, why = 1, e
+        t = torch.tensor(list(uid) + [failed], dtype=torch.uint8)
         dist.broadcast(t, 0)
-        uid = (C.c_uint8 * 128)(*t.tolist())
+        if int(t[-1]):
+            raise RuntimeError("rank 0 could not make the RCCL id: %s" % (why,))
+        uid = (C.c_uint8 * 128)(*t[:128].tolist())
         self._c = C.POINTER(_abi.Comm)()
         _abi.check(lib.soil_comm_rccl_create(C.byref(self._c), uid, self.rank, self.world))
 
@@ -122,11 +128,11 @@ class RcclComm:
         return {"backend": "rccl (libsoil_hip: ncclSend/ncclRecv groups)", "world_size": int(n.value),
                 "rank": int(r.value), "device": int(d.value)}
 
-    def close(self):
+    def close(self, keep_group=False):
         if self._c:
             _abi.lib().soil_comm_rccl_destroy(self._c)
             self._c = None
-        if self.dist.is_initialized():
+        if not keep_group and self.dist.is_initialized():
             self.dist.barrier()
             self.dist.destroy_process_group()
 
@@ -173,7 +179,8 @@ class CallbackComm:
         return self.impl.max_over_ranks(value)
 
     def describe(self):
-        return {"backend": type(self.impl).__name__, "world_size": self.world}
+        note = getattr(self, "note", None)
+        return {"backend": note or type(self.impl).__name__, "world_size": self.world}
 
     def close(self):
         if hasattr(self.impl, "close"):
@@ -259,7 +266,30 @@ def default_comm(device=True):
         return CallbackComm(wire.dist.get_rank(), wire.dist.get_world_size(), wire)
     if world == 1 and os.environ.get("SOIL_RCCL_WORLD1") != "1":
         return SelfComm()
-    return RcclComm()
+    # RCCL inside the library.  Should its bootstrap fail on any rank (library not found, IPC
+    # refused by the host driver, ...) every rank falls back to gloo on staged buffers — slow, and
+    # said so loudly in describe() / the bench line — rather than the job dying without a number.
+    import sys
+    import torch
+    comm, err = None, None
+    try:
+        comm = RcclComm()
+    except Exception as e:      # noqa: BLE001
+        err = e
+    dist = _init_gloo()
+    ok = torch.tensor([0 if comm is None else 1])
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if int(ok.item()) == 1:
+        return comm
+    if comm is not None:
+        comm.close(keep_group=True)
+    print("soillib_amd.parallel: RCCL bootstrap failed on %s (%s): FALLING BACK to gloo on staged "
+          "host buffers — the exchange times of this run are not RCCL's" %
+          ("this rank" if err is not None else "another rank", err), file=sys.stderr)
+    wire = GlooWire(device)
+    fallback = CallbackComm(wire.dist.get_rank(), wire.dist.get_world_size(), wire)
+    fallback.note = "gloo on staged host buffers — FALLBACK, the RCCL bootstrap failed: %s" % (err,)
+    return fallback
 
 
 # ---- the compute back-end ---------------------------------------------------------------

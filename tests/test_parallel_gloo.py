@@ -146,3 +146,26 @@ def test_multiflow_realisations_sharded_over_ranks(oracle, tmp_path, world):
         got = np.load(os.path.join(str(tmp_path), "multiflow_rank%d.npy" % rank))
         np.testing.assert_allclose(got, want, rtol=1e-13, atol=0)
     assert want.min() >= 1.0 - 1e-6
+
+
+def test_rccl_bootstrap_failure_falls_back_on_every_rank(tmp_path):
+    """default_comm(): when the library's RCCL bootstrap fails (here: no device at all) every
+    rank agrees on the gloo wire and says so in describe() — no rank is left waiting in a
+    collective the other never enters."""
+    script = tmp_path / "fallback.py"
+    script.write_text(
+        "import os, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "os.environ['SOIL_DIST_BACKEND'] = 'nccl'\n"
+        "from soillib_amd import parallel\n"
+        "c = parallel.default_comm(device=False)\n"
+        "d = c.describe()\n"
+        "assert 'FALLBACK' in d['backend'] and d['world_size'] == 2, d\n"
+        "c.barrier()\n"
+        "print('FALLBACK_OK')\n" % ROOT)
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
+    out = subprocess.run(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+         "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(script)],
+        capture_output=True, text=True, timeout=300, env=env, cwd=str(tmp_path))
+    assert out.returncode == 0 and out.stdout.count("FALLBACK_OK") == 2, out.stdout + out.stderr
