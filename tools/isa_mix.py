@@ -79,7 +79,7 @@ def main():
         asm = open(out).read()
     res = {}
     for kind, label, pat in ((0, "fluvial_rounds", r"^_ZN4soil13k_tiled_roundILi0ELi1ELi78ELi64ELi768ELb0E.*:"),
-                             (1, "debris_rounds", r"^_ZN4soil13k_tiled_roundILi1ELi1ELi68ELi64ELi512ELb0E.*:")):
+                             (1, "debris_rounds", r"^_ZN4soil13k_tiled_roundILi1ELi1ELi104ELi64ELi768ELb0E.*:")):
         loop = stepping_loop(asm, pat)
         valu = [i.split()[0] for i in loop if i.startswith("v_") and not i.startswith("v_readlane") or "dpp" in i]
         valu += [i.split()[0] for i in loop if i.startswith("v_readlane") or i.startswith("v_writelane")]
