@@ -225,10 +225,9 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-size", type=int, default=1024)
     ap.add_argument("--overlap-particles", action="store_true",
-                    help="multi-GPU slab runner: issue the fluvial and debris launches overlapped "
-                         "on two streams (soil_particles_pair_slab); on one GPU that is the default")
+                    help="(the default everywhere since round 3; kept for old command lines)")
     ap.add_argument("--sequential-particles", action="store_true",
-                    help="one GPU: the two particle launches back to back, each timed by itself")
+                    help="the two particle launches back to back, each timed by itself")
     ap.add_argument("--particle-mode", type=int, default=0,
                     help="0 auto, 1 direct (reference launch shape), 2 staged — ablation")
     return ap.parse_args()
@@ -358,14 +357,14 @@ def main():
         S = args.grid // world                   # rows per rank; the columns stay args.grid
     Wcols = args.grid if strong else S
     if args.overlap_particles:
-        os.environ["SOIL_STEP_PAIR"] = "1"       # the slab runner reads it (there overlap is opt-in)
+        os.environ["SOIL_STEP_PAIR"] = "1"
     param = script_param(soil)
     slabbed = world > 1 or os.environ.get("SOIL_BENCH_FORCE_SLAB") == "1"
     # one GPU: the two particle launches overlapped, as the library's step driver runs them
     # (soil_erode_step); --sequential-particles for the per-launch phase timings
+    # (the slab runner of a multi-GPU run does the same since round 3: a rank of an 8-GPU world
+    # 38.0 -> 35.7 ms per step in the single-GPU emulation, tools/bench_rank_of_world.py)
     serial = args.sequential_particles or os.environ.get("SOIL_STEP_PAIR") == "0"
-    if slabbed:                                   # slab runner: overlap is opt-in
-        serial = not (args.overlap_particles or os.environ.get("SOIL_STEP_PAIR") == "1")
     comm = None
     if slabbed:
         from soillib_amd import parallel

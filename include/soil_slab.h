@@ -117,7 +117,8 @@ typedef struct soil_slab_config {
   int32_t init;          /* 0: planes stay zero (the caller fills them through soil_slab_plane) */
   int32_t trim;          /* halos trimmed to the measured reach: 1 / 0; -1: on for world > 1 unless
                             SOIL_HALO_FULL=1 */
-  int32_t pair;          /* particle launches overlapped: 1 / 0; -1: SOIL_STEP_PAIR=1 */
+  int32_t pair;          /* particle launches overlapped: 1 / 0; -1: on unless SOIL_STEP_PAIR=0 (as
+                            soil_erode_step) */
   int32_t halo_need;     /* > 0: ghost rows to refresh whatever the history says (tests: a
                             prediction that is too small on purpose); 0: predicted; also SOIL_HALO_NEED */
 } soil_slab_config;

@@ -780,7 +780,7 @@ int soil_slab_create(soil_slab** out, const soil_slab_config* cfg, const soil_pa
   };
   s->trim = cfg->trim >= 0 ? cfg->trim != 0 : (s->world > 1 && !env_is("SOIL_HALO_FULL", "1"));
   if (s->world == 1 || !ops->ghost_extent) s->trim = false;
-  s->pair = cfg->pair >= 0 ? cfg->pair != 0 : env_is("SOIL_STEP_PAIR", "1");
+  s->pair = cfg->pair >= 0 ? cfg->pair != 0 : !env_is("SOIL_STEP_PAIR", "0");  // on by default, as in soil_erode_step
   s->halo_need = cfg->halo_need;
   if (s->halo_need <= 0)
     if (const char* e = std::getenv("SOIL_HALO_NEED")) s->halo_need = std::atoi(e);

@@ -132,7 +132,7 @@ class ErosionModel:
             self.step_index += 1
             return
         self.seed_step()                       # a slab of a larger grid (soillib_amd.parallel)
-        if os.environ.get("SOIL_STEP_PAIR") == "1":
+        if os.environ.get("SOIL_STEP_PAIR") != "0":
             self.particles_pair()
         else:
             self.particles_fluvial()
