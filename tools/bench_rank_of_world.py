@@ -44,6 +44,10 @@ def main():
     ap.add_argument("--size", type=int, default=8192)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--strong", type=int, default=0,
+                    help="strong scaling: ONE grid of this size cut into `world` slabs (BASELINE config 5: "
+                         "16384); the figure to compare with is the same grid on one GPU "
+                         "(python bench.py --size 16384)")
     args = ap.parse_args()
     from soillib_amd import soil
     from soillib_amd.parallel import CallbackComm, SlabRunner
@@ -51,9 +55,13 @@ def main():
     base = None
     for world in [int(w) for w in args.worlds.split(",")]:
         param = script_param(soil.param_t())
-        r = SlabRunner(rows_per_rank=args.size, W=args.size, param=param, particles_div=8, seed=0,
+        if args.strong:
+            S, Wc, cell = args.strong // world, args.strong, 20.0 / args.strong
+        else:
+            S, Wc, cell = args.size, args.size, 20.0 / args.size
+        r = SlabRunner(rows_per_rank=S, W=Wc, param=param, particles_div=8, seed=0,
                        comm=CallbackComm(world // 2, world, NullWire()),
-                       scale=[20.0 / args.size, 20.0 / args.size, 4.0], noise_rows=args.size)
+                       scale=[cell, cell, 4.0], noise_rows=Wc)
         for _ in range(args.warmup):
             r.step()
         r.sync()
@@ -66,8 +74,9 @@ def main():
         steps = soil.particle_steps(reset=True) / args.steps
         base = base or ms
         print("world %d rank %d: rows %d (+%d ghost), N %d: %.2f ms/step, %.2f G particle steps, "
-              "compute-side efficiency %.3f" % (world, r.rank, args.size, r.rows - args.size, r.N,
-                                                ms, steps / 1e9, base / ms), flush=True)
+              "compute-side efficiency %.3f" % (world, r.rank, S, r.rows - S, r.N,
+                                                ms, steps / 1e9,
+                                                base / ms / (world if args.strong else 1)), flush=True)
         r.close()
         del r
         from soillib_amd import silt
