@@ -87,11 +87,15 @@ struct soil_slab {
   float* stage[soil::kPlanes][2] = {};  // [plane][0: from the neighbour above, 1: from below]
   soil_rng *rng = nullptr, *rng_debris = nullptr;
   float* remote0 = nullptr;
-  float* ints = nullptr;  // all_ints scratch (world * 2 floats)
+  float* ints = nullptr;  // all_ints scratch (world * 4 floats)
   int up = -1, down = -1;
   int64_t gu = 0, gd = 0;  // my ghost rows above / below
-  std::vector<std::pair<int64_t, int64_t>> fresh_all;  // per rank: ghost rows (above, below) with fresh fields
-  std::vector<int> reach_hist;
+  // per rank: ghost rows (above, below) with fresh fields — those every walker reads (layers) and
+  // the fluvial walkers' (velocity, waterHeight) in `fresh_all`, the debris walkers' own field
+  // (debrisVelocity) in `fresh_debris`: debris walks end within a few cells at the example's
+  // parameters, so that plane's halo is a few rows where the others' are hundreds
+  std::vector<std::pair<int64_t, int64_t>> fresh_all, fresh_debris;
+  std::vector<int> reach_hist, reach_hist_debris;  // max over ranks and both kinds; debris alone
   int64_t fallbacks = 0, rows_flux = 0, rows_field = 0, rows_full = 0;
 
   // ---- helpers --------------------------------------------------------------------------------
@@ -181,13 +185,17 @@ struct soil_slab {
   // Refresh the ghost rows of the fields the next launches read.  need_*: rows I want from each
   // neighbour, give_*: rows I owe them (nearest the boundary first).  `layers_plane`: which of the
   // two layer buffers is the current one at this point of the step.
-  int field_exchange(int layers_plane, const Counts* counts, int lane) {
-    // Counts reused as (need_up, need_down, give_up, give_down)
-    Counts c = counts ? *counts : Counts{gu, gd, peer_ghost(up), peer_ghost(down)};
-    const int64_t need_up = c.send_up, need_down = c.send_down, give_up = c.recv_up, give_down = c.recv_down;
+  int field_exchange(int layers_plane, const Counts* counts, int lane, const Counts* counts_debris = nullptr) {
+    // Counts reused as (need_up, need_down, give_up, give_down); `counts_debris`: the same for
+    // debrisVelocity alone (NULL: as the others)
+    const Counts all{gu, gd, peer_ghost(up), peer_ghost(down)};
+    const Counts ca = counts ? *counts : all;
+    const Counts cdv = counts_debris ? *counts_debris : ca;
     std::vector<soil_xfer> sends, recvs;
     for (int i = 0; i < 4; ++i) {
       const int p = soil::kField[i] == soil::kLayers ? layers_plane : soil::kField[i];
+      const Counts& c = soil::kField[i] == soil::kDebrisVelocity ? cdv : ca;
+      const int64_t need_up = c.send_up, need_down = c.send_down, give_up = c.recv_up, give_down = c.recv_down;
       const int64_t rb = row_floats(p) * 4;
       if (up >= 0) {
         if (give_up) sends.push_back({rowp(p, lay.r0), give_up * rb, up});
@@ -197,8 +205,8 @@ struct soil_slab {
         if (give_down) sends.push_back({rowp(p, lay.r1 - give_down), give_down * rb, down});
         if (need_down) recvs.push_back({rowp(p, lay.r1), need_down * rb, down});
       }
+      rows_field += give_up + give_down;
     }
-    rows_field += (give_up + give_down) * 4;
     rows_full += (peer_ghost(up) + peer_ghost(down)) * 4;
     return exchange(sends, recvs, lane);
   }
@@ -214,10 +222,11 @@ struct soil_slab {
   }
   // Did a launch, on any rank, get within a row of ghost rows that were not refreshed?  (The cell
   // record of ghost row d is made of rows d - 1 .. d + 1.)  The same answer on every rank.
-  bool too_deep(const std::vector<int>& r) const {
+  bool too_deep(const std::vector<int>& r, bool debris = false) const {
+    const auto& fresh = debris ? fresh_debris : fresh_all;
     for (int k = 0; k < world; ++k) {
       const soil::Layout l = soil::slab_layout(k, world, S, G);
-      const int64_t f_up = fresh_all[static_cast<size_t>(k)].first, f_down = fresh_all[static_cast<size_t>(k)].second;
+      const int64_t f_up = fresh[static_cast<size_t>(k)].first, f_down = fresh[static_cast<size_t>(k)].second;
       const int64_t u = r[static_cast<size_t>(2 * k)], d = r[static_cast<size_t>(2 * k + 1)];
       if ((u >= f_up && f_up < l.r0) || (d >= f_down && f_down < l.rows - l.r1)) return true;
     }
@@ -229,6 +238,7 @@ struct soil_slab {
       const soil::Layout l = soil::slab_layout(k, world, S, G);
       fresh_all.emplace_back(l.r0, l.rows - l.r1);
     }
+    fresh_debris = fresh_all;
   }
   // The prediction was too small: fetch the whole ghost zones of the fields as they stand (the cell
   // phase of this step has not touched them yet).
@@ -241,12 +251,12 @@ struct soil_slab {
   // Ghost rows to refresh for the next step: as deep as the walks of the last steps got anywhere, a
   // tenth more and ten rows on top (the reach moves by a row or two from step to step); everything
   // while there is no history.
-  void predict_need(int64_t& nu, int64_t& nd) const {
-    if (reach_hist.empty()) {
+  void predict_need(const std::vector<int>& hist, int64_t& nu, int64_t& nd) const {
+    if (hist.empty()) {
       nu = gu, nd = gd;
       return;
     }
-    int64_t want = static_cast<int64_t>(1.1 * *std::max_element(reach_hist.begin(), reach_hist.end())) + 10;
+    int64_t want = static_cast<int64_t>(1.1 * *std::max_element(hist.begin(), hist.end())) + 10;
     if (halo_need > 0) want = halo_need;
     nu = std::min(gu, want), nd = std::min(gd, want);
   }
@@ -255,11 +265,13 @@ struct soil_slab {
                   up >= 0 ? r[static_cast<size_t>(2 * up + 1)] : 0, down >= 0 ? r[static_cast<size_t>(2 * down)] : 0};
   }
   void note_reach(const std::vector<int>& a, const std::vector<int>& b) {
-    int m = 0;
+    int m = 0, md = 0;
     for (int v : a) m = std::max(m, v);
-    for (int v : b) m = std::max(m, v);
-    reach_hist.push_back(m);
+    for (int v : b) md = std::max(md, v);
+    reach_hist.push_back(std::max(m, md));
     if (reach_hist.size() > 4) reach_hist.erase(reach_hist.begin());
+    reach_hist_debris.push_back(md);
+    if (reach_hist_debris.size() > 4) reach_hist_debris.erase(reach_hist_debris.begin());
   }
   int zero_planes(const soil::Plane* planes_, int n) {
     for (int i = 0; i < n; ++i) SLAB_TRY(ops->fill_f32(ops->ctx, P[planes_[i]], 0.0f, lay.rows * row_floats(planes_[i]), 0));
@@ -296,7 +308,8 @@ struct soil_slab {
       if (trim) {
         SLAB_TRY(reach(soil::kFluxFluvial, 3, rf));
         SLAB_TRY(reach(soil::kFluxDebris, 2, rd));
-        if (too_deep(rf) || too_deep(rd)) {  // rare: both launches again, on complete fields
+        // a fluvial walk reads layers, velocity, waterHeight; a debris walk layers and debrisVelocity
+        if (too_deep(rf) || too_deep(rd) || too_deep(rd, true)) {  // rare: both launches again, on complete fields
           SLAB_TRY(refresh_all());
           SLAB_TRY(zero_planes(soil::kFluxFluvial, 3));
           SLAB_TRY(zero_planes(soil::kFluxDebris, 2));
@@ -335,7 +348,7 @@ struct soil_slab {
       SLAB_TRY(ops->particles_debris(ops->ctx, &pl, rng, N, remote0, &dom, scale, &param));
       if (trim) {
         SLAB_TRY(reach(soil::kFluxDebris, 2, rd));
-        if (too_deep(rd)) {
+        if (too_deep(rd) || too_deep(rd, true)) {
           SLAB_TRY(refresh_all());
           SLAB_TRY(zero_planes(soil::kFluxDebris, 2));
           // the NaN walkers' debris deposits are entries 4..6 of remote0; the launch draws where
@@ -386,22 +399,27 @@ struct soil_slab {
       }
       // 3. the field halo travels while the interior rows are computed (they are G rows away from
       //    anything the exchange reads or writes)
-      Counts fc{};
-      const Counts* fcp = nullptr;
+      Counts fc{}, fd{};
+      const Counts *fcp = nullptr, *fdp = nullptr;
       if (trim) {  // as deep as next step's walks are expected to get; everybody says what it wants
-        int64_t nu, nd;
-        predict_need(nu, nd);
-        const int mine[2] = {static_cast<int>(nu), static_cast<int>(nd)};
+        int64_t nu, nd, du, dd;
+        predict_need(reach_hist, nu, nd);
+        predict_need(reach_hist_debris, du, dd);
+        const int mine[4] = {static_cast<int>(nu), static_cast<int>(nd), static_cast<int>(du), static_cast<int>(dd)};
         std::vector<int> wants;
-        SLAB_TRY(all_ints(mine, 2, wants));
-        fc = Counts{nu, nd, up >= 0 ? wants[static_cast<size_t>(2 * up + 1)] : 0,
-                    down >= 0 ? wants[static_cast<size_t>(2 * down)] : 0};
-        fcp = &fc;
-        fresh_all.clear();
-        for (int k = 0; k < world; ++k) fresh_all.emplace_back(wants[static_cast<size_t>(2 * k)], wants[static_cast<size_t>(2 * k + 1)]);
+        SLAB_TRY(all_ints(mine, 4, wants));
+        auto of = [&](int k, int i) { return static_cast<int64_t>(wants[static_cast<size_t>(4 * k + i)]); };
+        fc = Counts{nu, nd, up >= 0 ? of(up, 1) : 0, down >= 0 ? of(down, 0) : 0};
+        fd = Counts{du, dd, up >= 0 ? of(up, 3) : 0, down >= 0 ? of(down, 2) : 0};
+        fcp = &fc, fdp = &fd;
+        fresh_all.clear(), fresh_debris.clear();
+        for (int k = 0; k < world; ++k) {
+          fresh_all.emplace_back(of(k, 0), of(k, 1));
+          fresh_debris.emplace_back(of(k, 2), of(k, 3));
+        }
       }
       SLAB_TRY(ops->fork(ops->ctx));
-      SLAB_TRY(field_exchange(soil::kLayersNext, fcp, 1));
+      SLAB_TRY(field_exchange(soil::kLayersNext, fcp, 1, fdp));
       if (i1 > i0) {
         const soil_domain b = domain(i0, i1);
         SLAB_TRY(ops->cells(ops->ctx, &pl, &b, scale, &param));
@@ -813,7 +831,7 @@ int soil_slab_create(soil_slab** out, const soil_slab_config* cfg, const soil_pa
   }
   if (int rc = ops->alloc(ops->ctx, &q, 8 * 4); rc != SOIL_OK) return bail(rc);
   s->remote0 = static_cast<float*>(q);
-  if (int rc = ops->alloc(ops->ctx, &q, static_cast<int64_t>(s->world) * 2 * 4); rc != SOIL_OK) return bail(rc);
+  if (int rc = ops->alloc(ops->ctx, &q, static_cast<int64_t>(s->world) * 4 * 4); rc != SOIL_OK) return bail(rc);
   s->ints = static_cast<float*>(q);
   if (cfg->init) {
     if (int rc = ops->alloc(ops->ctx, &q, s->lay.rows * s->W * 4); rc != SOIL_OK) return bail(rc);
