@@ -145,7 +145,10 @@ int soil_slab_create(soil_slab** out, const soil_slab_config* cfg, const soil_pa
                      const soil_comm* comm, const soil_slab_ops* ops);
 int soil_slab_step(soil_slab* slab, soil_slab_mark_fn mark, void* mark_ctx);
 /* A plane of the slab by the names of soil_erosion_planes ("layers" is the current one): local
- * rows incl. ghost rows, `channels` floats per cell. */
+ * rows incl. ghost rows, `channels` floats per cell.  The five flux planes are scratch of a step:
+ * with the HIP back-end they are not re-zeroed behind the cell phase (the next step's launches
+ * overwrite them; SOIL_SLAB_LAZY=0 restores the zeros), so between two steps they hold the flux
+ * the last one consumed. */
 int soil_slab_plane(soil_slab* slab, const char* name, float** data, int64_t* rows,
                     int64_t* channels);
 int soil_slab_get_info(const soil_slab* slab, soil_slab_info* info);

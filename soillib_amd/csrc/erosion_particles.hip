@@ -464,9 +464,17 @@ int particles_debris_streams(const soil_erosion_planes& P, Streams rng, int64_t 
                                     &s.x, &p, st);
 }
 int particles_pair_streams(const soil_erosion_planes& P, Streams rf, Streams rd, int64_t N, float* remote0,
-                           const Dom& d, Scale3 s, const Param& p, hipStream_t st) {
+                           const Dom& d, Scale3 s, const Param& p, hipStream_t st, bool overwrite) {
+  if (N > 0 && use_tiled(N, d)) return launch_pair_tiled(P, rf, rd, N, remote0, d, s, p, st, overwrite);
+  if (overwrite) {  // a launch that cannot store its first round clears the planes it adds to
+    const size_t b = sizeof(float) * static_cast<size_t>(d.rows) * static_cast<size_t>(d.W);
+    SOIL_HIP(hipMemsetAsync(P.waterFlux, 0, b, st));
+    SOIL_HIP(hipMemsetAsync(P.massFlux, 0, b, st));
+    SOIL_HIP(hipMemsetAsync(P.velocityFlux, 0, 2 * b, st));
+    SOIL_HIP(hipMemsetAsync(P.debrisFlux, 0, b, st));
+    SOIL_HIP(hipMemsetAsync(P.debrisVelocityFlux, 0, 2 * b, st));
+  }
   if (N <= 0) return SOIL_OK;
-  if (use_tiled(N, d)) return launch_pair_tiled(P, rf, rd, N, remote0, d, s, p, st, false);
   if (int rc = materialise(rf, N, st); rc != SOIL_OK) return rc;
   if (int rc = materialise(rd, N, st); rc != SOIL_OK) return rc;
   return soil_particles_pair_slab(&P, rf.rng, rd.rng, N, remote0, reinterpret_cast<const soil_domain*>(&d), &s.x,

@@ -682,6 +682,9 @@ struct QueueScan {
   uint32_t seq;
   TiledCtl* ctl;
   ScanRule rule;
+  // a round that stores its tiles (SOIL_FLUX_OVERWRITE) wants a work-group for an EMPTY tile too —
+  // it stores the zeros (a slab's ghost rows hold whole tiles nobody spawns on)
+  uint32_t include_empty;
 };
 constexpr int scan_lds_words(int nt) { return 16 * nt + 256 + 256 + 8 + 16; }
 
@@ -822,12 +825,13 @@ __device__ void queue_scan_dev(const QueueScan& q, uint32_t* lds) {
     const uint32_t t = c.x + c.y + c.z + c.w;
     const uint32_t pos = atomicAdd(&base[bucket(t)], 1u);
     tile_order[pos] = static_cast<uint32_t>(i);
-    if (!cut && t > 0) block_list[pos] = make_uint4(static_cast<uint32_t>(i), start[i * kNB], t, 0u);
+    if (!cut && (t > 0 || q.include_empty != 0u))  // (empty tiles are the last in the order)
+      block_list[pos] = make_uint4(static_cast<uint32_t>(i), start[i * kNB], t, 0u);
   }
   if (!cut) {  // the common case on large grids: one work-group per non-empty tile
     if (tid == 0) {
-      host->whole = empty == 0 ? 1u : 0u;
-      publish(static_cast<uint32_t>(tiles) - empty);
+      host->whole = (empty == 0 || q.include_empty != 0u) ? 1u : 0u;
+      publish(static_cast<uint32_t>(tiles) - (q.include_empty != 0u ? 0u : empty));
     }
     return;
   }
@@ -1191,7 +1195,7 @@ __global__ void __launch_bounds__(NT, round_waves_per_simd(KIND, TR, TC, NT, ALB
   float* const s_c2 = s_c1 + (ALB ? kCells : 0);
   __shared__ uint32_t s_next, s_out, s_steps, s_last;
   do {  // the round's work proper (a chunk of a cut queue may be empty)
-  if (cnt == 0) break;
+  if (cnt == 0 && !store_all) break;  // (storing: an empty tile's zeros go out like any other's)
   if (tid == 0) {
     s_next = kBlock;  // the first kBlock queue entries go to the lanes directly, see below
     s_out = 0;
@@ -1927,6 +1931,7 @@ struct TiledRun {
     q.rule.tail = static_cast<uint32_t>(tail);
     q.rule.max_round = max_round > 0xffffffffull ? 0xffffffffu : static_cast<uint32_t>(max_round);
     q.rule.ticks_per_step_max = static_cast<float>(ticks_per_second / finish_rate);
+    q.include_empty = (r == 0 && overwrite && !fluxA && deposit == 0) ? 1u : 0u;
     return q;
   }
   // the scan of round 0 (the queues the spawn filled) is a kernel of its own; every later one runs at

@@ -98,6 +98,6 @@ int particles_fluvial_streams(const soil_erosion_planes& P, Streams rng, int64_t
 int particles_debris_streams(const soil_erosion_planes& P, Streams rng, int64_t N, float* remote0,
                              const Dom& d, Scale3 s, const Param& p, hipStream_t st);
 int particles_pair_streams(const soil_erosion_planes& P, Streams rng_fluvial, Streams rng_debris, int64_t N,
-                           float* remote0, const Dom& d, Scale3 s, const Param& p, hipStream_t st);
+                           float* remote0, const Dom& d, Scale3 s, const Param& p, hipStream_t st, bool overwrite = false);
 
 }  // namespace soil

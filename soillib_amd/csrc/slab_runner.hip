@@ -465,6 +465,27 @@ struct HipOps {
     const auto it = noted.find(rng);
     if (it != noted.end()) it->second.offset += 2;
   }
+  // Flux planes left as they are by the cell phase (SOIL_CELLS_KEEP_FLUX: 84 instead of 112 B per
+  // cell) whenever the launches that follow can overwrite them — the overlapped pair launch, whose
+  // first rounds store whole tiles, empty ones included (SOIL_FLUX_OVERWRITE), as soil_erode_step
+  // does on one GPU.  `flux_stale`: the planes `stale_planes` describes hold a finished step's
+  // flux; a launch that only adds clears them first.  Someone who reads a flux plane through
+  // soil_slab_plane between two steps sees the consumed flux of the last one (ghost rows: zeros).
+  // SOIL_SLAB_LAZY=0 switches it off.
+  bool lazy = true, last_pair = false, flux_stale = false;
+  soil_erosion_planes stale_planes{};
+  int64_t stale_cells = 0;
+  int clear_stale() {
+    if (!flux_stale) return SOIL_OK;
+    const size_t b = sizeof(float) * static_cast<size_t>(stale_cells);
+    SOIL_HIP(hipMemsetAsync(stale_planes.waterFlux, 0, b, main));
+    SOIL_HIP(hipMemsetAsync(stale_planes.massFlux, 0, b, main));
+    SOIL_HIP(hipMemsetAsync(stale_planes.velocityFlux, 0, 2 * b, main));
+    SOIL_HIP(hipMemsetAsync(stale_planes.debrisFlux, 0, b, main));
+    SOIL_HIP(hipMemsetAsync(stale_planes.debrisVelocityFlux, 0, 2 * b, main));
+    flux_stale = false;
+    return SOIL_OK;
+  }
 };
 
 #define HIP_OPS(c) HipOps& o = *static_cast<HipOps*>(c)
@@ -502,6 +523,8 @@ int hip_fluvial(void* c, const soil_erosion_planes* p, soil_rng* rng, int64_t N,
   HIP_OPS(c);
   const Dom d = to_dom(dom);
   if (int rc = check_domain(d); rc != SOIL_OK) return rc;
+  if (int rc = o.clear_stale(); rc != SOIL_OK) return rc;
+  o.last_pair = false;
   const int rc = particles_fluvial_streams(*p, o.streams(rng), N, remote0, d, Scale3{scale[0], scale[1], scale[2]},
                                            *param, o.main);
   o.drew(rng);
@@ -512,6 +535,8 @@ int hip_debris(void* c, const soil_erosion_planes* p, soil_rng* rng, int64_t N, 
   HIP_OPS(c);
   const Dom d = to_dom(dom);
   if (int rc = check_domain(d); rc != SOIL_OK) return rc;
+  if (int rc = o.clear_stale(); rc != SOIL_OK) return rc;
+  o.last_pair = false;
   const int rc = particles_debris_streams(*p, o.streams(rng), N, remote0, d, Scale3{scale[0], scale[1], scale[2]},
                                           *param, o.main);
   o.drew(rng);
@@ -523,7 +548,9 @@ int hip_pair(void* c, const soil_erosion_planes* p, soil_rng* rf, soil_rng* rd, 
   const Dom d = to_dom(dom);
   if (int rc = check_domain(d); rc != SOIL_OK) return rc;
   const int rc = particles_pair_streams(*p, o.streams(rf), o.streams(rd), N, remote0, d,
-                                        Scale3{scale[0], scale[1], scale[2]}, *param, o.main);
+                                        Scale3{scale[0], scale[1], scale[2]}, *param, o.main, o.flux_stale);
+  o.flux_stale = false;
+  o.last_pair = true;
   o.drew(rf);
   o.drew(rd);
   return rc;
@@ -532,7 +559,13 @@ int hip_cells(void* c, const soil_erosion_planes* p, const soil_domain* dom, con
               const soil_param* param) {
   HIP_OPS(c);
   if (dom->r1 <= dom->r0) return SOIL_OK;
-  return soil_erode_cells_fused(p, dom, scale, param, o.main);
+  const bool keep = o.lazy && o.last_pair;
+  if (keep) {
+    o.flux_stale = true;
+    o.stale_planes = *p;
+    o.stale_cells = dom->rows * dom->W;
+  }
+  return soil_erode_cells_fused_ex(p, dom, scale, param, keep ? SOIL_CELLS_KEEP_FLUX : 0, o.main);
 }
 int hip_extent(void* c, const float* plane, int64_t rows, int64_t row_floats, int64_t r0, int64_t r1,
                int32_t depth[2]) {
@@ -723,6 +756,7 @@ int soil_slab_ops_hip_create(soil_slab_ops** out) {
   SOIL_REQUIRE(out, "slab_ops_hip_create: null argument");
   HipOps* o = new HipOps;
   if (const char* e = std::getenv("SOIL_SLAB_UNIFORM")) o->uniform = e[0] != '0';
+  if (const char* e = std::getenv("SOIL_SLAB_LAZY")) o->lazy = e[0] != '0';
   SOIL_HIP(hipGetDevice(&o->device));
   SOIL_HIP(hipStreamCreateWithFlags(&o->main, hipStreamNonBlocking));
   SOIL_HIP(hipStreamCreateWithFlags(&o->comm, hipStreamNonBlocking));
