@@ -447,31 +447,6 @@ __global__ void __launch_bounds__(BLOCK)
   }
 }
 
-// Experiment (SOIL_CELLS_WARM=<stride in KiB>): one word of every `stride` bytes of every plane's
-// row range is read by every XCD right before the fused kernel, so that the kernel does not start
-// on cold address translations after the particle phase has walked its workspaces.
-struct TouchList {
-  const char* base[16];
-  int64_t bytes[16];
-  int n;
-};
-__global__ void __launch_bounds__(256)
-    k_touch_pages(TouchList t, int64_t stride, uint32_t* __restrict__ sink) {
-  const int64_t slot = static_cast<int64_t>(blockIdx.x / 8) * 256 + threadIdx.x;  // the same on all 8 XCDs
-  uint32_t acc = 0;
-  int64_t at = slot;
-  for (int p = 0; p < t.n; ++p) {
-    const int64_t pages = (t.bytes[p] + stride - 1) / stride;
-    if (at < pages) {
-      acc += *reinterpret_cast<const uint32_t*>(t.base[p] + at * stride);
-      at = -1;
-      break;
-    }
-    at -= pages;
-  }
-  if (acc == 0x7fc12345u && at == -2) *sink = acc;  // never: keeps the load
-}
-
 // scalar path for W % 4 != 0 (ragged widths): one thread per cell
 __global__ void __launch_bounds__(kBlock)
     k_erode_cells_fused_scalar(Planes P, Dom d, Scale3 s, Param p, bool rezero) {
@@ -702,26 +677,6 @@ int soil_erode_cells_fused_ex(const soil_erosion_planes* pl, const soil_domain* 
     static const bool nt = [] { const char* e = std::getenv("SOIL_CELLS_NT"); return e && e[0] == '1'; }();  // measured slower than plain accesses; kept for A/B
     const int variant = [] { const char* e = std::getenv("SOIL_CELLS_VARIANT"); return e ? std::atoi(e) : 0; }();  // read per call: bench.py alternates variants in one process
     const bool remap = nblk % 8 == 0 && nblk >= 64 && variant != 2;
-    if (const char* e = std::getenv("SOIL_CELLS_WARM"); e && std::atoi(e) > 0) {
-      const int64_t stride = static_cast<int64_t>(std::atoi(e)) * 1024;
-      TouchList t{};
-      const int64_t o1 = d.r0 * d.W * 4, b1 = (d.r1 - d.r0) * d.W * 4;
-      auto add = [&](const void* q, int ch) {
-        if (!q || t.n >= 16) return;
-        t.base[t.n] = static_cast<const char*>(q) + o1 * ch;
-        t.bytes[t.n] = b1 * ch;
-        ++t.n;
-      };
-      add(pl->layers, 2), add(pl->layers_next, 2), add(pl->height, 1), add(pl->uplift, 1), add(pl->rainfall, 1);
-      add(pl->waterHeight, 1), add(pl->waterFlux, 1), add(pl->mass, 1), add(pl->massFlux, 1);
-      add(pl->velocity, 2), add(pl->velocityFlux, 2), add(pl->debris, 1), add(pl->debrisFlux, 1);
-      add(pl->debrisVelocity, 2), add(pl->debrisVelocityFlux, 2);
-      int64_t pages = 0;
-      for (int i = 0; i < t.n; ++i) pages += (t.bytes[i] + stride - 1) / stride;
-      void* sink = nullptr;
-      if (int rc2 = workspace_get(8, 256, &sink); rc2 != SOIL_OK) return rc2;
-      k_touch_pages<<<static_cast<unsigned>(8 * ((pages + 255) / 256)), 256, 0, st>>>(t, stride, static_cast<uint32_t*>(sink));
-    }
     const bool keep = (flags & SOIL_CELLS_KEEP_FLUX) != 0;
     if (keep && remap)
       k_erode_cells_fused<true, false, kBlock, false, false><<<nblk, kBlock, 0, st>>>(P, d, s3(scale), *param, groups_per_row, total);
