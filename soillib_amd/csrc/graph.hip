@@ -151,33 +151,91 @@ __global__ void __launch_bounds__(kGBlock)
 // divisions that were most of this kernel's instructions — come from the index difference when the
 // receiver is one of the eight neighbours (every graph steepest / direction / random_weighted
 // make); any other index takes the divisions.
+// 32-bit index arithmetic throughout (the flow graph holds int32 cell indices, so H * W < 2^31):
+// with int64 rows and columns the kernel was ~150 instructions per cell, most of them the two
+// halves of 64-bit adds, multiplies and conversions — instruction-bound at 3.5 TB/s.
 __global__ void __launch_bounds__(kGBlock)
     k_slope(float* __restrict__ slope, const float* __restrict__ tensor,
-            const int32_t* __restrict__ flow, int64_t H, int64_t W, Scale2 s) {
-  const int64_t y = static_cast<int64_t>(blockIdx.x) * kGBlock + threadIdx.x;
+            const int32_t* __restrict__ flow, int32_t H, int32_t W, Scale2 s) {
+  const int32_t y = static_cast<int32_t>(blockIdx.x) * kGBlock + static_cast<int32_t>(threadIdx.x);
   if (y >= W) return;
-  SOIL_ROW_LOOP(x, H) {
-    const int64_t n = x * W + y;
-    const int64_t next = flow[n];  // :282
-    if (next < 0 || next == n) {   // :283-286
-      slope[n] = 0.0f;
-      continue;
+  const float iy = static_cast<float>(y);
+  for (int32_t band = static_cast<int32_t>(blockIdx.y); band * kRowBand < H; band += static_cast<int32_t>(gridDim.y)) {
+    const int32_t x_end = (band * kRowBand + kRowBand < H) ? band * kRowBand + kRowBand : H;
+    for (int32_t x = band * kRowBand; x < x_end; ++x) {
+      const int32_t n = x * W + y;
+      const int32_t next = flow[n];  // :282
+      if (next < 0 || next == n) {   // :283-286
+        slope[n] = 0.0f;
+        continue;
+      }
+      // row and column of the receiver relative to the cell: d = rd * W + cd with rd, cd in -1..1
+      const int32_t d = next - n;
+      const int32_t rd = d > 1 ? 1 : (d < -1 ? -1 : 0);
+      const int32_t cd = d - rd * W;
+      int32_t qx = x + rd, qy = y + cd;
+      if (cd < -1 || cd > 1 || qy < 0 || qy >= W) {  // not a neighbour (or W < 3): the general case
+        qx = next / W;
+        qy = next % W;
+      }
+      const float ix = static_cast<float>(x);                                // :288
+      const float nx = static_cast<float>(qx), ny = static_cast<float>(qy);  // :289
+      const float ival = tensor[n];                                          // :291
+      const float nval = tensor[next];                                       // :292
+      const float dx = s.x * (nx - ix), dy = s.y * (ny - iy);
+      slope[n] = (nval - ival) / sqrtf(dx * dx + dy * dy);  // :293
     }
-    // row and column of the receiver relative to the cell: d = rd * W + cd with rd, cd in -1..1
-    const int64_t d = next - n;
-    const int64_t rd = d > 1 ? 1 : (d < -1 ? -1 : 0);
-    const int64_t cd = d - rd * W;
-    int64_t qx = x + rd, qy = y + cd;
-    if (cd < -1 || cd > 1 || qy < 0 || qy >= W) {  // not a neighbour (or W < 3): the general case
-      qx = next / W;
-      qy = next % W;
+  }
+}
+
+// __slope with four cells per thread (window.hpp): the receiver of a cell is one of its eight
+// neighbours in every graph this library makes, and then its value is already in the thread's
+// three-row window — no gather; any other index takes the scalar kernel's general case.  16-byte
+// loads of the flow graph and the tensor, 16-byte stores.
+__global__ void __launch_bounds__(kWinBlock)
+    k_slope4(float* __restrict__ slope, const float* __restrict__ tensor,
+             const int32_t* __restrict__ flow, int64_t H, int64_t W, Scale2 s) {
+  const WinThread t = win_thread(W);
+  const int32_t iW = static_cast<int32_t>(W), iH = static_cast<int32_t>(H);
+  (void)iH;
+  RowWalk w;
+  SOIL_WIN_ROWS(x, w, tensor, H, W, t.y0) {
+    const int32_t n0 = static_cast<int32_t>(x * W + t.y0);
+    const int4 f = *reinterpret_cast<const int4*>(flow + n0);  // :282
+    const int32_t fi[4] = {f.x, f.y, f.z, f.w};
+    float4 o;
+    float* of = reinterpret_cast<float*>(&o);
+    const float ix = static_cast<float>(static_cast<int32_t>(x));  // :288
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int32_t n = n0 + c, next = fi[c], y = static_cast<int32_t>(t.y0) + c;
+      const float ival = w.mid.v[c + 1];  // :291
+      float res = 0.0f;                   // :283-286
+      if (!(next < 0 || next == n)) {
+        const int32_t d = next - n;
+        const int32_t rd = d > 1 ? 1 : (d < -1 ? -1 : 0);
+        const int32_t cd = d - rd * iW;
+        int32_t qx = static_cast<int32_t>(x) + rd, qy = y + cd;
+        float nval;
+        if (cd < -1 || cd > 1 || qy < 0 || qy >= iW) {  // not a neighbour (or W < 3): the general case
+          qx = next / iW;
+          qy = next % iW;
+          nval = tensor[next];  // :292
+        } else {                // column c + 1 + cd of row rd of the window
+          // (values picked one by one: a row picked as a whole lives in scratch memory)
+          const float u = cd < 0 ? w.up.v[c] : (cd > 0 ? w.up.v[c + 2] : w.up.v[c + 1]);
+          const float m = cd < 0 ? w.mid.v[c] : (cd > 0 ? w.mid.v[c + 2] : w.mid.v[c + 1]);
+          const float dn = cd < 0 ? w.dn.v[c] : (cd > 0 ? w.dn.v[c + 2] : w.dn.v[c + 1]);
+          nval = rd < 0 ? u : (rd > 0 ? dn : m);
+        }
+        const float iy = static_cast<float>(y);
+        const float nx = static_cast<float>(qx), ny = static_cast<float>(qy);  // :289
+        const float dx = s.x * (nx - ix), dy = s.y * (ny - iy);
+        res = (nval - ival) / sqrtf(dx * dx + dy * dy);  // :293
+      }
+      of[c] = res;
     }
-    const float ix = static_cast<float>(x), iy = static_cast<float>(y);    // :288
-    const float nx = static_cast<float>(qx), ny = static_cast<float>(qy);  // :289
-    const float ival = tensor[n];                                          // :291
-    const float nval = tensor[next];                                       // :292
-    const float dx = s.x * (nx - ix), dy = s.y * (ny - iy);
-    slope[n] = (nval - ival) / sqrtf(dx * dx + dy * dy);  // :293
+    if (t.live) *reinterpret_cast<float4*>(slope + x * W + t.y0) = o;
   }
 }
 
@@ -427,9 +485,14 @@ int soil_slope(float* slope, const float* tensor, const int32_t* flow, int64_t H
                const float scale[2], void* stream) {
   SOIL_DEVICE();
   SOIL_REQUIRE(slope && tensor && flow && scale, "slope: null argument");
-  SOIL_REQUIRE(H > 0 && W > 0, "slope: empty grid");
-  k_slope<<<grid_rows(H, W, kGBlock), kGBlock, 0, as_stream(stream)>>>(
-      slope, tensor, flow, H, W, Scale2{scale[0], scale[1]});
+  SOIL_REQUIRE(H > 0 && W > 0 && H * W <= INT32_MAX, "slope: grid must have 1..2^31-1 cells (int32 flow graph)");
+  if (W % 4 == 0 && W >= 4 && (reinterpret_cast<uintptr_t>(flow) & 15) == 0 &&
+      (reinterpret_cast<uintptr_t>(slope) & 15) == 0 && (reinterpret_cast<uintptr_t>(tensor) & 15) == 0)
+    k_slope4<<<win_grid(H, W), kWinBlock, 0, as_stream(stream)>>>(slope, tensor, flow, H, W,
+                                                                 Scale2{scale[0], scale[1]});
+  else
+    k_slope<<<grid_rows(H, W, kGBlock), kGBlock, 0, as_stream(stream)>>>(
+        slope, tensor, flow, static_cast<int32_t>(H), static_cast<int32_t>(W), Scale2{scale[0], scale[1]});
   SOIL_LAUNCH_CHECK();
   return SOIL_OK;
 }
