@@ -293,6 +293,65 @@ __global__ void __launch_bounds__(kGBlock)
   }
 }
 
+// The same with four cells per thread (window.hpp): the graph's three rows in registers — the
+// eight neighbours a cell asks are compile-time positions of the window, no gathers and no 64-bit
+// index arithmetic per neighbour —, count and value as 16-byte stores.  (The window moves the
+// int32 indices as float bit patterns: loads, shuffles and selects do not touch them.)
+template <int K, bool TENSOR_DECAY>
+__global__ void __launch_bounds__(kWinBlock)
+    k_donors4(int32_t* __restrict__ count, int32_t* __restrict__ donor, float* __restrict__ decay,
+              float* __restrict__ value, const int32_t* __restrict__ graph,
+              const float* __restrict__ source, const float* __restrict__ decayIn, int64_t H,
+              int64_t W) {
+  const WinThread t = win_thread(W);
+  const int64_t elem = H * W;
+  const int32_t iW = static_cast<int32_t>(W);
+  RowWalk w;
+  SOIL_WIN_ROWS(x, w, reinterpret_cast<const float*>(graph), H, W, t.y0) {
+    const int32_t n0 = static_cast<int32_t>(x * W + t.y0);
+    int4 cnt;
+    int32_t* ci = reinterpret_cast<int32_t*>(&cnt);
+    int32_t dn[4][K];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int32_t n = n0 + c;
+      int m = 0;
+#pragma unroll
+      for (int k = 0; k < K; ++k) dn[c][k] = -1;
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        // the cell whose k-th neighbour is n: row x - kDX[k], column y - kDY[k]
+        const bool row_ok = kDX[k] > 0 ? w.has_up : (kDX[k] < 0 ? w.has_dn : true);
+        const bool col_ok = kDY[k] > 0 ? (c > 0 || t.y0 > 0) : (kDY[k] < 0 ? (c < 3 || t.y0 + 4 < W) : true);
+        const Row6& r = kDX[k] > 0 ? w.up : (kDX[k] < 0 ? w.dn : w.mid);
+        const int32_t g = static_cast<int32_t>(f2bits(r.v[c + 1 - kDY[k]]));
+        const bool drains = row_ok && col_ok && g == n;  // :333-345
+        const int32_t d = n - kDX[k] * iW - kDY[k];
+        // slot m takes it (compacted in the order of k); written out as selects, no indexed array
+#pragma unroll
+        for (int j = 0; j < K; ++j) dn[c][j] = (drains && m == j) ? d : dn[c][j];
+        m += drains ? 1 : 0;
+      }
+      ci[c] = m;
+    }
+    if (t.live) {
+      *reinterpret_cast<int4*>(count + n0) = cnt;
+      *reinterpret_cast<float4*>(value + n0) = *reinterpret_cast<const float4*>(source + n0);  // :553
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          if (k < ci[c]) {
+            donor[k * elem + n0 + c] = dn[c][k];
+            const float D = TENSOR_DECAY ? decayIn[dn[c][k]] : 1.0f;
+            decay[k * elem + n0 + c] = (k < 4) ? D : powf_(D, 1.414f);
+          }
+        }
+      }
+    }
+  }
+}
+
 // __rake_compress, graph.cu:429-522: one synchronous round, in -> out.
 //
 // The arithmetic and its order are the reference's; two things keep finished work
@@ -385,7 +444,14 @@ static int accumulate_impl(float* out, const int32_t* graph, const float* source
   int* flags = reinterpret_cast<int*>(p);
 
   const unsigned nb = blocks_for(elem, kGBlock);
-  if (decayIn)  // :552-556
+  const bool wide = W % 4 == 0 && W >= 4 &&
+                    ((reinterpret_cast<uintptr_t>(graph) | reinterpret_cast<uintptr_t>(source) |
+                      reinterpret_cast<uintptr_t>(A.value) | reinterpret_cast<uintptr_t>(A.count)) & 15) == 0;
+  if (decayIn && wide)  // :552-556
+    k_donors4<K, true><<<win_grid(H, W), kWinBlock, 0, st>>>(A.count, A.donor, A.decay, A.value, graph, source, decayIn, H, W);
+  else if (wide)
+    k_donors4<K, false><<<win_grid(H, W), kWinBlock, 0, st>>>(A.count, A.donor, A.decay, A.value, graph, source, nullptr, H, W);
+  else if (decayIn)
     k_donors<K, true><<<grid_rows(H, W, kGBlock), kGBlock, 0, st>>>(A.count, A.donor, A.decay, A.value, graph, source,
                                               decayIn, H, W);
   else
