@@ -1808,7 +1808,9 @@ struct TiledRun {
       deposit = 0;  // compare-and-swap deposits
     }
     // (debris on its 104-row tiles, round 3: 32 / 40 / 48 steps 11.05 / 10.78 / 10.77 ms per launch)
-    steps_per_round = env_kind("SOIL_TILED_STEPS", KIND, (KIND == FLUVIAL || shape_early == kShapeFull) ? 40 : 32);
+    // (fluvial, in the overlapped 8192^2 step at the end of round 3: 40 / 44 / 48 steps 33.30 / 32.90 / 33.06 ms
+    // per step, four runs each on one box; by itself the launch does not tell them apart)
+    steps_per_round = env_kind("SOIL_TILED_STEPS", KIND, KIND == FLUVIAL ? 44 : (shape_early == kShapeFull ? 40 : 32));
     // A round is worth its fixed cost while it advances particles faster than the
     // finishing launch would (4 L2 atomics per step at 22.7 G/s = 5.7 G steps/s).
     // Particles that zig-zag along a tile edge get a handful of steps per round; on
