@@ -146,6 +146,60 @@ __global__ void __launch_bounds__(kGBlock)
   }
 }
 
+// The same for kRwBatch realisations at once (soil_multiflow): the cumulative weights of a cell do
+// not depend on the draw, so the eight exponentials and the twenty divisions are made once and
+// only the Philox draw and the comparison against CDF / Z are repeated — per realisation the same
+// operations on the same values as k_random_weighted, hence the same graphs.
+constexpr int kRwBatch = 4;
+struct RwBatch {
+  int32_t* graph[kRwBatch];
+  uint64_t offset[kRwBatch];
+};
+template <int K>
+__global__ void __launch_bounds__(kGBlock)
+    k_random_weighted_batch(RwBatch b, const float* __restrict__ height, int64_t H, int64_t W,
+                            uint64_t seed, float T) {
+  const int64_t y = static_cast<int64_t>(blockIdx.x) * kGBlock + threadIdx.x;
+  if (y >= W) return;
+  SOIL_ROW_LOOP(x, H) {
+    const int64_t n = x * W + y;
+    const float hlocal = height[n];  // :118
+    float Q[K];                      // CDF[k] / Z, :160
+    bool ok[K];
+    int32_t to[K];
+    float CDF[K];
+    float Z = 0.0f;  // :127
+#pragma unroll
+    for (int k = 0; k < K; ++k) {  // :129-143
+      CDF[k] = 0.0f;
+      const int64_t nx = x + kDX[k], ny = y + kDY[k];
+      ok[k] = !(nx < 0 || ny < 0 || nx >= H || ny >= W);
+      to[k] = static_cast<int32_t>(nx * W + ny);
+      if (!ok[k]) continue;
+      const float dE = (hlocal - height[nx * W + ny]) / kShiftLen[k];  // :138
+      const float P = (dE <= 0.0f) ? 0.0f : expf_(dE / T);             // :139
+      CDF[k] = Z + P;                                                  // :140
+      Z += P;                                                          // :141
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) Q[k] = CDF[k] / Z;
+#pragma unroll
+    for (int m = 0; m < kRwBatch; ++m) {
+      int32_t next = -1;                                                                 // :149
+      const float uniform = rng_uniform_at(seed, static_cast<uint64_t>(n), b.offset[m]);  // :100, :150
+      bool found = false;
+#pragma unroll
+      for (int k = 0; k < K; ++k) {  // :151-165
+        if (ok[k] && !found && uniform < Q[k]) {  // :160 (Z == 0 -> NaN -> false)
+          next = to[k];
+          found = true;
+        }
+      }
+      b.graph[m][n] = next;  // :171
+    }
+  }
+}
+
 // __slope, graph.cu:270-295.  Threads along the row, a work-group walks a band of rows: the
 // cell's own coordinates cost nothing, and the receiver's — `next / W`, `next % W`, 64-bit
 // divisions that were most of this kernel's instructions — come from the index difference when the
@@ -587,16 +641,35 @@ int soil_multiflow(double* sum, const float* height, const float* source, int64_
   const int64_t elem = H * W;
   auto align = [](size_t b) { return (b + 255) & ~static_cast<size_t>(255); };
   void* base = nullptr;
-  if (int rc = workspace_get(3, align(sizeof(int32_t) * elem) + sizeof(float) * elem, &base); rc != SOIL_OK)
+  const size_t b_graph = align(sizeof(int32_t) * elem);
+  if (int rc = workspace_get(3, kRwBatch * b_graph + sizeof(float) * elem, &base); rc != SOIL_OK)
     return rc;
-  int32_t* graph = static_cast<int32_t*>(base);
-  float* acc = reinterpret_cast<float*>(static_cast<char*>(base) + align(sizeof(int32_t) * elem));
+  char* ws = static_cast<char*>(base);
+  float* acc = reinterpret_cast<float*>(ws + kRwBatch * b_graph);
   hipStream_t st = as_stream(stream);
-  for (uint64_t k = k_first; k < k_end; k += k_stride) {
-    if (int rc = soil_random_weighted(graph, height, H, W, edge, seed, k, T, stream); rc != SOIL_OK) return rc;
-    if (int rc = soil_accumulate(acc, graph, source, nullptr, H, W, edge, stream); rc != SOIL_OK) return rc;
-    k_mean_add<<<blocks_for(elem, kGBlock), kGBlock, 0, st>>>(sum, acc, static_cast<float>(K), elem);
+  SOIL_REQUIRE(H > 0 && W > 0 && elem <= INT32_MAX, "multiflow: grid must have 1..2^31-1 cells");
+  SOIL_REQUIRE(edge == SOIL_D4 || edge == SOIL_D8, "invalid edge enumerator");
+  // kRwBatch realisations' graphs per pass over the heights (the weights of a cell are the same for
+  // every draw), then one accumulation each
+  for (uint64_t k = k_first; k < k_end;) {
+    RwBatch b{};
+    int m = 0;
+    for (; m < kRwBatch && k < k_end; ++m, k += k_stride) {
+      b.graph[m] = reinterpret_cast<int32_t*>(ws + m * b_graph);
+      b.offset[m] = k;
+    }
+    const int made = m;
+    for (; m < kRwBatch; ++m) b.graph[m] = b.graph[0], b.offset[m] = b.offset[0];  // (a short last batch repeats its first)
+    if (edge == SOIL_D4)
+      k_random_weighted_batch<4><<<grid_rows(H, W, kGBlock), kGBlock, 0, st>>>(b, height, H, W, seed, T);
+    else
+      k_random_weighted_batch<8><<<grid_rows(H, W, kGBlock), kGBlock, 0, st>>>(b, height, H, W, seed, T);
     SOIL_LAUNCH_CHECK();
+    for (int j = 0; j < made; ++j) {
+      if (int rc = soil_accumulate(acc, b.graph[j], source, nullptr, H, W, edge, stream); rc != SOIL_OK) return rc;
+      k_mean_add<<<blocks_for(elem, kGBlock), kGBlock, 0, st>>>(sum, acc, static_cast<float>(K), elem);
+      SOIL_LAUNCH_CHECK();
+    }
   }
   return SOIL_OK;
 }
