@@ -56,19 +56,51 @@ def build(force=False):
     return so
 
 
+def _declare(l):
+    l.orc_expf.restype = C.c_float
+    l.orc_expf.argtypes = [C.c_float]
+    l.orc_log2f.restype = C.c_float
+    l.orc_log2f.argtypes = [C.c_float]
+    l.orc_powf.restype = C.c_float
+    l.orc_powf.argtypes = [C.c_float, C.c_float]
+    l.orc_stepsize.restype = C.c_float
+    l.orc_stepsize.argtypes = [C.c_float] * 4
+    l.orc_accumulate.restype = C.c_int
+    return l
+
+
+_LIB_FMA = None
+
+
+class contracted:
+    """`with pyoracle.contracted(): ...` — every oracle call inside runs in liboracle_fma.so: the same
+    C sources compiled with -ffp-contract=fast -mfma, i.e. with every a*b+c the reference's statements
+    spell out fused the way nvcc's default -fmad=true fuses them in the reference's CUDA build.  The
+    difference between the two builds is the fp32 tolerance DESIGN.md 4 states against that build."""
+
+    def __enter__(self):
+        global _LIB, _LIB_FMA
+        lib()
+        if _LIB_FMA is None:
+            so = os.path.join(_HERE, "liboracle_fma.so")
+            srcs = [os.path.join(_HERE, f) for f in ("soil_oracle.c", "soil_oracle.h", "noise_oracle.c")]
+            if not os.path.exists(so) or any(os.path.getmtime(x) > os.path.getmtime(so) for x in srcs if os.path.exists(x)):
+                subprocess.check_call(["make", "-C", _HERE, "liboracle_fma.so"], stdout=subprocess.DEVNULL)
+            _LIB_FMA = _declare(C.CDLL(so))
+        self._plain = _LIB
+        _LIB = _LIB_FMA
+        return self
+
+    def __exit__(self, *exc):
+        global _LIB
+        _LIB = self._plain
+        return False
+
+
 def lib():
     global _LIB
     if _LIB is None:
-        _LIB = C.CDLL(build())
-        _LIB.orc_expf.restype = C.c_float
-        _LIB.orc_expf.argtypes = [C.c_float]
-        _LIB.orc_log2f.restype = C.c_float
-        _LIB.orc_log2f.argtypes = [C.c_float]
-        _LIB.orc_powf.restype = C.c_float
-        _LIB.orc_powf.argtypes = [C.c_float, C.c_float]
-        _LIB.orc_stepsize.restype = C.c_float
-        _LIB.orc_stepsize.argtypes = [C.c_float] * 4
-        _LIB.orc_accumulate.restype = C.c_int
+        _LIB = _declare(C.CDLL(build()))
     return _LIB
 
 

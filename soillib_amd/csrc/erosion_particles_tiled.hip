@@ -1165,10 +1165,19 @@ __global__ void __launch_bounds__(NT, round_waves_per_simd(KIND, TR, TC, NT, ALB
   // taking turns with the other launch of the step (PairGate): the last work-group of the round to
   // start — every one has been handed out, what follows is the round's tail — lets the other's next
   // round in
-  if (my_dense && threadIdx.x == 0 &&
-      __hip_atomic_fetch_add(&ctl->started, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
-          n_groups - 1u - static_cast<uint32_t>((static_cast<uint64_t>(n_groups - 1u) * gate_early) / 100u))
-    __hip_atomic_store(my_dense, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // The ticket is a returning device-scope atomic (carried out at the memory side, ~2.5 us): drawn
+  // where it stood — in front of the job's three dependent loads — it held wave 0, and with it the
+  // barrier behind the zeroing of the tile, up for that long in every work-group of the overlapped
+  // step.  It is drawn behind the record loads now and looked at behind that barrier.
+  const bool gate_lane = my_dense != nullptr && threadIdx.x == 0;
+  const uint32_t gate_target =
+      n_groups - 1u - static_cast<uint32_t>((static_cast<uint64_t>(n_groups - 1u) * gate_early) / 100u);
+  auto gate_draw = [&]() {
+    return __hip_atomic_fetch_add(&ctl->started, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  auto gate_look = [&](uint32_t ticket) {
+    if (ticket == gate_target) __hip_atomic_store(my_dense, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
   PROF_DECL;
   // this work-group's share of its tile's queue (the scan's block list)
   const uint4 job = block_list[blockIdx.x];
@@ -1194,8 +1203,21 @@ __global__ void __launch_bounds__(NT, round_waves_per_simd(KIND, TR, TC, NT, ALB
   float* const s_c1 = s_c0 + (ALB ? kCells : 0);
   float* const s_c2 = s_c1 + (ALB ? kCells : 0);
   __shared__ uint32_t s_next, s_out, s_steps, s_last;
+  // The ticket of the round's end (the work-group that draws the last one scans the queues of the
+  // round that follows): drawn by thread 0 as soon as this work-group's survivors are counted — behind
+  // the barrier that ends the stepping — and looked at behind the flush, which its round trip hides under.
+  uint32_t done_ticket = 0;
+  bool done_drawn = false;
+  auto done_draw = [&]() {
+    done_drawn = true;
+    if (next.host && tid == 0)
+      done_ticket = __hip_atomic_fetch_add(&ctl->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
   do {  // the round's work proper (a chunk of a cut queue may be empty)
-  if (cnt == 0 && !store_all) break;  // (storing: an empty tile's zeros go out like any other's)
+  if (cnt == 0 && !store_all) {  // (storing: an empty tile's zeros go out like any other's)
+    if (gate_lane) gate_look(gate_draw());
+    break;
+  }
   if (tid == 0) {
     s_next = kBlock;  // the first kBlock queue entries go to the lanes directly, see below
     s_out = 0;
@@ -1209,6 +1231,8 @@ __global__ void __launch_bounds__(NT, round_waves_per_simd(KIND, TR, TC, NT, ALB
   r.iter = -1;
   bool have = static_cast<uint32_t>(tid) < cnt;
   if (have) r = in[order[first + tid]];
+  uint32_t gate_ticket = 0;
+  if (gate_lane) gate_ticket = gate_draw();
 #pragma unroll
   for (int j = 0; j < kPer; ++j) {
     const int c = tid + j * kBlock;
@@ -1220,6 +1244,7 @@ __global__ void __launch_bounds__(NT, round_waves_per_simd(KIND, TR, TC, NT, ALB
     if (ALB) s_c0[c] = s_c1[c] = s_c2[c] = 0.0f;
   }
   __syncthreads();
+  if (gate_lane) gate_look(gate_ticket);
 
   // Cells of this tile a particle may take a step on: the tile, cut down to the rows whose
   // stencil this slab holds (the whole grid on a single device) and to the grid's columns.
@@ -1443,66 +1468,159 @@ __global__ void __launch_bounds__(NT, round_waves_per_simd(KIND, TR, TC, NT, ALB
   PROF_AT(6);  // survivors written out
   __syncthreads();
   PROF_AT(7);  // waiting for the slowest wave of the work-group
+  done_draw();
   if (tid == 0) atomicAdd(steps, static_cast<unsigned long long>(s_steps));
   for (uint32_t j = s_out + tid; j < cnt; j += kBlock) dest[first + j] = kNoTile;  // unused slots
 
   // flush the tile's flux into the global planes: with one work-group per tile per
   // round plain read-modify-writes suffice; the groups of a split tile add atomically.  Only cells that received a
   // deposit are touched (late rounds: the particles sit in channels and most of
-  // the tile is still zero).  Two cells per thread in flight: the register
-  // budget of the stepping loop decides the occupancy, not this epilogue.
-  for (int j0 = 0; j0 < kPer; j0 += 2) {
-    float a0[2], a1[2], ax[2], ay[2], g0[2], g1[2];
-    float2 gv[2];
-    int64_t l[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int c = tid + (j0 + j) * kBlock;
+  // the tile is still zero).  All of a thread's cells are in flight at once: the old words of every
+  // cell that changed are asked for before the first one is looked at (the stepping loop's
+  // registers are free by now) — a work-group holds its tile's LDS for one round trip to the
+  // planes, not for one per pair of cells (four of them: ~6 us of the ~40 a sparse tile's
+  // work-group lives).
+  auto flush_cell = [&](int j, int& c, int64_t& l) {  // -> inside the tile, the slab's rows and the grid's columns
+    c = tid + j * kBlock;
+    const int lx = row0 + c / TC, y = col0 + c % TC;
+    l = static_cast<int64_t>(lx) * k.W + y;
+    return c < kCells && lx >= 0 && y >= 0 && lx < static_cast<int>(d.rows) && y < k.W;
+  };
+  // Four consecutive cells of a row per thread where the planes allow 16-byte accesses (the width a
+  // multiple of four — tile columns and the half-tile shift are — and the planes aligned): the
+  // flush is a few hundred instructions per thread cell by cell, issued at a lone wave's pace while the
+  // work-group holds its tile; by groups of four it is a third of that.  A group none of whose
+  // cells took a deposit is left alone; in a group that is read, a cell is added to exactly when the
+  // cell-by-cell flush adds to it, so the planes hold the same bits either way.
+  const bool flush_vec = (k.W & 3) == 0 && !shared_tile && !ALB &&
+                         ((reinterpret_cast<uintptr_t>(flux0) | reinterpret_cast<uintptr_t>(flux1) |
+                           reinterpret_cast<uintptr_t>(fluxV)) & 15u) == 0;
+  if (flush_vec) {
+    constexpr int kGroups = kCells / 4, kGPer = (kGroups + NT - 1) / NT;
+    static_assert(kCells % 4 == 0 && TC % 4 == 0, "a group of four cells lies in one row of the tile");
+    const float4* const sa4 = reinterpret_cast<const float4*>(s_a);
+    const float4* const sv4 = reinterpret_cast<const float4*>(s_v);
+    auto group_at = [&](int j, int& gi, int64_t& l) {
+      gi = tid + j * kBlock;
+      const int c = 4 * gi;
       const int lx = row0 + c / TC, y = col0 + c % TC;
-      const bool ok = c < kCells && lx >= 0 && y >= 0 && lx < static_cast<int>(d.rows) && y < k.W;
-      l[j] = static_cast<int64_t>(lx) * k.W + y;
-      a0[j] = ok ? s_a[kA * c] : 0.0f;
-      a1[j] = (KIND == FLUVIAL && ok) ? s_a[2 * c + 1] : 0.0f;
-      ax[j] = ok ? s_v[2 * c] : 0.0f;
-      ay[j] = ok ? s_v[2 * c + 1] : 0.0f;
-    }
-    if (store_all) {
-      // The first round of a launch that was told to OVERWRITE the flux planes (soil_erode_step's
-      // lazy mode: the cell phase did not re-zero them): every tile has exactly one work-group, the
-      // tiles partition the plane, so plain stores of the tile's accumulators — zeros included —
-      // leave the planes holding this round's deposits and nothing else, without a read.
+      l = static_cast<int64_t>(lx) * k.W + y;
+      return gi < kGroups && lx >= 0 && y >= 0 && lx < static_cast<int>(d.rows) && y < k.W;
+    };
+    auto nz = [](float4 v) { return ((f2bits(v.x) | f2bits(v.y) | f2bits(v.z) | f2bits(v.w)) & 0x7fffffffu) != 0u; };
+    if (store_all) {  // (see below)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int c = tid + (j0 + j) * kBlock;
-        const int lx = row0 + c / TC, y = col0 + c % TC;
-        if (!(c < kCells && lx >= 0 && y >= 0 && lx < static_cast<int>(d.rows) && y < k.W)) continue;
-        flux0[l[j]] = a0[j];
-        if (KIND == FLUVIAL) flux1[l[j]] = a1[j];
-        fluxV[l[j]] = make_float2(ax[j], ay[j]);
+      for (int j = 0; j < kGPer; ++j) {
+        int gi;
+        int64_t l;
+        if (!group_at(j, gi, l)) continue;
+        if (KIND == FLUVIAL) {
+          const float4 a = sa4[2 * gi], b = sa4[2 * gi + 1];  // water | mass of cells 0 1, 2 3
+          *reinterpret_cast<float4*>(flux0 + l) = make_float4(a.x, a.z, b.x, b.z);
+          *reinterpret_cast<float4*>(flux1 + l) = make_float4(a.y, a.w, b.y, b.w);
+        } else {
+          *reinterpret_cast<float4*>(flux0 + l) = sa4[gi];
+        }
+        *reinterpret_cast<float4*>(fluxV + l) = sv4[2 * gi];
+        *reinterpret_cast<float4*>(fluxV + l + 2) = sv4[2 * gi + 1];
       }
-      continue;
-    }
-    if (shared_tile) {  // uniform per work-group
+    } else {
+      float4 g0[kGPer], g1[kGPer], gva[kGPer], gvb[kGPer];
+      bool hit[kGPer];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        if (a0[j] != 0.0f) atomicAdd(&flux0[l[j]], a0[j]);
-        if (KIND == FLUVIAL && a1[j] != 0.0f) atomicAdd(&flux1[l[j]], a1[j]);
-        if (ax[j] != 0.0f) atomicAdd(&fluxV[l[j]].x, ax[j]);
-        if (ay[j] != 0.0f) atomicAdd(&fluxV[l[j]].y, ay[j]);
+      for (int j = 0; j < kGPer; ++j) {  // every old word asked for before the first one is looked at
+        int gi;
+        int64_t l;
+        hit[j] = group_at(j, gi, l);
+        if (hit[j])
+          hit[j] = (KIND == FLUVIAL ? (nz(sa4[2 * gi]) || nz(sa4[2 * gi + 1])) : nz(sa4[gi])) ||
+                   nz(sv4[2 * gi]) || nz(sv4[2 * gi + 1]);
+        g0[j] = g1[j] = gva[j] = gvb[j] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (hit[j]) {
+          g0[j] = *reinterpret_cast<const float4*>(flux0 + l);
+          if (KIND == FLUVIAL) g1[j] = *reinterpret_cast<const float4*>(flux1 + l);
+          gva[j] = *reinterpret_cast<const float4*>(fluxV + l);
+          gvb[j] = *reinterpret_cast<const float4*>(fluxV + l + 2);
+        }
       }
-      continue;
+#pragma unroll
+      for (int j = 0; j < kGPer; ++j) {
+        int gi;
+        int64_t l;
+        (void)group_at(j, gi, l);
+        if (!hit[j]) continue;
+        auto add = [](float g, float a) { return a != 0.0f ? g + a : g; };
+        auto add2 = [](float g, float a, float other) { return (a != 0.0f || other != 0.0f) ? g + a : g; };
+        if (KIND == FLUVIAL) {
+          const float4 a = sa4[2 * gi], b = sa4[2 * gi + 1];
+          *reinterpret_cast<float4*>(flux0 + l) =
+              make_float4(add(g0[j].x, a.x), add(g0[j].y, a.z), add(g0[j].z, b.x), add(g0[j].w, b.z));
+          *reinterpret_cast<float4*>(flux1 + l) =
+              make_float4(add(g1[j].x, a.y), add(g1[j].y, a.w), add(g1[j].z, b.y), add(g1[j].w, b.w));
+        } else {
+          const float4 a = sa4[gi];
+          *reinterpret_cast<float4*>(flux0 + l) =
+              make_float4(add(g0[j].x, a.x), add(g0[j].y, a.y), add(g0[j].z, a.z), add(g0[j].w, a.w));
+        }
+        const float4 va = sv4[2 * gi], vb = sv4[2 * gi + 1];  // x | y of cells 0 1, 2 3
+        *reinterpret_cast<float4*>(fluxV + l) = make_float4(add2(gva[j].x, va.x, va.y), add2(gva[j].y, va.y, va.x),
+                                                            add2(gva[j].z, va.z, va.w), add2(gva[j].w, va.w, va.z));
+        *reinterpret_cast<float4*>(fluxV + l + 2) = make_float4(add2(gvb[j].x, vb.x, vb.y), add2(gvb[j].y, vb.y, vb.x),
+                                                                add2(gvb[j].z, vb.z, vb.w), add2(gvb[j].w, vb.w, vb.z));
+      }
+    }
+  } else if (store_all) {
+    // The first round of a launch that was told to OVERWRITE the flux planes (soil_erode_step's
+    // lazy mode: the cell phase did not re-zero them): every tile has exactly one work-group, the
+    // tiles partition the plane, so plain stores of the tile's accumulators — zeros included —
+    // leave the planes holding this round's deposits and nothing else, without a read.
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+      int c;
+      int64_t l;
+      if (!flush_cell(j, c, l)) continue;
+      flux0[l] = s_a[kA * c];
+      if (KIND == FLUVIAL) flux1[l] = s_a[2 * c + 1];
+      fluxV[l] = make_float2(s_v[2 * c], s_v[2 * c + 1]);
+    }
+  } else if (shared_tile) {  // uniform per work-group
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+      int c;
+      int64_t l;
+      if (!flush_cell(j, c, l)) continue;
+      const float a0 = s_a[kA * c], a1 = (KIND == FLUVIAL) ? s_a[2 * c + 1] : 0.0f;
+      const float ax = s_v[2 * c], ay = s_v[2 * c + 1];
+      if (a0 != 0.0f) atomicAdd(&flux0[l], a0);
+      if (KIND == FLUVIAL && a1 != 0.0f) atomicAdd(&flux1[l], a1);
+      if (ax != 0.0f) atomicAdd(&fluxV[l].x, ax);
+      if (ay != 0.0f) atomicAdd(&fluxV[l].y, ay);
+    }
+  } else {
+    float g0[kPer], g1[kPer];
+    float2 gv[kPer];
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+      int c;
+      int64_t l;
+      const bool ok = flush_cell(j, c, l);
+      g0[j] = g1[j] = 0.0f;
+      gv[j] = make_float2(0.0f, 0.0f);
+      if (!ok) continue;
+      if (s_a[kA * c] != 0.0f) g0[j] = flux0[l];
+      if (KIND == FLUVIAL && s_a[2 * c + 1] != 0.0f) g1[j] = flux1[l];
+      if (s_v[2 * c] != 0.0f || s_v[2 * c + 1] != 0.0f) gv[j] = fluxV[l];
     }
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      g0[j] = (a0[j] != 0.0f) ? flux0[l[j]] : 0.0f;
-      g1[j] = (KIND == FLUVIAL && a1[j] != 0.0f) ? flux1[l[j]] : 0.0f;
-      gv[j] = (ax[j] != 0.0f || ay[j] != 0.0f) ? fluxV[l[j]] : make_float2(0.0f, 0.0f);
-    }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      if (a0[j] != 0.0f) flux0[l[j]] = g0[j] + a0[j];
-      if (KIND == FLUVIAL && a1[j] != 0.0f) flux1[l[j]] = g1[j] + a1[j];
-      if (ax[j] != 0.0f || ay[j] != 0.0f) fluxV[l[j]] = make_float2(gv[j].x + ax[j], gv[j].y + ay[j]);
+    for (int j = 0; j < kPer; ++j) {
+      int c;
+      int64_t l;
+      if (!flush_cell(j, c, l)) continue;
+      const float a0 = s_a[kA * c], a1 = (KIND == FLUVIAL) ? s_a[2 * c + 1] : 0.0f;
+      const float ax = s_v[2 * c], ay = s_v[2 * c + 1];
+      if (a0 != 0.0f) flux0[l] = g0[j] + a0;
+      if (KIND == FLUVIAL && a1 != 0.0f) flux1[l] = g1[j] + a1;
+      if (ax != 0.0f || ay != 0.0f) fluxV[l] = make_float2(gv[j].x + ax, gv[j].y + ay);
     }
   }
   if (ALB) {  // the three colour planes, AoS (vec3) in global memory
@@ -1537,10 +1655,9 @@ __global__ void __launch_bounds__(NT, round_waves_per_simd(KIND, TR, TC, NT, ALB
   // done before the ticket is drawn; the scan reads the counts with device-scope loads.  Everything
   // else the round writes (records, ranks, flux) is for later kernels.
   if (!next.host) return;  // uniform: the scan is a launch of its own (SOIL_TILED_TAILSCAN=2)
-  __syncthreads();
-  if (tid == 0)
-    s_last = __hip_atomic_fetch_add(&ctl->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n_groups - 1u ? 1u : 0u;
-  __syncthreads();
+  if (!done_drawn) done_draw();  // (an empty chunk of a cut queue)
+  if (tid == 0) s_last = done_ticket == n_groups - 1u ? 1u : 0u;
+  __syncthreads();  // ... and every thread is done with the tile: the scan's scratch is the tile's LDS
   if (s_last != 0u) {
     if (tid == 0) {
       __hip_atomic_store(&ctl->done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1745,6 +1862,10 @@ struct TiledRun {
   int resident_groups[2] = {512, 512};  // work-groups of a round kernel the chip holds at once (early, late shape)
 
   int shape_of(uint64_t r) const { return r >= static_cast<uint64_t>(switch_round) ? shape_late : shape_early; }
+  // steps a walker may take in round r: `steps_late` from round `steps_late_from` on (SOIL_TILED_STEPS_LATE,
+  // SOIL_TILED_LATE_FROM; off by default)
+  int steps_late = 0, steps_late_from = 1 << 30;
+  int steps_of(uint64_t r) const { return (steps_late > 0 && r >= static_cast<uint64_t>(steps_late_from)) ? steps_late : steps_per_round; }
   // the tile grid of round r: shifted by half a tile on odd rounds (TileShape)
   bool stagger = true;
   int agg_min = 48, agg_groups = 4, retries = 2;
@@ -1811,6 +1932,8 @@ struct TiledRun {
     // (fluvial, in the overlapped 8192^2 step at the end of round 3: 40 / 44 / 48 steps 33.30 / 32.90 / 33.06 ms
     // per step, four runs each on one box; by itself the launch does not tell them apart)
     steps_per_round = env_kind("SOIL_TILED_STEPS", KIND, KIND == FLUVIAL ? 44 : (shape_early == kShapeFull ? 40 : 32));
+    steps_late = env_kind("SOIL_TILED_STEPS_LATE", KIND, 0);
+    steps_late_from = env_kind("SOIL_TILED_LATE_FROM", KIND, 1 << 30);
     // A round is worth its fixed cost while it advances particles faster than the
     // finishing launch would (4 L2 atomics per step at 22.7 G/s = 5.7 G steps/s).
     // Particles that zig-zag along a tile edge get a handful of steps per round; on
@@ -2032,7 +2155,7 @@ struct TiledRun {
                             static_cast<const uint4*>(block_list), flux0, flux1,
                             reinterpret_cast<float2*>(fluxV), fluxA, static_cast<const float4*>(p4),
                             remote0, steps_run, d, s, p, tiles_w, ts_cur.off_r, ts_cur.off_c,
-                            steps_per_round, ts_of(sh_next, r + 1),
+                            steps_of(r), ts_of(sh_next, r + 1),
                             tiles_w_of(sh_next, r + 1), agg_min, agg_groups, retries, store_all,
                             ctl, static_cast<uint32_t>(r), next_scan, my_dense, gate_early);
     else
@@ -2041,7 +2164,7 @@ struct TiledRun {
                             static_cast<const uint4*>(block_list), flux0, flux1,
                             reinterpret_cast<float2*>(fluxV), fluxA, static_cast<const float4*>(p4),
                             remote0, steps_run, d, s, p, tiles_w, ts_cur.off_r, ts_cur.off_c,
-                            steps_per_round, ts_of(sh_next, r + 1),
+                            steps_of(r), ts_of(sh_next, r + 1),
                             tiles_w_of(sh_next, r + 1), agg_min, agg_groups, retries, store_all,
                             ctl, static_cast<uint32_t>(r), next_scan, my_dense, gate_early);
     SOIL_LAUNCH_CHECK();
@@ -2064,6 +2187,25 @@ struct TiledRun {
     const uint32_t mode = __atomic_load_n(&host->mode, __ATOMIC_ACQUIRE);
     const int64_t slots_before = live_known;  // >= the slots round r's sort and the finishing launch look at
     if (mode == 0) live_known = std::min<int64_t>(live_known, static_cast<int64_t>(host->live));
+#ifdef SOIL_PROF
+    if (verbose) {  // where the waves of the round just done spent their cycles (depth 0: round r - 1 is over)
+      static const char* seg[10] = {"stops", "refill", "head", "gather+dep begin", "advance", "dep finish",
+                                    "survivors out", "barrier wait", "prologue", "flush"};
+      unsigned long long v[32];
+      SOIL_HIP(hipStreamSynchronize(st));
+      if (soil_prof_read(v, 1) == 0) {
+        const unsigned long long* w = v + 16 * KIND;
+        unsigned long long tot = 0;
+        for (int i = 0; i < 10; ++i) tot += w[i];
+        if (tot > 0) {
+          std::fprintf(stderr, "[prof kind %d] before scan %llu: %llu waves, %llu wave-iterations, %.0f ticks per wave;",
+                       KIND, static_cast<unsigned long long>(r), w[11], w[10], static_cast<double>(tot) / std::max<unsigned long long>(w[11], 1));
+          for (int i = 0; i < 10; ++i) std::fprintf(stderr, " %s %.1f%%", seg[i], 100.0 * w[i] / tot);
+          std::fprintf(stderr, "\n");
+        }
+      }
+    }
+#endif
     if (verbose) {  // queue-length statistics of the round (diagnostics only; depth 0: the word is scan r's)
       const int sh = shape_of(r);
       const int64_t tiles = tiles_of(sh, r);

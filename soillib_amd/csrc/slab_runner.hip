@@ -882,6 +882,11 @@ int soil_slab_create(soil_slab** out, const soil_slab_config* cfg, const soil_pa
     ops->release(ops->ctx, bed);
     if (rc != SOIL_OK) return bail(rc);
   }
+  // The back-end clears every block it hands out on its own lane (a non-blocking stream): nothing the
+  // caller does next — an upload through soil_slab_plane on the null or any stream of its own — is
+  // ordered against those fills unless they are done when this returns (with init == 0 nothing above
+  // waited for them: a late memset wiped uploaded layers, depending on timing and grid size).
+  if (int rc = ops->sync(ops->ctx); rc != SOIL_OK) return bail(rc);
   *out = s;
   return SOIL_OK;
 }

@@ -426,6 +426,7 @@ class SlabRunner:
         a = np.ascontiguousarray(array, np.float32)
         assert a.size == rows * self.W * ch, (a.shape, rows, self.W, ch)
         if self.cb_ops is None:
+            self.sync()  # nothing of the runner's own lanes may still be writing the plane
             _abi.check(self.lib.soil_memcpy_h2d(p, a.ctypes.data, 4 * a.size, None))
             _abi.check(self.lib.soil_device_synchronize())
         else:

@@ -8,22 +8,21 @@ from . import silt
 from . import soil as _soil
 
 
-def iter_tiff(path, max_files=None):
-    """Yields (file name, full path) of one file or of every file in a directory
-    (util.py:8-30)."""
-    import os
-    path = os.fsencode(path)
-    if not os.path.exists(path):
-        raise RuntimeError("path does not exist")
-    if os.path.isfile(path):
-        yield os.path.basename(path).decode("utf-8"), path.decode("utf-8")
-    elif os.path.isdir(path):
-        for k, file in enumerate(os.listdir(path)):
-            if max_files is not None and k > max_files:
-                break
-            yield file.decode("utf-8"), os.path.join(path, file).decode("utf-8")
+def iter_tiff(source, max_files=None):
+    """(name, path) pairs for `source`: the file itself, or the entries of a directory in sorted order,
+    at most `max_files` of them.  BASELINE config 1's script walks its input with this
+    (example/tiff_normal.py:9); raises RuntimeError for anything that is neither file nor directory."""
+    from itertools import islice
+    from pathlib import Path
+    src = Path(source)
+    if src.is_file():
+        entries = [src]
+    elif src.is_dir():
+        entries = islice(sorted(e for e in src.iterdir() if e.is_file()), max_files)
     else:
-        raise RuntimeError("path must be file or directory")
+        raise RuntimeError("iter_tiff: %r is neither a file nor a directory" % (str(source),))
+    for entry in entries:
+        yield entry.name, str(entry)
 
 
 def relief_shade(height, normal):
