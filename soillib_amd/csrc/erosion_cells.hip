@@ -447,6 +447,23 @@ __global__ void __launch_bounds__(BLOCK)
   }
 }
 
+// The re-zero of the five flux planes as a pass of its own (28 bytes per cell, write only): what the
+// eager path runs behind the 84-byte kernel when the two together beat the 112-byte kernel
+// (SOIL_CELLS_SPLIT, soil_erode_cells_fused_ex).  One thread per 4 cells of the owned rows: 7 stores of 16 bytes.
+__global__ void __launch_bounds__(kBlock)
+    k_zero_flux(Planes P, int64_t n_first, int64_t groups) {
+  const int64_t g = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (g >= groups) return;
+  const int64_t n0 = n_first + g * kVec;
+  const v4f z = {0.0f, 0.0f, 0.0f, 0.0f};
+  *reinterpret_cast<v4f*>(P.waterFlux + n0) = z;
+  *reinterpret_cast<v4f*>(P.massFlux + n0) = z;
+  *reinterpret_cast<v4f*>(P.debrisFlux + n0) = z;
+  v4f* zv = reinterpret_cast<v4f*>(P.velocityFlux + n0);
+  v4f* zd = reinterpret_cast<v4f*>(P.debrisVelocityFlux + n0);
+  zv[0] = z, zv[1] = z, zd[0] = z, zd[1] = z;
+}
+
 // scalar path for W % 4 != 0 (ragged widths): one thread per cell
 __global__ void __launch_bounds__(kBlock)
     k_erode_cells_fused_scalar(Planes P, Dom d, Scale3 s, Param p, bool rezero) {
@@ -677,7 +694,14 @@ int soil_erode_cells_fused_ex(const soil_erosion_planes* pl, const soil_domain* 
     static const bool nt = [] { const char* e = std::getenv("SOIL_CELLS_NT"); return e && e[0] == '1'; }();  // measured slower than plain accesses; kept for A/B
     const int variant = [] { const char* e = std::getenv("SOIL_CELLS_VARIANT"); return e ? std::atoi(e) : 0; }();  // read per call: bench.py alternates variants in one process
     const bool remap = nblk % 8 == 0 && nblk >= 64 && variant != 2;
-    const bool keep = (flags & SOIL_CELLS_KEEP_FLUX) != 0;
+    // split: the eager call as the 84-byte kernel + the zeroing pass (variant 5 / SOIL_CELLS_SPLIT=1)
+    // Measured back to back at 8192^2 on one box (tools/bench_cells.py, two processes each): 1.30 / 1.27 ms
+    // split against 1.38 / 1.29 ms for the one kernel that moves all 112 bytes — the kernel with seven
+    // store streams less plus a write-only pass at 7 TB/s is never the slower one.  SOIL_CELLS_SPLIT=0:
+    // the one kernel (variant 0) again.
+    static const bool split_env = [] { const char* e = std::getenv("SOIL_CELLS_SPLIT"); return !(e && e[0] == '0'); }();
+    const bool split = (flags & SOIL_CELLS_KEEP_FLUX) == 0 && (variant == 5 || (split_env && variant == 0));
+    const bool keep = (flags & SOIL_CELLS_KEEP_FLUX) != 0 || split;
     if (keep && remap)
       k_erode_cells_fused<true, false, kBlock, false, false><<<nblk, kBlock, 0, st>>>(P, d, s3(scale), *param, groups_per_row, total);
     else if (keep)
@@ -696,6 +720,7 @@ int soil_erode_cells_fused_ex(const soil_erosion_planes* pl, const soil_domain* 
       k_erode_cells_fused<false, true><<<nblk, kBlock, 0, st>>>(P, d, s3(scale), *param, groups_per_row, total);
     else
       k_erode_cells_fused<false, false><<<nblk, kBlock, 0, st>>>(P, d, s3(scale), *param, groups_per_row, total);
+    if (split) k_zero_flux<<<nblk, kBlock, 0, st>>>(P, d.r0 * d.W, total);
   } else {
     k_erode_cells_fused_scalar<<<blocks_for(cells, kBlock), kBlock, 0, st>>>(
         P, d, s3(scale), *param, (flags & SOIL_CELLS_KEEP_FLUX) == 0);

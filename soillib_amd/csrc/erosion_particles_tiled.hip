@@ -171,8 +171,10 @@ __device__ __forceinline__ uint32_t queue_key(int x0, float px, float py, float 
   const float inv = __builtin_amdgcn_rsqf(spx * spx + spy * spy);
   const float ux = spx * inv, uy = spy * inv;
   const float big = 1.0e9f;
-  const float tx = ux > 0.0f ? (x_hi - px) / ux : (ux < 0.0f ? (x_lo - px) / ux : big);
-  const float ty = uy > 0.0f ? (y_hi - py) / uy : (uy < 0.0f ? (y_lo - py) / uy : big);
+  // (an ordering hint: the hardware's approximate reciprocal will do — two IEEE divisions were a
+  // third of this function's instructions, on the path of a work-group's last wave)
+  const float tx = ux != 0.0f ? ((ux > 0.0f ? x_hi : x_lo) - px) * __builtin_amdgcn_rcpf(ux) : big;
+  const float ty = uy != 0.0f ? ((uy > 0.0f ? y_hi : y_lo) - py) * __builtin_amdgcn_rcpf(uy) : big;
   const float t = fminf(fminf(tx, ty), static_cast<float>(life));
   const float k = static_cast<float>(K);
   uint32_t section = t >= k ? 0u : (t >= 0.5f * k ? 1u : (t >= 0.25f * k ? 2u : 3u));
@@ -539,15 +541,18 @@ __global__ void __launch_bounds__(256)
 // group: one memory round trip per wave, not one per distinct key (a wave's survivors
 // head for up to a dozen queue sections).
 __device__ __forceinline__ uint32_t wave_key_append(uint32_t* __restrict__ counter, bool valid,
-                                                    int64_t key) {
+                                                    uint32_t key) {
   const int lane = threadIdx.x & 63;
-  uint64_t todo = __ballot(valid);
+  uint64_t todo = __builtin_amdgcn_ballot_w64(valid);
   int my_leader = lane;
   uint32_t my_rank = 0, my_count = 0;
   while (todo) {
+    // the leader is the same lane for the whole wave: its key comes through v_readlane (a
+    // shuffle is an LDS round trip, a dozen of them in a row where a wave's survivors head for a
+    // dozen sections — on the path of the work-group's last wave)
     const int leader = __ffsll(static_cast<long long>(todo)) - 1;
-    const int64_t k0 = __shfl(key, leader, 64);
-    const uint64_t group = __ballot(valid && key == k0);
+    const uint32_t k0 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(key), leader));
+    const uint64_t group = __builtin_amdgcn_ballot_w64(valid && key == k0);
     if (valid && key == k0) {
       my_leader = leader;
       my_rank = static_cast<uint32_t>(__popcll(group & ((1ull << lane) - 1ull)));
@@ -1256,7 +1261,20 @@ __global__ void __launch_bounds__(NT, round_waves_per_simd(KIND, TR, TC, NT, ALB
   if (r_hi < r_lo || c_hi < c_lo) r_lo = r_hi = c_lo = c_hi = 0x40000000;  // nothing to step on
   const uint32_t r_span = static_cast<uint32_t>(r_hi - r_lo), c_span = static_cast<uint32_t>(c_hi - c_lo);
   const int row_org = k.x0 + r_lo;                // global row of local row r_lo
-  const int c_org = (r_lo - row0) * TC + (c_lo - col0);  // LDS cell of (r_lo, c_lo)
+  // LDS cell of tile row `tr`, column `tc`.  A row of the tile is TC * 8 bytes of each pair plane — a
+  // whole number of bank rounds — so the cells of one column would share their banks, and walkers that
+  // follow a channel down a column would queue up on them.  Row r is rotated by kSkew * r columns
+  // (kSkew a multiple of 4: the flush reads groups of four cells) : neighbours in any direction lie on
+  // different banks.  SOIL_LDS_SKEW=0 at build time: rows as they are (A/B).
+#ifndef SOIL_LDS_SKEW
+#define SOIL_LDS_SKEW 4
+#endif
+  constexpr int kSkew = SOIL_LDS_SKEW;
+  static_assert(kSkew % 4 == 0 && (TC & (TC - 1)) == 0, "tile columns: a power of two; skew: whole groups");
+  auto tile_cell = [](int tr, int tc) {
+    return kSkew == 0 ? tr * TC + tc : tr * TC + ((tc + kSkew * tr) & (TC - 1));
+  };
+  const int tr_org = r_lo - row0, tc_org = c_lo - col0;  // tile row / column of (r_lo, c_lo)
   const uint32_t l_org = static_cast<uint32_t>(r_lo) * k.Wu + static_cast<uint32_t>(c_lo);  // its local cell index
   const int last_iter = static_cast<int>(k.maxage) - 1;  // `++iter < maxage` passes while iter < maxage - 1
 
@@ -1340,7 +1358,7 @@ __global__ void __launch_bounds__(NT, round_waves_per_simd(KIND, TR, TC, NT, ALB
       PROF_AT(2);  // head
       CasDeposit<kFluxPlanes + (ALB ? 3 : 0), (KIND == FLUVIAL) ? 2 : 1> dep;
       uint32_t lost_bits = 0;
-      const int c = c_org + static_cast<int>(dr) * TC + static_cast<int>(dc);  // LDS cell (any value when idle)
+      const int c = tile_cell(tr_org + static_cast<int>(dr), tc_org + static_cast<int>(dc));  // LDS cell (any value when idle)
       // rows, W < 2^24 and H*W < 2^31 (use_tiled): one v_mad_u32_u24 per index
       const uint32_t lcell = l_org + __umul24(dr, k.Wu) + dc;
       const uint32_t nind = lcell + k.base;  // global cell: cx * W + cy, :103 / :309
@@ -1420,7 +1438,7 @@ __global__ void __launch_bounds__(NT, round_waves_per_simd(KIND, TR, TC, NT, ALB
             r.ind = nind;
             float v[kFluxPlanes + 3];
             float* pp[kFluxPlanes + 3];
-            deposit_terms(c_org + static_cast<int>(dr) * TC + static_cast<int>(dc), v, pp);
+            deposit_terms(tile_cell(tr_org + static_cast<int>(dr), tc_org + static_cast<int>(dc)), v, pp);
 #pragma unroll
             for (int j = 0; j < kFluxPlanes + (ALB ? 3 : 0); ++j) atomicAdd(pp[j], v[j]);
           }
@@ -1453,14 +1471,14 @@ __global__ void __launch_bounds__(NT, round_waves_per_simd(KIND, TR, TC, NT, ALB
   }
   {  // everything still parked goes out together (convergent: aggregate the counters)
     const uint32_t slot = wave_append(&s_out, parked);
-    const int64_t dest_tile =
+    const uint32_t dest_tile =
         parked ? queue_key(k.x0, r.px, r.py, r.spx, r.spy, k.maxage - static_cast<uint32_t>(r.iter),
                            tiles_w_next, ts_next, steps_per_round)
-               : 0;
+               : 0u;
     const uint32_t place = wave_key_append(count_next, parked, dest_tile);
     if (parked) {
       out[first + slot] = r;
-      dest[first + slot] = static_cast<uint32_t>(dest_tile);
+      dest[first + slot] = dest_tile;
       rank[first + slot] = place;
     }
   }
@@ -1481,10 +1499,11 @@ __global__ void __launch_bounds__(NT, round_waves_per_simd(KIND, TR, TC, NT, ALB
   // planes, not for one per pair of cells (four of them: ~6 us of the ~40 a sparse tile's
   // work-group lives).
   auto flush_cell = [&](int j, int& c, int64_t& l) {  // -> inside the tile, the slab's rows and the grid's columns
-    c = tid + j * kBlock;
-    const int lx = row0 + c / TC, y = col0 + c % TC;
+    const int cc = tid + j * kBlock;                  // c: where the cell's accumulators live in LDS
+    const int lx = row0 + cc / TC, y = col0 + cc % TC;
+    c = tile_cell(cc / TC, cc % TC);
     l = static_cast<int64_t>(lx) * k.W + y;
-    return c < kCells && lx >= 0 && y >= 0 && lx < static_cast<int>(d.rows) && y < k.W;
+    return cc < kCells && lx >= 0 && y >= 0 && lx < static_cast<int>(d.rows) && y < k.W;
   };
   // Four consecutive cells of a row per thread where the planes allow 16-byte accesses (the width a
   // multiple of four — tile columns and the half-tile shift are — and the planes aligned): the
@@ -1500,12 +1519,13 @@ __global__ void __launch_bounds__(NT, round_waves_per_simd(KIND, TR, TC, NT, ALB
     static_assert(kCells % 4 == 0 && TC % 4 == 0, "a group of four cells lies in one row of the tile");
     const float4* const sa4 = reinterpret_cast<const float4*>(s_a);
     const float4* const sv4 = reinterpret_cast<const float4*>(s_v);
-    auto group_at = [&](int j, int& gi, int64_t& l) {
-      gi = tid + j * kBlock;
-      const int c = 4 * gi;
+    auto group_at = [&](int j, int& gi, int64_t& l) {  // gi: the group's place in LDS (rows rotated, tile_cell)
+      const int gg = tid + j * kBlock;
+      const int c = 4 * gg;
       const int lx = row0 + c / TC, y = col0 + c % TC;
+      gi = tile_cell(c / TC, c % TC) >> 2;
       l = static_cast<int64_t>(lx) * k.W + y;
-      return gi < kGroups && lx >= 0 && y >= 0 && lx < static_cast<int>(d.rows) && y < k.W;
+      return gg < kGroups && lx >= 0 && y >= 0 && lx < static_cast<int>(d.rows) && y < k.W;
     };
     auto nz = [](float4 v) { return ((f2bits(v.x) | f2bits(v.y) | f2bits(v.z) | f2bits(v.w)) & 0x7fffffffu) != 0u; };
     if (store_all) {  // (see below)
@@ -1628,7 +1648,8 @@ __global__ void __launch_bounds__(NT, round_waves_per_simd(KIND, TR, TC, NT, ALB
       const int lx = row0 + cc / TC, y = col0 + cc % TC;
       if (lx < 0 || y < 0 || lx >= static_cast<int>(d.rows) || y >= k.W) continue;
       const int64_t l3 = 3 * (static_cast<int64_t>(lx) * k.W + y);
-      const float c0 = s_c0[cc], c1 = s_c1[cc], c2 = s_c2[cc];
+      const int sc = tile_cell(cc / TC, cc % TC);
+      const float c0 = s_c0[sc], c1 = s_c1[sc], c2 = s_c2[sc];
       if (c0 == 0.0f && c1 == 0.0f && c2 == 0.0f) continue;
       if (shared_tile) {
         atomicAdd(&fluxA[l3], c0);

@@ -109,95 +109,145 @@ __global__ void __launch_bounds__(kWinBlock)
 // __seed (graph.cu:97-101) + __random_weighted (:103-173): the per-cell
 // generator state is never materialised — cell n reads its one uniform straight
 // from stream (seed, subsequence n) at position `offset`.
+//
+// Arithmetic (round 4).  The reference computes the Gibbs weights with the fast intrinsic,
+// `P = __expf(dE / T)` (graph.cu:139) = ex2.approx(dE / T * log2 e): they are a tolerance by
+// construction, and so is every receiver whose draw lies within the weights' error
+// of a CDF edge.  The kernel therefore takes gfx950's counterpart of that intrinsic and nothing
+// dearer: one multiplication by the host-made constant log2(e) / (|shift| T) and one v_exp_f32
+// per neighbour, and the inverse-CDF test `u < CDF[k] / Z` (:160) as `u Z < CDF[k]` — no division.
+// (Round 3 kept the oracle's bits here: eight software exponentials and twenty IEEE divisions per
+// cell, ~570 vector instructions, 0.98 ms at 8192^2 = 7 % of the HBM roofline.)  The oracle keeps the
+// exact statement (expf_, IEEE divisions); the parity tests count the receivers that differ, bound
+// them (a few per million) and check that each of them sits on a CDF edge
+// (tests/test_gpu_parity.py::test_random_weighted_against_the_oracle).
+struct RwConst {  // log2(e) / (|shift_k| T) for the straight and the diagonal neighbours
+  float straight, diagonal;
+};
+inline RwConst rw_const(float T) {
+  const double log2e = 1.4426950408889634;
+  return RwConst{static_cast<float>(log2e / static_cast<double>(T)),
+                 static_cast<float>(log2e / (static_cast<double>(kSqrt2) * static_cast<double>(T)))};
+}
+// cumulative weights of a cell (:126-143): `hn[k]`, `ok[k]`: neighbour k's height, and whether it
+// lies in the grid.  A neighbour outside leaves CDF[k] at the running sum; it is never looked at.
 template <int K>
-__global__ void __launch_bounds__(kGBlock)
-    k_random_weighted(int32_t* __restrict__ graph, const float* __restrict__ height, int64_t H,
-                      int64_t W, uint64_t seed, uint64_t offset, float T) {
-  const int64_t y = static_cast<int64_t>(blockIdx.x) * kGBlock + threadIdx.x;
-  if (y >= W) return;
-  SOIL_ROW_LOOP(x, H) {
-    const int64_t n = x * W + y;
-    const float hlocal = height[n];  // :118
-    float CDF[K];                    // :126
-    float Z = 0.0f;                  // :127
+__device__ __forceinline__ float rw_cdf(float CDF[K], float hlocal, const float hn[K], const bool ok[K],
+                                        RwConst rc) {
+  float Z = 0.0f;  // :127
 #pragma unroll
-    for (int k = 0; k < K; ++k) {  // :129-143
-      CDF[k] = 0.0f;
-      const int64_t nx = x + kDX[k], ny = y + kDY[k];
-      if (nx < 0 || ny < 0 || nx >= H || ny >= W) continue;
-      const float dE = (hlocal - height[nx * W + ny]) / kShiftLen[k];  // :138
-      const float P = (dE <= 0.0f) ? 0.0f : expf_(dE / T);             // :139
-      CDF[k] = Z + P;                                                  // :140
-      Z += P;                                                          // :141
-    }
-    int32_t next = -1;                                                            // :149
-    const float uniform = rng_uniform_at(seed, static_cast<uint64_t>(n), offset);  // :100, :150
-    bool found = false;
-#pragma unroll
-    for (int k = 0; k < K; ++k) {  // :151-165
-      const int64_t nx = x + kDX[k], ny = y + kDY[k];
-      if (nx < 0 || ny < 0 || nx >= H || ny >= W) continue;
-      if (!found && uniform < (CDF[k] / Z)) {  // :160 (Z == 0 -> NaN -> false)
-        next = static_cast<int32_t>(nx * W + ny);
-        found = true;
-      }
-    }
-    graph[n] = next;  // :171
+  for (int k = 0; k < K; ++k) {
+    const float diff = hlocal - hn[k];  // :138 (the division by |shift| is part of the constant)
+    // :139 — `dE <= 0 ? 0 : exp(dE / T)`, NaN heights included (NaN <= 0 is false: the weight is NaN)
+    float P = (diff <= 0.0f) ? 0.0f : __builtin_amdgcn_exp2f(diff * (k < 4 ? rc.straight : rc.diagonal));
+    if (!ok[k]) P = 0.0f;
+    CDF[k] = Z + P;  // :140
+    Z += P;          // :141
   }
+  return Z;
+}
+// the receiver a draw picks (:149-171): the first neighbour in the grid with u < CDF[k] / Z
+template <int K>
+__device__ __forceinline__ int32_t rw_pick(const float CDF[K], float Z, const bool ok[K], const int32_t to[K],
+                                           float uniform) {
+  const float uz = uniform * Z;  // (Z == 0: 0 < 0 is false like NaN < x; Z = inf: inf < inf is)
+  int32_t next = -1;             // :149
+#pragma unroll
+  for (int k = K - 1; k >= 0; --k)  // the lowest k that passes wins
+    if (ok[k] && uz < CDF[k]) next = to[k];
+  return next;
 }
 
-// The same for kRwBatch realisations at once (soil_multiflow): the cumulative weights of a cell do
-// not depend on the draw, so the eight exponentials and the twenty divisions are made once and
-// only the Philox draw and the comparison against CDF / Z are repeated — per realisation the same
-// operations on the same values as k_random_weighted, hence the same graphs.
 constexpr int kRwBatch = 4;
-struct RwBatch {
-  int32_t* graph[kRwBatch];
+struct RwBatch {  // up to kRwBatch realisations per pass over the heights (soil_multiflow): the
+  int32_t* graph[kRwBatch];  // cumulative weights of a cell do not depend on the draw
   uint64_t offset[kRwBatch];
+  int n;
 };
+
+// one thread per cell (any width)
 template <int K>
 __global__ void __launch_bounds__(kGBlock)
-    k_random_weighted_batch(RwBatch b, const float* __restrict__ height, int64_t H, int64_t W,
-                            uint64_t seed, float T) {
+    k_random_weighted(RwBatch b, const float* __restrict__ height, int64_t H, int64_t W,
+                      uint64_t seed, RwConst rc) {
   const int64_t y = static_cast<int64_t>(blockIdx.x) * kGBlock + threadIdx.x;
   if (y >= W) return;
   SOIL_ROW_LOOP(x, H) {
     const int64_t n = x * W + y;
     const float hlocal = height[n];  // :118
-    float Q[K];                      // CDF[k] / Z, :160
+    float hn[K], CDF[K];
     bool ok[K];
     int32_t to[K];
-    float CDF[K];
-    float Z = 0.0f;  // :127
 #pragma unroll
-    for (int k = 0; k < K; ++k) {  // :129-143
-      CDF[k] = 0.0f;
+    for (int k = 0; k < K; ++k) {  // :129-137
       const int64_t nx = x + kDX[k], ny = y + kDY[k];
       ok[k] = !(nx < 0 || ny < 0 || nx >= H || ny >= W);
       to[k] = static_cast<int32_t>(nx * W + ny);
-      if (!ok[k]) continue;
-      const float dE = (hlocal - height[nx * W + ny]) / kShiftLen[k];  // :138
-      const float P = (dE <= 0.0f) ? 0.0f : expf_(dE / T);             // :139
-      CDF[k] = Z + P;                                                  // :140
-      Z += P;                                                          // :141
+      hn[k] = ok[k] ? height[nx * W + ny] : 0.0f;
     }
-#pragma unroll
-    for (int k = 0; k < K; ++k) Q[k] = CDF[k] / Z;
+    const float Z = rw_cdf<K>(CDF, hlocal, hn, ok, rc);
 #pragma unroll
     for (int m = 0; m < kRwBatch; ++m) {
-      int32_t next = -1;                                                                 // :149
+      if (m >= b.n) break;
       const float uniform = rng_uniform_at(seed, static_cast<uint64_t>(n), b.offset[m]);  // :100, :150
-      bool found = false;
-#pragma unroll
-      for (int k = 0; k < K; ++k) {  // :151-165
-        if (ok[k] && !found && uniform < Q[k]) {  // :160 (Z == 0 -> NaN -> false)
-          next = to[k];
-          found = true;
-        }
-      }
-      b.graph[m][n] = next;  // :171
+      b.graph[m][n] = rw_pick<K>(CDF, Z, ok, to, uniform);                                // :171
     }
   }
+}
+
+// four cells per thread, the neighbours from the thread's three-row window (window.hpp): the same
+// operations on the same values as the kernel above
+template <int K>
+__global__ void __launch_bounds__(kWinBlock)
+    k_random_weighted4(RwBatch b, const float* __restrict__ height, int64_t H, int64_t W, uint64_t seed,
+                       RwConst rc) {
+  const WinThread t = win_thread(W);
+  RowWalk w;
+  SOIL_WIN_ROWS(x, w, height, H, W, t.y0) {
+    int4 o[kRwBatch];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int64_t y = t.y0 + c;
+      const int32_t n = static_cast<int32_t>(x * W + y);
+      float hn[K], CDF[K];
+      bool ok[K];
+      int32_t to[K];
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const bool row_ok = kDX[k] < 0 ? w.has_up : (kDX[k] > 0 ? w.has_dn : true);
+        const bool col_ok = kDY[k] < 0 ? (c > 0 || t.y0 > 0) : (kDY[k] > 0 ? (c < 3 || t.y0 + 4 < W) : true);
+        const Row6& r = kDX[k] < 0 ? w.up : (kDX[k] > 0 ? w.dn : w.mid);
+        ok[k] = row_ok && col_ok;
+        hn[k] = r.v[c + 1 + kDY[k]];
+        to[k] = n + kDX[k] * static_cast<int32_t>(W) + kDY[k];
+      }
+      const float Z = rw_cdf<K>(CDF, w.mid.v[c + 1], hn, ok, rc);
+#pragma unroll
+      for (int m = 0; m < kRwBatch; ++m) {
+        if (m >= b.n) break;
+        const float uniform = rng_uniform_at(seed, static_cast<uint64_t>(n), b.offset[m]);
+        reinterpret_cast<int32_t*>(&o[m])[c] = rw_pick<K>(CDF, Z, ok, to, uniform);
+      }
+    }
+    if (t.live) {
+#pragma unroll
+      for (int m = 0; m < kRwBatch; ++m) {
+        if (m >= b.n) break;
+        *reinterpret_cast<int4*>(b.graph[m] + x * W + t.y0) = o[m];
+      }
+    }
+  }
+}
+
+template <int K>
+static void launch_random_weighted(const RwBatch& b, const float* height, int64_t H, int64_t W, uint64_t seed,
+                                   float T, hipStream_t st) {
+  bool aligned = W % 4 == 0 && W >= 4 && (reinterpret_cast<uintptr_t>(height) & 15) == 0;
+  for (int m = 0; m < b.n; ++m) aligned = aligned && (reinterpret_cast<uintptr_t>(b.graph[m]) & 15) == 0;
+  if (aligned)
+    k_random_weighted4<K><<<win_grid(H, W), kWinBlock, 0, st>>>(b, height, H, W, seed, rw_const(T));
+  else
+    k_random_weighted<K><<<grid_rows(H, W, kGBlock), kGBlock, 0, st>>>(b, height, H, W, seed, rw_const(T));
 }
 
 // __slope, graph.cu:270-295.  Threads along the row, a work-group walks a band of rows: the
@@ -520,6 +570,11 @@ static int accumulate_impl(float* out, const int32_t* graph, const float* source
       static_cast<int64_t>(std::ceil(std::log2(static_cast<float>(elem)) / 2.0f));  // :559
   const int first_flags[3] = {1, 0, 0};
   SOIL_HIP(hipMemcpyAsync(flags, first_flags, sizeof(first_flags), hipMemcpyHostToDevice, st));
+  // (Round 4: a variant with two / four / eight cells in flight per thread and the donors' words asked
+  // for in batches — three round trips per group of cells instead of four to six per cell — ran at
+  // 2.23-2.32 / 2.38-2.59 / 3.1 ms per 4096^2 realisation against 2.27-2.36 for this kernel: the
+  // rounds are not bound by the length of a thread's chain of loads.  profiles/r04_accumulate has
+  // their bytes: round 0 moves 51 B/cell at 2.4 TB/s, the 26 rounds 279 B/cell in 2.03 ms.)
   for (int64_t i = 0; i <= iter; ++i) {                                             // :560-563
     k_rake_compress<K><<<nb, kGBlock, 0, st>>>(B, A, elem, flags, static_cast<int>(2 * i));
     k_rake_compress<K><<<nb, kGBlock, 0, st>>>(A, B, elem, flags, static_cast<int>(2 * i + 1));
@@ -595,9 +650,11 @@ int soil_random_weighted(int32_t* graph, const float* height, int64_t H, int64_t
   SOIL_REQUIRE(graph && height, "random_weighted: null tensor");
   SOIL_REQUIRE(H > 0 && W > 0 && H * W <= INT32_MAX,
                "random_weighted: grid must have 1..2^31-1 cells");
+  RwBatch b{};
+  b.graph[0] = graph, b.offset[0] = offset, b.n = 1;
   switch (edge) {
-    case SOIL_D4: k_random_weighted<4><<<grid_rows(H, W, kGBlock), kGBlock, 0, as_stream(stream)>>>(graph, height, H, W, seed, offset, T); break;
-    case SOIL_D8: k_random_weighted<8><<<grid_rows(H, W, kGBlock), kGBlock, 0, as_stream(stream)>>>(graph, height, H, W, seed, offset, T); break;
+    case SOIL_D4: launch_random_weighted<4>(b, height, H, W, seed, T, as_stream(stream)); break;
+    case SOIL_D8: launch_random_weighted<8>(b, height, H, W, seed, T, as_stream(stream)); break;
     default: return fail(SOIL_ERR_INVALID_ARGUMENT, "invalid edge enumerator");  // graph.cu:192
   }
   SOIL_LAUNCH_CHECK();
@@ -659,11 +716,11 @@ int soil_multiflow(double* sum, const float* height, const float* source, int64_
       b.offset[m] = k;
     }
     const int made = m;
-    for (; m < kRwBatch; ++m) b.graph[m] = b.graph[0], b.offset[m] = b.offset[0];  // (a short last batch repeats its first)
+    b.n = made;
     if (edge == SOIL_D4)
-      k_random_weighted_batch<4><<<grid_rows(H, W, kGBlock), kGBlock, 0, st>>>(b, height, H, W, seed, T);
+      launch_random_weighted<4>(b, height, H, W, seed, T, st);
     else
-      k_random_weighted_batch<8><<<grid_rows(H, W, kGBlock), kGBlock, 0, st>>>(b, height, H, W, seed, T);
+      launch_random_weighted<8>(b, height, H, W, seed, T, st);
     SOIL_LAUNCH_CHECK();
     for (int j = 0; j < made; ++j) {
       if (int rc = soil_accumulate(acc, b.graph[j], source, nullptr, H, W, edge, stream); rc != SOIL_OK) return rc;

@@ -141,6 +141,31 @@ def test_accumulation_drains_every_cell_at_4096(hip):
         assert (acc.reshape(-1)[recv] > acc[f >= 0]).all()
 
 
+def test_random_weighted_receivers_at_2048(hip, oracle):
+    """BASELINE config 3's graph maker at size against the oracle's exact statement: the DEM of
+    dem_multiflow.py (heights of ~100 m, T = 10, D8), 4.2 M cells, two draws.  The receivers are equal
+    but for a counted few, each of them a draw on a CDF edge (util.assert_receivers_close).
+    (Widths that are not a multiple of four take the one-cell-per-thread kernel — the same operations on
+    the same values: tests/test_gpu_parity.py::test_flow_maps_bit_exact runs both.)"""
+    from soillib_amd import silt, soil
+    from util import assert_receivers_close
+    S = 2048
+    p = soil.noise_t()
+    p.seed = 5.0
+    p.ext = [S, S]
+    h = soil.noise(silt.shape(S, S), p, host=silt.gpu)
+    silt.multiply(h, 100.0)
+    hn = h.cpu().numpy()
+    oracle.set_threads(16)
+    differ = 0
+    for off in (0, 511):
+        got = soil.random_weighted(h, soil.d8, 0, off, 10.0).cpu().numpy()
+        want = oracle.random_weighted(hn, 1, 0, off, 10.0)
+        assert_receivers_close(oracle, got, want, hn, 8, 0, off, 10.0)
+        differ += int((got != want).sum())
+    print("random_weighted at 2048^2: %d of %d receivers differ from the oracle's" % (differ, 2 * S * S))
+
+
 def test_fill_depressions_properties_at_2048(hip):
     from soillib_amd import silt, soil
     S = 2048

@@ -14,7 +14,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from util import (assert_bit_equal, product_param, rng_to_gpu, script_param, terrain,
+from util import (assert_bit_equal, assert_receivers_close, product_param, rng_to_gpu, script_param, terrain,
                   to_gpu, to_np)
 
 pytestmark = pytest.mark.gpu
@@ -550,9 +550,9 @@ def test_flow_maps_bit_exact(hip, oracle, H, W, edge):
     gh = to_gpu(h)
     assert_bit_equal(to_np(soil.steepest(gh, edge)), oracle.steepest(h, edge), "steepest")
     assert_bit_equal(to_np(soil.direction(gh, edge)), oracle.direction(h, edge), "direction")
-    for off in (0, 7):
-        assert_bit_equal(to_np(soil.random_weighted(gh, edge, 3, off, 10.0)),
-                         oracle.random_weighted(h, edge, 3, off, 10.0), "random_weighted")
+    for off in (0, 7):   # (a tolerance on the weights, SURVEY 8 a9: counted, and only on CDF edges)
+        assert_receivers_close(oracle, to_np(soil.random_weighted(gh, edge, 3, off, 10.0)),
+                               oracle.random_weighted(h, edge, 3, off, 10.0), h, 4 if edge == D4 else 8, 3, off, 10.0)
     flow = oracle.steepest(h, edge)
     assert_bit_equal(to_np(soil.slope(gh, to_gpu(flow), (0.3, 0.7))),
                      oracle.slope(h, flow, (0.3, 0.7)), "slope")

@@ -92,3 +92,42 @@ def product_param(oracle_param):
     p = soil.param_t()
     copy_param(oracle_param, p._c)
     return p
+
+
+# ---- random_weighted: tolerance on the receiver ---------------------------
+
+_D8 = ((-1, 0), (0, -1), (0, 1), (1, 0), (-1, -1), (-1, 1), (1, -1), (1, 1))   # graph.hpp:21-46
+
+
+def assert_receivers_close(oracle, got, want, height, K, seed, offset, T, what="random_weighted",
+                           max_frac=2e-5, edge_tol=2e-5):
+    """The Gibbs weights of `random_weighted` are the reference's fast `__expf` (graph.cu:139): a
+    tolerance, and with them every receiver whose draw lies within their error of a CDF edge.  The
+    product's map must equal the oracle's but for a counted handful of cells, and each of those must
+    be such a cell: its two receivers neighbours in the cumulative order, the draw within `edge_tol`
+    of the edge between them (weights recomputed here in float64)."""
+    got = np.asarray(got)
+    want = np.asarray(want)
+    assert got.shape == want.shape, what
+    H, W = got.shape
+    bad = np.argwhere(got != want)
+    assert len(bad) <= max(1, int(max_frac * got.size)), "%s: %d of %d receivers differ" % (what, len(bad), got.size)
+    h = np.asarray(height, np.float64)
+    for x, y in bad:
+        n = int(x) * W + int(y)
+        u = float(oracle.rng_uniform(oracle.rng_seed(1, seed, offset), [n])[0])
+        idx, cdf, z = [], [], 0.0
+        for k in range(K):
+            nx, ny = x + _D8[k][0], y + _D8[k][1]
+            if nx < 0 or ny < 0 or nx >= H or ny >= W:
+                continue
+            dE = (h[x, y] - h[nx, ny]) / (1.0 if k < 4 else float(np.float32(np.sqrt(np.float32(2.0)))))
+            z += np.exp(dE / T) if dE > 0 else 0.0
+            idx.append(int(nx) * W + int(ny))
+            cdf.append(z)
+        assert z > 0, "%s: cell (%d, %d) has no downhill neighbour, receivers %d vs %d" % (what, x, y, got[x, y], want[x, y])
+        edges = [c / z for c in cdf]
+        near = [e for e, i in zip(edges, idx) if abs(u - e) <= edge_tol]
+        assert near, "%s: cell (%d, %d): receivers %d vs %d, draw %.9f, edges %s" % (
+            what, x, y, got[x, y], want[x, y], u, ["%.9f" % e for e in edges])
+        assert got[x, y] in idx + [-1] and want[x, y] in idx + [-1], what
