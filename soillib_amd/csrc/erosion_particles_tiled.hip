@@ -109,6 +109,9 @@ struct TiledCtl {
   // blocks of round r in slot r & 1: the scan at the tail of round r writes the other slot, which no
   // work-group of round r reads — stragglers beyond the round's count may still be arriving then
   uint32_t blocks_of[2];
+  // ... and of the sparse tiles of round r (k_tiled_round<..., SPARSE>): the entries of the block list
+  // behind the blocks_of[r & 1] dense ones
+  uint32_t sparse_of[2];
 };
 struct ScanRule {  // when the rounds stop (TiledRun::setup)
   uint32_t round, tail, max_round;
@@ -158,6 +161,12 @@ __device__ int soil_ablate = 0;
 // carrying a few idle lanes to the end of the round.  Only an ordering hint: any
 // section is a valid place for any particle.
 constexpr int kNB = 4;
+
+// sparse tiles (k_tiled_round<..., SPARSE>, below)
+constexpr int kSparseMax = 63;        // walkers: the four lowest buckets of the scan's histogram
+constexpr int kSparseTab = 1024, kSparseTabBits = 10, kSparseProbe = 16;
+constexpr uint32_t kSparseEmpty = 0xffffffffu;
+constexpr int kSparseLanes = 64;
 
 __device__ __forceinline__ uint32_t queue_key(int x0, float px, float py, float spx, float spy,
                                               uint32_t life, int tiles_w, TileShape ts, int K) {
@@ -690,6 +699,10 @@ struct QueueScan {
   // a round that stores its tiles (SOIL_FLUX_OVERWRITE) wants a work-group for an EMPTY tile too —
   // it stores the zeros (a slab's ghost rows hold whole tiles nobody spawns on)
   uint32_t include_empty;
+  // the round may hand its sparse tiles (fewer than 64 walkers: the last non-empty buckets of the
+  // dispatch order) to the one-wave kernel (k_tiled_round<..., SPARSE>); the scan decides whether it does
+  uint32_t sparse_ok;
+  uint32_t sparse_min, sparse_pct;  // ... when there are at least so many of them, and so many per cent of the non-empty tiles
 };
 constexpr int scan_lds_words(int nt) { return 16 * nt + 256 + 256 + 8 + 16; }
 
@@ -726,9 +739,11 @@ __device__ void queue_scan_dev(const QueueScan& q, uint32_t* lds) {
   };
   // the host spins on host->seq (TiledRun::wait_word): everything it reads is stored, and
   // fenced out to system scope, before the number
-  auto publish = [&](uint32_t blocks) {
+  // `blocks`: entries of the block list; the last `n_sparse` of them are the sparse kernel's
+  auto publish = [&](uint32_t blocks, uint32_t n_sparse) {
     ctl->blocks = blocks;
-    ctl->blocks_of[q.rule.round & 1u] = blocks;
+    ctl->blocks_of[q.rule.round & 1u] = blocks - n_sparse;
+    ctl->sparse_of[q.rule.round & 1u] = n_sparse;
     host->blocks = blocks;
     // words of later scans overwrite this one while the host may still be reading it: the verdict
     // is a single word, and what goes with it is out before it
@@ -825,6 +840,16 @@ __device__ void queue_scan_dev(const QueueScan& q, uint32_t* lds) {
   const uint32_t chunk_cap = misc[3];
   const bool cut = misc[2] > chunk_cap;  // some queue needs more than one work-group
   const uint32_t empty = hist[255];
+  // Sparse tiles (1 .. kSparseMax walkers) are the last four non-empty buckets of the order.  They go
+  // to the one-wave kernel when they are at least a quarter of the round's tiles (in the dense early
+  // rounds the handful there is does not pay for a launch that stands in front of the dense one).
+  static_assert(kSparseMax == 63, "buckets of 16 walkers: 251 .. 254 hold 1 .. 63");
+  uint32_t n_sparse = 0;
+  if (q.sparse_ok != 0u) {
+    n_sparse = hist[251] + hist[252] + hist[253] + hist[254];
+    const uint32_t nonempty = static_cast<uint32_t>(tiles) - empty;
+    if (n_sparse * 100u < nonempty * q.sparse_pct || n_sparse < q.sparse_min) n_sparse = 0;
+  }
   for (int64_t i = tid; i < tiles; i += NT) {
     const uint4 c = counts_of(i);
     const uint32_t t = c.x + c.y + c.z + c.w;
@@ -836,7 +861,7 @@ __device__ void queue_scan_dev(const QueueScan& q, uint32_t* lds) {
   if (!cut) {  // the common case on large grids: one work-group per non-empty tile
     if (tid == 0) {
       host->whole = (empty == 0 || q.include_empty != 0u) ? 1u : 0u;
-      publish(static_cast<uint32_t>(tiles) - (q.include_empty != 0u ? 0u : empty));
+      publish(static_cast<uint32_t>(tiles) - (q.include_empty != 0u ? 0u : empty), q.include_empty != 0u ? 0u : n_sparse);
     }
     return;
   }
@@ -872,7 +897,7 @@ __device__ void queue_scan_dev(const QueueScan& q, uint32_t* lds) {
     if (tid == NT - 1) misc[0] += misc[4];
     __syncthreads();
   }
-  if (tid == 0) publish(misc[0]);
+  if (tid == 0) publish(misc[0], n_sparse);
 }
 
 // the word the host waits for when the scan it belongs to does not take place (the rounds were
@@ -1145,8 +1170,19 @@ __device__ __forceinline__ uint32_t opaque(uint32_t x) {
   return x;
 }
 
-template <int KIND, int DEP, int TR, int TC, int NT, bool ALB>
-__global__ void __launch_bounds__(NT, round_waves_per_simd(KIND, TR, TC, NT, ALB))
+// SPARSE (round 4): the work-group of a tile that holds fewer than 64 walkers.  In the late rounds of a
+// launch most tiles do — the walkers sit in channels — and each of them used to hold 78 KiB of LDS
+// and a dozen wave slots for the 30-40 us its longest walker needs: the chip was full of waiting waves
+// (profiles/r04_stalls: 83-92 % of the wave slots taken in every round, the vector pipes issuing on
+// one cycle in 13-19).  A sparse tile's walkers touch a few hundred cells, so its accumulators are a
+// hash table keyed by the cell (kSparseTab entries: 20 KiB fluvial / 16 KiB debris) in the LDS of a
+// ONE-wave work-group: eight of them per CU where two tiles fitted.  Same walks, same deposits per
+// cell; a cell that finds no slot within kSparseProbe probes adds straight to the planes.  The scan
+// decides per round whether the sparse tiles get this kernel (QueueScan::sparse_ok, k sparse tiles in
+// four non-empty ones); it runs in front of the dense kernel of the round, on the same stream.
+
+template <int KIND, int DEP, int TR, int TC, int NT, bool ALB, bool SPARSE = false>
+__global__ void __launch_bounds__(NT, SPARSE ? 2 : round_waves_per_simd(KIND, TR, TC, NT, ALB))
     k_tiled_round(PRec* __restrict__ out, uint32_t* __restrict__ dest, uint32_t* __restrict__ rank,
                   uint32_t* count_next, const PRec* __restrict__ in,
                   const uint32_t* __restrict__ order, const uint4* block_list,
@@ -1165,8 +1201,13 @@ __global__ void __launch_bounds__(NT, round_waves_per_simd(KIND, TR, TC, NT, ALB
     if (blockIdx.x == 0 && threadIdx.x == 0 && next.host) scan_skipped(next);
     return;
   }
-  const uint32_t n_groups = ctl->blocks_of[round & 1u];
-  if (blockIdx.x >= n_groups) return;
+  static_assert(!SPARSE || (NT == kSparseLanes && !ALB && DEP == 1), "a sparse tile: one wave, no colour planes");
+  const uint32_t n_dense = ctl->blocks_of[round & 1u];
+  const uint32_t n_groups = SPARSE ? ctl->sparse_of[round & 1u] : n_dense;
+  // (no dense tile at all — every tile of the round went to the sparse kernel, which has run: it stands
+  // in front of this one on the stream — : the first work-group is the round's last, see below)
+  const bool all_sparse = !SPARSE && n_groups == 0u;
+  if (blockIdx.x >= n_groups && !(all_sparse && blockIdx.x == 0)) return;
   // taking turns with the other launch of the step (PairGate): the last work-group of the round to
   // start — every one has been handed out, what follows is the round's tail — lets the other's next
   // round in
@@ -1185,7 +1226,7 @@ __global__ void __launch_bounds__(NT, round_waves_per_simd(KIND, TR, TC, NT, ALB
   };
   PROF_DECL;
   // this work-group's share of its tile's queue (the scan's block list)
-  const uint4 job = block_list[blockIdx.x];
+  const uint4 job = block_list[(SPARSE ? n_dense : 0u) + blockIdx.x];
   const int tile = static_cast<int>(job.x);
   const uint32_t first = job.y, cnt = job.z;
   const bool shared_tile = job.w != 0;  // other work-groups deposit into the same cells
@@ -1200,8 +1241,21 @@ __global__ void __launch_bounds__(NT, round_waves_per_simd(KIND, TR, TC, NT, ALB
   // scratch of the scan of the round that follows (queue_scan_dev)
   constexpr int kA = (KIND == FLUVIAL) ? 2 : 1;  // floats of s_a per cell
   constexpr int kAcc = kA * kCells + 2 * kCells + (ALB ? 3 * kCells : 0);
-  constexpr int kWords = kAcc > scan_lds_words(NT) ? kAcc : scan_lds_words(NT);
+  constexpr int kFluxPlanesL = (KIND == FLUVIAL) ? 4 : 3;
+  constexpr int kWords = SPARSE ? kSparseTab * (1 + kFluxPlanesL)
+                                : (kAcc > scan_lds_words(NT) ? kAcc : scan_lds_words(NT));
   __shared__ __attribute__((aligned(16))) float s_mem[kWords];
+  // SPARSE: the table — kSparseTab keys (the cell's index in the tile; kSparseEmpty: free), then one
+  // array of kSparseTab sums per flux plane, in deposit_terms' order
+  uint32_t* const t_key = reinterpret_cast<uint32_t*>(s_mem);
+  float* const t_val = s_mem + kSparseTab;
+  if constexpr (!SPARSE) {
+    if (all_sparse) {  // uniform: nothing to walk, the scan of the round that follows is this work-group's
+      if (my_dense && threadIdx.x == 0) __hip_atomic_store(my_dense, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (next.host) queue_scan_dev<NT>(next, reinterpret_cast<uint32_t*>(s_mem));
+      return;
+    }
+  }
   float* const s_a = s_mem;                                  // water | mass (fluvial), mass (debris)
   float* const s_v = s_mem + kA * kCells;                    // velocity flux x | y interleaved
   float* const s_c0 = s_v + 2 * kCells;                      // colour (ALB)
@@ -1238,15 +1292,26 @@ __global__ void __launch_bounds__(NT, round_waves_per_simd(KIND, TR, TC, NT, ALB
   if (have) r = in[order[first + tid]];
   uint32_t gate_ticket = 0;
   if (gate_lane) gate_ticket = gate_draw();
+  if constexpr (SPARSE) {
+    uint4* const t4 = reinterpret_cast<uint4*>(s_mem);
 #pragma unroll
-  for (int j = 0; j < kPer; ++j) {
-    const int c = tid + j * kBlock;
-    if (kCells % NT != 0 && c >= kCells) break;
-    s_a[kA * c] = 0.0f;
-    if (KIND == FLUVIAL) s_a[2 * c + 1] = 0.0f;
-    s_v[2 * c] = 0.0f;
-    s_v[2 * c + 1] = 0.0f;
-    if (ALB) s_c0[c] = s_c1[c] = s_c2[c] = 0.0f;
+    for (int j = 0; j < kWords / 4 / NT; ++j) {
+      const int i = tid + j * NT;
+      const uint32_t w = i < kSparseTab / 4 ? kSparseEmpty : 0u;
+      t4[i] = make_uint4(w, w, w, w);
+    }
+    static_assert(kWords % (4 * NT) == 0, "the table is cleared in whole 16-byte rounds of the wave");
+  } else {
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+      const int c = tid + j * kBlock;
+      if (kCells % NT != 0 && c >= kCells) break;
+      s_a[kA * c] = 0.0f;
+      if (KIND == FLUVIAL) s_a[2 * c + 1] = 0.0f;
+      s_v[2 * c] = 0.0f;
+      s_v[2 * c + 1] = 0.0f;
+      if (ALB) s_c0[c] = s_c1[c] = s_c2[c] = 0.0f;
+    }
   }
   __syncthreads();
   if (gate_lane) gate_look(gate_ticket);
@@ -1272,7 +1337,7 @@ __global__ void __launch_bounds__(NT, round_waves_per_simd(KIND, TR, TC, NT, ALB
   constexpr int kSkew = SOIL_LDS_SKEW;
   static_assert(kSkew % 4 == 0 && (TC & (TC - 1)) == 0, "tile columns: a power of two; skew: whole groups");
   auto tile_cell = [](int tr, int tc) {
-    return kSkew == 0 ? tr * TC + tc : tr * TC + ((tc + kSkew * tr) & (TC - 1));
+    return (kSkew == 0 || SPARSE) ? tr * TC + tc : tr * TC + ((tc + kSkew * tr) & (TC - 1));
   };
   const int tr_org = r_lo - row0, tc_org = c_lo - col0;  // tile row / column of (r_lo, c_lo)
   const uint32_t l_org = static_cast<uint32_t>(r_lo) * k.Wu + static_cast<uint32_t>(c_lo);  // its local cell index
@@ -1312,6 +1377,34 @@ __global__ void __launch_bounds__(NT, round_waves_per_simd(KIND, TR, TC, NT, ALB
       const float att = (KIND == FLUVIAL) ? r.a1 : r.a0;
       v[kFluxPlanes] = att * r.sa0, v[kFluxPlanes + 1] = att * r.sa1, v[kFluxPlanes + 2] = att * r.sa2;
       pp[kFluxPlanes] = &s_c0[c], pp[kFluxPlanes + 1] = &s_c1[c], pp[kFluxPlanes + 2] = &s_c2[c];
+    }
+  };
+  // SPARSE: what the walker adds, into the table slot of tile cell `c` (found or taken by a
+  // compare-and-swap on the key; linear probing); `lcell`: the cell's index in the planes, for the
+  // deposit that finds the table full around its hash
+  auto sparse_deposit = [&](int c, uint32_t lcell, const float* v) {
+    uint32_t slot = (static_cast<uint32_t>(c) * 2654435761u) >> (32 - kSparseTabBits);
+    bool placed = false;
+    for (int t = 0; t < retries; ++t) {  // (SPARSE: `retries` carries the probe count, kSparseProbe unless a test says otherwise)
+      const uint32_t old = atomicCAS(&t_key[slot], kSparseEmpty, static_cast<uint32_t>(c));
+      if (old == kSparseEmpty || old == static_cast<uint32_t>(c)) {
+        placed = true;
+        break;
+      }
+      slot = (slot + 1u) & static_cast<uint32_t>(kSparseTab - 1);
+    }
+    if (placed) {
+#pragma unroll
+      for (int j = 0; j < kFluxPlanes; ++j) atomicAdd(&t_val[j * kSparseTab + slot], v[j]);
+    } else if (KIND == FLUVIAL) {
+      atomicAdd(&flux0[lcell], v[0]);
+      atomicAdd(&flux1[lcell], v[1]);
+      atomicAdd(&fluxV[lcell].x, v[2]);
+      atomicAdd(&fluxV[lcell].y, v[3]);
+    } else {
+      atomicAdd(&fluxV[lcell].x, v[0]);
+      atomicAdd(&fluxV[lcell].y, v[1]);
+      atomicAdd(&flux0[lcell], v[2]);
     }
   };
   PROF_AT(8);  // prologue: flux tile zeroed, first records loaded
@@ -1377,8 +1470,10 @@ __global__ void __launch_bounds__(NT, round_waves_per_simd(KIND, TR, TC, NT, ALB
           float v[kFluxPlanes + 3];
           float* pp[kFluxPlanes + 3];
           deposit_terms(c, v, pp);
+          if constexpr (SPARSE) sparse_deposit(c, lcell, v);
 #pragma unroll
           for (int j = 0; j < kFluxPlanes + (ALB ? 3 : 0); ++j) {
+            if (SPARSE) break;
             if (ABLATED(4)) {
               *pp[j] = v[j];
             } else if (DEP == 1) {
@@ -1388,7 +1483,7 @@ __global__ void __launch_bounds__(NT, round_waves_per_simd(KIND, TR, TC, NT, ALB
               atomicAdd(pp[j], v[j]);
             }
           }
-          if (DEP == 1 && !ABLATED(4)) {
+          if (DEP == 1 && !ABLATED(4) && !SPARSE) {
             if (KIND == FLUVIAL) {
               dep.load();  // the old words travel while the geometry of the step is worked out
             } else {
@@ -1410,7 +1505,7 @@ __global__ void __launch_bounds__(NT, round_waves_per_simd(KIND, TR, TC, NT, ALB
         PROF_AT(4);  // the step's arithmetic
       }
       runm &= ~__builtin_amdgcn_ballot_w64(opaque(v_norm) < k.eps);  // ... the same exit, for the wave
-      if (DEP == 1) dep.finish(opaque(lost_bits), c, agg_min, agg_groups, retries);
+      if (DEP == 1 && !SPARSE) dep.finish(opaque(lost_bits), c, agg_min, agg_groups, retries);
       PROF_AT(5);  // deposit finished
     }
     const bool run = __builtin_amdgcn_inverse_ballot_w64(runm);
@@ -1438,9 +1533,14 @@ __global__ void __launch_bounds__(NT, round_waves_per_simd(KIND, TR, TC, NT, ALB
             r.ind = nind;
             float v[kFluxPlanes + 3];
             float* pp[kFluxPlanes + 3];
-            deposit_terms(tile_cell(tr_org + static_cast<int>(dr), tc_org + static_cast<int>(dc)), v, pp);
+            const int cn = tile_cell(tr_org + static_cast<int>(dr), tc_org + static_cast<int>(dc));
+            deposit_terms(cn, v, pp);
+            if constexpr (SPARSE) {
+              sparse_deposit(cn, lcell, v);
+            } else {
 #pragma unroll
-            for (int j = 0; j < kFluxPlanes + (ALB ? 3 : 0); ++j) atomicAdd(pp[j], v[j]);
+              for (int j = 0; j < kFluxPlanes + (ALB ? 3 : 0); ++j) atomicAdd(pp[j], v[j]);
+            }
           }
           if (!advance<KIND>(r, q, k)) {  // :121-122 / :326-327
             have = false;
@@ -1511,7 +1611,55 @@ __global__ void __launch_bounds__(NT, round_waves_per_simd(KIND, TR, TC, NT, ALB
   // work-group holds its tile; by groups of four it is a third of that.  A group none of whose
   // cells took a deposit is left alone; in a group that is read, a cell is added to exactly when the
   // cell-by-cell flush adds to it, so the planes hold the same bits either way.
-  const bool flush_vec = (k.W & 3) == 0 && !shared_tile && !ALB &&
+  if constexpr (SPARSE) {
+    // The table's cells go out one by one: the old words of a thread's occupied slots asked for together
+    // (device-scope loads: a deposit that found the table full has added to the planes behind this
+    // CU's vector cache), then added to and stored.  Nobody else touches this tile's cells in this
+    // round, and the round's dense kernel starts when this one is over.
+    constexpr int kTPer = kSparseTab / NT;
+    float g[kTPer][kFluxPlanes];
+    uint32_t key[kTPer];
+#pragma unroll
+    for (int j = 0; j < kTPer; ++j) {
+      const int i = tid + j * NT;
+      key[j] = t_key[i];
+#pragma unroll
+      for (int q = 0; q < kFluxPlanes; ++q) g[j][q] = 0.0f;
+      if (key[j] == kSparseEmpty) continue;
+      const int64_t l = static_cast<int64_t>(row0 + static_cast<int>(key[j]) / TC) * k.W + (col0 + static_cast<int>(key[j]) % TC);
+      float* const fv = reinterpret_cast<float*>(fluxV + l);
+      if (KIND == FLUVIAL) {
+        g[j][0] = __hip_atomic_load(flux0 + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        g[j][1] = __hip_atomic_load(flux1 + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        g[j][2] = __hip_atomic_load(fv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        g[j][3] = __hip_atomic_load(fv + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        g[j][0] = __hip_atomic_load(fv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        g[j][1] = __hip_atomic_load(fv + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        g[j][2] = __hip_atomic_load(flux0 + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < kTPer; ++j) {
+      const int i = tid + j * NT;
+      if (key[j] == kSparseEmpty) continue;
+      const int64_t l = static_cast<int64_t>(row0 + static_cast<int>(key[j]) / TC) * k.W + (col0 + static_cast<int>(key[j]) % TC);
+      float a[kFluxPlanes];
+#pragma unroll
+      for (int q = 0; q < kFluxPlanes; ++q) a[q] = t_val[q * kSparseTab + i];
+      // (the dense flush's conditions, cell for cell: a plane is added to where its sum is not zero,
+      // the velocity pair where either half is)
+      if (KIND == FLUVIAL) {
+        if (a[0] != 0.0f) flux0[l] = g[j][0] + a[0];
+        if (a[1] != 0.0f) flux1[l] = g[j][1] + a[1];
+        if (a[2] != 0.0f || a[3] != 0.0f) fluxV[l] = make_float2(g[j][2] + a[2], g[j][3] + a[3]);
+      } else {
+        if (a[2] != 0.0f) flux0[l] = g[j][2] + a[2];
+        if (a[0] != 0.0f || a[1] != 0.0f) fluxV[l] = make_float2(g[j][0] + a[0], g[j][1] + a[1]);
+      }
+    }
+  }
+  const bool flush_vec = !SPARSE && (k.W & 3) == 0 && !shared_tile && !ALB &&
                          ((reinterpret_cast<uintptr_t>(flux0) | reinterpret_cast<uintptr_t>(flux1) |
                            reinterpret_cast<uintptr_t>(fluxV)) & 15u) == 0;
   if (flush_vec) {
@@ -1589,6 +1737,8 @@ __global__ void __launch_bounds__(NT, round_waves_per_simd(KIND, TR, TC, NT, ALB
                                                                 add2(gvb[j].z, vb.z, vb.w), add2(gvb[j].w, vb.w, vb.z));
       }
     }
+  } else if (SPARSE) {
+    // (done above)
   } else if (store_all) {
     // The first round of a launch that was told to OVERWRITE the flux planes (soil_erode_step's
     // lazy mode: the cell phase did not re-zero them): every tile has exactly one work-group, the
@@ -1675,6 +1825,7 @@ __global__ void __launch_bounds__(NT, round_waves_per_simd(KIND, TR, TC, NT, ALB
   // a returning atomic whose answer this work-group has stored by now (barrier above), so it is
   // done before the ticket is drawn; the scan reads the counts with device-scope loads.  Everything
   // else the round writes (records, ranks, flux) is for later kernels.
+  if constexpr (SPARSE) return;  // (the round's ticket and scan belong to the dense kernel behind this one)
   if (!next.host) return;  // uniform: the scan is a launch of its own (SOIL_TILED_TAILSCAN=2)
   if (!done_drawn) done_draw();  // (an empty chunk of a cut queue)
   if (tid == 0) s_last = done_ticket == n_groups - 1u ? 1u : 0u;
@@ -1792,6 +1943,17 @@ static void launch_shape(unsigned grid, hipStream_t st, A... a) {
   static_assert(round_lds_bytes(KIND, S.tr, S.tc, ALB) <= kLdsPerCU, "tile does not fit the LDS");
   k_tiled_round<KIND, DEP, S.tr, S.tc, S.nt, ALB><<<grid, S.nt, 0, st>>>(a...);
 }
+// the one-wave kernel of the sparse tiles of a round (same tile geometry as the round's dense shape)
+template <int KIND, int SH, typename... A>
+static void launch_sparse_shape(unsigned grid, hipStream_t st, A... a) {
+  constexpr RoundShape S = Shapes<KIND>::v[SH];
+  k_tiled_round<KIND, 1, S.tr, S.tc, kSparseLanes, false, true><<<grid, kSparseLanes, 0, st>>>(a...);
+}
+template <int KIND, typename... A>
+static void launch_sparse(int shape, unsigned grid, hipStream_t st, A... a) {
+  if (shape == kShapeFull) launch_sparse_shape<KIND, kShapeFull>(grid, st, a...);
+  else launch_sparse_shape<KIND, 0>(grid, st, a...);  // shapes 0 and 1: 64 x 64 tiles
+}
 // work-groups of a shape's kernel one CU holds, as the runtime sees it
 template <int KIND, int SH, bool ALB>
 static int shape_occupancy() {
@@ -1889,6 +2051,9 @@ struct TiledRun {
   int steps_of(uint64_t r) const { return (steps_late > 0 && r >= static_cast<uint64_t>(steps_late_from)) ? steps_late : steps_per_round; }
   // the tile grid of round r: shifted by half a tile on odd rounds (TileShape)
   bool stagger = true;
+  bool sparse_ok = false;  // rounds >= 1 may hand their sparse tiles to the one-wave kernel (SOIL_TILED_SPARSE=2: off)
+  int sparse_min = 64, sparse_pct = 25;  // SOIL_TILED_SPARSE_MIN, _PCT: see QueueScan
+  int sparse_probe = kSparseProbe;       // SOIL_TILED_SPARSE_PROBE: slots a deposit tries before it adds to the planes directly
   int agg_min = 48, agg_groups = 4, retries = 2;
   PRec* recs_of(uint64_t r) const { return (r & 1) ? next : cur; }               // records round r reads
   uint32_t* count_of(uint64_t r) const { return (r & 1) ? count_next : count; }   // section counts round r's scan reads
@@ -1953,6 +2118,10 @@ struct TiledRun {
     // (fluvial, in the overlapped 8192^2 step at the end of round 3: 40 / 44 / 48 steps 33.30 / 32.90 / 33.06 ms
     // per step, four runs each on one box; by itself the launch does not tell them apart)
     steps_per_round = env_kind("SOIL_TILED_STEPS", KIND, KIND == FLUVIAL ? 44 : (shape_early == kShapeFull ? 40 : 32));
+    sparse_ok = deposit == 0 && !fluxA && env_kind("SOIL_TILED_SPARSE", KIND, 1) == 1;
+    sparse_probe = env_kind("SOIL_TILED_SPARSE_PROBE", KIND, kSparseProbe);
+    sparse_min = env_kind("SOIL_TILED_SPARSE_MIN", KIND, 64);
+    sparse_pct = env_kind("SOIL_TILED_SPARSE_PCT", KIND, 25);
     steps_late = env_kind("SOIL_TILED_STEPS_LATE", KIND, 0);
     steps_late_from = env_kind("SOIL_TILED_LATE_FROM", KIND, 1 << 30);
     // A round is worth its fixed cost while it advances particles faster than the
@@ -2078,6 +2247,9 @@ struct TiledRun {
     q.rule.max_round = max_round > 0xffffffffull ? 0xffffffffu : static_cast<uint32_t>(max_round);
     q.rule.ticks_per_step_max = static_cast<float>(ticks_per_second / finish_rate);
     q.include_empty = (r == 0 && overwrite && !fluxA && deposit == 0) ? 1u : 0u;
+    q.sparse_ok = (r >= 1 && sparse_ok && shape_of(r) != kShapeColour) ? 1u : 0u;
+    q.sparse_min = static_cast<uint32_t>(sparse_min);
+    q.sparse_pct = static_cast<uint32_t>(sparse_pct);
     return q;
   }
   // the scan of round 0 (the queues the spawn filled) is a kernel of its own; every later one runs at
@@ -2157,11 +2329,29 @@ struct TiledRun {
     // as many work-groups as a round can have (a tile each, plus the chunks long queues are cut into);
     // those beyond the scan's count return at once
     const int slots = resident_groups[r >= static_cast<uint64_t>(switch_round) ? 1 : 0];
-    const unsigned grid = static_cast<unsigned>(std::min<int64_t>(tiles + slots, std::max<int64_t>(live_known, 1)));
+    // (a round that stores its tiles has a work-group for every tile, the empty ones included,
+    // however few walkers there are: advisor finding of round 3)
+    const unsigned grid = (r == 0 && overwrite)
+                              ? static_cast<unsigned>(tiles + slots)
+                              : static_cast<unsigned>(std::min<int64_t>(tiles + slots, std::max<int64_t>(live_known, 1)));
     PRec* in = recs_of(r);
     PRec* out = recs_of(r + 1);
     uint32_t* my_dense = nullptr;
     static const uint32_t gate_early = static_cast<uint32_t>(std::min(100, std::max(0, env_int("SOIL_PAIR_EARLY", 20))));
+    QueueScan no_scan{};  // (the sparse kernel leaves the round's ticket and scan to the dense one)
+    no_scan.host = nullptr;
+    if (r >= 1 && sparse_ok && sh != kShapeColour) {
+      // the sparse tiles of the round, if its scan made any (ctl->sparse_of): in front of the gate —
+      // eight one-wave work-groups fit a CU beside whatever the other launch has there
+      const unsigned grid_sparse = static_cast<unsigned>(std::min<int64_t>(tiles, std::max<int64_t>(live_known, 1)));
+      launch_sparse<KIND>(sh, grid_sparse, st, out, dest, rank, count_of(r + 1), static_cast<const PRec*>(in),
+                          static_cast<const uint32_t*>(order), static_cast<const uint4*>(block_list), flux0, flux1,
+                          reinterpret_cast<float2*>(fluxV), fluxA, static_cast<const float4*>(p4), remote0, steps_run,
+                          d, s, p, tiles_w, ts_cur.off_r, ts_cur.off_c, steps_of(r), ts_of(sh_next, r + 1),
+                          tiles_w_of(sh_next, r + 1), agg_min, agg_groups, sparse_probe, 0, ctl, static_cast<uint32_t>(r),
+                          no_scan, static_cast<uint32_t*>(nullptr), 0u);
+      SOIL_LAUNCH_CHECK();
+    }
     if (gate && tail_scan) {  // (the `started` ticket is reset by the tail scan's work-group)
       k_pair_gate<<<1, 1, 0, st>>>(gate, KIND, ctl, static_cast<unsigned long long>(0.05 * ticks_per_second));
       SOIL_LAUNCH_CHECK();
@@ -2170,6 +2360,7 @@ struct TiledRun {
     QueueScan next_scan = make_scan(r + 1);
     const QueueScan standalone = next_scan;
     if (!tail_scan) next_scan.host = nullptr;  // the round kernel leaves the scan to a launch of its own
+
     if (deposit == 1)
       launch_round<KIND, 0>(sh, grid, st, out, dest, rank, count_of(r + 1),
                             static_cast<const PRec*>(in), static_cast<const uint32_t*>(order),

@@ -335,15 +335,21 @@ def _flux_close(got, want, what):
     assert (np.abs(got[want == 0]) <= 1e-30 * scale).all(), what + ": different set of visited cells"
 
 
-@pytest.fixture(params=["direct", "staged", "tiled", "tiled-full", "tiled-panels"])
+@pytest.fixture(params=["direct", "staged", "tiled", "tiled-full", "tiled-panels", "tiled-sparse", "tiled-sparse-full"])
 def particle_mode(request, hip, monkeypatch):
     """The launch shapes of the particle kernels (soil_set_particle_mode).  "tiled-full": the tiled
     shape with the LDS-filling tiles (78 / 104 rows) that large grids get by default;
-    "tiled-panels": with the queue scan of grids of more than 16384 tiles."""
+    "tiled-panels": with the queue scan of grids of more than 16384 tiles; "tiled-sparse": sparse tiles
+    (fewer than 64 walkers) on the one-wave kernel with its hashed accumulators, however few they are."""
     if request.param == "tiled-full":
         monkeypatch.setenv("SOIL_TILED_SHAPE", "3")
     if request.param == "tiled-panels":
         monkeypatch.setenv("SOIL_TILED_PANELS", "1")
+    if request.param.startswith("tiled-sparse"):   # every tile of under 64 walkers through the one-wave kernel, from round 1 on
+        monkeypatch.setenv("SOIL_TILED_SPARSE_MIN", "1")
+        monkeypatch.setenv("SOIL_TILED_SPARSE_PCT", "1")
+    if request.param == "tiled-sparse-full":       # ... whose table takes a cell only where its hash points:
+        monkeypatch.setenv("SOIL_TILED_SPARSE_PROBE", "1")   # colliding cells add to the planes directly
     assert hip.soil_set_particle_mode(1 if request.param == "direct" else 2 if request.param == "staged" else 3) == 0
     yield request.param
     hip.soil_set_particle_mode(0)
