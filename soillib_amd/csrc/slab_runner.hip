@@ -134,13 +134,22 @@ struct soil_slab {
   }
   // every rank's k small non-negative ints, as out[rank * k + i]: one all-reduce of a zero-padded
   // vector (any wire that can sum will do); blocks until the host has them
-  int all_ints(const int* mine, int k, std::vector<int>& out) {
+  // `with_remote0`: the 8 sums of remote0 (the NaN walkers' deposits for global cell (0,0)) ride behind
+  // the ints in the same all-reduce and stay on the device, at remote_sum()
+  float* remote_sum() const { return ints + static_cast<int64_t>(world) * 4; }
+  int all_ints(const int* mine, int k, std::vector<int>& out, bool with_remote0 = false) {
     const int64_t n = static_cast<int64_t>(world) * k;
     std::vector<float> h(static_cast<size_t>(n), 0.0f);
     for (int i = 0; i < k; ++i) h[static_cast<size_t>(rank) * k + i] = static_cast<float>(mine[i]);
     SLAB_TRY(ops->from_host(ops->ctx, ints, h.data(), n * 4));
+    int64_t total = n;
+    if (with_remote0) {  // (k == 4: the ints fill the block in front of remote_sum())
+      SLAB_TRY(ops->fill_f32(ops->ctx, remote_sum(), 0.0f, 8, 0));
+      SLAB_TRY(ops->add_f32(ops->ctx, remote_sum(), remote0, 8, 0));
+      total = static_cast<int64_t>(world) * 4 + 8;
+    }
     if (host_ordered) SLAB_TRY(ops->sync(ops->ctx));
-    SLAB_TRY(comm->all_reduce_sum_f32(comm->ctx, ints, n, stream(0)));
+    SLAB_TRY(comm->all_reduce_sum_f32(comm->ctx, ints, total, stream(0)));
     SLAB_TRY(ops->to_host(ops->ctx, h.data(), ints, n * 4));
     out.resize(static_cast<size_t>(n));
     for (int64_t i = 0; i < n; ++i) out[static_cast<size_t>(i)] = static_cast<int>(h[static_cast<size_t>(i)] + 0.5f);
@@ -220,6 +229,25 @@ struct soil_slab {
     const int mine[2] = {depth[0], depth[1]};
     return all_ints(mine, 2, all);
   }
+  // ... of both launches of the overlapped pair in ONE exchange (round 4: it was two, each with its
+  // blocking read-back), the NaN walkers' sums riding along: all[4 k .. 4 k + 3] = rank k's fluvial
+  // (above, below), debris (above, below)
+  int reach_pair(std::vector<int>& rf, std::vector<int>& rd) {
+    int32_t df[2] = {0, 0}, dd[2] = {0, 0};
+    for (int i = 0; i < 3; ++i)
+      SLAB_TRY(ops->ghost_extent(ops->ctx, P[soil::kFluxFluvial[i]], lay.rows, row_floats(soil::kFluxFluvial[i]), lay.r0, lay.r1, df));
+    for (int i = 0; i < 2; ++i)
+      SLAB_TRY(ops->ghost_extent(ops->ctx, P[soil::kFluxDebris[i]], lay.rows, row_floats(soil::kFluxDebris[i]), lay.r0, lay.r1, dd));
+    const int mine[4] = {df[0], df[1], dd[0], dd[1]};
+    std::vector<int> all;
+    SLAB_TRY(all_ints(mine, 4, all, true));
+    rf.assign(static_cast<size_t>(2 * world), 0), rd.assign(static_cast<size_t>(2 * world), 0);
+    for (int k = 0; k < world; ++k) {
+      rf[static_cast<size_t>(2 * k)] = all[static_cast<size_t>(4 * k)], rf[static_cast<size_t>(2 * k + 1)] = all[static_cast<size_t>(4 * k + 1)];
+      rd[static_cast<size_t>(2 * k)] = all[static_cast<size_t>(4 * k + 2)], rd[static_cast<size_t>(2 * k + 1)] = all[static_cast<size_t>(4 * k + 3)];
+    }
+    return SOIL_OK;
+  }
   // Did a launch, on any rank, get within a row of ghost rows that were not refreshed?  (The cell
   // record of ghost row d is made of rows d - 1 .. d + 1.)  The same answer on every rank.
   bool too_deep(const std::vector<int>& r, bool debris = false) const {
@@ -296,6 +324,7 @@ struct soil_slab {
     SLAB_TRY(ops->rng_seed(ops->ctx, rng, N, seed, off));
     SLAB_TRY(ops->fill_f32(ops->ctx, remote0, 0.0f, 8, 0));
     bool early = false;  // the fluvial planes' halo went out before the debris launch ended
+    bool remote_summed = false;  // the NaN walkers' sums rode with the reach exchange (remote_sum())
     Counts cf{}, cd{};
     std::vector<int> rf, rd;
     mk(0);
@@ -306,8 +335,8 @@ struct soil_slab {
       SLAB_TRY(ops->rng_seed(ops->ctx, rng_debris, N, seed, off + 2));
       SLAB_TRY(ops->particles_pair(ops->ctx, &pl, rng, rng_debris, N, remote0, &dom, scale, &param));
       if (trim) {
-        SLAB_TRY(reach(soil::kFluxFluvial, 3, rf));
-        SLAB_TRY(reach(soil::kFluxDebris, 2, rd));
+        SLAB_TRY(reach_pair(rf, rd));
+        remote_summed = true;
         // a fluvial walk reads layers, velocity, waterHeight; a debris walk layers and debrisVelocity
         if (too_deep(rf) || too_deep(rd) || too_deep(rd, true)) {  // rare: both launches again, on complete fields
           SLAB_TRY(refresh_all());
@@ -317,8 +346,7 @@ struct soil_slab {
           SLAB_TRY(ops->rng_seed(ops->ctx, rng, N, seed, off));
           SLAB_TRY(ops->rng_seed(ops->ctx, rng_debris, N, seed, off + 2));
           SLAB_TRY(ops->particles_pair(ops->ctx, &pl, rng, rng_debris, N, remote0, &dom, scale, &param));
-          SLAB_TRY(reach(soil::kFluxFluvial, 3, rf));
-          SLAB_TRY(reach(soil::kFluxDebris, 2, rd));
+          SLAB_TRY(reach_pair(rf, rd));
         }
         cf = counts_of(rf), cd = counts_of(rd);
         note_reach(rf, rd);
@@ -367,14 +395,19 @@ struct soil_slab {
       SLAB_TRY(ops->cells(ops->ctx, &pl, &dom, scale, &param));
     } else {
       // NaN walkers of the other ranks -> global cell (0,0) (8 floats, latency only)
-      if (host_ordered) SLAB_TRY(ops->sync(ops->ctx));
-      SLAB_TRY(comm->all_reduce_sum_f32(comm->ctx, remote0, 8, stream(0)));
+      const float* sums = remote0;
+      if (remote_summed) {
+        sums = remote_sum();
+      } else {
+        if (host_ordered) SLAB_TRY(ops->sync(ops->ctx));
+        SLAB_TRY(comm->all_reduce_sum_f32(comm->ctx, remote0, 8, stream(0)));
+      }
       if (rank == 0) {
-        SLAB_TRY(ops->add_f32(ops->ctx, P[soil::kWaterFlux], remote0 + 0, 1, 0));
-        SLAB_TRY(ops->add_f32(ops->ctx, P[soil::kMassFlux], remote0 + 1, 1, 0));
-        SLAB_TRY(ops->add_f32(ops->ctx, P[soil::kVelocityFlux], remote0 + 2, 2, 0));
-        SLAB_TRY(ops->add_f32(ops->ctx, P[soil::kDebrisFlux], remote0 + 4, 1, 0));
-        SLAB_TRY(ops->add_f32(ops->ctx, P[soil::kDebrisVelocityFlux], remote0 + 5, 2, 0));
+        SLAB_TRY(ops->add_f32(ops->ctx, P[soil::kWaterFlux], sums + 0, 1, 0));
+        SLAB_TRY(ops->add_f32(ops->ctx, P[soil::kMassFlux], sums + 1, 1, 0));
+        SLAB_TRY(ops->add_f32(ops->ctx, P[soil::kVelocityFlux], sums + 2, 2, 0));
+        SLAB_TRY(ops->add_f32(ops->ctx, P[soil::kDebrisFlux], sums + 4, 1, 0));
+        SLAB_TRY(ops->add_f32(ops->ctx, P[soil::kDebrisVelocityFlux], sums + 5, 2, 0));
       }
       // rows whose flux is complete without the neighbours' contribution
       const int64_t i0 = std::min(lay.r1, lay.r0 + (up >= 0 ? peer_ghost(up) : 0));
@@ -405,10 +438,18 @@ struct soil_slab {
         int64_t nu, nd, du, dd;
         predict_need(reach_hist, nu, nd);
         predict_need(reach_hist_debris, du, dd);
-        const int mine[4] = {static_cast<int>(nu), static_cast<int>(nd), static_cast<int>(du), static_cast<int>(dd)};
-        std::vector<int> wants;
-        SLAB_TRY(all_ints(mine, 4, wants));
-        auto of = [&](int k, int i) { return static_cast<int64_t>(wants[static_cast<size_t>(4 * k + i)]); };
+        // What the others want needs no exchange: the history holds the reach over ALL ranks (the same
+        // numbers everywhere), and a rank's ghost depths follow from its place in the world (round 4:
+        // this was a third blocking all-reduce per step).
+        auto of = [&](int k, int i) {
+          const soil::Layout l = soil::slab_layout(k, world, S, G);
+          const int64_t ghost = (i & 1) ? l.rows - l.r1 : l.r0;
+          const std::vector<int>& hist = i < 2 ? reach_hist : reach_hist_debris;
+          if (hist.empty()) return ghost;
+          int64_t want = static_cast<int64_t>(1.1 * *std::max_element(hist.begin(), hist.end())) + 10;
+          if (halo_need > 0) want = halo_need;
+          return std::min(ghost, want);
+        };
         fc = Counts{nu, nd, up >= 0 ? of(up, 1) : 0, down >= 0 ? of(down, 0) : 0};
         fd = Counts{du, dd, up >= 0 ? of(up, 3) : 0, down >= 0 ? of(down, 2) : 0};
         fcp = &fc, fdp = &fd;
@@ -865,7 +906,8 @@ int soil_slab_create(soil_slab** out, const soil_slab_config* cfg, const soil_pa
   }
   if (int rc = ops->alloc(ops->ctx, &q, 8 * 4); rc != SOIL_OK) return bail(rc);
   s->remote0 = static_cast<float*>(q);
-  if (int rc = ops->alloc(ops->ctx, &q, static_cast<int64_t>(s->world) * 4 * 4); rc != SOIL_OK) return bail(rc);
+  // (world * 4 small ints, and behind them the 8 sums of the NaN walkers' deposits: one all-reduce carries both)
+  if (int rc = ops->alloc(ops->ctx, &q, (static_cast<int64_t>(s->world) * 4 + 8) * 4); rc != SOIL_OK) return bail(rc);
   s->ints = static_cast<float*>(q);
   if (cfg->init) {
     if (int rc = ops->alloc(ops->ctx, &q, s->lay.rows * s->W * 4); rc != SOIL_OK) return bail(rc);
