@@ -164,7 +164,10 @@ constexpr int kNB = 4;
 
 // sparse tiles (k_tiled_round<..., SPARSE>, below)
 constexpr int kSparseMax = 63;        // walkers: the four lowest buckets of the scan's histogram
-constexpr int kSparseTab = 1024, kSparseTabBits = 10, kSparseProbe = 16;
+#ifndef SOIL_SPARSE_TAB_BITS
+#define SOIL_SPARSE_TAB_BITS 8  // 1024 / 512 / 256 / 128 / 64 entries: 32.13 32.21 31.92 | 31.35 31.53 31.68 ms per 8192^2 step (two boxes)
+#endif
+constexpr int kSparseTabBits = SOIL_SPARSE_TAB_BITS, kSparseTab = 1 << kSparseTabBits, kSparseProbe = 16;
 constexpr uint32_t kSparseEmpty = 0xffffffffu;
 constexpr int kSparseLanes = 64;
 
@@ -1179,8 +1182,8 @@ __device__ __forceinline__ uint32_t opaque(uint32_t x) {
 // and a dozen wave slots for the 30-40 us its longest walker needs: the chip was full of waiting waves
 // (profiles/r04_stalls: 83-92 % of the wave slots taken in every round, the vector pipes issuing on
 // one cycle in 13-19).  A sparse tile's walkers touch a few hundred cells, so its accumulators are a
-// hash table keyed by the cell (kSparseTab entries: 20 KiB fluvial / 16 KiB debris) in the LDS of a
-// ONE-wave work-group: eight of them per CU where two tiles fitted.  Same walks, same deposits per
+// hash table keyed by the cell (kSparseTab = 256 entries: 5 KiB fluvial / 4 KiB debris) in the LDS of a
+// ONE-wave work-group: thirty of them per CU where two tiles fitted.  Same walks, same deposits per
 // cell; a cell that finds no slot within kSparseProbe probes adds straight to the planes.  The scan
 // decides per round whether the sparse tiles get this kernel (QueueScan::sparse_ok, k sparse tiles in
 // four non-empty ones); it runs in front of the dense kernel of the round, on the same stream.
@@ -1299,12 +1302,12 @@ __global__ void __launch_bounds__(NT, SPARSE ? 2 : round_waves_per_simd(KIND, TR
   if constexpr (SPARSE) {
     uint4* const t4 = reinterpret_cast<uint4*>(s_mem);
 #pragma unroll
-    for (int j = 0; j < kWords / 4 / NT; ++j) {
+    for (int j = 0; j < (kWords / 4 + NT - 1) / NT; ++j) {
       const int i = tid + j * NT;
       const uint32_t w = i < kSparseTab / 4 ? kSparseEmpty : 0u;
-      t4[i] = make_uint4(w, w, w, w);
+      if (i < kWords / 4) t4[i] = make_uint4(w, w, w, w);
     }
-    static_assert(kWords % (4 * NT) == 0, "the table is cleared in whole 16-byte rounds of the wave");
+    static_assert(kWords % 4 == 0 && kSparseTab % 4 == 0, "the table is cleared 16 bytes at a time");
   } else {
 #pragma unroll
     for (int j = 0; j < kPer; ++j) {
@@ -1620,13 +1623,13 @@ __global__ void __launch_bounds__(NT, SPARSE ? 2 : round_waves_per_simd(KIND, TR
     // (device-scope loads: a deposit that found the table full has added to the planes behind this
     // CU's vector cache), then added to and stored.  Nobody else touches this tile's cells in this
     // round, and the round's dense kernel starts when this one is over.
-    constexpr int kTPer = kSparseTab / NT;
+    constexpr int kTPer = (kSparseTab + NT - 1) / NT;
     float g[kTPer][kFluxPlanes];
     uint32_t key[kTPer];
 #pragma unroll
     for (int j = 0; j < kTPer; ++j) {
       const int i = tid + j * NT;
-      key[j] = t_key[i];
+      key[j] = i < kSparseTab ? t_key[i] : kSparseEmpty;
 #pragma unroll
       for (int q = 0; q < kFluxPlanes; ++q) g[j][q] = 0.0f;
       if (key[j] == kSparseEmpty) continue;
@@ -2074,6 +2077,14 @@ struct TiledRun {
            ((d.rows + ts_of(sh, r).off_r + Shapes<KIND>::v[sh].tr - 1) / Shapes<KIND>::v[sh].tr);
   }
 
+  static int64_t resident_groups_hint() {  // work-groups of the LDS-filling round kernel the chip holds (2 per CU)
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
+      (void)hipGetLastError();
+      cus = 256;
+    }
+    return 2 * static_cast<int64_t>(cus);
+  }
   int setup() {
     // steps a particle may take per round: bounds the time a work-group waits for
     // its longest walker
@@ -2122,7 +2133,15 @@ struct TiledRun {
     // (fluvial, in the overlapped 8192^2 step at the end of round 3: 40 / 44 / 48 steps 33.30 / 32.90 / 33.06 ms
     // per step, four runs each on one box; by itself the launch does not tell them apart)
     steps_per_round = env_kind("SOIL_TILED_STEPS", KIND, KIND == FLUVIAL ? 44 : (shape_early == kShapeFull ? 40 : 32));
-    sparse_ok = deposit == 0 && !fluxA && env_kind("SOIL_TILED_SPARSE", KIND, 1) == 1;
+    // Worth its launch in front of every round only where a round is many generations of work-groups:
+    // measured on one box, ms per step with | without: 1024^2 1.48 | 1.45, 2048^2 4.44 | 4.17, 4096^2
+    // 9.11 | 8.99, 8192^2 31.97 | 32.23 — on from 16 tiles per resident work-group slot (SOIL_TILED_SPARSE=1
+    // forces it on, 2 off; the parity tests force it on small grids)
+    {
+      const int sparse_env = env_kind("SOIL_TILED_SPARSE", KIND, 0);
+      const bool by_size = tiles_of(shape_early, 0) >= 16 * static_cast<int64_t>(resident_groups_hint());
+      sparse_ok = deposit == 0 && !fluxA && (sparse_env == 1 || (sparse_env == 0 && by_size));
+    }
     sparse_probe = env_kind("SOIL_TILED_SPARSE_PROBE", KIND, kSparseProbe);
     sparse_min = env_kind("SOIL_TILED_SPARSE_MIN", KIND, 64);
     sparse_pct = env_kind("SOIL_TILED_SPARSE_PCT", KIND, 25);

@@ -346,6 +346,7 @@ def particle_mode(request, hip, monkeypatch):
     if request.param == "tiled-panels":
         monkeypatch.setenv("SOIL_TILED_PANELS", "1")
     if request.param.startswith("tiled-sparse"):   # every tile of under 64 walkers through the one-wave kernel, from round 1 on
+        monkeypatch.setenv("SOIL_TILED_SPARSE", "1")
         monkeypatch.setenv("SOIL_TILED_SPARSE_MIN", "1")
         monkeypatch.setenv("SOIL_TILED_SPARSE_PCT", "1")
     if request.param == "tiled-sparse-full":       # ... whose table takes a cell only where its hash points:

@@ -2,10 +2,11 @@
 # Kernel timeline of the last step of a sequential-launch bench run: every kernel of the two particle
 # launches in stream order with its duration (the round kernels tagged dense / sparse).
 #   gpurun -- 'tools/trace_rounds.sh gpurun_out/r04_trace [extra env assignments]'
+#   BENCH_ARGS="--size 1024 --steps 3 --warmup 300" picks another workload (default: the sequential 8192^2 step)
 out=/root/repo/${1:-gpurun_out/r04_trace}; shift
 rm -rf $out; mkdir -p $out
 cd /tmp; export TMPDIR=/tmp
-env "$@" rocprofv3 --kernel-trace --output-format csv -d $out/t -o p -- python /root/repo/bench.py --steps 2 --warmup 1 --no-cpu-baseline --sequential-particles > /dev/null 2>&1
+env "$@" rocprofv3 --kernel-trace --output-format csv -d $out/t -o p -- python /root/repo/bench.py ${BENCH_ARGS:---steps 2 --warmup 1 --sequential-particles} --no-cpu-baseline > /dev/null 2>&1
 cd /root/repo
 python - <<PY > $out/rounds.txt
 import csv, glob, re
@@ -25,4 +26,4 @@ for r in rows[lo:ends[-1] + 1]:
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
     print("%9.1f us  +%8.1f us  %s" % ((s - t0) / 1e3, (e - s) / 1e3, name))
 PY
-cat $out/rounds.txt | grep -v "k_pair_gate\|k_fold" | head -120
+cat $out/rounds.txt | grep -v "k_fold" | head -${TRACE_LINES:-120}
