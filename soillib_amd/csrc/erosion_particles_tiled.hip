@@ -2132,7 +2132,12 @@ struct TiledRun {
     // (debris on its 104-row tiles, round 3: 32 / 40 / 48 steps 11.05 / 10.78 / 10.77 ms per launch)
     // (fluvial, in the overlapped 8192^2 step at the end of round 3: 40 / 44 / 48 steps 33.30 / 32.90 / 33.06 ms
     // per step, four runs each on one box; by itself the launch does not tell them apart)
-    steps_per_round = env_kind("SOIL_TILED_STEPS", KIND, KIND == FLUVIAL ? 44 : (shape_early == kShapeFull ? 40 : 32));
+    // (round 4, with the cheaper epilogue and the sparse tiles' kernel: fluvial 36 / 40 / 44 / 48 / 52 / 56 / 60 /
+    // 64 / 68 / 72 steps 32.2 32.0 31.5 31.6 31.3 31.4 31.5 31.1 31.3 31.4 ms per overlapped 8192^2 step, one box;
+    // 4096^2 9.14 -> 8.99 at 64; 2048^2 4.00 -> 4.18 and 1024^2 1.65 -> 1.76: the 64-row tiles keep 44.
+    // Debris 32 / 40 / 48 / 56: 31.8 31.5 31.5 31.8)
+    steps_per_round = env_kind("SOIL_TILED_STEPS", KIND, KIND == FLUVIAL ? (shape_early == kShapeFull ? 64 : 44)
+                                                                         : (shape_early == kShapeFull ? 40 : 32));
     // Worth its launch in front of every round only where a round is many generations of work-groups:
     // measured on one box, ms per step with | without: 1024^2 1.48 | 1.45, 2048^2 4.44 | 4.17, 4096^2
     // 9.11 | 8.99, 8192^2 31.97 | 32.23 — on from 16 tiles per resident work-group slot (SOIL_TILED_SPARSE=1
