@@ -163,7 +163,11 @@ __device__ int soil_ablate = 0;
 constexpr int kNB = 4;
 
 // sparse tiles (k_tiled_round<..., SPARSE>, below)
-constexpr int kSparseMax = 63;        // walkers: the four lowest buckets of the scan's histogram
+#ifndef SOIL_SPARSE_BUCKETS
+#define SOIL_SPARSE_BUCKETS 4
+#endif
+constexpr int kSparseBuckets = SOIL_SPARSE_BUCKETS;   // the lowest buckets (16 walkers each) of the scan's histogram
+constexpr int kSparseMax = 16 * kSparseBuckets - 1;   // walkers; more than 64 of them: the wave refills from the queue
 #ifndef SOIL_SPARSE_TAB_BITS
 #define SOIL_SPARSE_TAB_BITS 8  // 1024 / 512 / 256 / 128 / 64 entries: 32.13 32.21 31.92 | 31.35 31.53 31.68 ms per 8192^2 step (two boxes)
 #endif
@@ -846,10 +850,10 @@ __device__ void queue_scan_dev(const QueueScan& q, uint32_t* lds) {
   // Sparse tiles (1 .. kSparseMax walkers) are the last four non-empty buckets of the order.  They go
   // to the one-wave kernel when they are at least a quarter of the round's tiles (in the dense early
   // rounds the handful there is does not pay for a launch that stands in front of the dense one).
-  static_assert(kSparseMax == 63, "buckets of 16 walkers: 251 .. 254 hold 1 .. 63");
   uint32_t n_sparse = 0;
   if (q.sparse_ok != 0u) {
-    n_sparse = hist[251] + hist[252] + hist[253] + hist[254];
+#pragma unroll
+    for (int b = 0; b < kSparseBuckets; ++b) n_sparse += hist[254 - b];  // buckets of 16 walkers: 254 holds 1 .. 15
     const uint32_t nonempty = static_cast<uint32_t>(tiles) - empty;
     if (n_sparse * 100u < nonempty * q.sparse_pct || n_sparse < q.sparse_min) n_sparse = 0;
   }

@@ -1,8 +1,8 @@
 #!/bin/bash
 # Collects everything profiles/<name>/ holds, on the GPU box:
-#   gpurun --timeout 2400 -- 'tools/profile_final.sh r03_final'
-# then, back in the container:  python tools/profile_post.py r03_final
-name=${1:-r03_final}
+#   gpurun --timeout 2400 -- 'tools/profile_final.sh r04_final'
+# then, back in the container:  python tools/profile_post.py r04_final
+name=${1:-r04_final}
 out=/root/repo/gpurun_out/$name; rm -rf $out; mkdir -p $out
 cd /tmp; export TMPDIR=/tmp
 python /root/repo/bench.py --steps 10 --warmup 2 2>/dev/null | tail -1 > $out/bench_line.json

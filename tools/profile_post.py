@@ -9,7 +9,7 @@ import shutil
 import sys
 
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
-name = sys.argv[1] if len(sys.argv) > 1 else "r03_final"
+name = sys.argv[1] if len(sys.argv) > 1 else "r04_final"
 src = os.path.join(ROOT, "gpurun_out", name)
 dst = os.path.join(ROOT, "profiles", name)
 os.makedirs(dst, exist_ok=True)
@@ -122,7 +122,8 @@ for kind, label in ((0, "fluvial_rounds"), (1, "debris_rounds")):
     for i, (a, b) in enumerate(zip(ra, rb)):
         cyc = a["GRBM_GUI_ACTIVE"] / 8
         rows.append({
-            "round": i, "duration_us": round(a["dur_us"], 1), "shader_clock_ghz": round(cyc / a["dur_us"] / 1e3, 2),
+            "round": i, "kernel": "sparse tiles (one wave, hashed accumulators)" if a["name"].rstrip(">").endswith("true") else "dense tiles",
+            "duration_us": round(a["dur_us"], 1), "shader_clock_ghz": round(cyc / a["dur_us"] / 1e3, 2),
             "SQ_INSTS_VALU": a["SQ_INSTS_VALU"], "SQ_INSTS_VALU_TRANS_F32": a["SQ_INSTS_VALU_TRANS_F32"],
             "active_inst_valu_x4_per_cycle": round(4 * a["SQ_ACTIVE_INST_VALU"] / (1024 * cyc), 3),
             "cycles_per_valu_instruction": round(1024 * cyc / a["SQ_INSTS_VALU"], 2),
