@@ -115,8 +115,10 @@ summary = {
 for kind, label in ((0, "fluvial_rounds"), (1, "debris_rounds")):
     # (round kernels queued ahead of the device's decision to stop return at once: not launches of a round)
     skipped = {c["id"] for c in valu if "k_tiled_round<%d" % kind in c["name"] and c.get("SQ_INSTS_VALU", 0) < 1e4}
-    ra = [c for c in valu if "k_tiled_round<%d" % kind in c["name"] and c.get("SQ_INSTS_VALU", 0) >= 1e4]
-    rb = [c for c in lds if "k_tiled_round<%d" % kind in c["name"] and c.get("SQ_INSTS_LDS", 0) > 0]
+    # (... and the sparse tiles' kernel of a round whose scan made none: a few us of work-groups that return)
+    real = lambda c: "k_tiled_round<%d" % kind in c["name"] and c.get("dur_us", 0.0) >= 20.0
+    ra = [c for c in valu if real(c)]
+    rb = [c for c in lds if real(c)]
     ra, rb = ra[len(ra) // 2:], rb[len(rb) // 2:]
     rows = []
     for i, (a, b) in enumerate(zip(ra, rb)):
@@ -160,7 +162,7 @@ roof = {}
 mix_ok = os.path.isdir(os.path.join(src, "mix"))
 mix = load("mix") if mix_ok else []
 for kind, label in ((0, "fluvial_rounds"), (1, "debris_rounds")):
-    rows = [c for c in mix if "k_tiled_round<%d" % kind in c["name"] and c.get("SQ_INSTS_VALU", 0) >= 1e4]
+    rows = [c for c in mix if "k_tiled_round<%d" % kind in c["name"] and c.get("dur_us", 0.0) >= 20.0]
     rows = rows[len(rows) // 2:]
     if not rows:
         continue
