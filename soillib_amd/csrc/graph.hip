@@ -574,7 +574,12 @@ static int accumulate_impl(float* out, const int32_t* graph, const float* source
   // for in batches — three round trips per group of cells instead of four to six per cell — ran at
   // 2.23-2.32 / 2.38-2.59 / 3.1 ms per 4096^2 realisation against 2.27-2.36 for this kernel: the
   // rounds are not bound by the length of a thread's chain of loads.  profiles/r04_accumulate has
-  // their bytes: round 0 moves 51 B/cell at 2.4 TB/s, the 26 rounds 279 B/cell in 2.03 ms.)
+  // their bytes: round 0 moves 51 B/cell at 2.4 TB/s, the 26 rounds 279 B/cell in 2.03 ms.  Nor by the
+  // number of their memory instructions or of the sectors their gathers touch: with a cell's count,
+  // value, first slot and first decay in ONE 16-byte record — one gather per donor instead of up to four,
+  // five memory instructions per pending cell instead of ten to twelve, the same bytes — the realisation
+  // took the same 2.28 ms; with the record kept as a mirror beside the arrays (16 bytes more written per
+  // pending cell and round) 3.08 ms.  Bytes are what a round costs, at ~2.4 TB/s.)
   for (int64_t i = 0; i <= iter; ++i) {                                             // :560-563
     k_rake_compress<K><<<nb, kGBlock, 0, st>>>(B, A, elem, flags, static_cast<int>(2 * i));
     k_rake_compress<K><<<nb, kGBlock, 0, st>>>(A, B, elem, flags, static_cast<int>(2 * i + 1));
