@@ -103,10 +103,15 @@ def _run(hip, oracle, H, W, steps, warm_steps=0):
                               ("debrisVelocity", "dv"), ("mass", "m"), ("debris", "d")):
                 want = st[key]
                 tol = dict(rtol=1e-4, atol=1e-5 * (np.nanmax(np.abs(want)) + 1e-30))
-                np.testing.assert_allclose(to_np(getattr(forced, name)), want,
-                                           err_msg="step %d forced %s" % (step, name), **tol)
+                _close_but_for_stray_walks(to_np(getattr(forced, name)), want, tol["rtol"], tol["atol"], 2e-6,
+                                           "step %d forced %s" % (step, name))   # (same walks: see below)
+                # (The first compared step walks the same trajectories on both sides; its fields still
+                # differ by the order in which a cell's deposits were added up, which changes from run to run
+                # — lost swaps, cut queues, the two launches overlapped.  Where a channel cell's deposits of
+                # opposite sign cancel, that noise goes with the terms, not with the sum: one cell of 4.2 M
+                # landed outside the tolerance in 2 of 40 runs of the 4096 x 512 strip.  A handful is allowed.)
                 _close_but_for_stray_walks(to_np(getattr(free, name)), want, tol["rtol"], tol["atol"],
-                                           0.0 if step == first else 2e-3,
+                                           2e-6 if step == first else 2e-3,
                                            "step %d free-running %s" % (step, name))
     finally:
         oracle.set_threads(1)
