@@ -55,6 +55,7 @@
 #include <vector>
 
 #include "particles_common.hpp"
+#include "window.hpp"
 
 namespace soil {
 
@@ -88,6 +89,15 @@ struct TiledHostWord {  // pinned, device-mapped
   uint32_t whole;   // 1: one work-group per tile and no tile empty (the round's flush may store, see `store_all`)
   uint32_t mode;    // TiledCtl::mode after this scan
   uint32_t stop_round;  // the round at which mode left 0 (valid when mode != 0)
+  // `live` of the scan with sequence number q, at [q % kLiveRing].  The host runs up to `depth` rounds
+  // ahead of the words it has read, so by the time it looks at the word of scan r the device may have
+  // written the words of scans r + 1 and r + 2 over it — and `live` of a LATER scan is too small a
+  // bound for the grids of the rounds the host queues next (a slot sort or a round kernel launched with
+  // fewer work-groups than the round has: walkers dropped).  Found by the eight-process run of
+  // BASELINE config 5 on one GPU, where the hosts lag behind a time-sliced device (round 4; the single
+  // `live` above was read since round 3's run-ahead).  One scan in kLiveRing writes a slot.
+  static constexpr uint32_t kLiveRing = 16;
+  uint32_t live_ring[kLiveRing];
 };
 
 // What the DEVICE decides between two rounds, and what the kernels of the following rounds look at
@@ -462,6 +472,109 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// The pair pass with four cells per thread (round 4; widths that are a multiple of four, 16-byte
+// aligned planes).  __glocal only ever looks at the SUM of a cell's two layers: the thread keeps the
+// heights of three rows of its four cells (+ one column either side, from the neighbouring lanes) in
+// registers, walks down a band of rows and evaluates glocal_from_heights on them — the operations
+// and the order of the pass above, so the same records bit for bit — with 16-byte loads of every
+// plane and the two records of its four cells (64 bytes each) handed through a wave-private 4 KiB of
+// LDS so that a store instruction of the wave covers 1 KiB of consecutive bytes.  The pass above
+// issues five 8-byte gathers of the layer plane per cell and ran at 4.5 TB/s (0.9 ms at 8192^2, in
+// front of everything else of the step).
+struct HRow6 {
+  float v[6];  // heights of columns y0 - 1 .. y0 + 4 of one row; NaN: outside the grid (the reference's sentinel)
+};
+__device__ __forceinline__ HRow6 load_hrow6(const float2* __restrict__ layers, int64_t lx, bool row_ok, int64_t W,
+                                            int64_t y0) {
+  const int lane = static_cast<int>(threadIdx.x & 63u);
+  const float nan = __builtin_nanf("");
+  float c[4] = {nan, nan, nan, nan};
+  const float2* row = layers + lx * W;
+  if (row_ok) {
+    const float4 a = *reinterpret_cast<const float4*>(row + y0), b = *reinterpret_cast<const float4*>(row + y0 + 2);
+    c[0] = a.x + a.y, c[1] = a.z + a.w, c[2] = b.x + b.y, c[3] = b.z + b.w;
+  }
+  float l = __shfl_up(c[3], 1, 64), r = __shfl_down(c[0], 1, 64);
+  if (lane == 0 && row_ok && y0 > 0) {
+    const float2 v = row[y0 - 1];
+    l = v.x + v.y;
+  }
+  if (lane == 63 && row_ok && y0 + 4 < W) {
+    const float2 v = row[y0 + 4];
+    r = v.x + v.y;
+  }
+  if (y0 == 0) l = nan;       // (also what a lane past the row's end must not hand to its neighbour)
+  if (y0 + 4 >= W) r = nan;
+  return HRow6{{l, c[0], c[1], c[2], c[3], r}};
+}
+__global__ void __launch_bounds__(kWinBlock)
+    k_tiled_pack_pair4(float4* __restrict__ q_fluvial, float4* __restrict__ q_debris,
+                       const float2* __restrict__ layers, const float2* __restrict__ velocity,
+                       const float* __restrict__ waterHeight, const float2* __restrict__ debrisVelocity,
+                       Dom d, Scale3 s, Param param, int64_t row_lo, int64_t row_end) {
+  __shared__ float4 s_tile[kWinBlock / 64][256];
+  const WinThread t = win_thread(d.W);
+  const int lane = static_cast<int>(threadIdx.x & 63u);
+  float4* const tile = s_tile[threadIdx.x >> 6];
+  const float g = param.gravity;
+  auto row_in_grid = [&](int64_t lx) { return d.x0 + lx >= 0 && d.x0 + lx < d.H; };
+  for (int64_t band = blockIdx.y; row_lo + band * kWinBand < row_end; band += gridDim.y) {
+    const int64_t x_first = row_lo + band * kWinBand;
+    const int64_t x_last = x_first + kWinBand < row_end ? x_first + kWinBand : row_end;
+    HRow6 up = load_hrow6(layers, x_first - 1, row_in_grid(x_first - 1), d.W, t.y0);
+    HRow6 mid = load_hrow6(layers, x_first, true, d.W, t.y0);
+    for (int64_t lx = x_first; lx < x_last; ++lx) {
+      const HRow6 dn = load_hrow6(layers, lx + 1, row_in_grid(lx + 1), d.W, t.y0);
+      const int64_t n0 = lx * d.W + t.y0;
+      const float4 va = *reinterpret_cast<const float4*>(velocity + n0), vb = *reinterpret_cast<const float4*>(velocity + n0 + 2);
+      const float4 da = *reinterpret_cast<const float4*>(debrisVelocity + n0), db = *reinterpret_cast<const float4*>(debrisVelocity + n0 + 2);
+      const float4 wh4 = *reinterpret_cast<const float4*>(waterHeight + n0);
+      const float velx[4] = {va.x, va.z, vb.x, vb.z}, vely[4] = {va.y, va.w, vb.y, vb.w};
+      const float dvx[4] = {da.x, da.z, db.x, db.z}, dvy[4] = {da.y, da.w, db.y, db.w};
+      const float wh[4] = {wh4.x, wh4.y, wh4.z, wh4.w};
+      float4 qf[4], qd[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float2 grad = glocal_from_heights(mid.v[c + 1], up.v[c + 1], dn.v[c + 1], mid.v[c], mid.v[c + 2], s,
+                                                param.exitSlope);
+        const float glen = length2(grad.x, grad.y);
+        {  // the fluvial record, as k_tiled_pack<FLUVIAL>
+          const float nu = param.viscosityWater;
+          const float fD = param.frictionFactor / 8.0f;  // :70
+          const float eps = 1E-12f;
+          const float v = length2(velx[c], vely[c]);                       // :83
+          const float shear = 0.125f * fD * param.densityWater * v * v;    // :84
+          const float power = powf_(shear * glen, param.fluvialExponent);  // :85
+          qf[c] = make_float4(-(g * grad.x) + nu * velx[c], -(g * grad.y) + nu * vely[c], 0.125f * fD / (eps + wh[c]), power);
+        }
+        {  // the debris record, as k_tiled_pack<DEBRIS>
+          const float nu = param.viscosityDebris;
+          qd[c] = make_float4(-(g * grad.x) + nu * dvx[c], -(g * grad.y) + nu * dvy[c], glen - param.critSlopeBedrock, 0.0f);
+        }
+      }
+      // 64 bytes per lane and plane -> 1 KiB-contiguous stores through the wave's tile
+      const int n_real = 4 * __popcll(__ballot(t.live));  // float4s of the wave that are real (live lanes are a prefix)
+      const int64_t wave_n0 = n0 - 4 * lane;              // the first cell of the wave's lane 0
+      auto put = [&](float4* plane, const float4* q) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) tile[4 * lane + c] = q[c];
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's own writes have landed
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float4 v = tile[j * 64 + lane];
+          if (j * 64 + lane < n_real) plane[wave_n0 + j * 64 + lane] = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+      };
+      put(q_fluvial, qf);
+      put(q_debris, qd);
+      up = mid;
+      mid = dn;
+    }
+  }
+}
+
 // ---- spawn: draws, ownership, trajectory initialisation (erosion.cu:49-96 / :262-302)
 
 template <int KIND>
@@ -832,6 +945,7 @@ __device__ void queue_scan_dev(const QueueScan& q, uint32_t* lds) {
     const uint32_t total = misc[0];
     start[tiles * kNB] = total;  // particles queued in total
     host->live = total;
+    host->live_ring[q.seq % TiledHostWord::kLiveRing] = total;
     host->steps = *q.steps_run;
     scan_decide(ctl, q.rule, total, *q.steps_run);
     const uint32_t share = (misc[1] + slots - 1) / slots;
@@ -913,6 +1027,7 @@ __device__ void queue_scan_dev(const QueueScan& q, uint32_t* lds) {
 // stopped by an earlier scan); one thread
 __device__ __forceinline__ void scan_skipped(const QueueScan& q) {
   q.host->live = q.ctl->live;
+  q.host->live_ring[q.seq % TiledHostWord::kLiveRing] = q.ctl->live;
   q.host->steps = *q.steps_run;
   q.host->whole = 0u;
   q.host->blocks = 0u;
@@ -2259,6 +2374,7 @@ struct TiledRun {
     tail_scan = env_int("SOIL_TILED_TAILSCAN", 1) == 1;
     depth = verbose ? 0 : env_int("SOIL_TILED_AHEAD", 2);
     if (std::getenv("SOIL_TILED_AHEAD") && std::atoi(std::getenv("SOIL_TILED_AHEAD")) == 0) depth = 0;
+    depth = std::min(depth, static_cast<int>(TiledHostWord::kLiveRing) / 2);  // (a ring slot is read before its scan + 16 writes it)
     ready = true;
     return SOIL_OK;
   }
@@ -2437,7 +2553,9 @@ struct TiledRun {
     const uint64_t r = seen++;  // the word of scan r (or of a later one carrying the same verdict)
     const uint32_t mode = __atomic_load_n(&host->mode, __ATOMIC_ACQUIRE);
     const int64_t slots_before = live_known;  // >= the slots round r's sort and the finishing launch look at
-    if (mode == 0) live_known = std::min<int64_t>(live_known, static_cast<int64_t>(host->live));
+    // (the count of scan r itself, not of whatever scan wrote the word last: see TiledHostWord::live_ring)
+    const uint32_t live_r = host->live_ring[(seq_first + static_cast<uint32_t>(r)) % TiledHostWord::kLiveRing];
+    if (mode == 0) live_known = std::min<int64_t>(live_known, static_cast<int64_t>(live_r));
 #ifdef SOIL_PROF
     if (verbose) {  // where the waves of the round just done spent their cycles (depth 0: round r - 1 is over)
       static const char* seg[10] = {"stops", "refill", "head", "gather+dep begin", "advance", "dep finish",
@@ -2603,7 +2721,16 @@ int launch_pair_tiled(const soil_erosion_planes& P, Streams rng_fluvial, Streams
     static const bool fused_pack = env_int("SOIL_PACK_PAIR", 1) == 1;   // 2: off (A/B)
     if (fused_pack) {
       const int64_t lo = stencil_lo(d), hi = stencil_hi(d);
-      if (hi >= lo)
+      static const bool pack4 = env_int("SOIL_PACK_WINDOW", 1) == 1;  // 2: the one-cell-per-thread pass (A/B)
+      const bool wide = pack4 && d.W % 4 == 0 && d.W >= 4 &&
+                        ((reinterpret_cast<uintptr_t>(P.layers) | reinterpret_cast<uintptr_t>(P.velocity) |
+                          reinterpret_cast<uintptr_t>(P.waterHeight) | reinterpret_cast<uintptr_t>(P.debrisVelocity) |
+                          reinterpret_cast<uintptr_t>(A.p4) | reinterpret_cast<uintptr_t>(B.p4)) & 15u) == 0;
+      if (hi >= lo && wide)
+        k_tiled_pack_pair4<<<win_grid(hi - lo + 1, d.W), kWinBlock, 0, st>>>(
+            A.p4, B.p4, reinterpret_cast<const float2*>(P.layers), reinterpret_cast<const float2*>(P.velocity),
+            P.waterHeight, reinterpret_cast<const float2*>(P.debrisVelocity), d, s, p, lo, hi + 1);
+      else if (hi >= lo)
         k_tiled_pack_pair<<<grid_rows(hi - lo + 1, d.W, 256), 256, 0, st>>>(
             A.p4, B.p4, reinterpret_cast<const float2*>(P.layers), reinterpret_cast<const float2*>(P.velocity),
             P.waterHeight, reinterpret_cast<const float2*>(P.debrisVelocity), d, s, p, lo, hi + 1);
