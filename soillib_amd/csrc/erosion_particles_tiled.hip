@@ -52,6 +52,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <map>
+#include <thread>
 #include <vector>
 
 #include "particles_common.hpp"
@@ -2187,6 +2188,7 @@ struct TiledRun {
   bool sparse_ok = false;  // rounds >= 1 may hand their sparse tiles to the one-wave kernel (SOIL_TILED_SPARSE=2: off)
   int sparse_min = 64, sparse_pct = 25;  // SOIL_TILED_SPARSE_MIN, _PCT: see QueueScan
   int sparse_probe = kSparseProbe;       // SOIL_TILED_SPARSE_PROBE: slots a deposit tries before it adds to the planes directly
+  int host_lag_us = 0;                   // SOIL_TILED_HOST_LAG_US (tests): the host sleeps that long before every look at a word
   int agg_min = 48, agg_groups = 4, retries = 2;
   PRec* recs_of(uint64_t r) const { return (r & 1) ? next : cur; }               // records round r reads
   uint32_t* count_of(uint64_t r) const { return (r & 1) ? count_next : count; }   // section counts round r's scan reads
@@ -2273,6 +2275,7 @@ struct TiledRun {
       const bool by_size = tiles_of(shape_early, 0) >= 16 * static_cast<int64_t>(resident_groups_hint());
       sparse_ok = deposit == 0 && !fluxA && (sparse_env == 1 || (sparse_env == 0 && by_size));
     }
+    host_lag_us = env_int("SOIL_TILED_HOST_LAG_US", 0);
     sparse_probe = env_kind("SOIL_TILED_SPARSE_PROBE", KIND, kSparseProbe);
     sparse_min = env_kind("SOIL_TILED_SPARSE_MIN", KIND, 64);
     sparse_pct = env_kind("SOIL_TILED_SPARSE_PCT", KIND, 25);
@@ -2549,6 +2552,9 @@ struct TiledRun {
   // them, queue the finishing launch for the records the last executed round left.
   int advance() {
     if (done) return SOIL_OK;
+    // (tests: a host that falls behind the device by so many microseconds before every look at a word —
+    // the rounds queued ahead run on, later scans write their words over the one awaited)
+    if (host_lag_us > 0) std::this_thread::sleep_for(std::chrono::microseconds(host_lag_us));
     if (int rc = wait_word(); rc != SOIL_OK) return rc;
     const uint64_t r = seen++;  // the word of scan r (or of a later one carrying the same verdict)
     const uint32_t mode = __atomic_load_n(&host->mode, __ATOMIC_ACQUIRE);

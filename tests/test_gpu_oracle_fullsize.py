@@ -122,6 +122,17 @@ def test_three_steps_at_1024(hip, oracle):
     _run(hip, oracle, 1024, 1024, steps=3)
 
 
+@pytest.mark.parametrize("lag_us", [200, 500, 1500])
+def test_step_at_1024_with_a_lagging_host(hip, oracle, monkeypatch, lag_us):
+    """The host queues rounds ahead of the queue words it has read.  A host that falls behind — here:
+    that sleeps before every look at a word — finds the words of later scans written over the one it
+    waits for, and must still size the rounds it queues next by the scan it asked about (round 3 took
+    whatever count the word held: walkers dropped; found by eight processes sharing a GPU, where the
+    hosts lag for real — tests/test_gpu_parallel.py)."""
+    monkeypatch.setenv("SOIL_TILED_HOST_LAG_US", str(lag_us))
+    _run(hip, oracle, 1024, 1024, steps=1)
+
+
 def test_strip_4096x512_after_channels_formed(hip, oracle):
     _run(hip, oracle, 4096, 512, steps=2, warm_steps=3)
 
