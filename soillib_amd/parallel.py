@@ -102,10 +102,22 @@ class RcclComm:
                 _abi.check(lib.soil_comm_rccl_unique_id(uid))
             except Exception as e:      # noqa: BLE001  (the broadcast below must still take place)
                 failed, why = 1, e
+        else:
+            # Every rank proves that it can load librccl and call into it BEFORE anybody enters the
+            # collective ncclCommInitRank: a rank that cannot would leave the others blocked in there, and
+            # the fallback to gloo could never be agreed on (advisor finding of round 3).  Making an id
+            # is local and free of side effects.  (What is left uncovered: a failure INSIDE the
+            # collective on a subset of ranks — RCCL's own bootstrap time-out ends that.)
+            try:
+                _abi.check(lib.soil_comm_rccl_unique_id((C.c_uint8 * 128)()))
+            except Exception as e:      # noqa: BLE001
+                failed, why = 1, e
+        bad = torch.tensor([failed])
+        dist.all_reduce(bad, op=dist.ReduceOp.MAX)
         t = torch.tensor(list(uid) + [failed], dtype=torch.uint8)
         dist.broadcast(t, 0)
-        if int(t[-1]):
-            raise RuntimeError("rank 0 could not make the RCCL id: %s" % (why,))
+        if int(bad.item()):
+            raise RuntimeError("librccl is not usable on %s: %s" % ("this rank" if failed else "another rank", why))
         uid = (C.c_uint8 * 128)(*t[:128].tolist())
         self._c = C.POINTER(_abi.Comm)()
         _abi.check(lib.soil_comm_rccl_create(C.byref(self._c), uid, self.rank, self.world))
