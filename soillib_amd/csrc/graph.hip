@@ -57,13 +57,24 @@ __global__ void __launch_bounds__(kGBlock)
 }
 
 // __steepest / __direction with four cells per thread (window.hpp); the scalar kernel above
-// serves widths that are not a multiple of four.  The four diagonal slopes are quotients over
-// sqrt(2): shared-reciprocal quotients checked per group (QuotWatch, soil_math.hpp), redone as
-// written when in doubt.
-template <int K, bool STORE_K, bool WRITTEN>
-__device__ __forceinline__ bool steepest_group(int32_t oi[4], const RowWalk& w, const WinThread& t,
-                                               int64_t x, int64_t W, const Recip& rdiag) {
-  QuotWatch watch;
+// serves widths that are not a multiple of four.
+//
+// steepest_group: the loop as written, the diagonal slopes as IEEE quotients over sqrt(2).
+// steepest_group_fast (round 4: the kernel is bound by the issue of vector instructions — 79 per
+// cell, 0.75-0.83 of the SIMDs' cycles, profiles/r04_stencils — not by memory): the same receiver with
+// ONE quotient per cell instead of four.  The four straight neighbours come first in the loop and
+// their slopes are the differences themselves; of the diagonal ones only the winner matters, and
+// d -> RN(d / sqrt 2) is monotone: the largest quotient is that of the largest difference `dmax`,
+// and the loop's choice among the diagonals is the FIRST k whose quotient equals it.  That is the
+// first k with d_k == dmax unless a smaller difference rounds to the same quotient — possible only
+// within 1.42 ulp of dmax (the quotient's rounding interval, times sqrt 2); a wave that holds such a
+// near-tie (bit distance 1 .. 4; none on a float terrain, and equal differences are not near-ties)
+// takes the loop as written, as does one whose window is not plain (window.hpp: the quotient of
+// `dmax` then is the IEEE one).  The winner replaces the straight maximum iff its quotient is
+// greater (:57), and the receiver is -1 iff no slope was positive (:42-43).
+template <int K, bool STORE_K, class Walk>
+__device__ __forceinline__ void steepest_group(int32_t oi[4], const Walk& w, const WinThread& t,
+                                               int64_t x, int64_t W) {
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     const float hlocal = w.mid.v[c + 1];  // :40
@@ -76,10 +87,7 @@ __device__ __forceinline__ bool steepest_group(int32_t oi[4], const RowWalk& w, 
       const bool col_ok = kDY[k] < 0 ? (c > 0 || t.y0 > 0) : (kDY[k] > 0 ? (c < 3 || t.y0 + 4 < W) : true);
       if (!row_ok || !col_ok) continue;  // :51-52
       const Row6& r = kDX[k] < 0 ? w.up : (kDX[k] > 0 ? w.dn : w.mid);
-      const float diff = hlocal - r.v[c + 1 + kDY[k]];
-      float scur;  // :56
-      if (k < 4) scur = diff / kShiftLen[k];  // length 1: the quotient is the difference
-      else scur = WRITTEN ? diff / kShiftLen[k] : watch(quot(diff, rdiag));
+      const float scur = (hlocal - r.v[c + 1 + kDY[k]]) / kShiftLen[k];  // :56
       if (scur > smax) {  // :57-60
         smax = scur;
         next = STORE_K ? static_cast<int32_t>(k)
@@ -88,21 +96,92 @@ __device__ __forceinline__ bool steepest_group(int32_t oi[4], const RowWalk& w, 
     }
     oi[c] = next;  // :68
   }
-  return watch.doubtful();
 }
 
-template <int K, bool STORE_K>
-__global__ void __launch_bounds__(kWinBlock)
+// returns false (wave-uniform) when the wave has to take steepest_group instead
+template <int K, bool STORE_K, class Walk>
+__device__ __forceinline__ bool steepest_group_fast(int32_t oi[4], const Walk& w, const WinThread& t,
+                                                    int64_t x, int64_t W, const Recip& rdiag) {
+  const int32_t iW = static_cast<int32_t>(W);
+  const int32_t n0 = static_cast<int32_t>(x * W + t.y0);
+  bool tie = false;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const float hlocal = w.mid.v[c + 1];
+    float smax = 0.0f;
+    int32_t pick = 0;  // k, or the receiver's index minus the cell's; looked at only if smax > 0
+    float dmax = 0.0f;
+    int32_t dpick = 0;
+    // (k, row, column and "exists" are compile-time / wave-uniform per k; the differences are
+    // taken again for the near-tie test instead of being kept: registers)
+    auto exists = [&](int k) {
+      const bool row_ok = kDX[k] < 0 ? w.has_up : (kDX[k] > 0 ? w.has_dn : true);
+      const bool col_ok = kDY[k] < 0 ? (c > 0 || t.y0 > 0) : (kDY[k] > 0 ? (c < 3 || t.y0 + 4 < W) : true);
+      return row_ok && col_ok;
+    };
+    auto diff = [&](int k) {
+      const Row6& r = kDX[k] < 0 ? w.up : (kDX[k] > 0 ? w.dn : w.mid);
+      return hlocal - r.v[c + 1 + kDY[k]];
+    };
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int32_t id = STORE_K ? static_cast<int32_t>(k) : kDX[k] * iW + kDY[k];
+      const float d = diff(k);
+      if (k < 4) {
+        if (exists(k) && d > smax) {
+          smax = d;
+          pick = id;
+        }
+      } else if (exists(k) && d > dmax) {
+        dmax = d;
+        dpick = id;
+      }
+    }
+    if (K > 4) {
+      const uint32_t below = f2bits(dmax) - 1u;  // a difference 1 .. 4 bit patterns under dmax: a near-tie
+      uint32_t nearest = 0xffffffffu;
+#pragma unroll
+      for (int k = 4; k < K; ++k)
+        if (exists(k)) nearest = min(nearest, below - f2bits(diff(k)));
+      tie = tie || nearest < 4u;
+      const float q = quot(dmax, rdiag);
+      if (q > smax) {
+        smax = q;
+        pick = dpick;
+      }
+    }
+    oi[c] = smax > 0.0f ? (STORE_K ? pick : n0 + c + pick) : -1;
+    __builtin_amdgcn_sched_barrier(0);  // cell by cell: interleaving the four costs registers (8 waves: 64)
+  }
+  return __ballot(tie) == 0ull;
+}
+
+template <int K, bool STORE_K, class Walk>
+__global__ void __launch_bounds__(kWinBlock) __attribute__((amdgpu_waves_per_eu(8, 8)))
     k_steepest4(int32_t* __restrict__ out, const float* __restrict__ height, int64_t H, int64_t W) {
-  const WinThread t = win_thread(W);
+  const WinThread t = Walk::thread(H, W);
   const Recip rdiag = recip(kSqrt2);
-  RowWalk w;
-  SOIL_WIN_ROWS(x, w, height, H, W, t.y0) {
+  SOIL_WIN_WALK(Walk, w, W);
+  SOIL_WIN_ROWS(x, w, height, H, W, t) {
     int4 o;
     int32_t* oi = reinterpret_cast<int32_t*>(&o);
-    if (K == 4 || steepest_group<K, STORE_K, false>(oi, w, t, x, W, rdiag))
-      (void)steepest_group<K, STORE_K, true>(oi, w, t, x, W, rdiag);
+    if (!w.plain() || !steepest_group_fast<K, STORE_K>(oi, w, t, x, W, rdiag))
+      steepest_group<K, STORE_K>(oi, w, t, x, W);
     if (t.live) *reinterpret_cast<int4*>(out + x * W + t.y0) = o;
+  }
+}
+
+template <int K, bool STORE_K, class Walk>
+void launch_steepest4_as(int32_t* out, const float* height, int64_t H, int64_t W, hipStream_t st) {
+  k_steepest4<K, STORE_K, Walk><<<Walk::grid(H, W), kWinBlock, 0, st>>>(out, height, H, W);
+}
+template <int K, bool STORE_K>
+void launch_steepest4(int32_t* out, const float* height, int64_t H, int64_t W, hipStream_t st) {
+  constexpr bool kWatch = K > 4;  // the straight slopes are the differences: nothing to watch for d4
+  switch (win_shape(0)) {
+    case 0: return launch_steepest4_as<K, STORE_K, RowWalkReg<kWatch>>(out, height, H, W, st);
+    case 1: return launch_steepest4_as<K, STORE_K, RowWalkLds<kWatch>>(out, height, H, W, st);
+    default: return launch_steepest4_as<K, STORE_K, RowWalkFlat<kWatch>>(out, height, H, W, st);
   }
 }
 
@@ -203,7 +282,7 @@ __global__ void __launch_bounds__(kWinBlock)
                        RwConst rc) {
   const WinThread t = win_thread(W);
   RowWalk w;
-  SOIL_WIN_ROWS(x, w, height, H, W, t.y0) {
+  SOIL_WIN_ROWS(x, w, height, H, W, t) {
     int4 o[kRwBatch];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -303,7 +382,7 @@ __global__ void __launch_bounds__(kWinBlock)
   const int32_t iW = static_cast<int32_t>(W), iH = static_cast<int32_t>(H);
   (void)iH;
   RowWalk w;
-  SOIL_WIN_ROWS(x, w, tensor, H, W, t.y0) {
+  SOIL_WIN_ROWS(x, w, tensor, H, W, t) {
     const int32_t n0 = static_cast<int32_t>(x * W + t.y0);
     const int4 f = *reinterpret_cast<const int4*>(flow + n0);  // :282
     const int32_t fi[4] = {f.x, f.y, f.z, f.w};
@@ -411,7 +490,7 @@ __global__ void __launch_bounds__(kWinBlock)
   const int64_t elem = H * W;
   const int32_t iW = static_cast<int32_t>(W);
   RowWalk w;
-  SOIL_WIN_ROWS(x, w, reinterpret_cast<const float*>(graph), H, W, t.y0) {
+  SOIL_WIN_ROWS(x, w, reinterpret_cast<const float*>(graph), H, W, t) {
     const int32_t n0 = static_cast<int32_t>(x * W + t.y0);
     int4 cnt;
     int32_t* ci = reinterpret_cast<int32_t*>(&cnt);
@@ -614,11 +693,11 @@ int soil_direction(int32_t* direction, const float* height, int64_t H, int64_t W
   hipStream_t st = as_stream(stream);
   switch (edge) {
     case SOIL_D4:
-      if (wide) k_steepest4<4, true><<<win_grid(H, W), kWinBlock, 0, st>>>(direction, height, H, W);
+      if (wide) launch_steepest4<4, true>(direction, height, H, W, st);
       else k_steepest<4, true><<<grid_rows(H, W, kGBlock), kGBlock, 0, st>>>(direction, height, H, W);
       break;
     case SOIL_D8:
-      if (wide) k_steepest4<8, true><<<win_grid(H, W), kWinBlock, 0, st>>>(direction, height, H, W);
+      if (wide) launch_steepest4<8, true>(direction, height, H, W, st);
       else k_steepest<8, true><<<grid_rows(H, W, kGBlock), kGBlock, 0, st>>>(direction, height, H, W);
       break;
     default: return fail(SOIL_ERR_INVALID_ARGUMENT, "invalid edge enumerator");  // graph.cu:262
@@ -636,11 +715,11 @@ int soil_steepest(int32_t* graph, const float* height, int64_t H, int64_t W, int
   hipStream_t st = as_stream(stream);
   switch (edge) {
     case SOIL_D4:
-      if (wide) k_steepest4<4, false><<<win_grid(H, W), kWinBlock, 0, st>>>(graph, height, H, W);
+      if (wide) launch_steepest4<4, false>(graph, height, H, W, st);
       else k_steepest<4, false><<<grid_rows(H, W, kGBlock), kGBlock, 0, st>>>(graph, height, H, W);
       break;
     case SOIL_D8:
-      if (wide) k_steepest4<8, false><<<win_grid(H, W), kWinBlock, 0, st>>>(graph, height, H, W);
+      if (wide) launch_steepest4<8, false>(graph, height, H, W, st);
       else k_steepest<8, false><<<grid_rows(H, W, kGBlock), kGBlock, 0, st>>>(graph, height, H, W);
       break;
     default: return fail(SOIL_ERR_INVALID_ARGUMENT, "invalid edge enumerator");  // graph.cu:88

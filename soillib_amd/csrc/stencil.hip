@@ -104,20 +104,34 @@ __global__ void __launch_bounds__(kSBlock)
 struct DivWritten {
   __device__ __forceinline__ float operator()(float a, float b, const Recip&) const { return a / b; }
 };
-// (for quotients that are only compared with zero or squared — negslope: the sign of a zero
-// quotient is not seen; one that is stored goes through QuotWatch's two-argument form)
-struct DivShared {
-  QuotWatch* watch;
-  __device__ __forceinline__ float operator()(float a, float, const Recip& rb) const {
-    return (*watch)(quot(a, rb));
-  }
+// (for the differences of two values of a plain window, window.hpp: nothing to check per quotient;
+// the sign of a zero quotient must not be seen)
+struct DivPlain {
+  __device__ __forceinline__ float operator()(float a, float, const Recip& rb) const { return quot(a, rb); }
 };
 // a scale the shared-reciprocal quotient may divide by (positive, 2^-40 .. 2^40)
 static bool plain_scale(float v) { return v >= 0x1p-40f && v <= 0x1p40f; }
 
+// one of a window kernel's builds: the flat shape, the band walk through LDS or through registers
+// (window.hpp; SOIL_WIN_SHAPE picks, `dflt` is the kernel's own choice), and the written-out
+// divisions for scales out of the plain range
+template <class Walk, class KF, class... A>
+static void win_launch_as(KF kernel, int64_t H, int64_t W, hipStream_t st, A... a) {
+  kernel<<<Walk::grid(H, W), kWinBlock, 0, st>>>(a...);
+}
+#define SOIL_WIN_LAUNCH(dflt, fast, K_FAST, K_WRITTEN, WATCH, H, W, st, ...)                         \
+  do {                                                                                              \
+    if (!(fast)) win_launch_as<RowWalk>(K_WRITTEN<RowWalk>, H, W, st, __VA_ARGS__);                 \
+    else switch (win_shape(dflt)) {                                                                 \
+      case 0: win_launch_as<RowWalkReg<WATCH>>(K_FAST<RowWalkReg<WATCH>>, H, W, st, __VA_ARGS__); break;   \
+      case 1: win_launch_as<RowWalkLds<WATCH>>(K_FAST<RowWalkLds<WATCH>>, H, W, st, __VA_ARGS__); break;   \
+      default: win_launch_as<RowWalkFlat<WATCH>>(K_FAST<RowWalkFlat<WATCH>>, H, W, st, __VA_ARGS__); break; \
+    }                                                                                               \
+  } while (0)
+
 // __gradient, grad.cu:22-87, for the four cells of a thread
-template <typename DIV>
-__device__ __forceinline__ void gradient_group(float of[8], const RowWalk& w, const WinThread& t,
+template <typename DIV, class Walk>
+__device__ __forceinline__ void gradient_group(float of[8], const Walk& w, const WinThread& t,
                                                int64_t W, Scale2 s, const Recip& rx, const Recip& ry,
                                                DIV div) {
   const float nan = __builtin_nanf("");
@@ -145,14 +159,14 @@ __device__ __forceinline__ void gradient_group(float of[8], const RowWalk& w, co
   }
 }
 
-template <bool FAST>
+template <bool FAST, class Walk>
 __global__ void __launch_bounds__(kWinBlock)
     k_gradient4(float2* __restrict__ out, const float* __restrict__ in, int64_t H, int64_t W, Scale2 s) {
   __shared__ float4 s_tile[kWinBlock / 64][128];
-  const WinThread t = win_thread(W);
+  const WinThread t = Walk::thread(H, W);
   const Recip rx = recip(s.x), ry = recip(s.y);
-  RowWalk w;
-  SOIL_WIN_ROWS(x, w, in, H, W, t.y0) {
+  SOIL_WIN_WALK(Walk, w, W);
+  SOIL_WIN_ROWS(x, w, in, H, W, t) {
     float4 o[2];
     float* of = reinterpret_cast<float*>(o);
     // at the grid's edge the NaN sentinels of :35-38 run through the quotients: written-out there
@@ -173,7 +187,7 @@ __global__ void __launch_bounds__(kWinBlock)
     if (redo) gradient_group(of, w, t, W, s, rx, ry, DivWritten{});
     // the wave's 256 cells start at column y0 - 4 * lane (lanes past the row's end sit on the last group)
     const int lane = static_cast<int>(threadIdx.x & 63u);
-    const int64_t wave_y0 = (static_cast<int64_t>(blockIdx.x) * kWinBlock + (threadIdx.x & ~63u)) * 4;
+    const int64_t wave_y0 = (t.group * kWinBlock + (threadIdx.x & ~63u)) * 4;
     (void)lane;
     store_pair_contiguous(reinterpret_cast<float4*>(out + x * W + wave_y0), o[0], o[1],
                           s_tile[threadIdx.x >> 6], t.live);
@@ -181,8 +195,8 @@ __global__ void __launch_bounds__(kWinBlock)
 }
 
 // __negslope, grad.cu:101-131
-template <typename DIV>
-__device__ __forceinline__ void negslope_group(float of[4], const RowWalk& w, const WinThread& t,
+template <typename DIV, class Walk>
+__device__ __forceinline__ void negslope_group(float of[4], const Walk& w, const WinThread& t,
                                                int64_t W, Scale2 s, const Recip& rx, const Recip& ry,
                                                DIV div) {
 #pragma unroll
@@ -210,34 +224,30 @@ __device__ __forceinline__ void negslope_group(float of[4], const RowWalk& w, co
   }
 }
 
-template <bool FAST>
+template <bool FAST, class Walk>
 __global__ void __launch_bounds__(kWinBlock)
     k_negslope4(float* __restrict__ out, const float* __restrict__ in, int64_t H, int64_t W, Scale2 s) {
-  const WinThread t = win_thread(W);
+  const WinThread t = Walk::thread(H, W);
   const Recip rx = recip(s.x), ry = recip(s.y);
-  RowWalk w;
-  SOIL_WIN_ROWS(x, w, in, H, W, t.y0) {
+  SOIL_WIN_WALK(Walk, w, W);
+  SOIL_WIN_ROWS(x, w, in, H, W, t) {
     float4 o;
     float* of = reinterpret_cast<float*>(&o);
-    bool redo = !FAST;
-    if (!redo) {
-      QuotWatch watch;
-      negslope_group(of, w, t, W, s, rx, ry, DivShared{&watch});
-      redo = watch.doubtful();
-    }
-    if (redo) negslope_group(of, w, t, W, s, rx, ry, DivWritten{});
+    // the quotients are of differences of the window's values and only compared with zero and
+    // squared: shared-reciprocal ones on a plain window (wave-uniform), as written otherwise
+    if (FAST && w.plain()) negslope_group(of, w, t, W, s, rx, ry, DivPlain{});
+    else negslope_group(of, w, t, W, s, rx, ry, DivWritten{});
     if (t.live) *reinterpret_cast<float4*>(out + x * W + t.y0) = o;
   }
 }
 
 // __laplacian<1>, grad.cu:147-183
+template <class Walk>
 __global__ void __launch_bounds__(kWinBlock)
-    k_laplacian4(float* __restrict__ out, const float* __restrict__ in, int64_t H, int64_t W, Scale2 s) {
-  const WinThread t = win_thread(W);
-  const float hx = (1.0f / s.x / s.x);  // :175
-  const float hy = (1.0f / s.y / s.y);  // :176
-  RowWalk w;
-  SOIL_WIN_ROWS(x, w, in, H, W, t.y0) {
+    k_laplacian4(float* __restrict__ out, const float* __restrict__ in, int64_t H, int64_t W, float hx, float hy) {
+  const WinThread t = Walk::thread(H, W);  // hx = 1 / s.x / s.x, hy likewise (:175-176), divided on the host
+  SOIL_WIN_WALK(Walk, w, W);
+  SOIL_WIN_ROWS(x, w, in, H, W, t) {
     float4 o;
     float* of = reinterpret_cast<float*>(&o);
 #pragma unroll
@@ -684,6 +694,13 @@ __global__ void __launch_bounds__(kSBlock)
 
 using namespace soil;
 
+// (the launch macro names a kernel by a template over the walk alone)
+template <class Walk> constexpr auto kGradientFast = k_gradient4<true, Walk>;
+template <class Walk> constexpr auto kGradientWritten = k_gradient4<false, Walk>;
+template <class Walk> constexpr auto kNegslopeFast = k_negslope4<true, Walk>;
+template <class Walk> constexpr auto kNegslopeWritten = k_negslope4<false, Walk>;
+template <class Walk> constexpr auto kLaplacian1 = k_laplacian4<Walk>;
+
 extern "C" {
 
 int soil_resize(float* dst, const float* src, int64_t Hn, int64_t Wn, int64_t Ho, int64_t Wo, int D,
@@ -706,12 +723,10 @@ int soil_gradient(float* out, const float* in, int64_t H, int64_t W, const float
   SOIL_DEVICE();
   SOIL_REQUIRE(out && in && scale, "gradient: null argument");
   SOIL_REQUIRE(H > 0 && W > 0, "gradient: empty grid");
-  if (W % 4 == 0 && W >= 4 && plain_scale(scale[0]) && plain_scale(scale[1]))
-    k_gradient4<true><<<win_grid(H, W), kWinBlock, 0, as_stream(stream)>>>(
-        reinterpret_cast<float2*>(out), in, H, W, Scale2{scale[0], scale[1]});
-  else if (W % 4 == 0 && W >= 4)
-    k_gradient4<false><<<win_grid(H, W), kWinBlock, 0, as_stream(stream)>>>(
-        reinterpret_cast<float2*>(out), in, H, W, Scale2{scale[0], scale[1]});
+  const bool fast = plain_scale(scale[0]) && plain_scale(scale[1]);
+  if (W % 4 == 0 && W >= 4)
+    SOIL_WIN_LAUNCH(0, fast, kGradientFast, kGradientWritten, false, H, W, as_stream(stream),
+                    reinterpret_cast<float2*>(out), in, H, W, Scale2{scale[0], scale[1]});
   else
     k_gradient<<<grid_rows(H, W, kSBlock), kSBlock, 0, as_stream(stream)>>>(
         reinterpret_cast<float2*>(out), in, H, W, Scale2{scale[0], scale[1]});
@@ -724,12 +739,10 @@ int soil_negslope(float* out, const float* in, int64_t H, int64_t W, const float
   SOIL_DEVICE();
   SOIL_REQUIRE(out && in && scale, "negslope: null argument");
   SOIL_REQUIRE(H > 0 && W > 0, "negslope: empty grid");
-  if (W % 4 == 0 && W >= 4 && plain_scale(scale[0]) && plain_scale(scale[1]))
-    k_negslope4<true><<<win_grid(H, W), kWinBlock, 0, as_stream(stream)>>>(out, in, H, W,
-                                                                           Scale2{scale[0], scale[1]});
-  else if (W % 4 == 0 && W >= 4)
-    k_negslope4<false><<<win_grid(H, W), kWinBlock, 0, as_stream(stream)>>>(out, in, H, W,
-                                                                            Scale2{scale[0], scale[1]});
+  const bool fast = plain_scale(scale[0]) && plain_scale(scale[1]);
+  if (W % 4 == 0 && W >= 4)
+    SOIL_WIN_LAUNCH(0, fast, kNegslopeFast, kNegslopeWritten, true, H, W, as_stream(stream), out, in, H, W,
+                    Scale2{scale[0], scale[1]});
   else
     k_negslope<<<grid_rows(H, W, kSBlock), kSBlock, 0, as_stream(stream)>>>(
         out, in, H, W, Scale2{scale[0], scale[1]});
@@ -744,7 +757,8 @@ int soil_laplacian(float* out, const float* in, int64_t H, int64_t W, int D, con
   SOIL_REQUIRE(H > 0 && W > 0, "laplacian: empty grid");
   const Scale2 s{scale[0], scale[1]};
   if (D == 1 && W % 4 == 0 && W >= 4)  // grad.cu:196-198
-    k_laplacian4<<<win_grid(H, W), kWinBlock, 0, as_stream(stream)>>>(out, in, H, W, s);
+    SOIL_WIN_LAUNCH(0, true, kLaplacian1, kLaplacian1, false, H, W, as_stream(stream), out, in, H, W,
+                    1.0f / s.x / s.x, 1.0f / s.y / s.y);  // (IEEE fp32 on the host: the same bits as on the device)
   else if (D == 1)
     k_laplacian<1><<<grid_rows(H, W, kSBlock), kSBlock, 0, as_stream(stream)>>>(out, in, H, W, s);
   else if (D == 2 && W % 4 == 0 && W >= 4)  // grad.cu:200-202

@@ -659,6 +659,46 @@ def test_window_kernels_across_seams(hip, oracle, H, W):
     assert_bit_equal(to_np(soil.normal(to_gpu(h), s3)), oracle.normal(h, s3), "normal")
 
 
+@pytest.mark.parametrize("kind", ["quantised", "one_ulp", "two_ulp_binade", "tiny", "huge", "mixed"])
+def test_steepest_ties_and_near_ties(hip, oracle, kind):
+    """k_steepest4 takes one quotient per cell — that of the largest diagonal difference — and
+    leaves the loop as written to the waves where a smaller difference could round to the same
+    quotient (graph.hip).  Terrains made of exactly those cases: many equal differences (the first k
+    must win), differences one and two bit patterns apart (the written loop must be taken: after the
+    division by sqrt 2 they may or may not be equal), across a binade, and heights outside the plain
+    range of the shared-reciprocal quotient (window.hpp)."""
+    from soillib_amd import soil
+    H, W = 96, 520                              # two waves per row and a ragged third
+    r = np.random.default_rng(17)
+    base = np.round(terrain(oracle, H, W)[..., 0] * 16.0) / 16.0   # plateaus, equal differences
+    h = base.astype(np.float32)
+    if kind != "quantised":
+        steps = {"one_ulp": (1,), "two_ulp_binade": (1, 2, 3), "tiny": (1,), "huge": (1,), "mixed": (0, 1, 2, 4, 5)}[kind]
+        if kind == "two_ulp_binade":
+            h = (1.0 + np.round(r.random((H, W)) * 4.0) / 4.0).astype(np.float32)   # differences around 2^-2 .. 2^0
+            h[::2, ::2] = 2.0
+        bits = h.view(np.int32).copy()
+        bump = r.choice(np.array(steps, np.int32), size=(H, W)) * (r.random((H, W)) < 0.5)
+        h = (bits + bump.astype(np.int32)).view(np.float32)
+        if kind == "tiny":
+            h = (h * np.float32(2.0 ** -70)).astype(np.float32)     # differences below 2^-80: not plain
+        if kind == "huge":
+            h = (h * np.float32(2.0 ** 60)).astype(np.float32)
+        if kind == "mixed":
+            h[5:9, :] *= np.float32(2.0 ** -60)
+            h[40, 100] = np.inf
+            h[41, 300] = np.nan
+            h[60:64, 250:262] = -0.0
+    gh = to_gpu(np.ascontiguousarray(h))
+    for edge in (D4, D8):
+        assert_bit_equal(to_np(soil.steepest(gh, edge)), oracle.steepest(h, edge), "steepest, " + kind)
+        assert_bit_equal(to_np(soil.direction(gh, edge)), oracle.direction(h, edge), "direction, " + kind)
+    sc = (0.4, 1.7)
+    assert_bit_equal(to_np(soil.negslope(gh, sc)), oracle.negslope(h, sc), "negslope, " + kind)
+    big = (3e11, 2e-12)                         # scales at the ends of the plain range of a denominator
+    assert_bit_equal(to_np(soil.negslope(gh, big)), oracle.negslope(h, big), "negslope, " + kind)
+
+
 @pytest.mark.parametrize("H,W", [(70, 1500), (33, 1025), (300, 7), (300, 1028), (131, 260), (64, 2048)])
 def test_gaussian_blur_across_tile_seams(hip, oracle, H, W):
     """Grids wider than one 1024-float LDS segment, taller than one 32-row band, row counts that
