@@ -328,6 +328,7 @@ def halo_report(runner):
     hr = runner.halo_rows
     return {"ghost_rows_bound": runner.G,
             "rows_shipped_vs_bound": (hr["flux"] + hr["field"]) / max(hr["full"], 1),
+            "ghost_rows_walked_vs_bound": hr["window"] / max(hr["window_full"], 1),
             "reach_rows_last_steps": runner.reach_hist, "repeated_launches": runner.fallbacks,
             "trimmed_by_measured_reach": bool(runner.trim)}
 

@@ -133,6 +133,8 @@ typedef struct soil_slab_info {
   int64_t repeated_launches;
   int32_t reach_hist[4];       /* max reach over all ranks, last steps (0: none yet) */
   int32_t n_reach;
+  int64_t rows_window, rows_window_full; /* ghost rows the particle launches were given so far (the rows with
+                                            fresh fields + 2, SOIL_HALO_WINDOW=0: all), and the bound's */
 } soil_slab_info;
 
 /* marks of one step for a timing harness (bench.py records a HIP event per mark on lane 0):

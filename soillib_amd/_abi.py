@@ -219,7 +219,8 @@ class SlabInfo(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ("H", "W", "S", "G", "x0", "rows", "r0", "r1", "N")] + [
         ("step_index", C.c_uint64), ("rank", C.c_int32), ("world", C.c_int32), ("trim", C.c_int32),
         ("pair", C.c_int32), ("rows_flux", C.c_int64), ("rows_field", C.c_int64), ("rows_full", C.c_int64),
-        ("repeated_launches", C.c_int64), ("reach_hist", C.c_int32 * 4), ("n_reach", C.c_int32)]
+        ("repeated_launches", C.c_int64), ("reach_hist", C.c_int32 * 4), ("n_reach", C.c_int32),
+        ("rows_window", C.c_int64), ("rows_window_full", C.c_int64)]
 
 
 MARK_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int32)

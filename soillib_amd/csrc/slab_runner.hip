@@ -68,7 +68,7 @@ using soil::fail;
 
 // what soillib_amd/_abi.py mirrors with ctypes
 static_assert(sizeof(soil_xfer) == 24 && sizeof(soil_comm) == 48 && sizeof(soil_slab_ops) == 19 * 8 &&
-                  sizeof(soil_slab_config) == 72 && sizeof(soil_slab_info) == 152,
+                  sizeof(soil_slab_config) == 72 && sizeof(soil_slab_info) == 168,
               "soil_slab.h struct layout changed: update soillib_amd/_abi.py");
 
 struct soil_slab {
@@ -97,6 +97,15 @@ struct soil_slab {
   std::vector<std::pair<int64_t, int64_t>> fresh_all, fresh_debris;
   std::vector<int> reach_hist, reach_hist_debris;  // max over ranks and both kinds; debris alone
   int64_t fallbacks = 0, rows_flux = 0, rows_field = 0, rows_full = 0;
+  // The rows a particle launch is given (round 4): the owned rows and, either side, the ghost rows
+  // with fresh fields plus kWindowMargin — not all G of them.  A walk that gets to a ghost row whose
+  // fields are stale makes the step repeat its launches anyway (too_deep()); the rows beyond can only
+  // be reached through such a row, so nothing valid ever happens there, and the pack pass, the tiles,
+  // the first round's stores and the reach scan need not cover them.  [w0, w1): local rows.
+  static constexpr int64_t kWindowMargin = 2;
+  bool window = true;  // SOIL_HALO_WINDOW=0: every launch on all the ghost rows (A/B)
+  int64_t w0 = 0, w1 = 0;
+  int64_t rows_window = 0, rows_window_full = 0;  // ghost rows the launches were given so far / the bound
 
   // ---- helpers --------------------------------------------------------------------------------
   int64_t row_floats(int p) const { return W * soil::kPlaneCh[p]; }
@@ -107,15 +116,30 @@ struct soil_slab {
     return peer > rank ? l.r0 : l.rows - l.r1;
   }
   soil_domain domain(int64_t r0, int64_t r1) const { return soil_domain{H, W, lay.x0, lay.rows, r0, r1}; }
-  soil_erosion_planes planes() const {
+  // the planes from local row `first` on (0: whole)
+  soil_erosion_planes planes(int64_t first = 0) const {
     soil_erosion_planes q{};
-    q.layers = P[soil::kLayers], q.layers_next = P[soil::kLayersNext], q.height = P[soil::kHeight];
-    q.uplift = P[soil::kUplift], q.rainfall = P[soil::kRainfall], q.waterHeight = P[soil::kWaterHeight];
-    q.waterFlux = P[soil::kWaterFlux], q.mass = P[soil::kMass], q.massFlux = P[soil::kMassFlux];
-    q.velocity = P[soil::kVelocity], q.velocityFlux = P[soil::kVelocityFlux], q.debris = P[soil::kDebris];
-    q.debrisFlux = P[soil::kDebrisFlux], q.debrisVelocity = P[soil::kDebrisVelocity];
-    q.debrisVelocityFlux = P[soil::kDebrisVelocityFlux];
+    auto at = [&](int p) { return rowp(p, first); };
+    q.layers = at(soil::kLayers), q.layers_next = at(soil::kLayersNext), q.height = at(soil::kHeight);
+    q.uplift = at(soil::kUplift), q.rainfall = at(soil::kRainfall), q.waterHeight = at(soil::kWaterHeight);
+    q.waterFlux = at(soil::kWaterFlux), q.mass = at(soil::kMass), q.massFlux = at(soil::kMassFlux);
+    q.velocity = at(soil::kVelocity), q.velocityFlux = at(soil::kVelocityFlux), q.debris = at(soil::kDebris);
+    q.debrisFlux = at(soil::kDebrisFlux), q.debrisVelocity = at(soil::kDebrisVelocity);
+    q.debrisVelocityFlux = at(soil::kDebrisVelocityFlux);
     return q;
+  }
+  // the launch window of this step, from the ghost rows that hold fresh fields right now
+  void set_window() {
+    w0 = 0, w1 = lay.rows;
+    if (!window || !trim || fresh_all.empty()) return;
+    const auto &fa = fresh_all[static_cast<size_t>(rank)], &fd = fresh_debris[static_cast<size_t>(rank)];
+    w0 = lay.r0 - std::min<int64_t>(lay.r0, std::max(fa.first, fd.first) + kWindowMargin);
+    w1 = lay.r1 + std::min<int64_t>(lay.rows - lay.r1, std::max(fa.second, fd.second) + kWindowMargin);
+  }
+  soil_domain window_domain() const { return soil_domain{H, W, lay.x0 + w0, w1 - w0, lay.r0 - w0, lay.r1 - w0}; }
+  void note_window() {
+    rows_window += (lay.r0 - w0) + (w1 - lay.r1);
+    rows_window_full += gu + gd;
   }
   void* stream(int lane) const { return ops->stream ? ops->stream(ops->ctx, lane) : nullptr; }
 
@@ -225,7 +249,7 @@ struct soil_slab {
   int reach(const soil::Plane* planes_, int n, std::vector<int>& all) {
     int32_t depth[2] = {0, 0};
     for (int i = 0; i < n; ++i)
-      SLAB_TRY(ops->ghost_extent(ops->ctx, P[planes_[i]], lay.rows, row_floats(planes_[i]), lay.r0, lay.r1, depth));
+      SLAB_TRY(ops->ghost_extent(ops->ctx, rowp(planes_[i], w0), w1 - w0, row_floats(planes_[i]), lay.r0 - w0, lay.r1 - w0, depth));
     const int mine[2] = {depth[0], depth[1]};
     return all_ints(mine, 2, all);
   }
@@ -235,9 +259,9 @@ struct soil_slab {
   int reach_pair(std::vector<int>& rf, std::vector<int>& rd) {
     int32_t df[2] = {0, 0}, dd[2] = {0, 0};
     for (int i = 0; i < 3; ++i)
-      SLAB_TRY(ops->ghost_extent(ops->ctx, P[soil::kFluxFluvial[i]], lay.rows, row_floats(soil::kFluxFluvial[i]), lay.r0, lay.r1, df));
+      SLAB_TRY(ops->ghost_extent(ops->ctx, rowp(soil::kFluxFluvial[i], w0), w1 - w0, row_floats(soil::kFluxFluvial[i]), lay.r0 - w0, lay.r1 - w0, df));
     for (int i = 0; i < 2; ++i)
-      SLAB_TRY(ops->ghost_extent(ops->ctx, P[soil::kFluxDebris[i]], lay.rows, row_floats(soil::kFluxDebris[i]), lay.r0, lay.r1, dd));
+      SLAB_TRY(ops->ghost_extent(ops->ctx, rowp(soil::kFluxDebris[i], w0), w1 - w0, row_floats(soil::kFluxDebris[i]), lay.r0 - w0, lay.r1 - w0, dd));
     const int mine[4] = {df[0], df[1], dd[0], dd[1]};
     std::vector<int> all;
     SLAB_TRY(all_ints(mine, 4, all, true));
@@ -320,6 +344,14 @@ struct soil_slab {
     auto mk = [&](int i) { if (mark) mark(mctx, i); };
     const soil_erosion_planes pl = planes();
     const soil_domain dom = domain(lay.r0, lay.r1);
+    set_window();
+    note_window();
+    soil_erosion_planes plw = planes(w0);  // what the particle launches get
+    soil_domain domw = window_domain();
+    auto rewindow = [&]() {  // after refresh_all(): every ghost row is fresh, the window is all of them
+      set_window();
+      plw = planes(w0), domw = window_domain();
+    };
     const uint64_t off = step_index * static_cast<uint64_t>(N);
     SLAB_TRY(ops->rng_seed(ops->ctx, rng, N, seed, off));
     SLAB_TRY(ops->fill_f32(ops->ctx, remote0, 0.0f, 8, 0));
@@ -333,19 +365,20 @@ struct soil_slab {
       // the debris launch draws from a tensor of its own, seeded where the fluvial launch leaves
       // the shared one in the sequential order
       SLAB_TRY(ops->rng_seed(ops->ctx, rng_debris, N, seed, off + 2));
-      SLAB_TRY(ops->particles_pair(ops->ctx, &pl, rng, rng_debris, N, remote0, &dom, scale, &param));
+      SLAB_TRY(ops->particles_pair(ops->ctx, &plw, rng, rng_debris, N, remote0, &domw, scale, &param));
       if (trim) {
         SLAB_TRY(reach_pair(rf, rd));
         remote_summed = true;
         // a fluvial walk reads layers, velocity, waterHeight; a debris walk layers and debrisVelocity
         if (too_deep(rf) || too_deep(rd) || too_deep(rd, true)) {  // rare: both launches again, on complete fields
           SLAB_TRY(refresh_all());
+          rewindow();
           SLAB_TRY(zero_planes(soil::kFluxFluvial, 3));
           SLAB_TRY(zero_planes(soil::kFluxDebris, 2));
           SLAB_TRY(ops->fill_f32(ops->ctx, remote0, 0.0f, 8, 0));
           SLAB_TRY(ops->rng_seed(ops->ctx, rng, N, seed, off));
           SLAB_TRY(ops->rng_seed(ops->ctx, rng_debris, N, seed, off + 2));
-          SLAB_TRY(ops->particles_pair(ops->ctx, &pl, rng, rng_debris, N, remote0, &dom, scale, &param));
+          SLAB_TRY(ops->particles_pair(ops->ctx, &plw, rng, rng_debris, N, remote0, &domw, scale, &param));
           SLAB_TRY(reach_pair(rf, rd));
         }
         cf = counts_of(rf), cd = counts_of(rd);
@@ -353,15 +386,16 @@ struct soil_slab {
       }
       mk(1);
     } else {
-      SLAB_TRY(ops->particles_fluvial(ops->ctx, &pl, rng, N, remote0, &dom, scale, &param));
+      SLAB_TRY(ops->particles_fluvial(ops->ctx, &plw, rng, N, remote0, &domw, scale, &param));
       if (trim) {
         SLAB_TRY(reach(soil::kFluxFluvial, 3, rf));
         if (too_deep(rf)) {  // rare: repeat the launch on complete fields
           SLAB_TRY(refresh_all());
+          rewindow();
           SLAB_TRY(zero_planes(soil::kFluxFluvial, 3));
           SLAB_TRY(ops->fill_f32(ops->ctx, remote0, 0.0f, 8, 0));
           SLAB_TRY(ops->rng_seed(ops->ctx, rng, N, seed, off));
-          SLAB_TRY(ops->particles_fluvial(ops->ctx, &pl, rng, N, remote0, &dom, scale, &param));
+          SLAB_TRY(ops->particles_fluvial(ops->ctx, &plw, rng, N, remote0, &domw, scale, &param));
           SLAB_TRY(reach(soil::kFluxFluvial, 3, rf));
         }
         cf = counts_of(rf);
@@ -373,17 +407,18 @@ struct soil_slab {
         SLAB_TRY(flux_exchange(soil::kFluxFluvial, 3, trim ? &cf : nullptr, 1));
         early = true;
       }
-      SLAB_TRY(ops->particles_debris(ops->ctx, &pl, rng, N, remote0, &dom, scale, &param));
+      SLAB_TRY(ops->particles_debris(ops->ctx, &plw, rng, N, remote0, &domw, scale, &param));
       if (trim) {
         SLAB_TRY(reach(soil::kFluxDebris, 2, rd));
         if (too_deep(rd) || too_deep(rd, true)) {
           SLAB_TRY(refresh_all());
+          rewindow();
           SLAB_TRY(zero_planes(soil::kFluxDebris, 2));
           // the NaN walkers' debris deposits are entries 4..6 of remote0; the launch draws where
           // the fluvial one left the streams (two draws per particle on)
           SLAB_TRY(ops->fill_f32(ops->ctx, remote0 + 4, 0.0f, 4, 0));
           SLAB_TRY(ops->rng_seed(ops->ctx, rng, N, seed, off + 2));
-          SLAB_TRY(ops->particles_debris(ops->ctx, &pl, rng, N, remote0, &dom, scale, &param));
+          SLAB_TRY(ops->particles_debris(ops->ctx, &plw, rng, N, remote0, &domw, scale, &param));
           SLAB_TRY(reach(soil::kFluxDebris, 2, rd));
         }
         cd = counts_of(rd);
@@ -875,6 +910,7 @@ int soil_slab_create(soil_slab** out, const soil_slab_config* cfg, const soil_pa
   if (s->world == 1 || !ops->ghost_extent) s->trim = false;
   s->pair = cfg->pair >= 0 ? cfg->pair != 0 : !env_is("SOIL_STEP_PAIR", "0");  // on by default, as in soil_erode_step
   s->halo_need = cfg->halo_need;
+  s->window = !env_is("SOIL_HALO_WINDOW", "0");
   if (s->halo_need <= 0)
     if (const char* e = std::getenv("SOIL_HALO_NEED")) s->halo_need = std::atoi(e);
   s->up = s->rank > 0 ? s->rank - 1 : -1;
@@ -959,6 +995,7 @@ int soil_slab_get_info(const soil_slab* s, soil_slab_info* info) {
   info->rank = s->rank, info->world = s->world, info->trim = s->trim, info->pair = s->pair;
   info->rows_flux = s->rows_flux, info->rows_field = s->rows_field, info->rows_full = s->rows_full;
   info->repeated_launches = s->fallbacks;
+  info->rows_window = s->rows_window, info->rows_window_full = s->rows_window_full;
   info->n_reach = static_cast<int32_t>(s->reach_hist.size());
   for (int i = 0; i < info->n_reach && i < 4; ++i) info->reach_hist[i] = s->reach_hist[static_cast<size_t>(i)];
   return SOIL_OK;

@@ -447,7 +447,8 @@ class SlabRunner:
     @property
     def halo_rows(self):
         i = self.info()
-        return {"flux": int(i.rows_flux), "field": int(i.rows_field), "full": int(i.rows_full)}
+        return {"flux": int(i.rows_flux), "field": int(i.rows_field), "full": int(i.rows_full),
+                "window": int(i.rows_window), "window_full": int(i.rows_window_full)}
 
     @property
     def fallbacks(self):

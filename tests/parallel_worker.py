@@ -185,7 +185,7 @@ def main():
              height=runner.plane("height", owned=True).copy(),
              ghost_layers=runner.plane("layers").copy(), x0=runner.x0, rows=runner.rows,
              G=runner.G, H=runner.H, fallbacks=runner.fallbacks,
-             halo_rows=np.array([runner.halo_rows[k] for k in ("flux", "field", "full")]))
+             halo_rows=np.array([runner.halo_rows[k] for k in ("flux", "field", "full", "window", "window_full")]))
     t = runner.max_over_ranks(float(runner.rank))
     assert t == runner.world - 1
     runner.barrier()

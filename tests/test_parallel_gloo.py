@@ -96,6 +96,8 @@ def test_slab_runner_matches_single_domain(oracle, tmp_path, world, S, W, maxage
                                        atol=1e-6)
         elif need is None:
             assert shipped < 0.8 * full and int(d["fallbacks"]) == 0, (shipped, full)
+            # ... and the launches were given the ghost rows with fresh fields (+ 2), not all G
+            assert 0 < int(d["halo_rows"][3]) < 0.9 * int(d["halo_rows"][4]), d["halo_rows"]
         else:
             assert int(d["fallbacks"]) > 0
     for k in got:

@@ -14,8 +14,9 @@ import os
 import sys
 import time
 
-# the stand-in communicator moves nothing, so the measured reach of the walks never comes back
-# as fresh ghost fields: with the halo trimming on, every step would take the repeat-launch path
+# the stand-in communicator moves nothing: the ghost fields a rank walks on are never refreshed (the
+# timing does not care).  SOIL_HALO_FULL=0 in the environment turns the trimming by measured reach on
+# (this rank's own reach; the launch window of round 4 with it, SOIL_HALO_WINDOW=0 without)
 os.environ.setdefault("SOIL_HALO_FULL", "1")
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -74,9 +75,10 @@ def main():
         steps = soil.particle_steps(reset=True) / args.steps
         base = base or ms
         print("world %d rank %d: rows %d (+%d ghost), N %d: %.2f ms/step, %.2f G particle steps, "
-              "compute-side efficiency %.3f" % (world, r.rank, S, r.rows - S, r.N,
-                                                ms, steps / 1e9,
-                                                base / ms / (world if args.strong else 1)), flush=True)
+              "compute-side efficiency %.3f; repeated launches %d, ghost rows walked / bound %.2f" % (
+                  world, r.rank, S, r.rows - S, r.N, ms, steps / 1e9,
+                  base / ms / (world if args.strong else 1), r.fallbacks,
+                  r.halo_rows["window"] / max(r.halo_rows["window_full"], 1)), flush=True)
         r.close()
         del r
         from soillib_amd import silt
