@@ -181,6 +181,7 @@ void launch_steepest4(int32_t* out, const float* height, int64_t H, int64_t W, h
   switch (win_shape(0)) {
     case 0: return launch_steepest4_as<K, STORE_K, RowWalkReg<kWatch>>(out, height, H, W, st);
     case 1: return launch_steepest4_as<K, STORE_K, RowWalkLds<kWatch>>(out, height, H, W, st);
+    case 3: return launch_steepest4_as<K, STORE_K, RowWalkTall<kWatch>>(out, height, H, W, st);
     default: return launch_steepest4_as<K, STORE_K, RowWalkFlat<kWatch>>(out, height, H, W, st);
   }
 }

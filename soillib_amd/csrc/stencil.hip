@@ -125,6 +125,7 @@ static void win_launch_as(KF kernel, int64_t H, int64_t W, hipStream_t st, A... 
     else switch (win_shape(dflt)) {                                                                 \
       case 0: win_launch_as<RowWalkReg<WATCH>>(K_FAST<RowWalkReg<WATCH>>, H, W, st, __VA_ARGS__); break;   \
       case 1: win_launch_as<RowWalkLds<WATCH>>(K_FAST<RowWalkLds<WATCH>>, H, W, st, __VA_ARGS__); break;   \
+      case 3: win_launch_as<RowWalkTall<WATCH>>(K_FAST<RowWalkTall<WATCH>>, H, W, st, __VA_ARGS__); break; \
       default: win_launch_as<RowWalkFlat<WATCH>>(K_FAST<RowWalkFlat<WATCH>>, H, W, st, __VA_ARGS__); break; \
     }                                                                                               \
   } while (0)

@@ -137,14 +137,19 @@ __device__ __forceinline__ bool win_row_plain(const float4& c, float edge) {
 // Rows x - 1, x, x + 1 as a thread walks down its band: start() loads all three, next() moves one
 // row down re-using two.  Every lane of the wave must make the calls (they shuffle).
 // WATCH: plain() says whether all three rows are plain for the whole wave.
-struct WinBandShape {  // a work-group walks bands of kWinBand rows: grid.y bands at a time
-  static constexpr int kBand = kWinBand;
-  static dim3 grid(int64_t H, int64_t W) { return win_grid(H, W); }
+template <int BAND>
+struct WinBandRows {  // a work-group walks bands of BAND rows: grid.y bands at a time
+  static constexpr int kBand = BAND;
+  static dim3 grid(int64_t H, int64_t W) {
+    const int64_t bands = (H + BAND - 1) / BAND;
+    return dim3(static_cast<unsigned>((W / 4 + kWinBlock - 1) / kWinBlock), static_cast<unsigned>(bands < 65535 ? bands : 65535));
+  }
   static __device__ __forceinline__ WinThread thread(int64_t, int64_t W) { return win_thread(W); }
   static __device__ __forceinline__ int64_t band_first(const WinThread&) { return blockIdx.y; }
   static __device__ __forceinline__ bool band_ok(int64_t band, int64_t H) { return band * kBand < H; }
   static __device__ __forceinline__ int64_t band_next(int64_t band) { return band + gridDim.y; }
 };
+using WinBandShape = WinBandRows<kWinBand>;
 struct WinFlatShape {  // a work-group owns one row
   static constexpr int kBand = 1;
   static dim3 grid(int64_t H, int64_t W) { return win_grid_flat(H, W); }
@@ -198,6 +203,8 @@ struct RowWalkReg : SHAPE {
 using RowWalk = RowWalkReg<false>;
 template <bool WATCH>
 using RowWalkFlat = RowWalkReg<WATCH, WinFlatShape>;
+template <bool WATCH>
+using RowWalkTall = RowWalkReg<WATCH, WinBandRows<kWinBand / 2>>;  // bands of 16 rows
 
 // ---- the same walk with the rows landing in LDS (round 4) ---------------------------------------
 //
@@ -333,11 +340,12 @@ constexpr int win_lds_floats() {
   Walk w;                                                                       \
   ::soil::win_bind(w, w##_lds, W)
 // SOIL_WIN_SHAPE (A/B): 0 the band walk through registers, 1 the band walk through LDS, 2 the flat
-// shape; unset: the kernel's own default
+// shape, 3 bands of 16 rows through registers (measured: as 32; 64 rows, half the waves: 20-30 % slower);
+// unset: the kernel's own default
 inline int win_shape(int dflt) {
   static const int env = [] {
     const char* e = std::getenv("SOIL_WIN_SHAPE");
-    return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : -1;
+    return (e && e[0] >= '0' && e[0] <= '3') ? e[0] - '0' : -1;
   }();
   return env >= 0 ? env : dflt;
 }

@@ -3,7 +3,7 @@
 # 2 flat), alternated on one box: tools/ab_win_shape.sh [pattern]
 pat=${1:-steepest|direction d8}
 for i in 1 2 3; do
-  for v in 0 1 2; do
+  for v in ${SHAPES:-0 1 2 3}; do
     SOIL_WIN_SHAPE=$v python tools/bench_stencils.py --reps 20 2>/dev/null | grep " ms " | grep -E "$pat" | sed "s/^/shape=$v /" | cut -c1-100
   done
 done
