@@ -1066,8 +1066,12 @@ struct PairGate {
   uint32_t dense[2];
 };
 __global__ void k_pair_gate(PairGate* gate, int me, const TiledCtl* __restrict__ ctl,
-                            unsigned long long ticks_max) {
+                            unsigned long long ticks_max, uint32_t free_below) {
   if (ctl->mode != 0) return;  // no round follows
+  // A round of few walkers does not fill the chip: it neither waits nor makes the other launch wait
+  // (SOIL_PAIR_FREE: its launch's chain of late rounds then runs under the other's dense rounds
+  // instead of in step with them, and is over before the step's end is all tails)
+  if (ctl->live < free_below) return;
   const unsigned long long t0 = realtime_ticks();
   while (__hip_atomic_load(&gate->dense[1 - me], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
     __builtin_amdgcn_s_sleep(32);
@@ -2188,6 +2192,7 @@ struct TiledRun {
   bool sparse_ok = false;  // rounds >= 1 may hand their sparse tiles to the one-wave kernel (SOIL_TILED_SPARSE=2: off)
   int sparse_min = 64, sparse_pct = 25;  // SOIL_TILED_SPARSE_MIN, _PCT: see QueueScan
   int sparse_probe = kSparseProbe;       // SOIL_TILED_SPARSE_PROBE: slots a deposit tries before it adds to the planes directly
+  uint32_t pair_free_below = 0;          // SOIL_PAIR_FREE (per cent of N): rounds of fewer walkers pass the gate (k_pair_gate)
   int host_lag_us = 0;                   // SOIL_TILED_HOST_LAG_US (tests): the host sleeps that long before every look at a word
   int agg_min = 48, agg_groups = 4, retries = 2;
   PRec* recs_of(uint64_t r) const { return (r & 1) ? next : cur; }               // records round r reads
@@ -2277,6 +2282,10 @@ struct TiledRun {
     }
     host_lag_us = env_int("SOIL_TILED_HOST_LAG_US", 0);
     sparse_probe = env_kind("SOIL_TILED_SPARSE_PROBE", KIND, kSparseProbe);
+    pair_free_below = static_cast<uint32_t>(std::min<int64_t>(0x7fffffff, N * env_kind("SOIL_PAIR_FREE", KIND, 20) / 100));
+    // (measured, ms per overlapped step at 0 | 6 | 12 | 25 | 50 per cent: 8192^2 30.93 | 30.88 | 30.83 | 30.83 | 30.99; debris
+    // alone at 25 | 60: 30.79 | 31.06; 4096^2 10.01 | 9.98 at 20, 2048^2 4.81 | 4.82: the late rounds' chain is bound by
+    // its own latencies, free or in step)
     sparse_min = env_kind("SOIL_TILED_SPARSE_MIN", KIND, 64);
     sparse_pct = env_kind("SOIL_TILED_SPARSE_PCT", KIND, 25);
     steps_late = env_kind("SOIL_TILED_STEPS_LATE", KIND, 0);
@@ -2511,7 +2520,7 @@ struct TiledRun {
       SOIL_LAUNCH_CHECK();
     }
     if (gate && tail_scan) {  // (the `started` ticket is reset by the tail scan's work-group)
-      k_pair_gate<<<1, 1, 0, st>>>(gate, KIND, ctl, static_cast<unsigned long long>(0.05 * ticks_per_second));
+      k_pair_gate<<<1, 1, 0, st>>>(gate, KIND, ctl, static_cast<unsigned long long>(0.05 * ticks_per_second), pair_free_below);
       SOIL_LAUNCH_CHECK();
       my_dense = &gate->dense[KIND];
     }
