@@ -68,9 +68,39 @@ static std::mutex g_ws_mutex;
 using WsKey = std::tuple<std::thread::id, int, int>;
 static std::map<WsKey, WsBlock> g_ws;
 
+// A host thread's blocks go when the thread does (a pool that makes a thread per request would
+// otherwise leave a full set of scratch behind each time — hundreds of MB for the tiled particle
+// launches).  Not for the thread that loaded the library: its thread_local destructors run at process
+// exit, next to the HIP runtime's own teardown.
+static const std::thread::id g_loader_thread = std::this_thread::get_id();
+struct WsThreadGuard {
+  ~WsThreadGuard() {
+    const std::thread::id me = std::this_thread::get_id();
+    if (me == g_loader_thread) return;
+    int before = 0;
+    if (hipGetDevice(&before) != hipSuccess) return;
+    std::lock_guard<std::mutex> lock(g_ws_mutex);
+    for (auto it = g_ws.begin(); it != g_ws.end();) {
+      if (std::get<0>(it->first) != me) {
+        ++it;
+        continue;
+      }
+      if (it->second.base && hipSetDevice(std::get<1>(it->first)) == hipSuccess) {
+        (void)hipDeviceSynchronize();  // the thread's launches may still be in flight on its streams
+        (void)hipFree(it->second.base);
+      }
+      it = g_ws.erase(it);
+    }
+    (void)hipSetDevice(before);
+    (void)hipGetLastError();
+  }
+};
+
 int workspace_get(int slot, size_t bytes, void** out) {
   int dev = 0;
   SOIL_HIP(hipGetDevice(&dev));
+  static thread_local WsThreadGuard guard;
+  (void)guard;
   std::lock_guard<std::mutex> lock(g_ws_mutex);
   WsBlock& w = g_ws[WsKey{std::this_thread::get_id(), dev, slot}];
   if (w.bytes < bytes) {

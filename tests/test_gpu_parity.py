@@ -1333,3 +1333,56 @@ def test_two_host_threads_share_a_device(hip, oracle):
     for i in range(2):
         # trajectories are the same bits; the flux sums (fp32 atomics) are a tolerance between runs
         np.testing.assert_allclose(res[i], alone["ref"], rtol=2e-4, atol=1e-5)
+
+
+def test_a_threads_scratch_goes_with_the_thread(hip, oracle):
+    """A host thread's workspace blocks (hundreds of MB for the tiled particle launches) are freed when
+    the thread ends: a caller that makes a thread per request does not pile them up (runtime.hip
+    WsThreadGuard)."""
+    import threading
+    import torch
+    from soillib_amd import erosion, silt, soil
+    H = W = 2048
+    param = script_param(soil.param_t())
+    param.maxage = 64
+    dem = terrain(oracle, 256, 256)
+    dem = np.ascontiguousarray(np.kron(dem, np.ones((8, 8, 1), np.float32)))
+
+    m = erosion.ErosionModel(H, W, (20.0 / H, 20.0 / W, 4.0), param, H * W // 8, seed=3)
+    m.set_layers(to_gpu(dem))
+    silt.set(m.rainfall, 1.0)
+
+    def run():
+        m.step()
+        hip.soil_device_synchronize()
+
+    def free_now():
+        hip.soil_device_synchronize()
+        return torch.cuda.mem_get_info(0)[0]
+
+    import time
+
+    def settled(previous=None):
+        # join() returns when the Python function has; the OS thread's thread_local destructors — where
+        # the blocks go — run a moment later
+        last = free_now()
+        for _ in range(40):
+            time.sleep(0.05)
+            now = free_now()
+            if now == last and (previous is None or previous - now < 64 * 2 ** 20):
+                break
+            last = now
+        return last
+
+    t = threading.Thread(target=run)        # (the first thread also pays one-off allocations of the runtime)
+    t.start()
+    t.join()
+    base = settled()
+    for _ in range(3):
+        t = threading.Thread(target=run)
+        t.start()
+        t.join()
+    after = settled(base)
+    # one thread's scratch at this size is ~300 MB; three leaked sets would be ~0.9 GB
+    assert base - after < 64 * 2 ** 20, "free memory fell by %d MB over three threads" % ((base - after) >> 20)
+
