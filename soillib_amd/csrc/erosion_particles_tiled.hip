@@ -123,6 +123,10 @@ struct TiledCtl {
   // ... and of the sparse tiles of round r (k_tiled_round<..., SPARSE>): the entries of the block list
   // behind the blocks_of[r & 1] dense ones
   uint32_t sparse_of[2];
+  // ... and how many of those — the last ones — hold fewer than 16 walkers: the sparse kernel takes
+  // them four to a wave (0: one tile per wave throughout)
+  uint32_t sparse_tiny[2];
+  uint32_t sparse_pair[2];  // ... and in front of those, the ones of 16 .. 31 walkers: two to a wave
 };
 struct ScanRule {  // when the rounds stop (TiledRun::setup)
   uint32_t round, tail, max_round;
@@ -832,6 +836,7 @@ struct QueueScan {
   // dispatch order) to the one-wave kernel (k_tiled_round<..., SPARSE>); the scan decides whether it does
   uint32_t sparse_ok;
   uint32_t sparse_min, sparse_pct;  // ... when there are at least so many of them, and so many per cent of the non-empty tiles
+  uint32_t sparse_pack;             // tiles of fewer than 16 walkers four to a wave (SOIL_TILED_SPARSE_PACK=2: off)
 };
 constexpr int scan_lds_words(int nt) { return 16 * nt + 256 + 256 + 8 + 16; }
 
@@ -873,6 +878,8 @@ __device__ void queue_scan_dev(const QueueScan& q, uint32_t* lds) {
     ctl->blocks = blocks;
     ctl->blocks_of[q.rule.round & 1u] = blocks - n_sparse;
     ctl->sparse_of[q.rule.round & 1u] = n_sparse;
+    ctl->sparse_tiny[q.rule.round & 1u] = (n_sparse != 0u && q.sparse_pack != 0u) ? hist[254] : 0u;  // bucket 254: 1 .. 15 walkers
+    ctl->sparse_pair[q.rule.round & 1u] = (n_sparse != 0u && q.sparse_pack != 0u && kSparseBuckets >= 2) ? hist[253] : 0u;
     host->blocks = blocks;
     // words of later scans overwrite this one while the host may still be reading it: the verdict
     // is a single word, and what goes with it is out before it
@@ -1342,7 +1349,24 @@ __global__ void __launch_bounds__(NT, SPARSE ? 2 : round_waves_per_simd(KIND, TR
   }
   static_assert(!SPARSE || (NT == kSparseLanes && !ALB && DEP == 1), "a sparse tile: one wave, no colour planes");
   const uint32_t n_dense = ctl->blocks_of[round & 1u];
-  const uint32_t n_groups = SPARSE ? ctl->sparse_of[round & 1u] : n_dense;
+  // SPARSE: the last `n_tiny` of the round's sparse tiles hold fewer than 16 walkers and go four to a
+  // wave, a quarter of the wave each (`sub`): a wave of 6-14 walkers issues every instruction for 64
+  // lanes, and thirty such waves per CU share the vector pipes — the late rounds' sparse kernels were
+  // bound by that, not by their walkers' chains.  Everything that derives from the job — the tile's
+  // origin, its bounds, the queue — is a per-lane value then; the table is shared (keyed by the cell's
+  // index in the slab, not in the tile).
+  const uint32_t n_sparse_tiles = SPARSE ? ctl->sparse_of[round & 1u] : 0u;
+  const uint32_t n_tiny = SPARSE ? ctl->sparse_tiny[round & 1u] : 0u;
+  const uint32_t n_pair = SPARSE ? ctl->sparse_pair[round & 1u] : 0u;  // (16 .. 31 walkers: two to a wave, the same way)
+  const uint32_t n_single = n_sparse_tiles - n_tiny - n_pair;
+  const uint32_t g_pair = (n_pair + 1u) / 2u, g_tiny = (n_tiny + 3u) / 4u;
+  const uint32_t n_groups = SPARSE ? n_single + g_pair + g_tiny : n_dense;
+  // (uniform) tiles per wave of this work-group: 1, 2 or 4
+  const uint32_t pack_shift = !SPARSE || blockIdx.x < n_single ? 0u : (blockIdx.x < n_single + g_pair ? 1u : 2u);
+  const bool packed = pack_shift != 0u;
+  const uint32_t sub_lanes = static_cast<uint32_t>(NT) >> pack_shift;
+  const uint32_t sub = packed ? threadIdx.x >> (6u - pack_shift) : 0u;  // (kSparseLanes = 64)
+  const uint32_t lane_sub = packed ? threadIdx.x & (sub_lanes - 1u) : threadIdx.x;  // the lane's place in its tile's share of the wave
   // (no dense tile at all — every tile of the round went to the sparse kernel, which has run: it stands
   // in front of this one on the stream — : the first work-group is the round's last, see below)
   const bool all_sparse = !SPARSE && n_groups == 0u;
@@ -1365,7 +1389,17 @@ __global__ void __launch_bounds__(NT, SPARSE ? 2 : round_waves_per_simd(KIND, TR
   };
   PROF_DECL;
   // this work-group's share of its tile's queue (the scan's block list)
-  const uint4 job = block_list[(SPARSE ? n_dense : 0u) + blockIdx.x];
+  uint4 job;
+  if (packed) {
+    // this share's tile: the pairs stand behind the single tiles in the list, the quads behind the pairs
+    const bool quad = pack_shift == 2u;
+    const uint32_t t = quad ? (blockIdx.x - n_single - g_pair) * 4u + sub : (blockIdx.x - n_single) * 2u + sub;
+    const uint32_t n_class = quad ? n_tiny : n_pair, at = n_dense + n_single + (quad ? n_pair : 0u);
+    job = block_list[at + (t < n_class ? t : n_class - 1u)];
+    if (t >= n_class) job.z = 0u;  // (the last wave's shares beyond the list: nothing queued)
+  } else {
+    job = block_list[(SPARSE ? n_dense : 0u) + blockIdx.x];
+  }
   const int tile = static_cast<int>(job.x);
   const uint32_t first = job.y, cnt = job.z;
   const bool shared_tile = job.w != 0;  // other work-groups deposit into the same cells
@@ -1384,7 +1418,7 @@ __global__ void __launch_bounds__(NT, SPARSE ? 2 : round_waves_per_simd(KIND, TR
   constexpr int kWords = SPARSE ? kSparseTab * (1 + kFluxPlanesL)
                                 : (kAcc > scan_lds_words(NT) ? kAcc : scan_lds_words(NT));
   __shared__ __attribute__((aligned(16))) float s_mem[kWords];
-  // SPARSE: the table — kSparseTab keys (the cell's index in the tile; kSparseEmpty: free), then one
+  // SPARSE: the table — kSparseTab keys (the cell's index in the slab; kSparseEmpty: free), then one
   // array of kSparseTab sums per flux plane, in deposit_terms' order
   uint32_t* const t_key = reinterpret_cast<uint32_t*>(s_mem);
   float* const t_val = s_mem + kSparseTab;
@@ -1401,6 +1435,7 @@ __global__ void __launch_bounds__(NT, SPARSE ? 2 : round_waves_per_simd(KIND, TR
   float* const s_c1 = s_c0 + (ALB ? kCells : 0);
   float* const s_c2 = s_c1 + (ALB ? kCells : 0);
   __shared__ uint32_t s_next, s_out, s_steps, s_last;
+  __shared__ uint32_t s_out_sub[4];  // SPARSE, packed: slots each quarter's tile has filled
   // The ticket of the round's end (the work-group that draws the last one scans the queues of the
   // round that follows): drawn by thread 0 as soon as this work-group's survivors are counted — behind
   // the barrier that ends the stepping — and looked at behind the flush, which its round trip hides under.
@@ -1412,7 +1447,7 @@ __global__ void __launch_bounds__(NT, SPARSE ? 2 : round_waves_per_simd(KIND, TR
       done_ticket = __hip_atomic_fetch_add(&ctl->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
   do {  // the round's work proper (a chunk of a cut queue may be empty)
-  if (cnt == 0 && !store_all) {  // (storing: an empty tile's zeros go out like any other's)
+  if (!packed && cnt == 0 && !store_all) {  // (storing: an empty tile's zeros go out like any other's)
     if (gate_lane) gate_look(gate_draw());
     break;
   }
@@ -1421,14 +1456,15 @@ __global__ void __launch_bounds__(NT, SPARSE ? 2 : round_waves_per_simd(KIND, TR
     s_out = 0;
     s_steps = 0;
   }
+  if (SPARSE && tid < 4) s_out_sub[tid] = 0;
   const StepConst k = make_const<KIND>(d, s, param);
   // Lane t starts on queue entry t — no counter involved, and the record's two dependent
   // loads (slot index, then the 64-byte record) travel while the flux tile is zeroed.
   // Only a queue longer than the work-group is handed out through s_next.
   PRec r;
   r.iter = -1;
-  bool have = static_cast<uint32_t>(tid) < cnt;
-  if (have) r = in[order[first + tid]];
+  bool have = lane_sub < cnt;
+  if (have) r = in[order[first + lane_sub]];
   uint32_t gate_ticket = 0;
   if (gate_lane) gate_ticket = gate_draw();
   if constexpr (SPARSE) {
@@ -1487,7 +1523,7 @@ __global__ void __launch_bounds__(NT, SPARSE ? 2 : round_waves_per_simd(KIND, TR
   // loop is over: a tile starts a round with about one particle per lane, so
   // refills are the exception.
   // `more`: the queue holds entries beyond the ones handed out so far (uniform per wave)
-  bool more = cnt > static_cast<uint32_t>(kBlock), parked = false;
+  bool more = !SPARSE && cnt > static_cast<uint32_t>(kBlock), parked = false;  // (a sparse tile fits its lanes)
   constexpr int kRefillLanes = 16;
   auto write_out = [&]() {
     const uint32_t slot = atomicAdd(&s_out, 1u);  // slots this tile's queue occupied
@@ -1522,11 +1558,12 @@ __global__ void __launch_bounds__(NT, SPARSE ? 2 : round_waves_per_simd(KIND, TR
   // compare-and-swap on the key; linear probing); `lcell`: the cell's index in the planes, for the
   // deposit that finds the table full around its hash
   auto sparse_deposit = [&](int c, uint32_t lcell, const float* v) {
-    uint32_t slot = (static_cast<uint32_t>(c) * 2654435761u) >> (32 - kSparseTabBits);
+    (void)c;  // keyed by the cell's index in the slab: four tiles may share the table (packed)
+    uint32_t slot = (lcell * 2654435761u) >> (32 - kSparseTabBits);
     bool placed = false;
     for (int t = 0; t < retries; ++t) {  // (SPARSE: `retries` carries the probe count, kSparseProbe unless a test says otherwise)
-      const uint32_t old = atomicCAS(&t_key[slot], kSparseEmpty, static_cast<uint32_t>(c));
-      if (old == kSparseEmpty || old == static_cast<uint32_t>(c)) {
+      const uint32_t old = atomicCAS(&t_key[slot], kSparseEmpty, lcell);
+      if (old == kSparseEmpty || old == lcell) {
         placed = true;
         break;
       }
@@ -1709,7 +1746,9 @@ __global__ void __launch_bounds__(NT, SPARSE ? 2 : round_waves_per_simd(KIND, TR
     PROF_AT(0);  // stops sorted out
   }
   {  // everything still parked goes out together (convergent: aggregate the counters)
-    const uint32_t slot = wave_append(&s_out, parked);
+    uint32_t slot;
+    if (packed) slot = parked ? atomicAdd(&s_out_sub[sub], 1u) : 0u;  // (a handful of lanes)
+    else slot = wave_append(&s_out, parked);
     const uint32_t dest_tile =
         parked ? queue_key(k.x0, r.px, r.py, r.spx, r.spy, k.maxage - static_cast<uint32_t>(r.iter),
                            tiles_w_next, ts_next, steps_per_round)
@@ -1727,7 +1766,7 @@ __global__ void __launch_bounds__(NT, SPARSE ? 2 : round_waves_per_simd(KIND, TR
   PROF_AT(7);  // waiting for the slowest wave of the work-group
   done_draw();
   if (tid == 0) atomicAdd(steps, static_cast<unsigned long long>(s_steps));
-  for (uint32_t j = s_out + tid; j < cnt; j += kBlock) dest[first + j] = kNoTile;  // unused slots
+  for (uint32_t j = (packed ? s_out_sub[sub] : s_out) + lane_sub; j < cnt; j += sub_lanes) dest[first + j] = kNoTile;  // unused slots
 
   // flush the tile's flux into the global planes: with one work-group per tile per
   // round plain read-modify-writes suffice; the groups of a split tile add atomically.  Only cells that received a
@@ -1765,7 +1804,7 @@ __global__ void __launch_bounds__(NT, SPARSE ? 2 : round_waves_per_simd(KIND, TR
 #pragma unroll
       for (int q = 0; q < kFluxPlanes; ++q) g[j][q] = 0.0f;
       if (key[j] == kSparseEmpty) continue;
-      const int64_t l = static_cast<int64_t>(row0 + static_cast<int>(key[j]) / TC) * k.W + (col0 + static_cast<int>(key[j]) % TC);
+      const int64_t l = static_cast<int64_t>(key[j]);  // the cell's index in the slab
       float* const fv = reinterpret_cast<float*>(fluxV + l);
       if (KIND == FLUVIAL) {
         g[j][0] = __hip_atomic_load(flux0 + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1782,7 +1821,7 @@ __global__ void __launch_bounds__(NT, SPARSE ? 2 : round_waves_per_simd(KIND, TR
     for (int j = 0; j < kTPer; ++j) {
       const int i = tid + j * NT;
       if (key[j] == kSparseEmpty) continue;
-      const int64_t l = static_cast<int64_t>(row0 + static_cast<int>(key[j]) / TC) * k.W + (col0 + static_cast<int>(key[j]) % TC);
+      const int64_t l = static_cast<int64_t>(key[j]);
       float a[kFluxPlanes];
 #pragma unroll
       for (int q = 0; q < kFluxPlanes; ++q) a[q] = t_val[q * kSparseTab + i];
@@ -2197,6 +2236,7 @@ struct TiledRun {
   bool stagger = true;
   bool sparse_ok = false;  // rounds >= 1 may hand their sparse tiles to the one-wave kernel (SOIL_TILED_SPARSE=2: off)
   int sparse_min = 64, sparse_pct = 25;  // SOIL_TILED_SPARSE_MIN, _PCT: see QueueScan
+  bool sparse_pack = true;               // SOIL_TILED_SPARSE_PACK=2: one tile per wave whatever it holds
   int sparse_probe = kSparseProbe;       // SOIL_TILED_SPARSE_PROBE: slots a deposit tries before it adds to the planes directly
   uint32_t pair_free_below = 0;          // SOIL_PAIR_FREE (per cent of N): rounds of fewer walkers pass the gate (k_pair_gate)
   int host_lag_us = 0;                   // SOIL_TILED_HOST_LAG_US (tests): the host sleeps that long before every look at a word
@@ -2294,6 +2334,7 @@ struct TiledRun {
     // its own latencies, free or in step)
     sparse_min = env_kind("SOIL_TILED_SPARSE_MIN", KIND, 64);
     sparse_pct = env_kind("SOIL_TILED_SPARSE_PCT", KIND, 25);
+    sparse_pack = env_kind("SOIL_TILED_SPARSE_PACK", KIND, 1) != 2;  // (2: off — env_int reads 0 as "unset")
     steps_late = env_kind("SOIL_TILED_STEPS_LATE", KIND, 0);
     steps_late_from = env_kind("SOIL_TILED_LATE_FROM", KIND, 1 << 30);
     // A round is worth its fixed cost while it advances particles faster than the
@@ -2423,6 +2464,7 @@ struct TiledRun {
     q.sparse_ok = (r >= 1 && sparse_ok && shape_of(r) != kShapeColour) ? 1u : 0u;
     q.sparse_min = static_cast<uint32_t>(sparse_min);
     q.sparse_pct = static_cast<uint32_t>(sparse_pct);
+    q.sparse_pack = sparse_pack ? 1u : 0u;
     return q;
   }
   // the scan of round 0 (the queues the spawn filled) is a kernel of its own; every later one runs at
