@@ -1,3 +1,6 @@
+#!/bin/bash
+# Vector instructions and LDS activity of the sparse round kernels with the small tiles packed into
+# waves (default) and one tile per wave (SOIL_TILED_SPARSE_PACK=2):  gpurun -- 'tools/pmc_sparse_pack.sh'
 cd /tmp; export TMPDIR=/tmp
 for p in 2 1; do
   rm -rf /tmp/pp$p
@@ -9,7 +12,7 @@ acc = collections.defaultdict(float)
 for r in csv.DictReader(open(f)):
     n = r["Kernel_Name"]
     if "k_tiled_round" in n and "true>" in n.split("(")[0]:
-        acc[("F" if "k_tiled_round<0" in n else "D", r["Counter_Name"])] += float(r["Counter_Value"])
-print("pack $p", {k: "%.3g" % v for k, v in sorted(acc.items())})
+        acc[("fluvial" if "k_tiled_round<0" in n else "debris", r["Counter_Name"])] += float(r["Counter_Value"])
+print("SOIL_TILED_SPARSE_PACK=$p", {k: "%.3g" % v for k, v in sorted(acc.items())})
 PY
 done
