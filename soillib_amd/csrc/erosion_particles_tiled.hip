@@ -184,7 +184,10 @@ constexpr int kNB = 4;
 // (tiles of up to 31 / 63 / 127 / 191 walkers on the one-wave kernel: 31.4 / 31.0 / 31.9 / 34.6 ms per 8192^2 step —
 // beyond one wave's worth the wave refills from the queue, its chain doubles and its table overflows)
 constexpr int kSparseBuckets = SOIL_SPARSE_BUCKETS;   // the lowest buckets (16 walkers each) of the scan's histogram
-constexpr int kSparseMax = 16 * kSparseBuckets - 1;   // walkers; more than 64 of them: the wave refills from the queue
+constexpr int kSparseMax = 16 * kSparseBuckets - 1;   // walkers
+static_assert(kSparseBuckets >= 2 && kSparseMax < 64,
+              "a sparse tile's walkers fit the wave's lanes (the kernel no longer refills: the tiles of under 16 / 32 walkers "
+              "are packed four / two to a wave) and the two packed classes are buckets of their own");
 #ifndef SOIL_SPARSE_TAB_BITS
 #define SOIL_SPARSE_TAB_BITS 8  // 1024 / 512 / 256 / 128 / 64 entries: 32.13 32.21 31.92 | 31.35 31.53 31.68 ms per 8192^2 step (two boxes)
 #endif
