@@ -42,6 +42,8 @@ for step in range(WARM + 2):
     for kind in (0, 1):
         v = [out[kind * 16 + i] for i in range(16)]
         tot = sum(v[:10])
+        if tot == 0:   # SOIL_TILED_VERBOSE reads (and clears) the counters round by round: see stderr
+            continue
         print("step %d %s: %d wave-iterations in %d waves, %.0f ticks per wave-iteration (all segments)"
               % (step, ("fluvial", "debris")[kind], v[10], v[11], tot / max(v[10], 1)))
         for i in range(10):
