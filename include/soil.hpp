@@ -300,6 +300,15 @@ class comm {
     return comm(c, &soil_comm_self_destroy);
   }
   const soil_comm* get() const { return c_.get(); }
+  // one grouped point-to-point exchange (ncclGroupStart .. ncclRecv / ncclSend .. ncclGroupEnd on an
+  // RCCL communicator), stream-ordered on `stream` — what soil_slab_step issues for its halos
+  void exchange(const std::vector<soil_xfer>& sends, const std::vector<soil_xfer>& recvs, void* stream = nullptr) const {
+    silt::check(c_->exchange(c_->ctx, sends.data(), static_cast<int32_t>(sends.size()), recvs.data(),
+                             static_cast<int32_t>(recvs.size()), stream));
+  }
+  void all_reduce_sum(float* buf, int64_t n, void* stream = nullptr) const {
+    silt::check(c_->all_reduce_sum_f32(c_->ctx, buf, n, stream));
+  }
   int rank() const { return c_->rank; }
   int world() const { return c_->world; }
  private:

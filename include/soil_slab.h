@@ -57,6 +57,9 @@ typedef struct soil_comm {
  * librccl is looked up at run time (an already loaded copy first — PyTorch ships one —, then
  * librccl.so.1, or the path in SOIL_RCCL_LIB): a single-GPU user never needs it. */
 int soil_comm_rccl_unique_id(uint8_t id[128]);
+/* binds librccl and reports ncclGetVersion: no device touched, no thread or socket started — what a
+ * rank calls to prove that it can enter the collective soil_comm_rccl_create at all */
+int soil_comm_rccl_probe(int32_t* version);
 int soil_comm_rccl_create(soil_comm** out, const uint8_t id[128], int32_t rank, int32_t world);
 int soil_comm_rccl_destroy(soil_comm* comm);
 /* what RCCL reports for the communicator: ncclCommCount, ncclCommUserRank, ncclCommCuDevice */

@@ -229,6 +229,7 @@ SLAB_SIGNATURES = {
     "soil_comm_rccl_unique_id": (cint, [C.POINTER(C.c_uint8)]),
     "soil_comm_rccl_create": (cint, [C.POINTER(C.POINTER(Comm)), C.POINTER(C.c_uint8), C.c_int32, C.c_int32]),
     "soil_comm_rccl_destroy": (cint, [C.POINTER(Comm)]),
+    "soil_comm_rccl_probe": (cint, [C.POINTER(C.c_int32)]),
     "soil_comm_rccl_info": (cint, [C.POINTER(Comm), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                    C.POINTER(C.c_int32)]),
     "soil_comm_self_create": (cint, [C.POINTER(C.POINTER(Comm))]),

@@ -568,7 +568,10 @@ __global__ void __launch_bounds__(kWinBlock)
       }
       // 64 bytes per lane and plane -> 1 KiB-contiguous stores through the wave's tile
       const int n_real = 4 * __popcll(__ballot(t.live));  // float4s of the wave that are real (live lanes are a prefix)
-      const int64_t wave_n0 = n0 - 4 * lane;              // the first cell of the wave's lane 0
+      // the first cell of the wave's lane 0 — from the thread index, not from the lane's own n0: a lane
+      // past the row's end has its y0 clamped to W - 4 and still stores its share of the live lanes'
+      // records below (widths that are a multiple of 4 but not of 256; advisor finding of round 4)
+      const int64_t wave_n0 = lx * d.W + (static_cast<int64_t>(blockIdx.x) * kWinBlock + (threadIdx.x & ~63u)) * 4;
       auto put = [&](float4* plane, const float4* q) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) tile[4 * lane + c] = q[c];

@@ -723,6 +723,7 @@ struct Rccl {
   int (*CommUserRank)(void*, int*) = nullptr;
   int (*CommCuDevice)(void*, int*) = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
+  int (*GetVersion)(int*) = nullptr;
 };
 
 Rccl g_rccl;
@@ -756,6 +757,7 @@ int rccl_load() {
   RCCL_BIND(CommUserRank, "ncclCommUserRank");
   RCCL_BIND(CommCuDevice, "ncclCommCuDevice");
   RCCL_BIND(GetErrorString, "ncclGetErrorString");
+  RCCL_BIND(GetVersion, "ncclGetVersion");
 #undef RCCL_BIND
   g_rccl.lib = h;
   return SOIL_OK;
@@ -1038,6 +1040,17 @@ int soil_comm_rccl_unique_id(uint8_t id[128]) {
   SOIL_REQUIRE(id, "comm_rccl_unique_id: null argument");
   if (int rc = rccl_load(); rc != SOIL_OK) return rc;
   SOIL_RCCL(g_rccl.GetUniqueId(id));
+  return SOIL_OK;
+}
+
+int soil_comm_rccl_probe(int32_t* version) {
+  // No SOIL_DEVICE(): binding the library and asking for its version touches no device and starts
+  // nothing (ncclGetUniqueId, which the non-root ranks used to call as their probe, starts a
+  // bootstrap thread and a listening socket per call — advisor finding of round 4).
+  if (int rc = rccl_load(); rc != SOIL_OK) return rc;
+  int v = 0;
+  SOIL_RCCL(g_rccl.GetVersion(&v));
+  if (version) *version = v;
   return SOIL_OK;
 }
 

@@ -105,11 +105,12 @@ class RcclComm:
         else:
             # Every rank proves that it can load librccl and call into it BEFORE anybody enters the
             # collective ncclCommInitRank: a rank that cannot would leave the others blocked in there, and
-            # the fallback to gloo could never be agreed on (advisor finding of round 3).  Making an id
-            # is local and free of side effects.  (What is left uncovered: a failure INSIDE the
-            # collective on a subset of ranks — RCCL's own bootstrap time-out ends that.)
+            # the fallback to gloo could never be agreed on (advisor finding of round 3).  The probe binds
+            # the library and asks for its version — no thread, no socket (round 4's probe made a unique
+            # id on every rank, which starts a bootstrap root per call).  (What is left uncovered: a
+            # failure INSIDE the collective on a subset of ranks — RCCL's own bootstrap time-out ends that.)
             try:
-                _abi.check(lib.soil_comm_rccl_unique_id((C.c_uint8 * 128)()))
+                _abi.check(lib.soil_comm_rccl_probe(None))
             except Exception as e:      # noqa: BLE001
                 failed, why = 1, e
         bad = torch.tensor([failed])

@@ -99,6 +99,73 @@ int main() {
     }
     EXPECT(std::fabs(sums[0] - sums[1]) <= 1e-6 * std::fabs(sums[0]));
   }
+  // The wire itself on the real library: a one-rank RCCL communicator exchanging with ITSELF
+  // (ncclSend / ncclRecv to one's own rank inside a group are legal), so that the grouped
+  // point-to-point path of csrc/slab_runner.hip (rccl_exchange) executes on RCCL on a one-GPU box:
+  // one pair at BASELINE config 5's fluvial flux halo (250 rows x 16384 cells x 16 B = 65.5 MB), then
+  // the grouped four-transfer pattern of a step's field exchange (two sends + two receives per side).
+  {
+    soil::comm wire = soil::comm::rccl(soil::comm::rccl_unique_id(), 0, 1);
+    int32_t n = 0, r = -1, dev = -1;
+    check(soil_comm_rccl_info(wire.get(), &n, &r, &dev));
+    EXPECT(n == 1 && r == 0 && dev >= 0);
+    const size_t big = size_t(250) * 16384 * 16, words = big / 4;
+    float *src = nullptr, *dst = nullptr;
+    check(soil_malloc(reinterpret_cast<void**>(&src), big));
+    check(soil_malloc(reinterpret_cast<void**>(&dst), big));
+    std::vector<float> pat(words);
+    for (size_t i = 0; i < words; ++i) pat[i] = float(i % 8191) - 4000.0f;
+    check(soil_memcpy_h2d(src, pat.data(), big, nullptr));
+    check(soil_set_f32(dst, -1.0f, int64_t(words), nullptr));
+    check(soil_device_synchronize());
+    void *e0 = nullptr, *e1 = nullptr;
+    check(soil_event_create(&e0));
+    check(soil_event_create(&e1));
+    float ms_first = 0, ms = 0;
+    for (int rep = 0; rep < 4; ++rep) {  // the first call sets the channels up
+      check(soil_event_record(e0, nullptr));
+      wire.exchange({soil_xfer{src, int64_t(big), 0}}, {soil_xfer{dst, int64_t(big), 0}});
+      check(soil_event_record(e1, nullptr));
+      check(soil_event_elapsed_ms(e0, e1, rep == 0 ? &ms_first : &ms));
+    }
+    std::vector<float> back(words);
+    check(soil_memcpy_d2h(back.data(), dst, big, nullptr));
+    size_t bad = 0;
+    for (size_t i = 0; i < words; ++i) bad += back[i] != pat[i];
+    EXPECT(bad == 0);
+    // four transfers in one group, unequal sizes, sources and destinations interleaved in one block
+    const size_t q = words / 8;
+    check(soil_set_f32(dst, -1.0f, int64_t(words), nullptr));
+    check(soil_device_synchronize());
+    std::vector<soil_xfer> sends, recvs;
+    const size_t len[4] = {q, q / 2, 3 * q / 4, 1024};
+    size_t so = 0, ro = 0;
+    for (int k = 0; k < 4; ++k) {
+      sends.push_back(soil_xfer{src + so, int64_t(len[k] * 4), 0});
+      recvs.push_back(soil_xfer{dst + ro, int64_t(len[k] * 4), 0});
+      so += len[k] + 64, ro += len[k] + 256;
+    }
+    wire.exchange(sends, recvs);
+    check(soil_memcpy_d2h(back.data(), dst, big, nullptr));
+    so = 0, ro = 0;
+    for (int k = 0; k < 4; ++k) {  // the k-th receive holds the k-th send (matched in order), the gaps are untouched
+      for (size_t i = 0; i < len[k]; ++i) bad += back[ro + i] != pat[so + i];
+      for (size_t i = 0; i < 256; ++i) bad += back[ro + len[k] + i] != -1.0f;
+      so += len[k] + 64, ro += len[k] + 256;
+    }
+    EXPECT(bad == 0);
+    float one[4] = {1.5f, -2.0f, 0.25f, 8.0f};
+    check(soil_memcpy_h2d(dst, one, 16, nullptr));
+    wire.all_reduce_sum(dst, 4);
+    check(soil_memcpy_d2h(back.data(), dst, 16, nullptr));
+    EXPECT(back[0] == 1.5f && back[1] == -2.0f && back[2] == 0.25f && back[3] == 8.0f);  // a world of one sums to itself
+    std::printf("RCCL_SELF ranks %d bytes %zu first_ms %.3f ms %.3f GBps %.1f\n", n, big, ms_first, ms,
+                double(big) / (double(ms) * 1e6));
+    check(soil_event_destroy(e0));
+    check(soil_event_destroy(e1));
+    check(soil_free(src));
+    check(soil_free(dst));
+  }
   std::printf("CPP_API_OK\n");
   return 0;
 }

@@ -29,7 +29,10 @@ def test_bare_multi_gpu_bench_reaches_its_ranks_and_fails_loudly_without_a_devic
                          capture_output=True, text=True, timeout=600)
     assert res.returncode != 0
     assert "launch with torch.distributed.run" not in res.stdout + res.stderr
-    assert res.stderr.count("no usable HIP device") >= 2, res.stderr[-3000:]
+    # both ranks were started (the launcher's report names them) and the library refused in sight; the
+    # launcher ends the second rank as soon as the first has failed, so its own refusal may not get out
+    assert res.stderr.count("no usable HIP device") >= 1, res.stderr[-3000:]
+    assert "local_rank: 1" in res.stderr, res.stderr[-3000:]
 
 
 @pytest.mark.gpu

@@ -32,6 +32,10 @@ def test_cpp_mirror_on_gpu(tmp_path):
     exe = _build(tmp_path)
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "CPP_API_OK" in out.stdout, out.stdout + out.stderr
+    # the grouped ncclSend / ncclRecv path on the real RCCL (a one-rank communicator exchanging with itself)
+    rccl = [l for l in out.stdout.splitlines() if l.startswith("RCCL_SELF")]
+    assert rccl and rccl[0].split()[2] == "1", out.stdout
+    print(rccl[0])
     # the same three steps through the Python binding of the same step driver (legacy soil.erode)
     import numpy as np
     import soillib as soil

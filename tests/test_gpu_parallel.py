@@ -88,9 +88,69 @@ class LocalWire:
         return m
 
 
-def _run_world(world, S, W, param, steps, maxage, pair=False, halo_need=0, info=None):
+class RcclLoopWire(LocalWire):
+    """LocalWire whose bytes travel through RCCL: every transfer of the runners' real schedule — sizes,
+    grouping, order — is carried out by the library's grouped point-to-point path (rccl_exchange in
+    csrc/slab_runner.hip: ncclGroupStart, ncclRecv / ncclSend, ncclGroupEnd) on a ONE-rank RCCL
+    communicator whose only peer is itself; RCCL accepts send / recv to one's own rank inside a
+    group and matches them in order.  The receiving runner issues the group: k receives into its ghost
+    rows, k sends from the rows its neighbours posted.  No node has been available to any round, so
+    this is how the wire code runs on the real library before it meets one."""
+
+    class Shared(LocalWire.Shared):
+        def __init__(self, world):
+            super().__init__(world)
+            from soillib_amd import _abi
+            lib = _abi.lib()
+            uid = (C.c_uint8 * 128)()
+            _abi.check(lib.soil_comm_rccl_unique_id(uid))
+            self.comm = C.POINTER(_abi.Comm)()
+            _abi.check(lib.soil_comm_rccl_create(C.byref(self.comm), uid, 0, 1))
+            n, r, d = C.c_int32(), C.c_int32(), C.c_int32()
+            _abi.check(lib.soil_comm_rccl_info(self.comm, C.byref(n), C.byref(r), C.byref(d)))
+            assert (n.value, r.value) == (1, 0)
+            self.rccl_lock = threading.Lock()     # one communicator, several runner threads
+            self.groups, self.transfers, self.bytes = 0, 0, 0
+
+        def close(self):
+            from soillib_amd import _abi
+            _abi.lib().soil_comm_rccl_destroy(self.comm)
+
+    def exchange(self, sends, recvs):
+        self.s.token.release()
+        try:
+            waits = []
+            for addr, n, peer in sends:
+                done = threading.Event()
+                self.s.q[(self.rank, peer)].put((addr, n, done))
+                waits.append(done)
+            got = []
+            for addr, n, peer in recvs:
+                src, m, done = self.s.q[(peer, self.rank)].get(timeout=300)
+                assert m == n, (m, n)
+                got.append((addr, src, n, done))
+            if got:
+                k = len(got)
+                xs = (self.abi.Xfer * k)(*[self.abi.Xfer(C.c_void_p(src), n, 0) for _, src, n, _ in got])
+                xr = (self.abi.Xfer * k)(*[self.abi.Xfer(C.c_void_p(dst), n, 0) for dst, _, n, _ in got])
+                with self.s.rccl_lock:
+                    c = self.s.comm.contents
+                    self.abi.check(c.exchange(c.ctx, xs, k, xr, k, None))
+                    self.abi.check(self.lib.soil_device_synchronize())
+                    self.s.groups += 1
+                    self.s.transfers += k
+                    self.s.bytes += sum(n for _, _, n, _ in got)
+                for _, _, _, done in got:
+                    done.set()
+            for d in waits:
+                assert d.wait(300)
+        finally:
+            self.s.token.acquire()
+
+
+def _run_world(world, S, W, param, steps, maxage, pair=False, halo_need=0, info=None, wire=LocalWire, shared=None):
     from soillib_amd.parallel import CallbackComm, SlabRunner
-    shared = LocalWire.Shared(world)
+    shared = shared or wire.Shared(world)
     out, errs = [None] * world, []
 
     def worker(rank):
@@ -99,7 +159,7 @@ def _run_world(world, S, W, param, steps, maxage, pair=False, halo_need=0, info=
             shared.token.acquire()
             held = True
             r = SlabRunner(rows_per_rank=S, W=W, param=param, particles_div=8, seed=0,
-                           comm=CallbackComm(rank, world, LocalWire(shared, rank)), device=0, pair=pair,
+                           comm=CallbackComm(rank, world, wire(shared, rank)), device=0, pair=pair,
                            halo_need=halo_need)
             for _ in range(steps):
                 r.step()
@@ -155,6 +215,105 @@ def test_slab_runner_on_one_gpu_matches_single_domain(hip, oracle, world, S, W, 
     for k in got:
         np.testing.assert_allclose(got[k], want[k], rtol=1e-4,
                                    atol=1e-5 * (np.nanmax(np.abs(want[k])) + 1e-30), err_msg=k)
+
+
+@pytest.mark.parametrize("world,S,W,maxage,halo_need", [(2, 64, 128, 16, 0), (3, 96, 128, 48, 2)])
+def test_slab_runner_halos_over_rccl_self_exchange(hip, oracle, world, S, W, maxage, halo_need):
+    """The runners' halo schedule with every transfer carried by ncclSend / ncclRecv groups on the real
+    RCCL (RcclLoopWire): trimmed halos, and with a refresh depth forced too small the repeated
+    launches and full-depth exchanges as well.  Same result as the single-domain step."""
+    from soillib_amd import silt, soil
+    from soillib_amd.erosion import ErosionModel
+    op = script_param(oracle.default_param())
+    op.maxage = maxage
+    pp = product_param(op)
+    steps = 3
+    H = world * S
+    shared = RcclLoopWire.Shared(world)
+    try:
+        info = [None] * world
+        got = _run_world(world, S, W, pp, steps, maxage, pair=True, halo_need=halo_need, info=info,
+                         wire=RcclLoopWire, shared=shared)
+        assert shared.groups >= 2 * steps * (world - 1) and shared.transfers > shared.groups and shared.bytes > 0
+        if halo_need:
+            assert sum(i["fallbacks"] for i in info) > 0
+        print("rccl self-exchange: %d groups, %d transfers, %.1f MB" % (shared.groups, shared.transfers,
+                                                                       shared.bytes / 1e6))
+    finally:
+        shared.close()
+    m = ErosionModel(H, W, (20.0 / H, 20.0 / W, 4.0), pp, H * W // 8, seed=0)
+    npar = soil.noise_t()
+    npar.seed = 3.0
+    npar.ext = [H, W]
+    bed = soil.noise(silt.shape(H, W), npar, host=silt.gpu)
+    layers0 = np.zeros((H, W, 2), np.float32)
+    layers0[..., 0] = to_np(bed)
+    m.set_layers(to_gpu(layers0))
+    silt.set(m.rainfall, 1.0)
+    for _ in range(steps):
+        m.step()
+    for k in got:
+        want = to_np(getattr(m, k))
+        np.testing.assert_allclose(got[k], want, rtol=1e-4,
+                                   atol=1e-5 * (np.nanmax(np.abs(want)) + 1e-30), err_msg=k)
+
+
+def test_rccl_self_exchange_at_config5_halo_size(hip):
+    """One pair at BASELINE config 5's fluvial flux halo (250 rows x 16384 cells x 16 B = 65.5 MB) and
+    the grouped four-transfer pattern, on a runner's COMMUNICATION stream (the non-blocking stream
+    soil_slab_step issues its halos on), through the library's RCCL communicator exchanging with
+    itself: bytes checked, time printed."""
+    from soillib_amd import _abi, soil
+    from soillib_amd.parallel import SelfComm, SlabRunner
+    lib = _abi.lib()
+    shared = RcclLoopWire.Shared(1)
+    p = soil.param_t()
+    p.maxage = 8
+    runner = SlabRunner(rows_per_rank=64, W=64, param=p, particles_div=8, seed=0, comm=SelfComm())
+    try:
+        st = runner.stream(1)
+        assert st.value                      # lane 1: a stream of its own, not the null stream
+        nbytes = 250 * 16384 * 16
+        words = nbytes // 4
+        pat = (np.arange(words, dtype=np.int64) % 8191 - 4000).astype(np.float32)
+        src, dst = to_gpu(pat), to_gpu(np.full(words, -1.0, np.float32))
+        c = shared.comm.contents
+        ev = [C.c_void_p(), C.c_void_p()]
+        for e in ev:
+            _abi.check(lib.soil_event_create(C.byref(e)))
+        times = []
+        for rep in range(4):
+            xs = (_abi.Xfer * 1)(_abi.Xfer(C.c_void_p(src.c_ptr.value), nbytes, 0))
+            xr = (_abi.Xfer * 1)(_abi.Xfer(C.c_void_p(dst.c_ptr.value), nbytes, 0))
+            _abi.check(lib.soil_event_record(ev[0], st))
+            _abi.check(c.exchange(c.ctx, xs, 1, xr, 1, st))
+            _abi.check(lib.soil_event_record(ev[1], st))
+            ms = C.c_float()
+            _abi.check(lib.soil_event_elapsed_ms(ev[0], ev[1], C.byref(ms)))
+            times.append(ms.value)
+        _abi.check(lib.soil_stream_synchronize(st))
+        assert (to_np(dst) == pat).all()
+        # grouped: two "up" and two "down" transfers of unequal size in one group
+        lens = [words // 8, words // 16, 3 * words // 32, 1024]
+        dst2 = to_gpu(np.full(words, -1.0, np.float32))
+        so, ro, xs, xr, spans = 0, 0, [], [], []
+        for n in lens:
+            xs.append(_abi.Xfer(C.c_void_p(src.c_ptr.value + 4 * so), 4 * n, 0))
+            xr.append(_abi.Xfer(C.c_void_p(dst2.c_ptr.value + 4 * ro), 4 * n, 0))
+            spans.append((so, ro, n))
+            so, ro = so + n + 64, ro + n + 256
+        _abi.check(c.exchange(c.ctx, (_abi.Xfer * 4)(*xs), 4, (_abi.Xfer * 4)(*xr), 4, st))
+        _abi.check(lib.soil_stream_synchronize(st))
+        back = to_np(dst2)
+        for so, ro, n in spans:
+            assert (back[ro:ro + n] == pat[so:so + n]).all() and (back[ro + n:ro + n + 256] == -1.0).all()
+        print("rccl self-exchange of %.1f MB on the communication stream: first %.3f ms, then %.3f ms = %.0f GB/s"
+              % (nbytes / 1e6, times[0], min(times[1:]), nbytes / (min(times[1:]) * 1e6)))
+        for e in ev:
+            lib.soil_event_destroy(e)
+    finally:
+        runner.close()
+        shared.close()
 
 
 def test_strong_split_of_a_square_grid_matches_single_domain(hip, oracle):

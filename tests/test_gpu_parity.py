@@ -823,26 +823,45 @@ def test_fill_depressions_bit_exact(hip, oracle, H, W, edge):
             assert np.nanmin(nb) >= got[x, y]
 
 
-@pytest.mark.parametrize("S,maxage", [(512, 96), (96, 64)])
-def test_particle_pair_equals_sequential_launches(hip, S, maxage):
+@pytest.mark.parametrize("H,W,maxage,tiled", [(512, 512, 96, False), (96, 96, 64, False),
+                                                # widths that are a multiple of 4 but not of 256: the last
+                                                # wave of a row of the four-cell pack pass has lanes past the
+                                                # row's end (advisor finding of round 4: they stored their
+                                                # share of the wave's records at another cell's address)
+                                                (300, 520, 64, True), (200, 1000, 64, True), (130, 1928, 48, True),
+                                                (260, 36, 48, True)])
+def test_particle_pair_equals_sequential_launches(hip, H, W, maxage, tiled):
     """soil_particles_pair_slab (both launches overlapped on two streams, the debris launch
     on an rng tensor seeded two draws further) walks the same trajectories as the
-    reference's order — fluvial, then debris on the same rng tensor."""
+    reference's order — fluvial, then debris on the same rng tensor.  The pair shares one pack
+    pass (four cells per thread on widths that are a multiple of four), the sequential launches
+    run the one-cell pass each: the cell records of the two are compared through the walks."""
     from soillib_amd import silt, soil
     from soillib_amd.erosion import ErosionModel
     param = script_param(soil.param_t())
     param.maxage = maxage
     param.critSlopeBedrock = 0.05
     param.yieldStress = 0.001
-    m = ErosionModel(S, S, (20.0 / S, 20.0 / S, 4.0), param, S * S // 8, seed=3)
+    if tiled:
+        assert hip.soil_set_particle_mode(3) == 0
+    try:
+        _pair_equals_sequential(hip, H, W, param)
+    finally:
+        hip.soil_set_particle_mode(0)
+
+
+def _pair_equals_sequential(hip, H, W, param):
+    from soillib_amd import silt, soil
+    from soillib_amd.erosion import ErosionModel
+    m = ErosionModel(H, W, (20.0 / H, 20.0 / W, 4.0), param, H * W // 8, seed=3)
     p = soil.noise_t()
     p.seed = 3.0
-    p.ext = [S, S]
-    bed = soil.noise(silt.shape(S, S), p, host=silt.gpu)
-    zero = silt.tensor(silt.float32, silt.shape(S, S), silt.gpu)
+    p.ext = [H, W]
+    bed = soil.noise(silt.shape(H, W), p, host=silt.gpu)
+    zero = silt.tensor(silt.float32, silt.shape(H, W), silt.gpu)
     silt.set(zero, 0.0)
     from soillib_amd import _abi
-    _abi.check(hip.soil_layers_from_planes(m.layers.c_ptr, bed.c_ptr, zero.c_ptr, S * S, None))
+    _abi.check(hip.soil_layers_from_planes(m.layers.c_ptr, bed.c_ptr, zero.c_ptr, H * W, None))
     silt.set(m.rainfall, 1.0)
     m.step()
     m.step()
