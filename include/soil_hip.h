@@ -397,6 +397,18 @@ int soil_erode(const soil_erode_model* model, int64_t H, int64_t W, int64_t N, u
  * shapes produce the same trajectories and deposits; only the order of the
  * fp32 additions into a cell differs.  For ablation and tests. */
 int soil_set_particle_mode(int mode);
+/* Arithmetic of the particle step (the loops of erosion.cu:100-139 / :306-349) in the tiled shape:
+ * 0 = exact (default): every `/` of the reference's step a correctly rounded IEEE quotient, sqrt
+ *     correctly rounded — the walks of the oracle, step for step (the parity tests' contract);
+ * 1 = fast: quotients as numerator x v_rcp_f32(denominator), v_sqrt_f32, debris' mass attenuation on the
+ *     hardware exponential (what nvcc -use_fast_math makes of the same statements: __fdividef,
+ *     sqrt.approx, __expf).  Walks are chaotic in the last bit, so results agree with the exact
+ *     mode statistically: plane sums within 2e-3, visited cells within 0.5 %, step counts within
+ *     0.5 % (tests/test_fast_particles.py).  9 % less time per 8192^2 step.
+ * Launches that carry colour planes and the direct / staged shapes always run exact.
+ * SOIL_PARTICLE_DIV=fast in the environment makes 1 the default of the process. */
+int soil_set_particle_arith(int mode);
+int soil_get_particle_arith(void);
 /* Ghost rows a slab needs on each interior side so that no trajectory can
  * leave it: ceil(sqrt(2) * maxage) + 2 (one __stepsize step moves a particle
  * by at most sqrt(2) cells, erosion_map.cu:61-76). */

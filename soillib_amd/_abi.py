@@ -125,6 +125,8 @@ SIGNATURES = {
     "soil_erode": (cint, [C.POINTER(ErodeModel), i64, i64, i64, u64, u64, cint, F3, C.POINTER(Param),
                           vp]),
     "soil_set_particle_mode": (cint, [cint]),
+    "soil_set_particle_arith": (cint, [cint]),
+    "soil_get_particle_arith": (cint, []),
     "soil_ghost_rows": (i64, [C.POINTER(Param)]),
     "soil_particle_steps": (cint, [C.POINTER(u64), cint, vp]),
     "soil_ghost_extent": (cint, [vp, vp, i64, i64, i64, i64, vp]),

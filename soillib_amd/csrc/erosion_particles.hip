@@ -37,6 +37,14 @@ int launch_normalize_debris(const float* massFlux, const float* velocityFlux, fl
                             hipStream_t st);
 
 static int g_particle_mode = 0;  // 0 auto, 1 direct, 2 staged, 3 tiled
+// Arithmetic of the particle step in the tiled shape: 0 exact (IEEE quotients and square root: the
+// oracle's walks step for step), 1 fast (v_rcp_f32 / v_sqrt_f32, erosion_particles_tiled.hip:
+// step_geom_fast; statistical parity).  SOIL_PARTICLE_DIV=fast in the environment sets the default.
+static int g_particle_arith = [] {
+  const char* e = std::getenv("SOIL_PARTICLE_DIV");
+  return (e && (e[0] == 'f' || e[0] == 'F' || e[0] == '1')) ? 1 : 0;
+}();
+bool particle_arith_fast() { return g_particle_arith == 1; }
 
 // ---- where a step gets grad(cell) and velocity(cell) from -------------------
 
@@ -592,6 +600,13 @@ int soil_set_particle_mode(int mode) {
   g_particle_mode = mode;
   return SOIL_OK;
 }
+
+int soil_set_particle_arith(int mode) {
+  SOIL_REQUIRE(mode == 0 || mode == 1, "particle arithmetic: 0 exact, 1 fast");
+  g_particle_arith = mode;
+  return SOIL_OK;
+}
+int soil_get_particle_arith(void) { return g_particle_arith; }
 
 int64_t soil_ghost_rows(const soil_param* param) {
   const double travel = 1.41421356237309515 * static_cast<double>(param ? param->maxage : 512);

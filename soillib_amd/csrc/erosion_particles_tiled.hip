@@ -330,6 +330,70 @@ struct StepGeom {
   bool alive, ok;  // alive: past the `v_norm < eps` exit; ok: every operand plain (fluvial)
   // the exit itself as one plain comparison of v_norm (for wave ballots): !alive
 };
+// ---- the step in FAST arithmetic (round 5; soil_set_particle_arith(1), SOIL_PARTICLE_DIV=fast) ----
+//
+// The reference's step divides nine (debris: thirteen) times with correctly rounded IEEE quotients
+// and takes a correctly rounded square root; the exact step above reproduces every bit of that
+// (its trajectories equal the oracle's step for step).  nvcc's own fast build of the same source
+// (-use_fast_math: __fdividef, sqrt.approx) would not, and neither does this mode: every quotient is
+// numerator x v_rcp_f32(denominator) (<= 1.5 ulp), the norm v_sqrt_f32 (<= 1 ulp), debris' att_d the
+// hardware exponential the other attenuations already use.  A walk is chaotic in the last bit of its
+// speed (a contracted multiply-add already moves walkers across cell edges), so parity
+// in this mode is the statistical kind SURVEY.md 8 a5 asks of the transport — plane sums, visited
+// sets, step counts against the oracle within the bounds of tests/test_fast_particles.py — not equal
+// walks.  What it buys: 120 instead of 172 vector instructions per fluvial step, 13 IEEE divisions
+// fewer per debris step; 8192^2 step 30.4 -> 27.6 ms (A/B on one box, three alternations).
+__device__ __forceinline__ float fast_quot(float a, float r) { return a * r; }
+template <int KIND>
+__device__ __forceinline__ StepGeom step_geom_fast(const PRec& r, const StepConst& k) {
+  StepGeom g;
+  g.v_norm = __builtin_amdgcn_sqrtf(r.spx * r.spx + r.spy * r.spy);  // :116 / :321
+  g.alive = !(g.v_norm < k.eps);
+  g.ok = true;
+  const float rn = __builtin_amdgcn_rcpf(g.v_norm);
+  g.ux = fast_quot(r.spx, rn);  // :117 / :322
+  g.uy = fast_quot(r.spy, rn);
+  // stepsize (erosion_map.cu:56-78) with the quotient over the face the direction points at
+  const float x_neg = floorf(r.px), y_neg = floorf(r.py);
+  const float nx = ((g.ux > 0.0f) ? 1.0f + x_neg : x_neg) - r.px;
+  const float ny = ((g.uy > 0.0f) ? 1.0f + y_neg : y_neg) - r.py;
+  const float tx = fminf(fast_quot(nx, __builtin_amdgcn_rcpf(g.ux)), kSqrt2);
+  const float ty = fminf(fast_quot(ny, __builtin_amdgcn_rcpf(g.uy)), kSqrt2);
+  g.v_step = 0.5f * (tx + ty);
+  g.dL = g.v_step * k.lenL;       // :119 / :324
+  g.ds = fast_quot(g.dL, rn);     // :120 / :325
+  g.rd = Recip{g.v_norm, rn};     // (carries 1 / v_norm for debris' decay_d)
+  return g;
+}
+template <int KIND>
+__device__ __forceinline__ bool step_apply_fast(PRec& r, const float4 q, const StepConst& k, const StepGeom& g) {
+  if (KIND == FLUVIAL) {
+    const float ax = q.x + k.fx, ay = q.y + k.fy;                          // :126
+    const float w0 = __builtin_amdgcn_rcpf(1.0f + g.dL * (k.tau + k.nu));  // :127
+    const float w1 = g.dL * w0;
+    r.spx = w0 * r.spx + w1 * ax;
+    r.spy = w0 * r.spy + w1 * ay;
+    r.a1 = r.a1 * att_exp(-g.ds * k.kd);    // att_m :134
+    r.a0 = r.a0 * att_exp(-g.ds * k.evap);  // att_w :135
+    r.a2 = r.a2 * att_exp(-g.dL * q.z);     // att_v :136
+  } else {
+    const float debrisHeight = k.eps + r.a0 * r.s0;                        // :331
+    const float rh = __builtin_amdgcn_rcpf(debrisHeight);
+    const float decay = k.nu + fast_quot(k.tau, rh);                       // :333 (= decay_v, :343)
+    const float w = __builtin_amdgcn_rcpf(1.0f + g.dL * decay);            // :334
+    r.spx = w * r.spx + w * g.dL * q.x;                                    // :335
+    r.spy = w * r.spy + w * g.dL * q.y;
+    const float excessStress = k.g * (q.z - fast_quot(k.tau_y, rh));       // :340
+    const float shearRate = (excessStress < 0.0f) ? k.kdd : k.kds;         // :341
+    const float decay_d = fast_quot(g.ds * shearRate * excessStress, g.rd.r);  // :342
+    r.a0 = r.a0 * att_exp(decay_d);                                        // :345
+    r.a1 = r.a1 * att_exp(-g.dL * decay);                                  // :346
+  }
+  r.px += g.v_step * g.ux;  // :137 / :347
+  r.py += g.v_step * g.uy;
+  return g.alive;
+}
+
 template <int KIND>
 __device__ __forceinline__ StepGeom step_geom(const PRec& r, const StepConst& k) {
   StepGeom g;
@@ -389,9 +453,10 @@ __device__ __forceinline__ bool step_apply(PRec& r, const float4 q, const StepCo
   r.py += g.v_step * g.uy;
   return g.alive;
 }
-template <int KIND>
+template <int KIND, bool FAST = false>
 __device__ __forceinline__ bool advance(PRec& r, const float4 q, const StepConst& k) {
-  return step_apply<KIND>(r, q, k, step_geom<KIND>(r, k));
+  if constexpr (FAST) return step_apply_fast<KIND>(r, q, k, step_geom_fast<KIND>(r, k));
+  else return step_apply<KIND>(r, q, k, step_geom<KIND>(r, k));
 }
 
 // a NaN walker's deposit for global cell (0,0) held by another rank (soil_hip.h)
@@ -1307,6 +1372,13 @@ constexpr int round_groups_per_cu(int kind, int tr, int tc, int nt, bool alb) {
 constexpr int round_waves_per_simd(int kind, int tr, int tc, int nt, bool alb) {
   return round_groups_per_cu(kind, tr, tc, nt, alb) * ((nt / 64 + 3) / 4);
 }
+// The deposit's LDS round trips are placed around the step's arithmetic on purpose (reads asked for, the
+// geometry, swaps issued, the speed update, answers looked at).  With the short arithmetic of the fast
+// step the compiler merges the deposit's two conditional blocks and the waits land right behind the
+// requests; an empty volatile statement that names the phase's results keeps them apart (measured: no
+// difference at 8192^2 — the other waves of the SIMD cover the round trips either way; kept because
+// the listing then reads like the source).
+__device__ __forceinline__ void pin3(float& a, float& b, float& c) { asm volatile("" : "+v"(a), "+v"(b), "+v"(c) : : "memory"); }
 __device__ __forceinline__ bool any_lane(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0; }
 // A value the compiler may not look through.  A ballot wants to be the ballot of a comparison of
 // register values (v_cmp writes the mask); given a predicate that was merged over divergent
@@ -1333,7 +1405,7 @@ __device__ __forceinline__ uint32_t opaque(uint32_t x) {
 // decides per round whether the sparse tiles get this kernel (QueueScan::sparse_ok, k sparse tiles in
 // four non-empty ones); it runs in front of the dense kernel of the round, on the same stream.
 
-template <int KIND, int DEP, int TR, int TC, int NT, bool ALB, bool SPARSE = false>
+template <int KIND, int DEP, int TR, int TC, int NT, bool ALB, bool SPARSE = false, bool FAST = false>
 __global__ void __launch_bounds__(NT, SPARSE ? 2 : round_waves_per_simd(KIND, TR, TC, NT, ALB))
     k_tiled_round(PRec* __restrict__ out, uint32_t* __restrict__ dest, uint32_t* __restrict__ rank,
                   uint32_t* count_next, const PRec* __restrict__ in,
@@ -1675,14 +1747,25 @@ __global__ void __launch_bounds__(NT, SPARSE ? 2 : round_waves_per_simd(KIND, TR
           }
         }
         PROF_AT(3);  // gather issued, deposit begun
-        const StepGeom geom = step_geom<KIND>(r, k);             // needs neither q nor LDS
+        StepGeom geom;                                           // needs neither q nor LDS
+        if constexpr (FAST) {
+          geom = step_geom_fast<KIND>(r, k);
+          pin3(geom.v_step, geom.ds, geom.dL);                   // (the swaps go out behind the geometry)
+        } else {
+          geom = step_geom<KIND>(r, k);
+        }
         // (round 3: swapping right behind the load, as the debris launch does, times the same — 24.07-24.14 ms
         // either way at 8192^2)
         if (KIND == FLUVIAL && deposit) dep.swap_all();          // the swaps' round trip hides under step_apply
         v_norm = geom.v_norm;
         // :121-122 / :326-327: a walk that is over shows in `ended` (a value, not a lane mask merged
         // through the branches of the iteration: `have` stays what it was when the loop began)
-        ended |= step_apply<KIND>(r, q, k, geom) ? 0u : 1u;
+        if constexpr (FAST) {
+          ended |= step_apply_fast<KIND>(r, q, k, geom) ? 0u : 1u;
+          pin3(r.spx, r.spy, r.px);                              // (... and their answers are looked at behind the update)
+        } else {
+          ended |= step_apply<KIND>(r, q, k, geom) ? 0u : 1u;
+        }
         if (deposit) lost_bits = dep.lost_bits();                // the swaps' answers, only now
         PROF_AT(4);  // the step's arithmetic
       }
@@ -1724,7 +1807,7 @@ __global__ void __launch_bounds__(NT, SPARSE ? 2 : round_waves_per_simd(KIND, TR
               for (int j = 0; j < kFluxPlanes + (ALB ? 3 : 0); ++j) atomicAdd(pp[j], v[j]);
             }
           }
-          if (!advance<KIND>(r, q, k)) {  // :121-122 / :326-327
+          if (!advance<KIND, FAST>(r, q, k)) {  // :121-122 / :326-327
             have = false;
             break;
           }
@@ -2025,7 +2108,7 @@ __global__ void __launch_bounds__(NT, SPARSE ? 2 : round_waves_per_simd(KIND, TR
 
 // ---- the last launch: walk the remaining particles to the end against HBM ----------
 
-template <int KIND>
+template <int KIND, bool FAST = false>
 __global__ void __launch_bounds__(256)
     k_tiled_finish(const PRec* __restrict__ recs, const uint32_t* __restrict__ dest,
                    const TiledCtl* __restrict__ ctl, float* __restrict__ flux0,
@@ -2077,7 +2160,7 @@ __global__ void __launch_bounds__(256)
         atomicAdd(&fluxA[3 * l + 2], att * r.sa2);
       }
     }
-    if (!advance<KIND>(r, q, k)) break;
+    if (!advance<KIND, FAST>(r, q, k)) break;
   }
   atomicAdd(steps, static_cast<unsigned long long>(nsteps));  // one atomic per wave
 }
@@ -2126,22 +2209,32 @@ struct Shapes {
       KIND == FLUVIAL ? RoundShape{78, 64, 768} : RoundShape{104, 64, 768}};
 };
 
+// `fast`: the step in fast arithmetic (step_geom_fast; soil_set_particle_arith).  Instantiated for the
+// compare-and-swap deposits without colour planes — what every launch of N >= 45 000 particles runs
+// unless it carries colour; the other variants stay on the exact step.
 template <int KIND, int DEP, int SH, bool ALB, typename... A>
-static void launch_shape(unsigned grid, hipStream_t st, A... a) {
+static void launch_shape(bool fast, unsigned grid, hipStream_t st, A... a) {
   constexpr RoundShape S = Shapes<KIND>::v[SH];
   static_assert(round_lds_bytes(KIND, S.tr, S.tc, ALB) <= kLdsPerCU, "tile does not fit the LDS");
+  if constexpr (DEP == 1 && !ALB) {
+    if (fast) {
+      k_tiled_round<KIND, DEP, S.tr, S.tc, S.nt, ALB, false, true><<<grid, S.nt, 0, st>>>(a...);
+      return;
+    }
+  }
   k_tiled_round<KIND, DEP, S.tr, S.tc, S.nt, ALB><<<grid, S.nt, 0, st>>>(a...);
 }
 // the one-wave kernel of the sparse tiles of a round (same tile geometry as the round's dense shape)
 template <int KIND, int SH, typename... A>
-static void launch_sparse_shape(unsigned grid, hipStream_t st, A... a) {
+static void launch_sparse_shape(bool fast, unsigned grid, hipStream_t st, A... a) {
   constexpr RoundShape S = Shapes<KIND>::v[SH];
-  k_tiled_round<KIND, 1, S.tr, S.tc, kSparseLanes, false, true><<<grid, kSparseLanes, 0, st>>>(a...);
+  if (fast) k_tiled_round<KIND, 1, S.tr, S.tc, kSparseLanes, false, true, true><<<grid, kSparseLanes, 0, st>>>(a...);
+  else k_tiled_round<KIND, 1, S.tr, S.tc, kSparseLanes, false, true><<<grid, kSparseLanes, 0, st>>>(a...);
 }
 template <int KIND, typename... A>
-static void launch_sparse(int shape, unsigned grid, hipStream_t st, A... a) {
-  if (shape == kShapeFull) launch_sparse_shape<KIND, kShapeFull>(grid, st, a...);
-  else launch_sparse_shape<KIND, 0>(grid, st, a...);  // shapes 0 and 1: 64 x 64 tiles
+static void launch_sparse(bool fast, int shape, unsigned grid, hipStream_t st, A... a) {
+  if (shape == kShapeFull) launch_sparse_shape<KIND, kShapeFull>(fast, grid, st, a...);
+  else launch_sparse_shape<KIND, 0>(fast, grid, st, a...);  // shapes 0 and 1: 64 x 64 tiles
 }
 // work-groups of a shape's kernel one CU holds, as the runtime sees it
 template <int KIND, int SH, bool ALB>
@@ -2164,15 +2257,15 @@ static int occupancy_of(int shape) {
   }
 }
 template <int KIND, int DEP, typename... A>
-static void launch_round(int shape, unsigned grid, hipStream_t st, A... a) {
+static void launch_round(bool fast, int shape, unsigned grid, hipStream_t st, A... a) {
   switch (shape) {
-    case 1: launch_shape<KIND, DEP, 1, false>(grid, st, a...); break;
+    case 1: launch_shape<KIND, DEP, 1, false>(fast, grid, st, a...); break;
     case kShapeColour:
       if constexpr (DEP == 1)  // colour only with the compare-and-swap deposits
-        launch_shape<KIND, 1, kShapeColour, true>(grid, st, a...);
+        launch_shape<KIND, 1, kShapeColour, true>(false, grid, st, a...);
       break;
-    case kShapeFull: if constexpr (DEP == 1) launch_shape<KIND, 1, kShapeFull, false>(grid, st, a...); break;
-    default: launch_shape<KIND, DEP, 0, false>(grid, st, a...); break;
+    case kShapeFull: if constexpr (DEP == 1) launch_shape<KIND, 1, kShapeFull, false>(fast, grid, st, a...); break;
+    default: launch_shape<KIND, DEP, 0, false>(fast, grid, st, a...); break;
   }
 }
 
@@ -2247,6 +2340,7 @@ struct TiledRun {
   uint32_t pair_free_below = 0;          // SOIL_PAIR_FREE (per cent of N): rounds of fewer walkers pass the gate (k_pair_gate)
   int host_lag_us = 0;                   // SOIL_TILED_HOST_LAG_US (tests): the host sleeps that long before every look at a word
   int agg_min = 48, agg_groups = 4, retries = 2;
+  bool fast = false;  // the step in fast arithmetic (soil_set_particle_arith; not with colour planes or native adds)
   PRec* recs_of(uint64_t r) const { return (r & 1) ? next : cur; }               // records round r reads
   uint32_t* count_of(uint64_t r) const { return (r & 1) ? count_next : count; }   // section counts round r's scan reads
   TileShape ts_of(int sh, uint64_t r) const {
@@ -2384,6 +2478,7 @@ struct TiledRun {
     retries = 2;
     if (const char* e = std::getenv("SOIL_TILED_RETRIES")) retries = std::atoi(e) > 0 ? std::atoi(e) : 0;  // 0: none
     stagger = env_int("SOIL_TILED_STAGGER", KIND == FLUVIAL ? 1 : 2) == 1;
+    fast = particle_arith_fast() && deposit == 0 && !fluxA;
     const int64_t max_tiles = std::max(std::max(tiles_of(shape_early, 0), tiles_of(shape_late, 0)),
                                        std::max(tiles_of(shape_early, 1), tiles_of(shape_late, 1)));
     auto align = [](size_t b) { return (b + 255) & ~static_cast<size_t>(255); };
@@ -2565,7 +2660,7 @@ struct TiledRun {
       // the sparse tiles of the round, if its scan made any (ctl->sparse_of): in front of the gate —
       // eight one-wave work-groups fit a CU beside whatever the other launch has there
       const unsigned grid_sparse = static_cast<unsigned>(std::min<int64_t>(tiles, std::max<int64_t>(live_known, 1)));
-      launch_sparse<KIND>(sh, grid_sparse, st, out, dest, rank, count_of(r + 1), static_cast<const PRec*>(in),
+      launch_sparse<KIND>(fast, sh, grid_sparse, st, out, dest, rank, count_of(r + 1), static_cast<const PRec*>(in),
                           static_cast<const uint32_t*>(order), static_cast<const uint4*>(block_list), flux0, flux1,
                           reinterpret_cast<float2*>(fluxV), fluxA, static_cast<const float4*>(p4), remote0, steps_run,
                           d, s, p, tiles_w, ts_cur.off_r, ts_cur.off_c, steps_of(r), ts_of(sh_next, r + 1),
@@ -2583,7 +2678,7 @@ struct TiledRun {
     if (!tail_scan) next_scan.host = nullptr;  // the round kernel leaves the scan to a launch of its own
 
     if (deposit == 1)
-      launch_round<KIND, 0>(sh, grid, st, out, dest, rank, count_of(r + 1),
+      launch_round<KIND, 0>(false, sh, grid, st, out, dest, rank, count_of(r + 1),
                             static_cast<const PRec*>(in), static_cast<const uint32_t*>(order),
                             static_cast<const uint4*>(block_list), flux0, flux1,
                             reinterpret_cast<float2*>(fluxV), fluxA, static_cast<const float4*>(p4),
@@ -2592,7 +2687,7 @@ struct TiledRun {
                             tiles_w_of(sh_next, r + 1), agg_min, agg_groups, retries, store_all,
                             ctl, static_cast<uint32_t>(r), next_scan, my_dense, gate_early);
     else
-      launch_round<KIND, 1>(sh, grid, st, out, dest, rank, count_of(r + 1),
+      launch_round<KIND, 1>(fast, sh, grid, st, out, dest, rank, count_of(r + 1),
                             static_cast<const PRec*>(in), static_cast<const uint32_t*>(order),
                             static_cast<const uint4*>(block_list), flux0, flux1,
                             reinterpret_cast<float2*>(fluxV), fluxA, static_cast<const float4*>(p4),
@@ -2680,8 +2775,12 @@ struct TiledRun {
     if (mode != 0) {
       if (mode == 1) {  // the records round `stop_round` would have read, and the slots in use among them
         const uint64_t stop = host->stop_round;
-        k_tiled_finish<KIND><<<blocks_for(std::max<int64_t>(slots_before, 1), 256), 256, 0, st>>>(
-            recs_of(stop), dest, ctl, flux0, flux1, fluxV, fluxA, p4, remote0, steps_run, d, s, p);
+        if (fast)
+          k_tiled_finish<KIND, true><<<blocks_for(std::max<int64_t>(slots_before, 1), 256), 256, 0, st>>>(
+              recs_of(stop), dest, ctl, flux0, flux1, fluxV, fluxA, p4, remote0, steps_run, d, s, p);
+        else
+          k_tiled_finish<KIND><<<blocks_for(std::max<int64_t>(slots_before, 1), 256), 256, 0, st>>>(
+              recs_of(stop), dest, ctl, flux0, flux1, fluxV, fluxA, p4, remote0, steps_run, d, s, p);
         SOIL_LAUNCH_CHECK();
       }
       return finish_steps();

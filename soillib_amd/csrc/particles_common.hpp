@@ -71,6 +71,7 @@ __device__ __forceinline__ float2 spawn_position(const Streams& st, int64_t n, c
 }
 // the launch shape a launch of N particles on domain d gets (erosion_particles.hip)
 bool use_tiled_launch(int64_t N, const Dom& d);
+bool particle_arith_fast();  // soil_set_particle_arith(1) / SOIL_PARTICLE_DIV=fast (erosion_particles.hip)
 
 // exclusive scan of per-tile counts, start[tiles] = total (one 1024-thread group;
 // defined in erosion_particles.hip)

@@ -295,6 +295,19 @@ def particle_steps(reset=True):
     return n.value
 
 
+def particle_arith(mode=None):
+    """Arithmetic of the particle step in the tiled launch shape (soil_hip.h: soil_set_particle_arith;
+    not in the reference): "exact" — IEEE quotients, the oracle's walks step for step (default) — or
+    "fast" — v_rcp_f32 quotients, statistical parity (tests/test_fast_particles.py).  Returns the mode
+    in force; with an argument, sets it first."""
+    names = {"exact": 0, "ieee": 0, 0: 0, "fast": 1, 1: 1}
+    if mode is not None:
+        if mode not in names:
+            raise ValueError("particle_arith: 'exact' or 'fast'")
+        _call("soil_set_particle_arith", names[mode])
+    return "fast" if _abi.lib().soil_get_particle_arith() == 1 else "exact"
+
+
 def layer_merge(height, layers):
     """model.cpp:343-351 -> soil::layer_merge (erosion.cu:747-757)."""
     _call("soil_layer_merge", _f(height, "height"), _f(layers, "layers"), height.elem(),
