@@ -228,6 +228,12 @@ def parse_args():
                     help="(the default everywhere since round 3; kept for old command lines)")
     ap.add_argument("--sequential-particles", action="store_true",
                     help="the two particle launches back to back, each timed by itself")
+    ap.add_argument("--particle-arith", choices=("fast", "exact"),
+                    default=os.environ.get("SOIL_BENCH_ARITH", "fast"),
+                    help="arithmetic of the particle step (soil_set_particle_arith): 'fast' = v_rcp_f32 quotients, "
+                         "statistical parity (tests/test_fast_particles.py), the mode of the line's `value`; "
+                         "'exact' = IEEE quotients, the oracle's walks step for step.  A single-GPU run in fast "
+                         "mode also times the exact mode and reports it as `exact_arithmetic`")
     ap.add_argument("--particle-mode", type=int, default=0,
                     help="0 auto, 1 direct (reference launch shape), 2 staged — ablation")
     return ap.parse_args()
@@ -349,6 +355,7 @@ def main():
     lib = _abi.lib()
     _abi.check(lib.soil_set_device(local_rank))
     _abi.check(lib.soil_set_particle_mode(args.particle_mode))
+    soil.particle_arith(args.particle_arith)
 
     S = args.size
     strong = args.grid > 0
@@ -378,6 +385,17 @@ def main():
 
     ev = Events(_abi, 6)
     elapsed, phase, psteps_rank = timed_steps(runner, ev, args.steps, args.warmup, world)
+    exact_block = None
+    if world == 1 and not slabbed and args.particle_arith == "fast" and os.environ.get("SOIL_BENCH_NO_EXACT") != "1":
+        # the same model a few steps on in the exact mode (the parity tests' arithmetic), same harness
+        soil.particle_arith("exact")
+        ke = max(2, min(args.steps, 6))
+        e_el, e_ph, e_ps = timed_steps(runner, ev, ke, 1, world)
+        soil.particle_arith("fast")
+        exact_block = {"ms_per_step": e_el / ke * 1e3, "value": H_global * W / (e_el / ke) / 1e6, "unit": "Mcells/s",
+                       "steps": ke, "warmup": 1, "gparticle_steps_per_s": e_ps / e_el / 1e9,
+                       "note": "IEEE quotients and square root in the particle step: trajectories equal to the "
+                               "oracle's step for step (the mode of the -m gpu parity tests)"}
     final = None
     if not slabbed:
         # sanity of the evolved terrain (outside the timed region): no NaN/inf may appear
@@ -466,6 +484,12 @@ def main():
                             "slabs, same harness" % (G, world) if strong_block else ""),
             "grid": [H_global, W], "particles": cells // args.particles_div, "maxage": 256,
             "parallelism": "row-slabs x%d" % world if world > 1 else "single GPU",
+            "particle_arithmetic": (
+                "fast: quotients of the particle step as numerator x v_rcp_f32(denominator), v_sqrt_f32 "
+                "(soil_set_particle_arith(1)); statistical parity with the oracle — plane sums 2e-3, visited "
+                "cells 0.5 %, step counts 0.5 % — tests/test_fast_particles.py; the exact mode is timed beside it "
+                "(`exact_arithmetic`)" if args.particle_arith == "fast" else
+                "exact: IEEE quotients and square root (soil_set_particle_arith(0)), the oracle's walks step for step"),
         },
         "final_state": final,
         "halo": halo,
@@ -497,6 +521,8 @@ def main():
                      "avg_launch_ms": t_cells * 1e3},
     }
     out["roofline_particles"] = proof
+    if exact_block:
+        out["exact_arithmetic"] = exact_block
     if strong_block:
         out["strong16384"] = strong_block
     if world == 1 and not args.no_cpu_baseline:

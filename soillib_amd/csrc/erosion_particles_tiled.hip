@@ -357,8 +357,12 @@ __device__ __forceinline__ StepGeom step_geom_fast(const PRec& r, const StepCons
   const float x_neg = floorf(r.px), y_neg = floorf(r.py);
   const float nx = ((g.ux > 0.0f) ? 1.0f + x_neg : x_neg) - r.px;
   const float ny = ((g.uy > 0.0f) ? 1.0f + y_neg : y_neg) - r.py;
-  const float tx = fminf(fast_quot(nx, __builtin_amdgcn_rcpf(g.ux)), kSqrt2);
-  const float ty = fminf(fast_quot(ny, __builtin_amdgcn_rcpf(g.uy)), kSqrt2);
+  // (nx and ux have the same sign whenever ux is not zero, so the face time is |nx| / |ux|; written
+  // that way a direction component of exactly zero — every walker that runs down an axis-aligned
+  // slope from rest has one — gives |nx| x inf = +inf (or NaN for nx = 0), which the minimum turns into
+  // sqrt(2) as the reference's fmax / fmin pair does, where nx x rcp(+-0) would be -inf)
+  const float tx = fminf(fast_quot(fabsf(nx), __builtin_amdgcn_rcpf(fabsf(g.ux))), kSqrt2);
+  const float ty = fminf(fast_quot(fabsf(ny), __builtin_amdgcn_rcpf(fabsf(g.uy))), kSqrt2);
   g.v_step = 0.5f * (tx + ty);
   g.dL = g.v_step * k.lenL;       // :119 / :324
   g.ds = fast_quot(g.dL, rn);     // :120 / :325

@@ -61,8 +61,13 @@ def test_mode_switch_and_its_refusals(hip):
         assert soil.particle_arith("exact") == "exact"
 
 
-@pytest.mark.parametrize("H,W,maxage,shape", [(192, 192, 128, None), (320, 256, 200, "3")])
-def test_fluvial_launch_fast_against_the_oracle(fast, oracle, monkeypatch, H, W, maxage, shape):
+@pytest.mark.parametrize("H,W,maxage,shape,rest", [(192, 192, 128, None, False), (320, 256, 200, "3", False),
+                                                   # from rest (the model's first step: zero velocity and water
+                                                   # planes): speeds are axis-aligned wherever one component of
+                                                   # the downhill gradient is clamped to zero — direction
+                                                   # components of EXACTLY zero, the face-time quotient's edge
+                                                   (256, 192, 160, None, True)])
+def test_fluvial_launch_fast_against_the_oracle(fast, oracle, monkeypatch, H, W, maxage, shape, rest):
     from soillib_amd import soil
     if shape:
         monkeypatch.setenv("SOIL_TILED_SHAPE", shape)       # the LDS-filling tiles large grids get
@@ -74,6 +79,8 @@ def test_fluvial_launch_fast_against_the_oracle(fast, oracle, monkeypatch, H, W,
     r = np.random.default_rng(3)
     vel = ((r.random((H, W, 2)) - 0.5) * 0.1).astype(np.float32)
     wh = (r.random((H, W)) * 0.01).astype(np.float32)
+    if rest:
+        vel[:], wh[:] = 0.0, 0.0
     rain = np.ones((H, W), np.float32)
     z1 = lambda: np.zeros((H, W), np.float32)
     z2 = lambda: np.zeros((H, W, 2), np.float32)
