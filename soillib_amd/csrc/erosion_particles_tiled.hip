@@ -1719,7 +1719,12 @@ __global__ void __launch_bounds__(NT, SPARSE ? 2 : round_waves_per_simd(KIND, TR
         ++nsteps;
         // the cell's record comes from the packed plane through L1/L2 (the tile's
         // 64 KiB are touched ~4x per round); issued first, the gather's latency
-        // hides under the deposit and the other waves of the SIMD
+        // hides under the deposit and the other waves of the SIMD.  (Round 5, tried: the record of the
+        // NEXT cell asked for as soon as the step's geometry gives it, one iteration ahead, checked and
+        // asked for again when the guess was wrong — with the record switched off the fluvial launch
+        // takes 16 % less, tools/ablate_fast.sh — : 8192^2 step 28.0 -> 29.3 ms fast, 30.7 -> 32.8 exact.
+        // What the gather costs is its 64 lines per wave instruction through the vector cache, not
+        // their latency; a second request in flight and the guesses that miss only add to that.)
         const float4 q = p4[ABLATED(8) ? l_org : lcell];
         bool deposit = false;
         if (nind != r.ind && !ABLATED(2)) {    // :104-113 / :310-318
