@@ -438,8 +438,9 @@ int soil_direction(int32_t* direction, const float* height, int64_t H, int64_t W
 int soil_steepest(int32_t* graph, const float* height, int64_t H, int64_t W, int edge,
                   void* stream);
 /* soil::random_weighted — graph.hpp:54, graph.cu:175-195 (__seed :97-101,
- * __random_weighted :103-173), model.cpp:173-175.  Stateless: cell n draws
- * its one uniform from (seed, subsequence n, offset). */
+ * __random_weighted :103-173), model.cpp:173-175.  Stateless: cell n draws its one uniform in (0, 1]
+ * from the Philox4x32-10 block (key seed; counter {offset, n >> 2}), word n & 3 — the reference's
+ * curand_init(seed, n, offset) + one curand_uniform per cell, with one block serving four cells. */
 int soil_random_weighted(int32_t* graph, const float* height, int64_t H, int64_t W, int edge,
                          uint64_t seed, uint64_t offset, float T, void* stream);
 /* soil::slope — graph.hpp:63, graph.cu:297-311 (__slope :270-295), model.cpp:161-163. */

@@ -184,6 +184,14 @@ def rng_uniform(rng, subsequence):
     return out
 
 
+def rng_uniform_cell(seed, offset, cells):
+    """random_weighted's draw of every cell index in `cells` (block (offset, n >> 2), word n & 3)."""
+    fn = lib().orc_rng_uniform_cell
+    fn.restype = C.c_float
+    return np.array([fn(C.c_uint64(int(seed)), C.c_uint64(int(offset)), C.c_uint64(int(n))) for n in cells],
+                    np.float32)
+
+
 def stepsize(px, py, dx, dy):
     return lib().orc_stepsize(px, py, dx, dy)
 

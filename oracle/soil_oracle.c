@@ -184,6 +184,22 @@ float orc_rng_uniform(orc_rng* s, uint64_t subsequence) {
   return (float)((r >> 8) + 1u) * 5.9604644775390625e-08f; /* 2^-24 */
 }
 
+/* The one uniform cell n of a flow-graph draw takes (random_weighted): the reference seeds a state
+ * per cell, curand_init(seed, subsequence = n, offset), and draws once (graph.cu:97-101, :150).  The
+ * stand-in generator makes four 32-bit words per block and one block per (offset, subsequence): this
+ * build's addressing gives block (offset, n >> 2) to cells 4 (n >> 2) .. + 3, cell n takes word n & 3 —
+ * a quarter of the blocks for the same number of independent draws (the generator is build-defined
+ * on both sides; the particle streams keep subsequence = n, word 0). */
+float orc_rng_uniform_cell(uint64_t seed, uint64_t offset, uint64_t n) {
+  const uint64_t subsequence = n >> 2;
+  const uint32_t ctr[4] = {(uint32_t)offset, (uint32_t)(offset >> 32), (uint32_t)subsequence,
+                           (uint32_t)(subsequence >> 32)};
+  const uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+  uint32_t out[4];
+  orc_philox4x32_10(ctr, key, out);
+  return (float)((out[n & 3u] >> 8) + 1u) * 5.9604644775390625e-08f; /* 2^-24: (0, 1] */
+}
+
 void orc_rng_seed(orc_rng* rng, int64_t n, uint64_t seed, uint64_t offset) {
   for (int64_t i = 0; i < n; ++i) {
     rng[i].seed = seed;
@@ -827,8 +843,8 @@ void orc_random_weighted(int32_t* graph, const float* height, int64_t H, int64_t
         Z += P;                                                     /* :141 */
       }
       int32_t next = -1;                                  /* :149 */
-      orc_rng st = {seed, offset};                        /* curand_init(seed, n, offset), :100 */
-      const float uniform = orc_rng_uniform(&st, (uint64_t)n); /* :150 */
+      /* curand_init(seed, n, offset) :100 + curand_uniform :150, in this build's addressing */
+      const float uniform = orc_rng_uniform_cell(seed, offset, (uint64_t)n);
       for (int k = 0; k < K; ++k) {                       /* :151-165 */
         const int64_t nx = x + ORC_SHIFT[k][0], ny = y + ORC_SHIFT[k][1];
         if (nx < 0 || ny < 0 || nx >= H || ny >= W) continue;

@@ -60,6 +60,7 @@ float orc_powf(float x, float y);
 void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 uint32_t orc_rng_next(orc_rng* state, uint64_t subsequence);
 float orc_rng_uniform(orc_rng* state, uint64_t subsequence);
+float orc_rng_uniform_cell(uint64_t seed, uint64_t offset, uint64_t n); /* random_weighted's draw of cell n */
 void orc_rng_seed(orc_rng* rng, int64_t n, uint64_t seed, uint64_t offset);
 
 /* helpers exposed for known-answer tests */

@@ -188,7 +188,8 @@ void launch_steepest4(int32_t* out, const float* height, int64_t H, int64_t W, h
 
 // __seed (graph.cu:97-101) + __random_weighted (:103-173): the per-cell
 // generator state is never materialised — cell n reads its one uniform straight
-// from stream (seed, subsequence n) at position `offset`.
+// from block (seed; offset, subsequence n >> 2), word n & 3 (round 5: one Philox block per FOUR cells,
+// soil_math.hpp rng_uniform_quad; rounds 1-4 spent a block per cell on its word 0).
 //
 // Arithmetic (round 4).  The reference computes the Gibbs weights with the fast intrinsic,
 // `P = __expf(dE / T)` (graph.cu:139) = ex2.approx(dE / T * log2 e): they are a tolerance by
@@ -269,8 +270,11 @@ __global__ void __launch_bounds__(kGBlock)
 #pragma unroll
     for (int m = 0; m < kRwBatch; ++m) {
       if (m >= b.n) break;
-      const float uniform = rng_uniform_at(seed, static_cast<uint64_t>(n), b.offset[m]);  // :100, :150
-      b.graph[m][n] = rw_pick<K>(CDF, Z, ok, to, uniform);                                // :171
+      float u4[4];  // :100, :150 — the block of cells 4 (n >> 2) .. + 3, this cell's word (soil_math.hpp)
+      rng_uniform_quad(seed, static_cast<uint64_t>(n) >> 2, b.offset[m], u4);
+      const int word = static_cast<int>(n & 3);
+      const float uniform = word == 0 ? u4[0] : (word == 1 ? u4[1] : (word == 2 ? u4[2] : u4[3]));
+      b.graph[m][n] = rw_pick<K>(CDF, Z, ok, to, uniform);  // :171
     }
   }
 }
@@ -285,6 +289,13 @@ __global__ void __launch_bounds__(kWinBlock)
   RowWalk w;
   SOIL_WIN_ROWS(x, w, height, H, W, t) {
     int4 o[kRwBatch];
+    // the thread's four cells are one block's four words: W and y0 are multiples of four
+    float u[kRwBatch][4];
+#pragma unroll
+    for (int m = 0; m < kRwBatch; ++m) {
+      if (m >= b.n) break;
+      rng_uniform_quad(seed, static_cast<uint64_t>(x * W + t.y0) >> 2, b.offset[m], u[m]);
+    }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const int64_t y = t.y0 + c;
@@ -305,8 +316,7 @@ __global__ void __launch_bounds__(kWinBlock)
 #pragma unroll
       for (int m = 0; m < kRwBatch; ++m) {
         if (m >= b.n) break;
-        const float uniform = rng_uniform_at(seed, static_cast<uint64_t>(n), b.offset[m]);
-        reinterpret_cast<int32_t*>(&o[m])[c] = rw_pick<K>(CDF, Z, ok, to, uniform);
+        reinterpret_cast<int32_t*>(&o[m])[c] = rw_pick<K>(CDF, Z, ok, to, u[m][c]);
       }
     }
     if (t.live) {

@@ -241,6 +241,40 @@ SOIL_HD uint32_t philox4x32_10_w0(uint32_t c0, uint32_t c1, uint32_t c2, uint32_
   return c0;
 }
 
+// ... the whole block
+SOIL_HD void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                           uint32_t out[4]) {
+#pragma unroll
+  for (int round = 0; round < 10; ++round) {
+    const uint64_t p0 = static_cast<uint64_t>(0xD2511F53u) * c0;
+    const uint64_t p1 = static_cast<uint64_t>(0xCD9E8D57u) * c2;
+    const uint32_t n0 = static_cast<uint32_t>(p1 >> 32) ^ c1 ^ k0;
+    const uint32_t n1 = static_cast<uint32_t>(p1);
+    const uint32_t n2 = static_cast<uint32_t>(p0 >> 32) ^ c3 ^ k1;
+    const uint32_t n3 = static_cast<uint32_t>(p0);
+    c0 = n0;
+    c1 = n1;
+    c2 = n2;
+    c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0, out[1] = c1, out[2] = c2, out[3] = c3;
+}
+SOIL_HD float uniform_of_word(uint32_t r) { return static_cast<float>((r >> 8) + 1u) * 5.9604644775390625e-08f; }  // (0, 1]
+// The draws of the four cells 4 q .. 4 q + 3 of a flow graph (random_weighted): block (offset,
+// subsequence q), cell n takes word n & 3.  The reference seeds a generator state per cell,
+// curand_init(seed, n, offset), for ONE uniform (graph.cu:97-101, :150); Philox makes four words a
+// block, so one block serves four cells — a quarter of what was half of the kernel's instructions
+// (the generator is build-defined on both sides; oracle: orc_rng_uniform_cell).
+SOIL_HD void rng_uniform_quad(uint64_t seed, uint64_t q, uint64_t offset, float u[4]) {
+  uint32_t w[4];
+  philox4x32_10(static_cast<uint32_t>(offset), static_cast<uint32_t>(offset >> 32), static_cast<uint32_t>(q),
+                static_cast<uint32_t>(q >> 32), static_cast<uint32_t>(seed), static_cast<uint32_t>(seed >> 32), w);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) u[i] = uniform_of_word(w[i]);
+}
+
 // One draw in (0, 1] from stream (seed, subsequence) at position `offset` —
 // the addressing of curand_init(seed, subsequence, offset) + curand_uniform.
 SOIL_HD float rng_uniform_at(uint64_t seed, uint64_t subsequence, uint64_t offset) {

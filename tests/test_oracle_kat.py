@@ -38,6 +38,21 @@ def test_uniform_range_and_state(oracle):
     assert oracle.rng_uniform(rng2, [5])[0] == u[5]
 
 
+def test_flow_graph_draws_share_a_block_between_four_cells(oracle):
+    """random_weighted's draw of cell n: word n & 3 of the Philox block (key seed; counter {offset, n >> 2})
+    — one block per four cells (oracle: orc_rng_uniform_cell; device: soil_math.hpp rng_uniform_quad)."""
+    seed, offset = 0x1234567890ab, 0x100000007
+    cells = np.arange(40, 72)
+    u = oracle.rng_uniform_cell(seed, offset, cells)
+    for n, got in zip(cells, u):
+        words = oracle.philox([offset & 0xffffffff, offset >> 32, int(n) >> 2, 0], [seed & 0xffffffff, seed >> 32])
+        assert got == np.float32(((words[int(n) & 3] >> 8) + 1) * 2.0 ** -24)
+    assert (u > 0).all() and (u <= 1).all() and len(set(u.tolist())) == len(u)
+    # word 0 of a block is what a particle stream of that subsequence draws at that offset
+    rng = oracle.rng_seed(1, seed, offset)
+    assert oracle.rng_uniform(rng, [44 >> 2])[0] == u[44 - 40]
+
+
 def test_expf_within_one_ulp_of_libm(oracle):
     xs = np.concatenate([np.linspace(-87, 88, 20001), np.linspace(-1, 1, 2001)]).astype(np.float32)
     mine = oracle.expf(xs).astype(np.float64)

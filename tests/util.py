@@ -115,7 +115,7 @@ def assert_receivers_close(oracle, got, want, height, K, seed, offset, T, what="
     h = np.asarray(height, np.float64)
     for x, y in bad:
         n = int(x) * W + int(y)
-        u = float(oracle.rng_uniform(oracle.rng_seed(1, seed, offset), [n])[0])
+        u = float(oracle.rng_uniform_cell(seed, offset, [n])[0])
         idx, cdf, z = [], [], 0.0
         for k in range(K):
             nx, ny = x + _D8[k][0], y + _D8[k][1]
