@@ -178,10 +178,13 @@ void launch_steepest4_as(int32_t* out, const float* height, int64_t H, int64_t W
 template <int K, bool STORE_K>
 void launch_steepest4(int32_t* out, const float* height, int64_t H, int64_t W, hipStream_t st) {
   constexpr bool kWatch = K > 4;  // the straight slopes are the differences: nothing to watch for d4
-  switch (win_shape(0)) {
+  // (steepest D8 on blocks of four rows spills its 64 registers; direction does not)
+  switch (win_shape_for(STORE_K ? 4 : 0, STORE_K ? 4 : 5, H, W)) {
     case 0: return launch_steepest4_as<K, STORE_K, RowWalkReg<kWatch>>(out, height, H, W, st);
     case 1: return launch_steepest4_as<K, STORE_K, RowWalkLds<kWatch>>(out, height, H, W, st);
     case 3: return launch_steepest4_as<K, STORE_K, RowWalkTall<kWatch>>(out, height, H, W, st);
+    case 4: return launch_steepest4_as<K, STORE_K, RowWalkBlock4<kWatch>>(out, height, H, W, st);
+    case 5: return launch_steepest4_as<K, STORE_K, RowWalkBlock2<kWatch>>(out, height, H, W, st);
     default: return launch_steepest4_as<K, STORE_K, RowWalkFlat<kWatch>>(out, height, H, W, st);
   }
 }
@@ -281,12 +284,12 @@ __global__ void __launch_bounds__(kGBlock)
 
 // four cells per thread, the neighbours from the thread's three-row window (window.hpp): the same
 // operations on the same values as the kernel above
-template <int K>
+template <int K, class Walk>
 __global__ void __launch_bounds__(kWinBlock)
     k_random_weighted4(RwBatch b, const float* __restrict__ height, int64_t H, int64_t W, uint64_t seed,
                        RwConst rc) {
-  const WinThread t = win_thread(W);
-  RowWalk w;
+  const WinThread t = Walk::thread(H, W);
+  SOIL_WIN_WALK(Walk, w, W);
   SOIL_WIN_ROWS(x, w, height, H, W, t) {
     int4 o[kRwBatch];
     // the thread's four cells are one block's four words: W and y0 are multiples of four
@@ -334,8 +337,12 @@ static void launch_random_weighted(const RwBatch& b, const float* height, int64_
                                    float T, hipStream_t st) {
   bool aligned = W % 4 == 0 && W >= 4 && (reinterpret_cast<uintptr_t>(height) & 15) == 0;
   for (int m = 0; m < b.n; ++m) aligned = aligned && (reinterpret_cast<uintptr_t>(b.graph[m]) & 15) == 0;
-  if (aligned)
-    k_random_weighted4<K><<<win_grid(H, W), kWinBlock, 0, st>>>(b, height, H, W, seed, rw_const(T));
+  if (aligned) {
+    const int shape = win_shape_for(4, 4, H, W);
+    if (shape == 4) k_random_weighted4<K, RowWalkBlock4<false>><<<RowWalkBlock4<false>::grid(H, W), kWinBlock, 0, st>>>(b, height, H, W, seed, rw_const(T));
+    else if (shape == 5) k_random_weighted4<K, RowWalkBlock2<false>><<<RowWalkBlock2<false>::grid(H, W), kWinBlock, 0, st>>>(b, height, H, W, seed, rw_const(T));
+    else k_random_weighted4<K, RowWalk><<<win_grid(H, W), kWinBlock, 0, st>>>(b, height, H, W, seed, rw_const(T));
+  }
   else
     k_random_weighted<K><<<grid_rows(H, W, kGBlock), kGBlock, 0, st>>>(b, height, H, W, seed, rw_const(T));
 }
@@ -386,13 +393,14 @@ __global__ void __launch_bounds__(kGBlock)
 // neighbours in every graph this library makes, and then its value is already in the thread's
 // three-row window — no gather; any other index takes the scalar kernel's general case.  16-byte
 // loads of the flow graph and the tensor, 16-byte stores.
+template <class Walk>
 __global__ void __launch_bounds__(kWinBlock)
     k_slope4(float* __restrict__ slope, const float* __restrict__ tensor,
              const int32_t* __restrict__ flow, int64_t H, int64_t W, Scale2 s) {
-  const WinThread t = win_thread(W);
+  const WinThread t = Walk::thread(H, W);
   const int32_t iW = static_cast<int32_t>(W), iH = static_cast<int32_t>(H);
   (void)iH;
-  RowWalk w;
+  SOIL_WIN_WALK(Walk, w, W);
   SOIL_WIN_ROWS(x, w, tensor, H, W, t) {
     const int32_t n0 = static_cast<int32_t>(x * W + t.y0);
     const int4 f = *reinterpret_cast<const int4*>(flow + n0);  // :282
@@ -762,10 +770,13 @@ int soil_slope(float* slope, const float* tensor, const int32_t* flow, int64_t H
   SOIL_REQUIRE(slope && tensor && flow && scale, "slope: null argument");
   SOIL_REQUIRE(H > 0 && W > 0 && H * W <= INT32_MAX, "slope: grid must have 1..2^31-1 cells (int32 flow graph)");
   if (W % 4 == 0 && W >= 4 && (reinterpret_cast<uintptr_t>(flow) & 15) == 0 &&
-      (reinterpret_cast<uintptr_t>(slope) & 15) == 0 && (reinterpret_cast<uintptr_t>(tensor) & 15) == 0)
-    k_slope4<<<win_grid(H, W), kWinBlock, 0, as_stream(stream)>>>(slope, tensor, flow, H, W,
-                                                                 Scale2{scale[0], scale[1]});
-  else
+      (reinterpret_cast<uintptr_t>(slope) & 15) == 0 && (reinterpret_cast<uintptr_t>(tensor) & 15) == 0) {
+    // (round 5, ms at 8192^2 by shape — band walk | blocks of four rows | of two: see DESIGN.md 3.3)
+    const int shape = win_shape_for(5, 5, H, W);
+    auto k = shape == 4 ? k_slope4<RowWalkBlock4<false>> : (shape == 5 ? k_slope4<RowWalkBlock2<false>> : k_slope4<RowWalk>);
+    const dim3 grid = shape == 4 ? RowWalkBlock4<false>::grid(H, W) : (shape == 5 ? RowWalkBlock2<false>::grid(H, W) : win_grid(H, W));
+    k<<<grid, kWinBlock, 0, as_stream(stream)>>>(slope, tensor, flow, H, W, Scale2{scale[0], scale[1]});
+  } else
     k_slope<<<grid_rows(H, W, kGBlock), kGBlock, 0, as_stream(stream)>>>(
         slope, tensor, flow, static_cast<int32_t>(H), static_cast<int32_t>(W), Scale2{scale[0], scale[1]});
   SOIL_LAUNCH_CHECK();

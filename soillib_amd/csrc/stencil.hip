@@ -119,13 +119,15 @@ template <class Walk, class KF, class... A>
 static void win_launch_as(KF kernel, int64_t H, int64_t W, hipStream_t st, A... a) {
   kernel<<<Walk::grid(H, W), kWinBlock, 0, st>>>(a...);
 }
-#define SOIL_WIN_LAUNCH(dflt, fast, K_FAST, K_WRITTEN, WATCH, H, W, st, ...)                         \
+#define SOIL_WIN_LAUNCH(large, small, fast, K_FAST, K_WRITTEN, WATCH, H, W, st, ...)                 \
   do {                                                                                              \
     if (!(fast)) win_launch_as<RowWalk>(K_WRITTEN<RowWalk>, H, W, st, __VA_ARGS__);                 \
-    else switch (win_shape(dflt)) {                                                                 \
+    else switch (win_shape_for(large, small, H, W)) {                                               \
       case 0: win_launch_as<RowWalkReg<WATCH>>(K_FAST<RowWalkReg<WATCH>>, H, W, st, __VA_ARGS__); break;   \
       case 1: win_launch_as<RowWalkLds<WATCH>>(K_FAST<RowWalkLds<WATCH>>, H, W, st, __VA_ARGS__); break;   \
       case 3: win_launch_as<RowWalkTall<WATCH>>(K_FAST<RowWalkTall<WATCH>>, H, W, st, __VA_ARGS__); break; \
+      case 4: win_launch_as<RowWalkBlock4<WATCH>>(K_FAST<RowWalkBlock4<WATCH>>, H, W, st, __VA_ARGS__); break; \
+      case 5: win_launch_as<RowWalkBlock2<WATCH>>(K_FAST<RowWalkBlock2<WATCH>>, H, W, st, __VA_ARGS__); break; \
       default: win_launch_as<RowWalkFlat<WATCH>>(K_FAST<RowWalkFlat<WATCH>>, H, W, st, __VA_ARGS__); break; \
     }                                                                                               \
   } while (0)
@@ -726,7 +728,7 @@ int soil_gradient(float* out, const float* in, int64_t H, int64_t W, const float
   SOIL_REQUIRE(H > 0 && W > 0, "gradient: empty grid");
   const bool fast = plain_scale(scale[0]) && plain_scale(scale[1]);
   if (W % 4 == 0 && W >= 4)
-    SOIL_WIN_LAUNCH(0, fast, kGradientFast, kGradientWritten, false, H, W, as_stream(stream),
+    SOIL_WIN_LAUNCH(5, 5, fast, kGradientFast, kGradientWritten, false, H, W, as_stream(stream),
                     reinterpret_cast<float2*>(out), in, H, W, Scale2{scale[0], scale[1]});
   else
     k_gradient<<<grid_rows(H, W, kSBlock), kSBlock, 0, as_stream(stream)>>>(
@@ -742,7 +744,7 @@ int soil_negslope(float* out, const float* in, int64_t H, int64_t W, const float
   SOIL_REQUIRE(H > 0 && W > 0, "negslope: empty grid");
   const bool fast = plain_scale(scale[0]) && plain_scale(scale[1]);
   if (W % 4 == 0 && W >= 4)
-    SOIL_WIN_LAUNCH(0, fast, kNegslopeFast, kNegslopeWritten, true, H, W, as_stream(stream), out, in, H, W,
+    SOIL_WIN_LAUNCH(4, 4, fast, kNegslopeFast, kNegslopeWritten, true, H, W, as_stream(stream), out, in, H, W,
                     Scale2{scale[0], scale[1]});
   else
     k_negslope<<<grid_rows(H, W, kSBlock), kSBlock, 0, as_stream(stream)>>>(
@@ -758,7 +760,7 @@ int soil_laplacian(float* out, const float* in, int64_t H, int64_t W, int D, con
   SOIL_REQUIRE(H > 0 && W > 0, "laplacian: empty grid");
   const Scale2 s{scale[0], scale[1]};
   if (D == 1 && W % 4 == 0 && W >= 4)  // grad.cu:196-198
-    SOIL_WIN_LAUNCH(0, true, kLaplacian1, kLaplacian1, false, H, W, as_stream(stream), out, in, H, W,
+    SOIL_WIN_LAUNCH(0, 4, true, kLaplacian1, kLaplacian1, false, H, W, as_stream(stream), out, in, H, W,
                     1.0f / s.x / s.x, 1.0f / s.y / s.y);  // (IEEE fp32 on the host: the same bits as on the device)
   else if (D == 1)
     k_laplacian<1><<<grid_rows(H, W, kSBlock), kSBlock, 0, as_stream(stream)>>>(out, in, H, W, s);

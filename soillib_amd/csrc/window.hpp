@@ -206,6 +206,111 @@ using RowWalkFlat = RowWalkReg<WATCH, WinFlatShape>;
 template <bool WATCH>
 using RowWalkTall = RowWalkReg<WATCH, WinBandRows<kWinBand / 2>>;  // bands of 16 rows
 
+// ---- blocks of a few rows, asked for at once (round 5) -------------------------------------------
+//
+// tools/microbench/copy_shapes.hip again, with what round 4 had not tried (8192^2, 8 B per cell, us):
+//   flat 87.8 | rows3 87.9 | block 2 87.9 | block 4 92.6 | block 8 100.3 | block 16 108.6 | band 8 101.8 |
+//   band 16 107.4 | band 32 111.1 | band 64 104.6 | band 128 122.7 | band 32 with two rows in flight 111.3 |
+//   band 32, an XCD sweeping its own eighth of the rows 112.5
+// The fewer rows a work-group lives for, the faster the plane streams: short-lived work-groups handed
+// out in address order keep the chip's accesses on a narrow front of DRAM pages, a band walk has 2048
+// fronts a megabyte apart whatever is done about its loads in flight.  A block of R rows asks for its
+// R + 2 rows at once (independent 16-byte loads, the two extra rows out of the L2 the vertical
+// neighbours fill — work-groups b G + g and (b +- 1) G + g run on the same XCD when G = W / 1024 is a
+// multiple of 8), walks them out of registers and is gone.  Round 4's flat shape is the block of ONE
+// row: it pays the per-thread set-up (reciprocals, halo columns, index arithmetic) once per row and
+// lost to the band walk on every kernel; at R = 4 that cost is a quarter and the plane still streams
+// at 5.8 TB/s where the band walk gets 4.8.
+// The halo columns: a lane's left / right neighbour cells are its neighbour lanes' (wave shifts on DPP,
+// no LDS crossbar); lanes 0 and 63 take the cell beside the wave's 256 from one more load that every
+// lane issues (theirs the edge columns, everybody else's a harmless repeat) — no divergent reload.
+template <int CTRL>
+__device__ __forceinline__ float dpp_wave_shift(float v) {  // 0x138: wave_shr:1 (lane i reads lane i - 1), 0x130: wave_shl:1
+  return bits2f(static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(f2bits(v)), CTRL, 0xf, 0xf, false)));
+}
+// `x` is a row of the grid (the caller clamps); `row_ok`: it is the row asked for (else zeros)
+__device__ __forceinline__ Row6 load_row6_dpp(const float* __restrict__ in, int64_t x, int64_t W, int64_t y0,
+                                              bool row_ok) {
+  const int lane = static_cast<int>(threadIdx.x & 63u);
+  const float* row = in + x * W;
+  const int64_t ec = lane == 63 ? (y0 + 4 < W ? y0 + 4 : W - 1) : (y0 > 0 ? y0 - 1 : 0);
+  float4 c = *reinterpret_cast<const float4*>(row + y0);
+  float e = row[ec];
+  if (!row_ok) {
+    c = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    e = 0.0f;
+  }
+  float l = dpp_wave_shift<0x138>(c.w), r = dpp_wave_shift<0x130>(c.x);
+  if (lane == 0) l = y0 > 0 ? e : 0.0f;
+  if (lane == 63) r = y0 + 4 < W ? e : 0.0f;
+  return Row6{{l, c.x, c.y, c.z, c.w, r}};
+}
+inline int64_t win_groups_of(int64_t W) { return (W / 4 + kWinBlock - 1) / kWinBlock; }
+template <int R>
+struct WinBlockRows {  // a work-group owns R rows of 1024 columns; work-groups in address order
+  static constexpr int kBand = R;
+  static dim3 grid(int64_t H, int64_t W) {
+    return dim3(static_cast<unsigned>(win_groups_of(W) * ((H + R - 1) / R)));
+  }
+  static __device__ __forceinline__ WinThread thread(int64_t, int64_t W) {
+    const uint32_t G = static_cast<uint32_t>((W / 4 + kWinBlock - 1) / kWinBlock);
+    const uint32_t b = blockIdx.x / G, g = blockIdx.x - b * G;
+    const int64_t y = (static_cast<int64_t>(g) * kWinBlock + threadIdx.x) * 4;
+    return WinThread{y < W ? y : W - 4, y < W, static_cast<int64_t>(g), static_cast<int64_t>(b)};
+  }
+  static __device__ __forceinline__ int64_t band_first(const WinThread& t) { return t.row; }
+  static __device__ __forceinline__ bool band_ok(int64_t band, int64_t H) { return band >= 0 && band * R < H; }
+  static __device__ __forceinline__ int64_t band_next(int64_t) { return -1; }
+};
+template <bool WATCH, int R>
+struct RowBlockReg : WinBlockRows<R> {
+  static constexpr int kLdsFloats = 4;
+  Row6 up, mid, dn;
+  Row6 ahead[R > 1 ? R - 1 : 1];  // rows x + 2 .. x + R of the block's first row x, taken by next()
+  bool has_up, has_dn;
+  bool p_up = true, p_mid = true, p_dn = true, p_ahead[R > 1 ? R - 1 : 1];
+  __device__ __forceinline__ bool plain() const { return p_up && p_mid && p_dn; }
+  __device__ __forceinline__ bool watch(const Row6& r) const {
+    if (!WATCH) return true;
+    const int lane = static_cast<int>(threadIdx.x & 63u);
+    return win_row_plain(make_float4(r.v[1], r.v[2], r.v[3], r.v[4]), lane == 0 ? r.v[0] : r.v[5]);
+  }
+  __device__ __forceinline__ void start(const float* __restrict__ in, int64_t x, int64_t H, int64_t W, int64_t y0) {
+    has_up = x > 0;
+    has_dn = x + 1 < H;
+    auto row = [&](int64_t xr) { return load_row6_dpp(in, xr < 0 ? 0 : (xr < H ? xr : H - 1), W, y0, xr >= 0 && xr < H); };
+    up = row(x - 1);
+    mid = row(x);
+    dn = row(x + 1);
+#pragma unroll
+    for (int i = 0; i < R - 1; ++i) ahead[i] = row(x + 2 + i);
+    p_up = watch(up);
+    p_mid = watch(mid);
+    p_dn = watch(dn);
+#pragma unroll
+    for (int i = 0; i < R - 1; ++i) p_ahead[i] = watch(ahead[i]);
+  }
+  __device__ __forceinline__ void next(const float* __restrict__, int64_t x, int64_t H, int64_t, int64_t) {
+    up = mid;
+    mid = dn;
+    dn = ahead[0];
+    p_up = p_mid;
+    p_mid = p_dn;
+    p_dn = p_ahead[0];
+#pragma unroll
+    for (int i = 0; i + 1 < R - 1; ++i) {
+      ahead[i] = ahead[i + 1];
+      p_ahead[i] = p_ahead[i + 1];
+    }
+    has_up = true;
+    has_dn = x + 1 < H;
+  }
+};
+template <bool WATCH>
+using RowWalkBlock4 = RowBlockReg<WATCH, 4>;
+template <bool WATCH>
+using RowWalkBlock2 = RowBlockReg<WATCH, 2>;
+
 // ---- the same walk with the rows landing in LDS (round 4) ---------------------------------------
 //
 // RowWalk has ONE 16-byte load per wave in flight and waits for it before the shuffles: a launch at
@@ -329,6 +434,8 @@ using RowWalkDma = RowWalkLds<false>;
 // `SOIL_WIN_WALK(Walk, w, W);` declares walk `w` of either kind with the LDS it needs
 template <bool WATCH, class SHAPE>
 __device__ __forceinline__ void win_bind(RowWalkReg<WATCH, SHAPE>&, float*, int64_t) {}
+template <bool WATCH, int R>
+__device__ __forceinline__ void win_bind(RowBlockReg<WATCH, R>&, float*, int64_t) {}
 template <bool WATCH>
 __device__ __forceinline__ void win_bind(RowWalkLds<WATCH>& w, float* lds, int64_t W) { w.bind(lds, W); }
 template <class Walk>
@@ -340,14 +447,25 @@ constexpr int win_lds_floats() {
   Walk w;                                                                       \
   ::soil::win_bind(w, w##_lds, W)
 // SOIL_WIN_SHAPE (A/B): 0 the band walk through registers, 1 the band walk through LDS, 2 the flat
-// shape, 3 bands of 16 rows through registers (measured: as 32; 64 rows, half the waves: 20-30 % slower);
-// unset: the kernel's own default
+// shape, 3 bands of 16 rows through registers (measured: as 32; 64 rows, half the waves: 20-30 % slower),
+// 4 / 5 blocks of four / two rows asked for at once (round 5); unset: the kernel's own default
 inline int win_shape(int dflt) {
   static const int env = [] {
     const char* e = std::getenv("SOIL_WIN_SHAPE");
-    return (e && e[0] >= '0' && e[0] <= '3') ? e[0] - '0' : -1;
+    return (e && e[0] >= '0' && e[0] <= '5') ? e[0] - '0' : -1;
   }();
   return env >= 0 ? env : dflt;
+}
+// A kernel's own choice by grid (round 5; ms at 8192^2, band walk | blocks of four rows | of two, one box,
+// tools/bench_stencils.py: gradient 0.162 | 0.154 | 0.140, slope 0.165 | 0.178 | 0.152, negslope 0.119 |
+// 0.110 | 0.119, direction 0.140 | 0.131 | 0.139, random_weighted 0.260 | 0.223 | 0.230, laplacian D = 1
+// 0.109 | 0.113 | 0.122, steepest D8 0.134 | 0.318 (its 64 registers spill) | 0.170): `large`.  A grid
+// whose band walk would be fewer than 2048 work-groups — 4096^2 has 512, half a generation of the chip —
+// takes `small` instead: at 4096^2 gradient 0.062 | 0.042 | 0.042, slope 0.070 | 0.045 | 0.045, negslope
+// 0.048 | 0.033 | 0.034, direction 0.056 | 0.039 | 0.038.
+inline int win_shape_for(int large, int small, int64_t H, int64_t W) {
+  const int64_t band_groups = ((W / 4 + kWinBlock - 1) / kWinBlock) * ((H + kWinBand - 1) / kWinBand);
+  return win_shape(band_groups < 2048 ? small : large);
 }
 
 // A lane that has 32 contiguous bytes to store (two float4: four cells of a two-channel plane) would
@@ -371,9 +489,11 @@ __device__ __forceinline__ void store_pair_contiguous(float4* __restrict__ wave_
 }
 
 // for (x over the rows of this work-group) with `w` holding rows x - 1 .. x + 1; `t`: w.thread(H, W)
+#define SOIL_WIN_PRAGMA(x) _Pragma(#x)
 #define SOIL_WIN_ROWS(x, w, in, H, W, t)                                                         \
   for (int64_t x##_band = (w).band_first(t); (w).band_ok(x##_band, H);                           \
        x##_band = (w).band_next(x##_band))                                                       \
+    SOIL_WIN_PRAGMA(unroll((w).kBand <= 4 ? (w).kBand : 1))                                      \
     for (int64_t x = x##_band * (w).kBand, x##_end = (x + (w).kBand < (H)) ? x + (w).kBand : (H), \
                  x##_go = ((w).start(in, x, H, W, (t).y0), 1);                                   \
          x < x##_end && x##_go; ++x, (x < x##_end ? (w).next(in, x, H, W, (t).y0) : (void)0))

@@ -49,6 +49,65 @@ __global__ void __launch_bounds__(256) k_rows3(float* __restrict__ o, const floa
       make_float4(up.x + mid.x + dn.x, up.y + mid.y + dn.y, up.z + mid.z + dn.z, up.w + mid.w + dn.w);
 }
 
+// block R (round 5): 256 threads own 1024 columns of R rows; every thread asks for its R + 2 rows at once
+// (independent 16-byte loads), then writes its R outputs: a short-lived work-group like `flat`, in
+// address order, with (R + 2) / R of the reads (the two extra rows out of the L2 the vertical
+// neighbours fill: work-groups b * G + g and (b +- 1) * G + g share an XCD when G = W / 1024 is 8)
+template <int R>
+__global__ void __launch_bounds__(256) k_block(float* __restrict__ o, const float* __restrict__ in, int64_t H, int64_t W) {
+  const int64_t G = W / 1024;
+  const int64_t g = blockIdx.x % G, b = blockIdx.x / G;
+  const int64_t y0 = (g * 256 + threadIdx.x) * 4;
+  const int64_t x0 = b * R;
+  float4 r[R + 2];
+#pragma unroll
+  for (int i = 0; i < R + 2; ++i) {
+    int64_t x = x0 - 1 + i;
+    x = x < 0 ? 0 : (x >= H ? H - 1 : x);
+    r[i] = *reinterpret_cast<const float4*>(in + x * W + y0);
+  }
+#pragma unroll
+  for (int i = 0; i < R; ++i)
+    if (x0 + i < H)
+      *reinterpret_cast<float4*>(o + (x0 + i) * W + y0) =
+          make_float4(r[i].x + r[i + 1].x + r[i + 2].x, r[i].y + r[i + 1].y + r[i + 2].y,
+                      r[i].z + r[i + 1].z + r[i + 2].z, r[i].w + r[i + 1].w + r[i + 2].w);
+}
+// band R with the row after next asked for before the current one is used (two loads in flight)
+template <int R>
+__global__ void __launch_bounds__(256) k_band2(float* __restrict__ o, const float* __restrict__ in, int64_t H, int64_t W) {
+  const int64_t y0 = (static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x) * 4;
+  const int64_t x0 = static_cast<int64_t>(blockIdx.y) * R;
+  auto row = [&](int64_t x) { x = x < 0 ? 0 : (x >= H ? H - 1 : x); return *reinterpret_cast<const float4*>(in + x * W + y0); };
+  float4 up = row(x0 - 1), mid = row(x0), dn = row(x0 + 1);
+  for (int64_t x = x0; x < x0 + R && x < H; ++x) {
+    const float4 nx = row(x + 2);
+    *reinterpret_cast<float4*>(o + x * W + y0) =
+        make_float4(up.x + mid.x + dn.x, up.y + mid.y + dn.y, up.z + mid.z + dn.z, up.w + mid.w + dn.w);
+    up = mid;
+    mid = dn;
+    dn = nx;
+  }
+}
+// band R, work-groups numbered so that an XCD sweeps its own eighth of the rows top to bottom
+template <int R>
+__global__ void __launch_bounds__(256) k_band_xcd(float* __restrict__ o, const float* __restrict__ in, int64_t H, int64_t W) {
+  const int64_t G = W / 1024, bands = H / R;
+  const int64_t k = blockIdx.x & 7, i = blockIdx.x >> 3;      // XCD k, its i-th work-group
+  const int64_t g = i % G, b = k * (bands / 8) + i / G;
+  const int64_t y0 = (g * 256 + threadIdx.x) * 4;
+  const int64_t x0 = b * R;
+  float4 up = *reinterpret_cast<const float4*>(in + (x0 > 0 ? x0 - 1 : 0) * W + y0);
+  float4 mid = *reinterpret_cast<const float4*>(in + x0 * W + y0);
+  for (int64_t x = x0; x < x0 + R && x < H; ++x) {
+    const float4 dn = *reinterpret_cast<const float4*>(in + (x + 1 < H ? x + 1 : x) * W + y0);
+    *reinterpret_cast<float4*>(o + x * W + y0) =
+        make_float4(up.x + mid.x + dn.x, up.y + mid.y + dn.y, up.z + mid.z + dn.z, up.w + mid.w + dn.w);
+    up = mid;
+    mid = dn;
+  }
+}
+
 int main() {
   const int64_t H = 8192, W = 8192, n = H * W;
   float *a, *b;
@@ -80,5 +139,15 @@ int main() {
   timed("band 64", 8.0 * n, [&] { k_band<64><<<dim3(W / 1024, H / 64), 256>>>(b, a, H, W); });
   timed("band 128", 8.0 * n, [&] { k_band<128><<<dim3(W / 1024, H / 128), 256>>>(b, a, H, W); });
   timed("rows3", 8.0 * n, [&] { k_rows3<<<flat_blocks, 256>>>(b, a, H, W); });
+  timed("block 2", 8.0 * n, [&] { k_block<2><<<static_cast<unsigned>(W / 1024 * (H / 2)), 256>>>(b, a, H, W); });
+  timed("block 4", 8.0 * n, [&] { k_block<4><<<static_cast<unsigned>(W / 1024 * (H / 4)), 256>>>(b, a, H, W); });
+  timed("block 8", 8.0 * n, [&] { k_block<8><<<static_cast<unsigned>(W / 1024 * (H / 8)), 256>>>(b, a, H, W); });
+  timed("block 16", 8.0 * n, [&] { k_block<16><<<static_cast<unsigned>(W / 1024 * (H / 16)), 256>>>(b, a, H, W); });
+  timed("band2 16", 8.0 * n, [&] { k_band2<16><<<dim3(W / 1024, H / 16), 256>>>(b, a, H, W); });
+  timed("band2 32", 8.0 * n, [&] { k_band2<32><<<dim3(W / 1024, H / 32), 256>>>(b, a, H, W); });
+  timed("band2 64", 8.0 * n, [&] { k_band2<64><<<dim3(W / 1024, H / 64), 256>>>(b, a, H, W); });
+  timed("bandx 16", 8.0 * n, [&] { k_band_xcd<16><<<static_cast<unsigned>(W / 1024 * (H / 16)), 256>>>(b, a, H, W); });
+  timed("bandx 32", 8.0 * n, [&] { k_band_xcd<32><<<static_cast<unsigned>(W / 1024 * (H / 32)), 256>>>(b, a, H, W); });
+  timed("bandx 64", 8.0 * n, [&] { k_band_xcd<64><<<static_cast<unsigned>(W / 1024 * (H / 64)), 256>>>(b, a, H, W); });
   return 0;
 }
