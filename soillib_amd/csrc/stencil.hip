@@ -585,16 +585,23 @@ __device__ __forceinline__ float at4(const float4& v, int k) {
   return k == 0 ? v.x : k == 1 ? v.y : k == 2 ? v.z : v.w;
 }
 
-__global__ void __launch_bounds__(kWinBlock)
-    k_normal4(float* __restrict__ out, const float* __restrict__ in, int64_t H, int64_t W, Scale3 s) {
+// (round 5: the kernel took 93 registers = 5 waves per SIMD; held to 80 = 6 waves 0.318 -> 0.289 ms at 8192^2,
+// to 64 = 8 waves it spills, 0.65 ms; bands of 32 | 16 | 8 | 4 rows 0.348 | 0.324 | 0.318 | 0.319 ms)
+#ifndef SOIL_NORMAL_WAVES
+#define SOIL_NORMAL_WAVES 6
+#endif
+template <int BAND>
+__global__ void __launch_bounds__(kWinBlock) __attribute__((amdgpu_waves_per_eu(SOIL_NORMAL_WAVES, 8)))
+    k_normal4(float* __restrict__ out, const float* __restrict__ in, int64_t H, int64_t W, Scale3 s, bool fast) {
   __shared__ float4 s_tile[kWinBlock / 64][192];
   const WinThread t = win_thread(W);
+  const Recip r12 = recip(12.0f), rx = recip(s.x), ry = recip(s.y);
   const int lane = static_cast<int>(threadIdx.x & 63u);
   float4* tile = s_tile[threadIdx.x >> 6];
   const int64_t wave_y0 = (static_cast<int64_t>(blockIdx.x) * kWinBlock + (threadIdx.x & ~63u)) * 4;
-  for (int64_t band = blockIdx.y; band * kWinBand < H; band += gridDim.y) {
-    int64_t x = band * kWinBand;
-    const int64_t x_end = (x + kWinBand < H) ? x + kWinBand : H;
+  for (int64_t band = blockIdx.y; band * BAND < H; band += gridDim.y) {
+    int64_t x = band * BAND;
+    const int64_t x_end = (x + BAND < H) ? x + BAND : H;
     // rows x - 2 .. x + 2; the halo columns are wanted for the row a cell's y-derivative is taken
     // in, the centre one: loaded with every row that will get there (not the two above the band)
     float4 m2 = load_row_n(in, x - 2, H, W, t.y0, false).c, m1 = load_row_n(in, x - 1, H, W, t.y0, false).c;
@@ -606,6 +613,35 @@ __global__ void __launch_bounds__(kWinBlock)
       const float rowv[8] = {c0.l2, c0.l1, c0.c.x, c0.c.y, c0.c.z, c0.c.w, c0.r1, c0.r2};
       // a thread past the end of the row sits on the last group (t.y0 = W - 4): its columns exist
       const float nan = __builtin_nanf("");
+      // Round 5: the cell's five IEEE divisions (two by 12, by the two cell sizes, 1 / length) and its
+      // square root were ~60 of its ~115 vector instructions.  Away from the grid's edge, with every
+      // sample finite, lerp5 is its fourth-order formula and the quotients are shared-reciprocal ones
+      // (soil_math.hpp: the IEEE quotient's own instruction sequence on a reciprocal refined once per
+      // thread / per cell) whose results are watched; a group in doubt — a non-finite sample shows as a
+      // NaN or an infinity in the results, a denormal difference, a -0 numerator, the sentinels at the
+      // edge — is redone as written.  Same bits either way (the parity tests run both).
+      bool redo = !fast || x < 2 || x + 2 >= H || t.y0 < 2 || t.y0 + 5 >= W;
+      if (!redo) {
+        QuotWatch watch;
+        bool len_ok = true;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float nx = (at4(m2, k) - 8.0f * at4(m1, k)) + (8.0f * at4(p1.c, k) - at4(p2.c, k));
+          const float ny = (rowv[k] - 8.0f * rowv[k + 1]) + (8.0f * rowv[k + 3] - rowv[k + 4]);
+          const float dx = watch(quot(nx, r12), nx), dy = watch(quot(ny, r12), ny);
+          const float ax = dx * s.z, ay = dy * s.z;
+          const float gx = watch(quot(ax, rx), ax), gy = watch(quot(ay, ry), ay);  // :31-32
+          const float vx = -gx, vy = -gy, vz = 1.0f;                               // :33
+          const float len = sqrt_rn(vx * vx + vy * vy + vz * vz);                  // (>= 1: no scaling wanted)
+          len_ok = len_ok && len <= kDenHi;
+          const float inv = quot(1.0f, recip(len));
+          o[3 * k] = vx * inv;
+          o[3 * k + 1] = vy * inv;
+          o[3 * k + 2] = vz * inv;
+        }
+        redo = watch.doubtful() || !len_ok;
+      }
+      if (redo) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int64_t y = t.y0 + k;
@@ -623,6 +659,7 @@ __global__ void __launch_bounds__(kWinBlock)
         o[3 * k] = vx * inv;
         o[3 * k + 1] = vy * inv;
         o[3 * k + 2] = vz * inv;
+      }
       }
       {  // the wave's 64 x 48 bytes, contiguous in memory, as three instructions of 1 KiB each
         const int n = 3 * __popcll(__ballot(t.live));  // float4s of the wave that are real
@@ -806,8 +843,19 @@ int soil_normal(float* out, const float* in, int64_t H, int64_t W, const float s
   SOIL_REQUIRE(out && in && scale, "normal: null argument");
   SOIL_REQUIRE(H > 0 && W > 0, "normal: empty grid");
   if (W % 4 == 0 && W >= 4)
-    k_normal4<<<win_grid(H, W), kWinBlock, 0, as_stream(stream)>>>(out, in, H, W,
-                                                                 Scale3{scale[0], scale[1], scale[2]});
+  {
+    static const int band = [] { const char* e = std::getenv("SOIL_NORMAL_BAND"); return e ? std::atoi(e) : 8; }();
+    const bool fast = plain_scale(scale[0]) && plain_scale(scale[1]);
+    const Scale3 s3{scale[0], scale[1], scale[2]};
+    auto grid = [&](int b) {
+      const int64_t bands = (H + b - 1) / b;
+      return dim3(static_cast<unsigned>((W / 4 + kWinBlock - 1) / kWinBlock), static_cast<unsigned>(bands < 65535 ? bands : 65535));
+    };
+    if (band == 4) k_normal4<4><<<grid(4), kWinBlock, 0, as_stream(stream)>>>(out, in, H, W, s3, fast);
+    else if (band == 8) k_normal4<8><<<grid(8), kWinBlock, 0, as_stream(stream)>>>(out, in, H, W, s3, fast);
+    else if (band == 16) k_normal4<16><<<grid(16), kWinBlock, 0, as_stream(stream)>>>(out, in, H, W, s3, fast);
+    else k_normal4<32><<<grid(32), kWinBlock, 0, as_stream(stream)>>>(out, in, H, W, s3, fast);
+  }
   else
     k_normal<<<grid_rows(H, W, kSBlock), kSBlock, 0, as_stream(stream)>>>(
         out, in, H, W, Scale3{scale[0], scale[1], scale[2]});
