@@ -489,11 +489,9 @@ __device__ __forceinline__ void store_pair_contiguous(float4* __restrict__ wave_
 }
 
 // for (x over the rows of this work-group) with `w` holding rows x - 1 .. x + 1; `t`: w.thread(H, W)
-#define SOIL_WIN_PRAGMA(x) _Pragma(#x)
 #define SOIL_WIN_ROWS(x, w, in, H, W, t)                                                         \
   for (int64_t x##_band = (w).band_first(t); (w).band_ok(x##_band, H);                           \
        x##_band = (w).band_next(x##_band))                                                       \
-    SOIL_WIN_PRAGMA(unroll((w).kBand <= 4 ? (w).kBand : 1))                                      \
     for (int64_t x = x##_band * (w).kBand, x##_end = (x + (w).kBand < (H)) ? x + (w).kBand : (H), \
                  x##_go = ((w).start(in, x, H, W, (t).y0), 1);                                   \
          x < x##_end && x##_go; ++x, (x < x##_end ? (w).next(in, x, H, W, (t).y0) : (void)0))
