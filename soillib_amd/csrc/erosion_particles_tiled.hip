@@ -594,16 +594,16 @@ __global__ void __launch_bounds__(kWinBlock)
     k_tiled_pack_pair4(float4* __restrict__ q_fluvial, float4* __restrict__ q_debris,
                        const float2* __restrict__ layers, const float2* __restrict__ velocity,
                        const float* __restrict__ waterHeight, const float2* __restrict__ debrisVelocity,
-                       Dom d, Scale3 s, Param param, int64_t row_lo, int64_t row_end) {
+                       Dom d, Scale3 s, Param param, int64_t row_lo, int64_t row_end, int band_rows) {
   __shared__ float4 s_tile[kWinBlock / 64][256];
   const WinThread t = win_thread(d.W);
   const int lane = static_cast<int>(threadIdx.x & 63u);
   float4* const tile = s_tile[threadIdx.x >> 6];
   const float g = param.gravity;
   auto row_in_grid = [&](int64_t lx) { return d.x0 + lx >= 0 && d.x0 + lx < d.H; };
-  for (int64_t band = blockIdx.y; row_lo + band * kWinBand < row_end; band += gridDim.y) {
-    const int64_t x_first = row_lo + band * kWinBand;
-    const int64_t x_last = x_first + kWinBand < row_end ? x_first + kWinBand : row_end;
+  for (int64_t band = blockIdx.y; row_lo + band * band_rows < row_end; band += gridDim.y) {
+    const int64_t x_first = row_lo + band * band_rows;
+    const int64_t x_last = x_first + band_rows < row_end ? x_first + band_rows : row_end;
     HRow6 up = load_hrow6(layers, x_first - 1, row_in_grid(x_first - 1), d.W, t.y0);
     HRow6 mid = load_hrow6(layers, x_first, true, d.W, t.y0);
     for (int64_t lx = x_first; lx < x_last; ++lx) {
@@ -2424,7 +2424,11 @@ struct TiledRun {
     // 64 / 68 / 72 steps 32.2 32.0 31.5 31.6 31.3 31.4 31.5 31.1 31.3 31.4 ms per overlapped 8192^2 step, one box;
     // 4096^2 9.14 -> 8.99 at 64; 2048^2 4.00 -> 4.18 and 1024^2 1.65 -> 1.76: the 64-row tiles keep 44.
     // Debris 32 / 40 / 48 / 56: 31.8 31.5 31.5 31.8)
-    steps_per_round = env_kind("SOIL_TILED_STEPS", KIND, KIND == FLUVIAL ? (shape_early == kShapeFull ? 64 : 44)
+    // (round 5, fast arithmetic, 64-row tiles: 1024^2 — every tile's work-group resident at once, a round is its
+    // hottest tile's chain — 44 | 36 | 32 | 28 | 24 steps: 1.51 | 1.49 | 1.49 ms per step early in a run, 1.39 | 1.28 |
+    // 1.29 | 1.29 | 1.30 late (steps 6000-7500, three runs each); 2048^2 2.76 | 2.81 | 2.82: keeps 44)
+    const bool all_resident = tiles_of(shape_early, 0) <= resident_groups_hint();
+    steps_per_round = env_kind("SOIL_TILED_STEPS", KIND, KIND == FLUVIAL ? (shape_early == kShapeFull ? 64 : (all_resident ? 36 : 44))
                                                                          : (shape_early == kShapeFull ? 40 : 32));
     // Worth its launch in front of every round only where a round is many generations of work-groups:
     // measured on one box, ms per step with | without: 1024^2 1.48 | 1.45, 2048^2 4.44 | 4.17, 4096^2
@@ -2903,10 +2907,17 @@ int launch_pair_tiled(const soil_erosion_planes& P, Streams rng_fluvial, Streams
                         ((reinterpret_cast<uintptr_t>(P.layers) | reinterpret_cast<uintptr_t>(P.velocity) |
                           reinterpret_cast<uintptr_t>(P.waterHeight) | reinterpret_cast<uintptr_t>(P.debrisVelocity) |
                           reinterpret_cast<uintptr_t>(A.p4) | reinterpret_cast<uintptr_t>(B.p4)) & 15u) == 0;
-      if (hi >= lo && wide)
-        k_tiled_pack_pair4<<<win_grid(hi - lo + 1, d.W), kWinBlock, 0, st>>>(
+      if (hi >= lo && wide) {
+        // rows per work-group: the window shape's 32 where that still makes four work-groups per CU, fewer
+        // on small grids (1024^2 is ONE column group: 32 work-groups of 256 threads for the whole chip,
+        // 107 us per step of BASELINE config 2's 1.4 ms; round 5)
+        const int64_t rows = hi - lo + 1, groups = (d.W / 4 + kWinBlock - 1) / kWinBlock;
+        const int band_rows = static_cast<int>(std::max<int64_t>(2, std::min<int64_t>(kWinBand, rows * groups / 1024)));
+        const int64_t bands = (rows + band_rows - 1) / band_rows;
+        k_tiled_pack_pair4<<<dim3(static_cast<unsigned>(groups), static_cast<unsigned>(std::min<int64_t>(bands, 65535))), kWinBlock, 0, st>>>(
             A.p4, B.p4, reinterpret_cast<const float2*>(P.layers), reinterpret_cast<const float2*>(P.velocity),
-            P.waterHeight, reinterpret_cast<const float2*>(P.debrisVelocity), d, s, p, lo, hi + 1);
+            P.waterHeight, reinterpret_cast<const float2*>(P.debrisVelocity), d, s, p, lo, hi + 1, band_rows);
+      }
       else if (hi >= lo)
         k_tiled_pack_pair<<<grid_rows(hi - lo + 1, d.W, 256), 256, 0, st>>>(
             A.p4, B.p4, reinterpret_cast<const float2*>(P.layers), reinterpret_cast<const float2*>(P.velocity),
