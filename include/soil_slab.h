@@ -123,7 +123,8 @@ typedef struct soil_slab_config {
   int32_t pair;          /* particle launches overlapped: 1 / 0; -1: on unless SOIL_STEP_PAIR=0 (as
                             soil_erode_step) */
   int32_t halo_need;     /* > 0: ghost rows to refresh whatever the history says (tests: a
-                            prediction that is too small on purpose); 0: predicted; also SOIL_HALO_NEED */
+                            prediction that is too small on purpose); 0: predicted; also SOIL_HALO_NEED.
+                            Must be the same on every rank (checked by soil_slab_create) */
 } soil_slab_config;
 
 typedef struct soil_slab_info {
@@ -152,8 +153,8 @@ int soil_slab_step(soil_slab* slab, soil_slab_mark_fn mark, void* mark_ctx);
 /* A plane of the slab by the names of soil_erosion_planes ("layers" is the current one): local
  * rows incl. ghost rows, `channels` floats per cell.  The five flux planes are scratch of a step:
  * with the HIP back-end they are not re-zeroed behind the cell phase (the next step's launches
- * overwrite them; SOIL_SLAB_LAZY=0 restores the zeros), so between two steps they hold the flux
- * the last one consumed. */
+ * overwrite them; SOIL_SLAB_LAZY=0 restores the zeros), so between two steps their OWNED rows hold
+ * the flux the last one consumed; their ghost rows have no stated content. */
 int soil_slab_plane(soil_slab* slab, const char* name, float** data, int64_t* rows,
                     int64_t* channels);
 int soil_slab_get_info(const soil_slab* slab, soil_slab_info* info);

@@ -546,7 +546,12 @@ struct HipOps {
   // first rounds store whole tiles, empty ones included (SOIL_FLUX_OVERWRITE), as soil_erode_step
   // does on one GPU.  `flux_stale`: the planes `stale_planes` describes hold a finished step's
   // flux; a launch that only adds clears them first.  Someone who reads a flux plane through
-  // soil_slab_plane between two steps sees the consumed flux of the last one (ghost rows: zeros).
+  // soil_slab_plane between two steps sees the consumed flux of the last one in the owned rows.  The
+  // GHOST rows of the flux planes are scratch without a stated content: inside the step's launch window
+  // (set_window) they were stored by the first rounds and zeroed again behind the exchange, outside of
+  // it — rows no walk can reach without the step repeating its launches on all rows — they keep whatever
+  // an earlier, wider window left there.  Nothing reads them: the reach scan, the flux exchange and the
+  // stores all stop at the window, and a fallback zeroes every row first (advisor finding of round 4).
   // SOIL_SLAB_LAZY=0 switches it off.
   bool lazy = true, last_pair = false, flux_stale = false;
   soil_erosion_planes stale_planes{};
@@ -947,6 +952,17 @@ int soil_slab_create(soil_slab** out, const soil_slab_config* cfg, const soil_pa
   // (world * 4 small ints, and behind them the 8 sums of the NaN walkers' deposits: one all-reduce carries both)
   if (int rc = ops->alloc(ops->ctx, &q, (static_cast<int64_t>(s->world) * 4 + 8) * 4); rc != SOIL_OK) return bail(rc);
   s->ints = static_cast<float*>(q);
+  // The neighbours' refresh depths are computed, not exchanged (round 4): that is only right when every
+  // rank runs with the same forced depth (cfg->halo_need / SOIL_HALO_NEED: tests).  One sum at create time.
+  if (s->world > 1) {
+    std::vector<int> all;
+    const int mine[1] = {s->halo_need > 0 ? s->halo_need : 0};
+    if (int rc = s->all_ints(mine, 1, all); rc != SOIL_OK) return bail(rc);
+    for (int v : all)
+      if (v != mine[0])
+        return bail(fail(SOIL_ERR_INVALID_ARGUMENT, "slab_create: halo_need differs between the ranks (" +
+                                                        std::to_string(mine[0]) + " here, " + std::to_string(v) + " elsewhere)"));
+  }
   if (cfg->init) {
     if (int rc = ops->alloc(ops->ctx, &q, s->lay.rows * s->W * 4); rc != SOIL_OK) return bail(rc);
     float* bed = static_cast<float*>(q);
