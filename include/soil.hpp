@@ -322,7 +322,7 @@ class slab_runner {
   static soil_slab_config config(int64_t rows_per_rank, int64_t W, int64_t particles_div = 8, uint64_t seed = 0) {
     soil_slab_config c{};
     c.rows_per_rank = rows_per_rank, c.W = W, c.particles_div = particles_div, c.seed = seed;
-    c.noise_seed = 3.0f, c.init = 1, c.trim = -1, c.pair = -1;
+    c.noise_seed = 3.0f, c.init = 1, c.trim = -1, c.pair = -1, c.mode = -1;
     return c;
   }
   slab_runner(const soil_slab_config& cfg, const param_t& param, comm wire) : wire_(std::move(wire)) {

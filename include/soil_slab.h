@@ -103,11 +103,35 @@ typedef struct soil_slab_ops {
   int (*join)(void* ctx);  /* lane 0 waits for lane 1 */
   int (*sync)(void* ctx);  /* the host waits for both lanes */
   void* (*stream)(void* ctx, int32_t lane);
+  /* SOIL_SLAB_MIGRATE (below): one launch of `kind` (0 fluvial, 1 debris) that ADDS to the kind's flux
+   * planes — from the streams' spawns (`inbox` NULL) or from `n_in` walkers handed over by the neighbours
+   * (64-byte records, taken as they are).  A walker that steps off the owned rows [dom->r0, dom->r1), in
+   * the grid and with life left, is written to `out_up` / `out_down` (room for `cap` records each) at the
+   * top of that iteration, state untouched; out_count[0..1] (back-end memory, zeroed by the caller)
+   * count them.  NULL: the back-end has no such launch and the mode is refused. */
+  int (*particles_pass)(void* ctx, int32_t kind, const soil_erosion_planes* planes, soil_rng* rng, int64_t N,
+                        float* remote0, const soil_domain* dom, const float scale[3],
+                        const soil_param* param, const void* inbox, int64_t n_in, void* out_up,
+                        void* out_down, uint32_t* out_count, int64_t cap);
 } soil_slab_ops;
 
 /* ------------------------------------------------------------ the slab runner */
 
 typedef struct soil_slab soil_slab; /* opaque */
+
+/* How a walk that crosses a slab's edge is served (soil_slab_config.mode).
+ * SOIL_SLAB_DEEP_HALO  every rank carries ceil(sqrt(2) maxage) + 2 ghost rows a side and walks its own
+ *                      walkers to their end; rows of flux and fields travel, trimmed to the measured
+ *                      reach (the default; SURVEY.md 8e's option A made exact by the halo's depth).
+ * SOIL_SLAB_MIGRATE    a shallow halo (16 ghost rows a side, SOIL_MIGRATE_HALO); a walker that reaches its far
+ *                      end is handed over as the 64-byte record the tiled transport parks it as anyway, the
+ *                      neighbour walks it on in a further launch of the same step (SURVEY.md 8e's option
+ *                      B).  What travels: the walkers that cross (a few per cent, 64 B each) and 16 rows of
+ *                      flux and fields; slabs down to 16 rows, 1.6 % ghost rows at 2048-row slabs.  What it
+ *                      costs: a host look at two counters and an all-reduce per pass, one or two short
+ *                      launches per kind and step for the immigrants.  Same walks either way. */
+#define SOIL_SLAB_DEEP_HALO 0
+#define SOIL_SLAB_MIGRATE 1
 
 typedef struct soil_slab_config {
   int64_t rows_per_rank; /* S: rows every rank owns; the global grid is (world * S) x W */
@@ -125,6 +149,8 @@ typedef struct soil_slab_config {
   int32_t halo_need;     /* > 0: ghost rows to refresh whatever the history says (tests: a
                             prediction that is too small on purpose); 0: predicted; also SOIL_HALO_NEED.
                             Must be the same on every rank (checked by soil_slab_create) */
+  int32_t mode;          /* SOIL_SLAB_DEEP_HALO / SOIL_SLAB_MIGRATE; -1: SOIL_SLAB_MODE=migrate in the
+                            environment, else deep halo */
 } soil_slab_config;
 
 typedef struct soil_slab_info {
@@ -139,6 +165,9 @@ typedef struct soil_slab_info {
   int32_t n_reach;
   int64_t rows_window, rows_window_full; /* ghost rows the particle launches were given so far (the rows with
                                             fresh fields + 2, SOIL_HALO_WINDOW=0: all), and the bound's */
+  int64_t passes, walkers_handed;        /* migrate mode: launches of either kind so far (>= 2 per step), walkers
+                                            this rank handed to its neighbours so far */
+  int32_t mode, reserved;
 } soil_slab_info;
 
 /* marks of one step for a timing harness (bench.py records a HIP event per mark on lane 0):

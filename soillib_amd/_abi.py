@@ -202,6 +202,8 @@ OPS_FIELDS = [
     ("join", C.CFUNCTYPE(C.c_int, C.c_void_p)),
     ("sync", C.CFUNCTYPE(C.c_int, C.c_void_p)),
     ("stream", C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_int32)),
+    ("particles_pass", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, _PP, C.c_void_p, C.c_int64, C.c_void_p, _DP, _F3P,
+                                   _PARP, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64)),
 ]
 
 
@@ -214,7 +216,7 @@ class SlabConfig(C.Structure):
     _fields_ = [("rows_per_rank", C.c_int64), ("W", C.c_int64), ("particles_div", C.c_int64),
                 ("seed", C.c_uint64), ("scale", C.c_float * 3), ("noise_seed", C.c_float),
                 ("noise_rows", C.c_int64), ("init", C.c_int32), ("trim", C.c_int32), ("pair", C.c_int32),
-                ("halo_need", C.c_int32)]
+                ("halo_need", C.c_int32), ("mode", C.c_int32)]
 
 
 class SlabInfo(C.Structure):
@@ -222,7 +224,8 @@ class SlabInfo(C.Structure):
         ("step_index", C.c_uint64), ("rank", C.c_int32), ("world", C.c_int32), ("trim", C.c_int32),
         ("pair", C.c_int32), ("rows_flux", C.c_int64), ("rows_field", C.c_int64), ("rows_full", C.c_int64),
         ("repeated_launches", C.c_int64), ("reach_hist", C.c_int32 * 4), ("n_reach", C.c_int32),
-        ("rows_window", C.c_int64), ("rows_window_full", C.c_int64)]
+        ("rows_window", C.c_int64), ("rows_window_full", C.c_int64), ("passes", C.c_int64),
+        ("walkers_handed", C.c_int64), ("mode", C.c_int32), ("reserved", C.c_int32)]
 
 
 MARK_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int32)

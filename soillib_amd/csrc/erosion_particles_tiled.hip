@@ -479,6 +479,12 @@ __device__ __forceinline__ void park_remote(const PRec& r, float* __restrict__ r
   }
 }
 
+// a walker that left the launch's rows through their upper (lx < lo) or lower edge: into the box
+__device__ __forceinline__ void migrate_out(const PRec& r, const MigrateBox& box, bool up) {
+  const uint32_t slot = atomicAdd(&box.count[up ? 0 : 1], 1u);
+  if (slot < box.cap) static_cast<PRec*>(up ? box.up : box.down)[slot] = r;
+}
+
 // ---- pre-pass: everything a step needs from the cell it stands on ------------------
 //
 // All cell-only sub-expressions of the loop body are evaluated once per cell
@@ -746,6 +752,25 @@ __global__ void __launch_bounds__(256)
     recs[n] = r;
   }
   dest[n] = tile;
+}
+
+// ---- a launch that starts from handed-over walkers instead of spawns (MigrateBox) ---------------
+// record i of the inbox takes slot i: its queue section and its rank there, as the spawn gives them
+template <int KIND>
+__global__ void __launch_bounds__(256)
+    k_tiled_inject(PRec* __restrict__ recs, uint32_t* __restrict__ dest, uint32_t* __restrict__ rank,
+                   uint32_t* __restrict__ count, const PRec* __restrict__ inbox, uint32_t n_in, Dom d, Param param,
+                   int tiles_w, TileShape ts, int steps_per_round, TiledCtl* __restrict__ ctl) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i == 0) ctl->live = n_in;
+  if (i >= n_in) return;
+  const PRec r = inbox[i];
+  const uint32_t maxage = param.maxage > 0x7fffffffull ? 0x7fffffffu : static_cast<uint32_t>(param.maxage);
+  const uint32_t key = queue_key(static_cast<int>(d.x0), r.px, r.py, r.spx, r.spy, maxage - static_cast<uint32_t>(r.iter),
+                                 tiles_w, ts, steps_per_round);
+  rank[i] = atomicAdd(&count[key], 1u);
+  recs[i] = r;
+  dest[i] = key;
 }
 
 // Convergent per-key aggregation of atomicAdd(&counter[key], 1): lanes of a wave
@@ -1457,7 +1482,8 @@ __global__ void __launch_bounds__(NT, SPARSE ? 2 : round_waves_per_simd(KIND, TR
                   Scale3 s, Param param, int tiles_w, int off_r, int off_c, int steps_per_round,
                   TileShape ts_next,
                   int tiles_w_next, int agg_min, int agg_groups, int retries, int store_all,
-                  TiledCtl* __restrict__ ctl, uint32_t round, QueueScan next, uint32_t* my_dense, uint32_t gate_early) {
+                  TiledCtl* __restrict__ ctl, uint32_t round, QueueScan next, uint32_t* my_dense, uint32_t gate_early,
+                  MigrateBox box) {
   constexpr int kCells = TR * TC, kBlock = NT, kPer = (kCells + NT - 1) / NT;
   // Queued ahead of the scan's verdict: no round at all (the word the host waits for at the end of
   // this round still goes out), or fewer work-groups than the launch has.
@@ -1872,8 +1898,13 @@ __global__ void __launch_bounds__(NT, SPARSE ? 2 : round_waves_per_simd(KIND, TR
         // rank (only a NaN walker's deposit travels, park_remote) or, state untouched,
         // in this slab's next round
         if (!oob && !aged) {
-          if (esc) park_remote<KIND>(r, remote0);
-          else parked = true;
+          if (esc) {
+            // (a NaN walker stands for cell (0, 0) and never moves: only its deposit travels)
+            if (box.count && !(r.px != r.px || r.py != r.py)) migrate_out(r, box, lx < k.lo);
+            else park_remote<KIND>(r, remote0);
+          } else {
+            parked = true;
+          }
         }
       }
     }
@@ -2155,7 +2186,7 @@ __global__ void __launch_bounds__(NT, SPARSE ? 2 : round_waves_per_simd(KIND, TR
 
 template <int KIND, bool FAST = false>
 __global__ void __launch_bounds__(256)
-    k_tiled_finish(const PRec* __restrict__ recs, const uint32_t* __restrict__ dest,
+    k_tiled_finish(MigrateBox box, const PRec* __restrict__ recs, const uint32_t* __restrict__ dest,
                    const TiledCtl* __restrict__ ctl, float* __restrict__ flux0,
                    float* __restrict__ flux1, float* __restrict__ fluxV, float* __restrict__ fluxA,
                    const float4* __restrict__ p4, float* __restrict__ remote0,
@@ -2179,7 +2210,12 @@ __global__ void __launch_bounds__(256)
     const bool esc = lx < k.lo || lx > k.hi;
     if (static_cast<uint32_t>(++r.iter) >= k.maxage) break;
     if (esc) {
-      park_remote<KIND>(r, remote0);
+      if (box.count && !(r.px != r.px || r.py != r.py)) {
+        --r.iter;  // handed over as it stood at the top of this iteration
+        migrate_out(r, box, lx < k.lo);
+      } else {
+        park_remote<KIND>(r, remote0);
+      }
       break;
     }
     ++nsteps;
@@ -2386,6 +2422,9 @@ struct TiledRun {
   int host_lag_us = 0;                   // SOIL_TILED_HOST_LAG_US (tests): the host sleeps that long before every look at a word
   int agg_min = 48, agg_groups = 4, retries = 2;
   bool fast = false;  // the step in fast arithmetic (soil_set_particle_arith; not with colour planes or native adds)
+  MigrateBox box{};                 // where walkers that leave the launch's rows go (null count: dropped, as ever)
+  const PRec* inbox = nullptr;      // the launch starts from these records instead of the streams' spawns
+  uint32_t n_in = 0;
   PRec* recs_of(uint64_t r) const { return (r & 1) ? next : cur; }               // records round r reads
   uint32_t* count_of(uint64_t r) const { return (r & 1) ? count_next : count; }   // section counts round r's scan reads
   TileShape ts_of(int sh, uint64_t r) const {
@@ -2664,11 +2703,16 @@ struct TiledRun {
     // the step counter of the run and, behind it, the device's control block: mode 0, the N spawn
     // slots as what "the round before" left
     SOIL_HIP(hipMemsetAsync(steps_run, 0, 64 + sizeof(TiledCtl), st));
-    k_tiled_spawn<KIND><<<blocks_for(N, 256), 256, 0, st>>>(
-        cur, dest, rank, count, rng, N, p4, waterSource, albedoSource, d, s, p, tiles_w_of(shape_of(0), 0),
-        ts_of(shape_of(0), 0), steps_per_round, ctl);
+    if (inbox) {
+      k_tiled_inject<KIND><<<blocks_for(std::max<int64_t>(n_in, 1), 256), 256, 0, st>>>(
+          cur, dest, rank, count, inbox, n_in, d, p, tiles_w_of(shape_of(0), 0), ts_of(shape_of(0), 0), steps_per_round, ctl);
+    } else {
+      k_tiled_spawn<KIND><<<blocks_for(N, 256), 256, 0, st>>>(
+          cur, dest, rank, count, rng, N, p4, waterSource, albedoSource, d, s, p, tiles_w_of(shape_of(0), 0),
+          ts_of(shape_of(0), 0), steps_per_round, ctl);
+    }
     SOIL_LAUNCH_CHECK();
-    live_known = N;  // slots of the record array to look at (spawn output, then survivor slots)
+    live_known = inbox ? static_cast<int64_t>(n_in) : N;  // slots of the record array to look at (spawn output, then survivor slots)
     round = scans = seen = 0;
     return queue_scan();
   }
@@ -2718,7 +2762,7 @@ struct TiledRun {
                           reinterpret_cast<float2*>(fluxV), fluxA, static_cast<const float4*>(p4), remote0, steps_run,
                           d, s, p, tiles_w, ts_cur.off_r, ts_cur.off_c, steps_of(r), ts_of(sh_next, r + 1),
                           tiles_w_of(sh_next, r + 1), agg_min, agg_groups, sparse_probe, 0, ctl, static_cast<uint32_t>(r),
-                          no_scan, static_cast<uint32_t*>(nullptr), 0u);
+                          no_scan, static_cast<uint32_t*>(nullptr), 0u, box);
       SOIL_LAUNCH_CHECK();
     }
     if (gate && tail_scan) {  // (the `started` ticket is reset by the tail scan's work-group)
@@ -2738,7 +2782,7 @@ struct TiledRun {
                             remote0, steps_run, d, s, p, tiles_w, ts_cur.off_r, ts_cur.off_c,
                             steps_of(r), ts_of(sh_next, r + 1),
                             tiles_w_of(sh_next, r + 1), agg_min, agg_groups, retries, store_all,
-                            ctl, static_cast<uint32_t>(r), next_scan, my_dense, gate_early);
+                            ctl, static_cast<uint32_t>(r), next_scan, my_dense, gate_early, box);
     else
       launch_round<KIND, 1>(fast, sh, grid, st, out, dest, rank, count_of(r + 1),
                             static_cast<const PRec*>(in), static_cast<const uint32_t*>(order),
@@ -2747,7 +2791,7 @@ struct TiledRun {
                             remote0, steps_run, d, s, p, tiles_w, ts_cur.off_r, ts_cur.off_c,
                             steps_of(r), ts_of(sh_next, r + 1),
                             tiles_w_of(sh_next, r + 1), agg_min, agg_groups, retries, store_all,
-                            ctl, static_cast<uint32_t>(r), next_scan, my_dense, gate_early);
+                            ctl, static_cast<uint32_t>(r), next_scan, my_dense, gate_early, box);
     SOIL_LAUNCH_CHECK();
     if (!tail_scan) {
       k_queue_scan<<<1, 1024, 0, st>>>(standalone);
@@ -2830,10 +2874,10 @@ struct TiledRun {
         const uint64_t stop = host->stop_round;
         if (fast)
           k_tiled_finish<KIND, true><<<blocks_for(std::max<int64_t>(slots_before, 1), 256), 256, 0, st>>>(
-              recs_of(stop), dest, ctl, flux0, flux1, fluxV, fluxA, p4, remote0, steps_run, d, s, p);
+              box, recs_of(stop), dest, ctl, flux0, flux1, fluxV, fluxA, p4, remote0, steps_run, d, s, p);
         else
           k_tiled_finish<KIND><<<blocks_for(std::max<int64_t>(slots_before, 1), 256), 256, 0, st>>>(
-              recs_of(stop), dest, ctl, flux0, flux1, fluxV, fluxA, p4, remote0, steps_run, d, s, p);
+              box, recs_of(stop), dest, ctl, flux0, flux1, fluxV, fluxA, p4, remote0, steps_run, d, s, p);
         SOIL_LAUNCH_CHECK();
       }
       return finish_steps();
@@ -3015,6 +3059,27 @@ int launch_debris_tiled(float* massFlux, float* velocityFlux, float* albedoFlux,
                         const Param& p, hipStream_t st) {
   return run_tiled<DEBRIS>(massFlux, nullptr, velocityFlux, albedoFlux, albedoSource, rng, N, layers,
                            nullptr, nullptr, velocity, remote0, d, s, p, st);
+}
+
+// One launch of one kind for the slab runner's migrate mode: spawns (inbox null) or handed-over records,
+// leavers into `box`.  Later passes of a step find the kind's cell records where the first one packed them.
+int launch_pass_tiled(int kind, const soil_erosion_planes& P, Streams rng, int64_t N, float* remote0, const Dom& d,
+                      Scale3 s, const Param& p, hipStream_t st, const void* inbox, uint32_t n_in, MigrateBox box) {
+  auto run = [&](auto r) -> int {
+    r.box = box;
+    r.inbox = static_cast<const PRec*>(inbox);
+    r.n_in = n_in;
+    r.skip_pack = inbox != nullptr;
+    if (int rc = r.begin(); rc != SOIL_OK) return rc;
+    while (!r.done)
+      if (int rc = r.advance(); rc != SOIL_OK) return rc;
+    return SOIL_OK;
+  };
+  if (kind == FLUVIAL)
+    return run(make_run<FLUVIAL>(P.waterFlux, P.massFlux, P.velocityFlux, nullptr, nullptr, rng, N, P.layers, P.rainfall,
+                                 P.waterHeight, P.velocity, remote0, d, s, p, st));
+  return run(make_run<DEBRIS>(P.debrisFlux, nullptr, P.debrisVelocityFlux, nullptr, nullptr, rng, N, P.layers, nullptr,
+                              nullptr, P.debrisVelocity, remote0, d, s, p, st));
 }
 
 }  // namespace soil

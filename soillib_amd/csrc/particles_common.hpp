@@ -69,6 +69,24 @@ __device__ __forceinline__ float2 spawn_position(const Streams& st, int64_t n, c
     y = 0.5f + rng_uniform_at(st.seed, static_cast<uint64_t>(n), st.offset + 1) * static_cast<float>(d.W - 1);
   return make_float2(x, y);
 }
+// Walkers handed over at the slab's edge (SURVEY.md 8e option B; the slab runner's `migrate` mode,
+// round 5): a walker that steps off the rows this launch may walk on, inside the grid and with life
+// left, is written — state untouched, at the top of an iteration, as at a tile edge — into the box of
+// the side it left through instead of being dropped (the deep-halo runner never lets one get there).
+// 64-byte records (erosion_particles_tiled.hip: PRec), global coordinates: the neighbour injects them
+// into its own queues as they are.  count[0] / count[1]: records written up / down (may exceed `cap`:
+// the caller checks).
+struct MigrateBox {
+  void* up = nullptr;
+  void* down = nullptr;
+  uint32_t* count = nullptr;
+  uint32_t cap = 0;
+};
+// one launch of `kind` (0 fluvial, 1 debris) in the tiled shape whatever N: from the streams' spawns
+// (`inbox` null) or from `n_in` handed-over records; deposits into P's flux planes of that kind
+int launch_pass_tiled(int kind, const soil_erosion_planes& P, Streams rng, int64_t N, float* remote0, const Dom& d,
+                      Scale3 s, const Param& p, hipStream_t st, const void* inbox, uint32_t n_in, MigrateBox box);
+
 // the launch shape a launch of N particles on domain d gets (erosion_particles.hip)
 bool use_tiled_launch(int64_t N, const Dom& d);
 bool particle_arith_fast();  // soil_set_particle_arith(1) / SOIL_PARTICLE_DIV=fast (erosion_particles.hip)

@@ -67,8 +67,8 @@ const Plane kFluxDebris[2] = {kDebrisFlux, kDebrisVelocityFlux};              //
 using soil::fail;
 
 // what soillib_amd/_abi.py mirrors with ctypes
-static_assert(sizeof(soil_xfer) == 24 && sizeof(soil_comm) == 48 && sizeof(soil_slab_ops) == 19 * 8 &&
-                  sizeof(soil_slab_config) == 72 && sizeof(soil_slab_info) == 168,
+static_assert(sizeof(soil_xfer) == 24 && sizeof(soil_comm) == 48 && sizeof(soil_slab_ops) == 20 * 8 &&
+                  sizeof(soil_slab_config) == 80 && sizeof(soil_slab_info) == 192,
               "soil_slab.h struct layout changed: update soillib_amd/_abi.py");
 
 struct soil_slab {
@@ -106,6 +106,16 @@ struct soil_slab {
   bool window = true;  // SOIL_HALO_WINDOW=0: every launch on all the ghost rows (A/B)
   int64_t w0 = 0, w1 = 0;
   int64_t rows_window = 0, rows_window_full = 0;  // ghost rows the launches were given so far / the bound
+  // SOIL_SLAB_MIGRATE: walkers handed over at the slab's edge (soil_slab.h).  One ghost row a side; the
+  // boxes hold 64-byte walker records: out[0] / out[1] what this rank hands up / down, `inbox` what the
+  // neighbours handed it ([from above | from below]); two counters on the device.
+  int mode = SOIL_SLAB_DEEP_HALO;
+  static constexpr int64_t kRecBytes = 64;
+  void* out_box[2] = {nullptr, nullptr};
+  void* inbox = nullptr;
+  uint32_t* out_count = nullptr;
+  int64_t box_cap = 0;
+  int64_t passes = 0, walkers_handed = 0;
 
   // ---- helpers --------------------------------------------------------------------------------
   int64_t row_floats(int p) const { return W * soil::kPlaneCh[p]; }
@@ -330,6 +340,56 @@ struct soil_slab {
     return SOIL_OK;
   }
 
+  // ---- SOIL_SLAB_MIGRATE: the particle phase ------------------------------------------------------
+  // Per kind: a launch from the streams' spawns; the walkers that stepped onto a neighbour's row are
+  // counted (two ints to the host), every rank learns every rank's counts (one all-reduce: the same
+  // exchange that says whether anybody has anything left), the records travel to the neighbours, who
+  // walk them on in a launch of their own; until no rank handed anything over.  A walker crosses at
+  // most reach / S slab edges, so two or three passes; a walker may come back (it is handed over again).
+  // Deposits land on owned rows and the shallow halo (soil_slab_create): the flux halo of a few rows goes
+  // home once, after the last pass of both kinds.  Same walks as the single-domain launch: a walker is
+  // handed over at the top of an iteration with its state untouched, and the neighbour's record of the
+  // cell it stands on is made of the same fields.
+  int migrate_kind(int kind, const soil_erosion_planes& pl, const soil_domain& dom) {
+    const void* in = nullptr;
+    int64_t n_in = 0;
+    // (every pass walks a handed-over walker at least one step further: maxage + 2 passes always suffice)
+    const int64_t max_pass = static_cast<int64_t>(std::min<uint64_t>(param.maxage, 1u << 20)) + 2;
+    for (int64_t pass = 0; pass <= max_pass; ++pass) {
+      SLAB_TRY(ops->fill_f32(ops->ctx, reinterpret_cast<float*>(out_count), 0.0f, 2, 0));  // (all-zero bits)
+      if (pass == 0 || n_in > 0) {
+        SLAB_TRY(ops->particles_pass(ops->ctx, kind, &pl, rng, N, remote0, &dom, scale, &param, in, n_in, out_box[0],
+                                     out_box[1], out_count, box_cap));
+        ++passes;
+      }
+      uint32_t mine_u[2] = {0, 0};
+      SLAB_TRY(ops->to_host(ops->ctx, mine_u, out_count, 8));
+      if (mine_u[0] > box_cap || mine_u[1] > box_cap)
+        return fail(SOIL_ERR_OUT_OF_MEMORY, "slab step (migrate): more walkers left the slab in one pass than its boxes hold");
+      // a rank without a neighbour on a side hands nothing that way (the grid ends there: such walkers are out of bounds)
+      const int mine[2] = {up >= 0 ? static_cast<int>(mine_u[0]) : 0, down >= 0 ? static_cast<int>(mine_u[1]) : 0};
+      std::vector<int> all;
+      SLAB_TRY(all_ints(mine, 2, all));
+      int64_t total = 0;
+      for (int v : all) total += v;
+      if (total == 0) return SOIL_OK;
+      walkers_handed += mine[0] + mine[1];
+      const int64_t from_up = up >= 0 ? all[static_cast<size_t>(2 * up + 1)] : 0;
+      const int64_t from_down = down >= 0 ? all[static_cast<size_t>(2 * down)] : 0;
+      if (from_up + from_down > 2 * box_cap)
+        return fail(SOIL_ERR_OUT_OF_MEMORY, "slab step (migrate): more walkers arrive than the inbox holds");
+      std::vector<soil_xfer> sends, recvs;
+      if (mine[0]) sends.push_back({out_box[0], mine[0] * kRecBytes, up});
+      if (mine[1]) sends.push_back({out_box[1], mine[1] * kRecBytes, down});
+      if (from_up) recvs.push_back({inbox, from_up * kRecBytes, up});
+      if (from_down) recvs.push_back({static_cast<char*>(inbox) + from_up * kRecBytes, from_down * kRecBytes, down});
+      SLAB_TRY(exchange(sends, recvs, 0));
+      in = inbox;
+      n_in = from_up + from_down;
+    }
+    return fail(SOIL_ERR_HIP, "slab step (migrate): walkers still crossing after maxage + 2 passes");
+  }
+
   // ---- one step ----------------------------------------------------------------------------------
   //   1 fluvial particles            -
   //   2 debris particles             overlapped: flux halo-accumulate of the fluvial planes
@@ -361,7 +421,12 @@ struct soil_slab {
     std::vector<int> rf, rd;
     mk(0);
     const bool paired = pair && ops->particles_pair && rng_debris;
-    if (paired) {
+    if (mode == SOIL_SLAB_MIGRATE) {
+      // (the cell phase re-zeroed the flux planes behind the last step; the launches add)
+      SLAB_TRY(migrate_kind(0, pl, dom));
+      mk(1);
+      SLAB_TRY(migrate_kind(1, pl, dom));
+    } else if (paired) {
       // the debris launch draws from a tensor of its own, seeded where the fluvial launch leaves
       // the shared one in the sequential order
       SLAB_TRY(ops->rng_seed(ops->ctx, rng_debris, N, seed, off + 2));
@@ -636,6 +701,25 @@ int hip_pair(void* c, const soil_erosion_planes* p, soil_rng* rf, soil_rng* rd, 
   o.drew(rd);
   return rc;
 }
+int hip_pass(void* c, int32_t kind, const soil_erosion_planes* p, soil_rng* rng, int64_t N, float* remote0,
+             const soil_domain* dom, const float scale[3], const soil_param* param, const void* inbox, int64_t n_in,
+             void* out_up, void* out_down, uint32_t* out_count, int64_t cap) {
+  HIP_OPS(c);
+  const Dom d = to_dom(dom);
+  if (int rc = check_domain(d); rc != SOIL_OK) return rc;
+  if (int rc = o.clear_stale(); rc != SOIL_OK) return rc;
+  o.last_pair = false;
+  SOIL_REQUIRE(kind == 0 || kind == 1, "particles_pass: kind 0 (fluvial) or 1 (debris)");
+  SOIL_REQUIRE(N > 0 && N <= 0x7fffffffll && d.H * d.W <= 0x7fffffffll && d.H < (1 << 24) && d.W < (1 << 24),
+               "particles_pass: the tiled launch shape needs 1 .. 2^31 - 1 particles and cells, rows and columns below 2^24");
+  SOIL_REQUIRE(n_in >= 0 && n_in <= 0xffffffffll && cap >= 0 && cap <= 0xffffffffll, "particles_pass: bad record counts");
+  MigrateBox box;
+  box.up = out_up, box.down = out_down, box.count = out_count, box.cap = static_cast<uint32_t>(cap);
+  const int rc = launch_pass_tiled(kind, *p, o.streams(rng), N, remote0, d, Scale3{scale[0], scale[1], scale[2]}, *param,
+                                   o.main, inbox, static_cast<uint32_t>(n_in), box);
+  if (!inbox) o.drew(rng);
+  return rc;
+}
 int hip_cells(void* c, const soil_erosion_planes* p, const soil_domain* dom, const float scale[3],
               const soil_param* param) {
   HIP_OPS(c);
@@ -854,6 +938,7 @@ int soil_slab_ops_hip_create(soil_slab_ops** out) {
   t->noise_rows = hip_noise, t->layers_from_bedrock = hip_layers, t->to_host = hip_to_host;
   t->from_host = hip_from_host, t->fork = hip_fork, t->join = hip_join, t->sync = hip_sync;
   t->stream = hip_stream;
+  t->particles_pass = hip_pass;
   *out = t;
   return SOIL_OK;
 }
@@ -899,6 +984,24 @@ int soil_slab_create(soil_slab** out, const soil_slab_config* cfg, const soil_pa
   s->host_ordered = (comm->flags & SOIL_COMM_HOST_ORDERED) != 0;
   s->S = cfg->rows_per_rank, s->W = cfg->W, s->H = s->world * s->S;
   s->G = soil_ghost_rows(param);
+  s->mode = cfg->mode >= 0 ? cfg->mode : SOIL_SLAB_DEEP_HALO;
+  if (cfg->mode < 0)
+    if (const char* e = std::getenv("SOIL_SLAB_MODE")) s->mode = (e[0] == 'm' || e[0] == '1') ? SOIL_SLAB_MIGRATE : SOIL_SLAB_DEEP_HALO;
+  if (s->mode != SOIL_SLAB_DEEP_HALO && s->mode != SOIL_SLAB_MIGRATE)
+    return bail(fail(SOIL_ERR_INVALID_ARGUMENT, "slab_create: mode must be SOIL_SLAB_DEEP_HALO or SOIL_SLAB_MIGRATE"));
+  if (s->mode == SOIL_SLAB_MIGRATE) {
+    if (!ops->particles_pass)
+      return bail(fail(SOIL_ERR_INVALID_ARGUMENT, "slab_create: this back-end cannot hand walkers over (no particles_pass): SOIL_SLAB_MIGRATE refused"));
+    // A shallow halo instead of none: with one ghost row a walker that zig-zags along the slab's edge is
+    // handed back and forth, a pass of all ranks per crossing (the first version of this mode: 48-step
+    // walks on 64-row slabs were still crossing after four passes).  On kMigrateHalo ghost rows it walks
+    // on as the deep-halo walkers do — its deposits there go home with the flux halo, that many rows —
+    // and is handed over only at their far end, well inside the neighbour's rows: coming back takes
+    // another kMigrateHalo steps.
+    int64_t halo = 16;
+    if (const char* e = std::getenv("SOIL_MIGRATE_HALO")) halo = std::max(1, std::atoi(e));
+    s->G = std::min<int64_t>(std::min<int64_t>(halo, s->S), soil_ghost_rows(param));
+  }
   if (s->world > 1 && s->G > s->S)
     return bail(fail(SOIL_ERR_INVALID_ARGUMENT, "ghost depth " + std::to_string(s->G) + " exceeds the " +
                                                     std::to_string(s->S) + " rows a neighbour owns"));
@@ -914,7 +1017,7 @@ int soil_slab_create(soil_slab** out, const soil_slab_config* cfg, const soil_pa
     return e && std::strcmp(e, v) == 0;
   };
   s->trim = cfg->trim >= 0 ? cfg->trim != 0 : (s->world > 1 && !env_is("SOIL_HALO_FULL", "1"));
-  if (s->world == 1 || !ops->ghost_extent) s->trim = false;
+  if (s->world == 1 || !ops->ghost_extent || s->mode == SOIL_SLAB_MIGRATE) s->trim = false;
   s->pair = cfg->pair >= 0 ? cfg->pair != 0 : !env_is("SOIL_STEP_PAIR", "0");  // on by default, as in soil_erode_step
   s->halo_need = cfg->halo_need;
   s->window = !env_is("SOIL_HALO_WINDOW", "0");
@@ -952,6 +1055,18 @@ int soil_slab_create(soil_slab** out, const soil_slab_config* cfg, const soil_pa
   // (world * 4 small ints, and behind them the 8 sums of the NaN walkers' deposits: one all-reduce carries both)
   if (int rc = ops->alloc(ops->ctx, &q, (static_cast<int64_t>(s->world) * 4 + 8) * 4); rc != SOIL_OK) return bail(rc);
   s->ints = static_cast<float*>(q);
+  if (s->mode == SOIL_SLAB_MIGRATE) {
+    // (the counts travel as floats in the all-reduce: exact below 2^24)
+    s->box_cap = std::min<int64_t>(std::max<int64_t>(s->N, 1), (1 << 24) - 1);
+    for (int side = 0; side < 2; ++side) {
+      if (int rc = ops->alloc(ops->ctx, &q, s->box_cap * soil_slab::kRecBytes); rc != SOIL_OK) return bail(rc);
+      s->out_box[side] = q;
+    }
+    if (int rc = ops->alloc(ops->ctx, &q, 2 * s->box_cap * soil_slab::kRecBytes); rc != SOIL_OK) return bail(rc);
+    s->inbox = q;
+    if (int rc = ops->alloc(ops->ctx, &q, 8); rc != SOIL_OK) return bail(rc);
+    s->out_count = static_cast<uint32_t*>(q);
+  }
   // The neighbours' refresh depths are computed, not exchanged (round 4): that is only right when every
   // rank runs with the same forced depth (cfg->halo_need / SOIL_HALO_NEED: tests).  One sum at create time.
   if (s->world > 1) {
@@ -1014,6 +1129,8 @@ int soil_slab_get_info(const soil_slab* s, soil_slab_info* info) {
   info->rows_flux = s->rows_flux, info->rows_field = s->rows_field, info->rows_full = s->rows_full;
   info->repeated_launches = s->fallbacks;
   info->rows_window = s->rows_window, info->rows_window_full = s->rows_window_full;
+  info->passes = s->passes, info->walkers_handed = s->walkers_handed;
+  info->mode = s->mode, info->reserved = 0;
   info->n_reach = static_cast<int32_t>(s->reach_hist.size());
   for (int i = 0; i < info->n_reach && i < 4; ++i) info->reach_hist[i] = s->reach_hist[static_cast<size_t>(i)];
   return SOIL_OK;
@@ -1043,6 +1160,7 @@ int soil_slab_destroy(soil_slab* s) {
       drop(s->stage[p][1]);
     }
     drop(s->rng), drop(s->rng_debris), drop(s->remote0), drop(s->ints);
+    drop(s->out_box[0]), drop(s->out_box[1]), drop(s->inbox), drop(s->out_count);
   }
   if (s->own_ops) soil_slab_ops_hip_destroy(s->own_ops);
   delete s;

@@ -350,7 +350,7 @@ class SlabRunner:
 
     def __init__(self, rows_per_rank, W, param, particles_div=8, seed=0, ops=None, scale=None,
                  noise_seed=3.0, init=True, comm=None, noise_rows=None, trim=None, pair=None,
-                 halo_need=0, device=None):
+                 halo_need=0, device=None, mode=None):
         """comm: SelfComm / RcclComm / CallbackComm (default: default_comm()); ops: CallbackOps or
         None for the HIP back-end on device `device` (default: SOIL_DEVICE or LOCAL_RANK)."""
         lib = self.lib = _abi.lib()
@@ -371,6 +371,9 @@ class SlabRunner:
         cfg.trim = -1 if trim is None else int(bool(trim))
         cfg.pair = -1 if pair is None else int(bool(pair))
         cfg.halo_need = int(halo_need)
+        # how a walk that crosses a slab's edge is served (soil_slab.h): "deep" halos or "migrate"; None: the
+        # library's default (SOIL_SLAB_MODE in the environment, else deep halos)
+        cfg.mode = -1 if mode is None else {"deep": 0, "migrate": 1}[mode]
         self._h = C.c_void_p()
         pref = param._ref() if hasattr(param, "_ref") else C.byref(param)
         self._check(lib.soil_slab_create(C.byref(self._h), C.byref(cfg), pref, self.comm.c_comm(),
@@ -380,6 +383,7 @@ class SlabRunner:
         self.S, self.W, self.H, self.G, self.N = i.S, i.W, i.H, i.G, i.N
         self.x0, self.rows, self.r0, self.r1 = i.x0, i.rows, i.r0, i.r1
         self.trim, self.pair = bool(i.trim), bool(i.pair)
+        self.mode = "migrate" if i.mode == 1 else "deep"
         self.scale = list(scale) if scale is not None else [20.0 / self.H, 20.0 / self.W, 4.0]
         self._mark = None
 
@@ -450,6 +454,11 @@ class SlabRunner:
         i = self.info()
         return {"flux": int(i.rows_flux), "field": int(i.rows_field), "full": int(i.rows_full),
                 "window": int(i.rows_window), "window_full": int(i.rows_window_full)}
+
+    @property
+    def migration(self):
+        i = self.info()
+        return {"passes": int(i.passes), "walkers_handed": int(i.walkers_handed)}
 
     @property
     def fallbacks(self):

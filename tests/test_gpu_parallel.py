@@ -148,7 +148,8 @@ class RcclLoopWire(LocalWire):
             self.s.token.acquire()
 
 
-def _run_world(world, S, W, param, steps, maxage, pair=False, halo_need=0, info=None, wire=LocalWire, shared=None):
+def _run_world(world, S, W, param, steps, maxage, pair=False, halo_need=0, info=None, wire=LocalWire, shared=None,
+               mode=None):
     from soillib_amd.parallel import CallbackComm, SlabRunner
     shared = shared or wire.Shared(world)
     out, errs = [None] * world, []
@@ -160,14 +161,15 @@ def _run_world(world, S, W, param, steps, maxage, pair=False, halo_need=0, info=
             held = True
             r = SlabRunner(rows_per_rank=S, W=W, param=param, particles_div=8, seed=0,
                            comm=CallbackComm(rank, world, wire(shared, rank)), device=0, pair=pair,
-                           halo_need=halo_need)
+                           halo_need=halo_need, mode=mode)
             for _ in range(steps):
                 r.step()
                 r.sync()
             out[rank] = {k: r.plane(k, owned=True) for k in
                          ("layers", "waterHeight", "velocity", "debris", "height")}
             if info is not None:
-                info[rank] = dict(fallbacks=r.fallbacks, halo=r.halo_rows, reach=r.reach_hist, G=r.G)
+                info[rank] = dict(fallbacks=r.fallbacks, halo=r.halo_rows, reach=r.reach_hist, G=r.G, mode=r.mode,
+                                  migration=r.migration, rows=r.rows)
             assert r.max_over_ranks(float(rank)) == world - 1
             r.close()
         except BaseException as e:  # surface worker failures in the main thread
@@ -314,6 +316,75 @@ def test_rccl_self_exchange_at_config5_halo_size(hip):
     finally:
         runner.close()
         shared.close()
+
+
+def _single_domain(oracle, H, W, pp, steps):
+    from soillib_amd import silt, soil
+    from soillib_amd.erosion import ErosionModel
+    m = ErosionModel(H, W, (20.0 / H, 20.0 / W, 4.0), pp, H * W // 8, seed=0)
+    npar = soil.noise_t()
+    npar.seed = 3.0
+    npar.ext = [H, W]
+    bed = soil.noise(silt.shape(H, W), npar, host=silt.gpu)
+    layers0 = np.zeros((H, W, 2), np.float32)
+    layers0[..., 0] = to_np(bed)
+    m.set_layers(to_gpu(layers0))
+    silt.set(m.rainfall, 1.0)
+    for _ in range(steps):
+        m.step()
+    return m, layers0
+
+
+@pytest.mark.parametrize("world,S,W,maxage,wire", [(2, 64, 128, 48, "local"), (3, 96, 128, 96, "local"),
+                                                  (4, 48, 192, 128, "local"), (3, 64, 256, 64, "rccl")])
+def test_walkers_handed_over_at_the_slab_edge_match_single_domain(hip, oracle, world, S, W, maxage, wire):
+    """SOIL_SLAB_MIGRATE (soil_slab.h; SURVEY.md 8e option B): a shallow halo of 16 ghost rows, a walker
+    that gets to its far end travels as its 64-byte record and is walked on by the neighbour — in slabs so
+    low that a walker crosses several of them (48 rows, 128 steps).  Same walks as the single-domain step: the same
+    particle-step count and, up to the fp32 summation order of the deposits, the same planes."""
+    from soillib_amd import soil
+    op = script_param(oracle.default_param())
+    op.maxage = maxage
+    pp = product_param(op)
+    steps = 3
+    H = world * S
+    info = [None] * world
+    shared = RcclLoopWire.Shared(world) if wire == "rccl" else None
+    try:
+        got = _run_world(world, S, W, pp, steps, maxage, info=info, mode="migrate",
+                         wire=RcclLoopWire if wire == "rccl" else LocalWire, shared=shared)
+        if shared is not None:
+            assert shared.groups > 0 and shared.bytes > 0
+    finally:
+        if shared is not None:
+            shared.close()
+    assert all(i["mode"] == "migrate" and i["G"] == 16 for i in info)
+    assert all(i["rows"] <= S + 2 * 16 for i in info)                  # owned rows and the shallow halo
+    assert sum(i["migration"]["walkers_handed"] for i in info) > 0     # walkers did cross
+    assert all(i["migration"]["passes"] >= 2 * steps for i in info)
+    m, layers0 = _single_domain(oracle, H, W, pp, steps)
+    for k in got:
+        want = to_np(getattr(m, k))
+        np.testing.assert_allclose(got[k], want, rtol=1e-4, atol=1e-5 * (np.nanmax(np.abs(want)) + 1e-30), err_msg=k)
+    assert np.abs(to_np(m.layers) - layers0).max() > 0
+
+
+def test_migrate_mode_on_a_strong_split_with_full_lives(hip, oracle):
+    """The proportions of BASELINE config 5 in the small, walkers handed over instead of deep halos: a
+    2048^2 grid in two 1024-row slabs, script parameters (maxage 256), two free-running steps."""
+    from test_gpu_parity import _close_but_for_stray_walks
+    world, S, W, maxage, steps = 2, 1024, 2048, 256, 2
+    op = script_param(oracle.default_param())
+    pp = product_param(op)
+    info = [None] * world
+    got = _run_world(world, S, W, pp, steps, maxage, info=info, mode="migrate")
+    handed = sum(i["migration"]["walkers_handed"] for i in info)
+    assert 0 < handed < steps * 2 * (world * S * W // 8)               # a fraction of the walkers, not all
+    m, _ = _single_domain(oracle, world * S, W, pp, steps)
+    for k in got:
+        want = to_np(getattr(m, k))
+        _close_but_for_stray_walks(got[k], want, 1e-4, 1e-5 * (np.nanmax(np.abs(want)) + 1e-30), 1e-3,
+                                   "migrate, strong split, " + k)
 
 
 def test_strong_split_of_a_square_grid_matches_single_domain(hip, oracle):
