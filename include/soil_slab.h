@@ -108,9 +108,12 @@ typedef struct soil_slab_ops {
    * (64-byte records, taken as they are).  A walker that steps off the owned rows [dom->r0, dom->r1), in
    * the grid and with life left, is written to `out_up` / `out_down` (room for `cap` records each) at the
    * top of that iteration, state untouched; out_count[0..1] (back-end memory, zeroed by the caller)
-   * count them.  NULL: the back-end has no such launch and the mode is refused. */
-  int (*particles_pass)(void* ctx, int32_t kind, const soil_erosion_planes* planes, soil_rng* rng, int64_t N,
-                        float* remote0, const soil_domain* dom, const float scale[3],
+   * count them.  kind 2: both kinds' spawn launches overlapped (soil_particles_pair_slab; the debris
+   * launch draws from `rng_debris`); fluvial records go to the first cap / 2 slots of the boxes, debris
+   * records to the second half, out_count[0..3] = fluvial up, down, debris up, down.
+   * NULL: the back-end has no such launch and the mode is refused. */
+  int (*particles_pass)(void* ctx, int32_t kind, const soil_erosion_planes* planes, soil_rng* rng,
+                        soil_rng* rng_debris, int64_t N, float* remote0, const soil_domain* dom, const float scale[3],
                         const soil_param* param, const void* inbox, int64_t n_in, void* out_up,
                         void* out_down, uint32_t* out_count, int64_t cap);
 } soil_slab_ops;

@@ -202,7 +202,7 @@ OPS_FIELDS = [
     ("join", C.CFUNCTYPE(C.c_int, C.c_void_p)),
     ("sync", C.CFUNCTYPE(C.c_int, C.c_void_p)),
     ("stream", C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_int32)),
-    ("particles_pass", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, _PP, C.c_void_p, C.c_int64, C.c_void_p, _DP, _F3P,
+    ("particles_pass", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, _PP, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, _DP, _F3P,
                                    _PARP, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64)),
 ]
 

@@ -2920,7 +2920,8 @@ static int run_tiled(float* flux0, float* flux1, float* fluxV, float* fluxA,
 // Both launches of a step, overlapped: two internal streams forked from `st` and joined
 // back into it; the host alternates between the two runs' decisions.
 int launch_pair_tiled(const soil_erosion_planes& P, Streams rng_fluvial, Streams rng_debris, int64_t N,
-                      float* remote0, const Dom& d, Scale3 s, const Param& p, hipStream_t st, bool overwrite) {
+                      float* remote0, const Dom& d, Scale3 s, const Param& p, hipStream_t st, bool overwrite,
+                      MigrateBox box_fluvial, MigrateBox box_debris) {
   // forked streams and their events, one set per (thread, device)
   struct Fork {
     hipStream_t sA = nullptr, sB = nullptr;
@@ -2980,6 +2981,7 @@ int launch_pair_tiled(const soil_erosion_planes& P, Streams rng_fluvial, Streams
   // Whatever happens in between, `st` is joined with both streams before this returns: rounds may
   // still be in flight on the workspace the next call reuses.
   A.overwrite = B.overwrite = overwrite;
+  A.box = box_fluvial, B.box = box_debris;
   auto run = [&]() -> int {
     if (int rc = A.setup(); rc != SOIL_OK) return rc;
     if (int rc = B.setup(); rc != SOIL_OK) return rc;

@@ -110,7 +110,8 @@ int launch_debris_tiled(float* massFlux, float* velocityFlux, float* albedoFlux,
 // (`overwrite`: the flux planes hold stale values — SOIL_FLUX_OVERWRITE, soil_hip.h)
 int launch_pair_tiled(const soil_erosion_planes& P, Streams rng_fluvial, Streams rng_debris,
                       int64_t N, float* remote0, const Dom& d, Scale3 s, const Param& p,
-                      hipStream_t st, bool overwrite);
+                      hipStream_t st, bool overwrite, MigrateBox box_fluvial = MigrateBox{},
+                      MigrateBox box_debris = MigrateBox{});
 // the slab entry points of soil_hip.h on explicit streams (the slab runner's HIP back-end)
 int particles_fluvial_streams(const soil_erosion_planes& P, Streams rng, int64_t N, float* remote0,
                               const Dom& d, Scale3 s, const Param& p, hipStream_t st);

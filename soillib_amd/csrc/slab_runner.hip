@@ -350,46 +350,97 @@ struct soil_slab {
   // home once, after the last pass of both kinds.  Same walks as the single-domain launch: a walker is
   // handed over at the top of an iteration with its state untouched, and the neighbour's record of the
   // cell it stands on is made of the same fields.
-  int migrate_kind(int kind, const soil_erosion_planes& pl, const soil_domain& dom) {
-    const void* in = nullptr;
-    int64_t n_in = 0;
+  // counts[0..1] walkers this rank has just handed up / down (already in out_box); exchanges them, returns
+  // the walkers that arrived (in `inbox`) and whether anybody anywhere handed anything over
+  int hand_over(const uint32_t counts[2], const void* const src[2], int64_t& n_in, bool& any) {
+    if (counts[0] > box_cap || counts[1] > box_cap)
+      return fail(SOIL_ERR_OUT_OF_MEMORY, "slab step (migrate): more walkers left the slab in one pass than its boxes hold");
+    // (no neighbour on a side: the grid ends there, such walkers are out of bounds and never get here)
+    const int mine[2] = {up >= 0 ? static_cast<int>(counts[0]) : 0, down >= 0 ? static_cast<int>(counts[1]) : 0};
+    std::vector<int> all;
+    SLAB_TRY(all_ints(mine, 2, all));
+    int64_t total = 0;
+    for (int v : all) total += v;
+    any = total > 0;
+    n_in = 0;
+    if (!any) return SOIL_OK;
+    walkers_handed += mine[0] + mine[1];
+    const int64_t from_up = up >= 0 ? all[static_cast<size_t>(2 * up + 1)] : 0;
+    const int64_t from_down = down >= 0 ? all[static_cast<size_t>(2 * down)] : 0;
+    if (from_up + from_down > 2 * box_cap)
+      return fail(SOIL_ERR_OUT_OF_MEMORY, "slab step (migrate): more walkers arrive than the inbox holds");
+    std::vector<soil_xfer> sends, recvs;
+    if (mine[0]) sends.push_back({const_cast<void*>(src[0]), mine[0] * kRecBytes, up});
+    if (mine[1]) sends.push_back({const_cast<void*>(src[1]), mine[1] * kRecBytes, down});
+    if (from_up) recvs.push_back({inbox, from_up * kRecBytes, up});
+    if (from_down) recvs.push_back({static_cast<char*>(inbox) + from_up * kRecBytes, from_down * kRecBytes, down});
+    SLAB_TRY(exchange(sends, recvs, 0));
+    n_in = from_up + from_down;
+    return SOIL_OK;
+  }
+  // the launches that walk handed-over walkers of `kind` on, until nobody hands any over
+  // (`first`: what the kind's spawn launch handed this rank's neighbours, already counted on the host)
+  int migrate_on(int kind, const soil_erosion_planes& pl, const soil_domain& dom, const uint32_t first[2],
+                 const void* const first_src[2], int64_t cap) {
     // (every pass walks a handed-over walker at least one step further: maxage + 2 passes always suffice)
     const int64_t max_pass = static_cast<int64_t>(std::min<uint64_t>(param.maxage, 1u << 20)) + 2;
+    uint32_t counts[2] = {first[0], first[1]};
+    const void* src[2] = {first_src[0], first_src[1]};
     for (int64_t pass = 0; pass <= max_pass; ++pass) {
-      SLAB_TRY(ops->fill_f32(ops->ctx, reinterpret_cast<float*>(out_count), 0.0f, 2, 0));  // (all-zero bits)
-      if (pass == 0 || n_in > 0) {
-        SLAB_TRY(ops->particles_pass(ops->ctx, kind, &pl, rng, N, remote0, &dom, scale, &param, in, n_in, out_box[0],
-                                     out_box[1], out_count, box_cap));
+      int64_t n_in = 0;
+      bool any = false;
+      SLAB_TRY(hand_over(counts, src, n_in, any));
+      if (!any) return SOIL_OK;
+      SLAB_TRY(ops->fill_f32(ops->ctx, reinterpret_cast<float*>(out_count), 0.0f, 4, 0));  // (all-zero bits)
+      if (n_in > 0) {
+        SLAB_TRY(ops->particles_pass(ops->ctx, kind, &pl, rng, nullptr, N, remote0, &dom, scale, &param, inbox, n_in,
+                                     out_box[0], out_box[1], out_count, cap));
         ++passes;
       }
-      uint32_t mine_u[2] = {0, 0};
-      SLAB_TRY(ops->to_host(ops->ctx, mine_u, out_count, 8));
-      if (mine_u[0] > box_cap || mine_u[1] > box_cap)
+      SLAB_TRY(ops->to_host(ops->ctx, counts, out_count, 8));
+      if (counts[0] > cap || counts[1] > cap)
         return fail(SOIL_ERR_OUT_OF_MEMORY, "slab step (migrate): more walkers left the slab in one pass than its boxes hold");
-      // a rank without a neighbour on a side hands nothing that way (the grid ends there: such walkers are out of bounds)
-      const int mine[2] = {up >= 0 ? static_cast<int>(mine_u[0]) : 0, down >= 0 ? static_cast<int>(mine_u[1]) : 0};
-      std::vector<int> all;
-      SLAB_TRY(all_ints(mine, 2, all));
-      int64_t total = 0;
-      for (int v : all) total += v;
-      if (total == 0) return SOIL_OK;
-      walkers_handed += mine[0] + mine[1];
-      const int64_t from_up = up >= 0 ? all[static_cast<size_t>(2 * up + 1)] : 0;
-      const int64_t from_down = down >= 0 ? all[static_cast<size_t>(2 * down)] : 0;
-      if (from_up + from_down > 2 * box_cap)
-        return fail(SOIL_ERR_OUT_OF_MEMORY, "slab step (migrate): more walkers arrive than the inbox holds");
-      std::vector<soil_xfer> sends, recvs;
-      if (mine[0]) sends.push_back({out_box[0], mine[0] * kRecBytes, up});
-      if (mine[1]) sends.push_back({out_box[1], mine[1] * kRecBytes, down});
-      if (from_up) recvs.push_back({inbox, from_up * kRecBytes, up});
-      if (from_down) recvs.push_back({static_cast<char*>(inbox) + from_up * kRecBytes, from_down * kRecBytes, down});
-      SLAB_TRY(exchange(sends, recvs, 0));
-      in = inbox;
-      n_in = from_up + from_down;
+      src[0] = out_box[0], src[1] = out_box[1];
     }
     return fail(SOIL_ERR_HIP, "slab step (migrate): walkers still crossing after maxage + 2 passes");
   }
-
+  // Per step: the spawn launches of both kinds (overlapped like soil_erode_step's when the runner pairs
+  // its launches, else one after the other), then per kind the immigrants' launches.
+  int migrate_particles(const soil_erosion_planes& pl, const soil_domain& dom, uint64_t off, bool paired,
+                        soil_slab_mark_fn mark, void* mctx) {
+    uint32_t c[4] = {0, 0, 0, 0};
+    SLAB_TRY(ops->fill_f32(ops->ctx, reinterpret_cast<float*>(out_count), 0.0f, 4, 0));
+    if (paired) {
+      SLAB_TRY(ops->rng_seed(ops->ctx, rng_debris, N, seed, off + 2));
+      SLAB_TRY(ops->particles_pass(ops->ctx, 2, &pl, rng, rng_debris, N, remote0, &dom, scale, &param, nullptr, 0,
+                                   out_box[0], out_box[1], out_count, box_cap));
+      passes += 2;
+      SLAB_TRY(ops->to_host(ops->ctx, c, out_count, 16));
+      if (mark) mark(mctx, 1);
+      const int64_t half = box_cap / 2;
+      if (c[0] > half || c[1] > half || c[2] > half || c[3] > half)
+        return fail(SOIL_ERR_OUT_OF_MEMORY, "slab step (migrate): more walkers left the slab than half a box holds");
+      // The fluvial leavers lie in the boxes' first halves, the debris ones in the second.  The launches
+      // that walk immigrants on write THEIR leavers into the first halves only (cap = half): the debris
+      // records stay where they are until their turn.
+      const void* src_f[2] = {out_box[0], out_box[1]};
+      const void* src_d[2] = {static_cast<char*>(out_box[0]) + half * kRecBytes, static_cast<char*>(out_box[1]) + half * kRecBytes};
+      SLAB_TRY(migrate_on(0, pl, dom, c, src_f, half));
+      SLAB_TRY(migrate_on(1, pl, dom, c + 2, src_d, half));
+      return SOIL_OK;
+    }
+    for (int kind = 0; kind < 2; ++kind) {
+      SLAB_TRY(ops->fill_f32(ops->ctx, reinterpret_cast<float*>(out_count), 0.0f, 4, 0));
+      SLAB_TRY(ops->particles_pass(ops->ctx, kind, &pl, rng, nullptr, N, remote0, &dom, scale, &param, nullptr, 0, out_box[0],
+                                   out_box[1], out_count, box_cap));
+      ++passes;
+      SLAB_TRY(ops->to_host(ops->ctx, c, out_count, 8));
+      if (kind == 0 && mark) mark(mctx, 1);
+      const void* src[2] = {out_box[0], out_box[1]};
+      SLAB_TRY(migrate_on(kind, pl, dom, c, src, box_cap));
+    }
+    return SOIL_OK;
+  }
   // ---- one step ----------------------------------------------------------------------------------
   //   1 fluvial particles            -
   //   2 debris particles             overlapped: flux halo-accumulate of the fluvial planes
@@ -422,10 +473,7 @@ struct soil_slab {
     mk(0);
     const bool paired = pair && ops->particles_pair && rng_debris;
     if (mode == SOIL_SLAB_MIGRATE) {
-      // (the cell phase re-zeroed the flux planes behind the last step; the launches add)
-      SLAB_TRY(migrate_kind(0, pl, dom));
-      mk(1);
-      SLAB_TRY(migrate_kind(1, pl, dom));
+      SLAB_TRY(migrate_particles(pl, dom, off, paired, mark, mctx));
     } else if (paired) {
       // the debris launch draws from a tensor of its own, seeded where the fluvial launch leaves
       // the shared one in the sequential order
@@ -701,22 +749,42 @@ int hip_pair(void* c, const soil_erosion_planes* p, soil_rng* rf, soil_rng* rd, 
   o.drew(rd);
   return rc;
 }
-int hip_pass(void* c, int32_t kind, const soil_erosion_planes* p, soil_rng* rng, int64_t N, float* remote0,
+// kind 0 / 1: one launch of that kind (soil_slab.h).  kind 2: both kinds' SPAWN launches overlapped, as
+// hip_pair runs them (`rng`: the fluvial streams; the debris launch draws from `rng_debris`, two draws on):
+// the boxes are halves — fluvial records in the first `cap / 2` slots of out_up / out_down, debris in the
+// second, out_count[0..3] = fluvial up, down, debris up, down.
+int hip_pass(void* c, int32_t kind, const soil_erosion_planes* p, soil_rng* rng, soil_rng* rng_debris, int64_t N, float* remote0,
              const soil_domain* dom, const float scale[3], const soil_param* param, const void* inbox, int64_t n_in,
              void* out_up, void* out_down, uint32_t* out_count, int64_t cap) {
   HIP_OPS(c);
   const Dom d = to_dom(dom);
   if (int rc = check_domain(d); rc != SOIL_OK) return rc;
-  if (int rc = o.clear_stale(); rc != SOIL_OK) return rc;
-  o.last_pair = false;
-  SOIL_REQUIRE(kind == 0 || kind == 1, "particles_pass: kind 0 (fluvial) or 1 (debris)");
+  SOIL_REQUIRE(kind >= 0 && kind <= 2, "particles_pass: kind 0 (fluvial), 1 (debris) or 2 (both spawn launches)");
   SOIL_REQUIRE(N > 0 && N <= 0x7fffffffll && d.H * d.W <= 0x7fffffffll && d.H < (1 << 24) && d.W < (1 << 24),
                "particles_pass: the tiled launch shape needs 1 .. 2^31 - 1 particles and cells, rows and columns below 2^24");
   SOIL_REQUIRE(n_in >= 0 && n_in <= 0xffffffffll && cap >= 0 && cap <= 0xffffffffll, "particles_pass: bad record counts");
+  const Scale3 s3{scale[0], scale[1], scale[2]};
+  if (kind == 2) {
+    SOIL_REQUIRE(!inbox && rng_debris, "particles_pass: the overlapped launches start from the streams (two tensors)");
+    const uint32_t half = static_cast<uint32_t>(cap / 2);
+    MigrateBox bf, bd;
+    bf.up = out_up, bf.down = out_down, bf.count = out_count, bf.cap = half;
+    bd.up = static_cast<char*>(out_up) + static_cast<size_t>(half) * 64, bd.down = static_cast<char*>(out_down) + static_cast<size_t>(half) * 64;
+    bd.count = out_count + 2, bd.cap = half;
+    const int rc = launch_pair_tiled(*p, o.streams(rng), o.streams(rng_debris), N, remote0, d, s3, *param, o.main,
+                                     o.flux_stale, bf, bd);
+    o.flux_stale = false;
+    o.last_pair = true;
+    o.drew(rng);
+    o.drew(rng_debris);
+    return rc;
+  }
+  if (int rc = o.clear_stale(); rc != SOIL_OK) return rc;
+  if (!inbox) o.last_pair = false;  // (a launch of immigrants behind the overlapped pair leaves the step a paired one)
   MigrateBox box;
   box.up = out_up, box.down = out_down, box.count = out_count, box.cap = static_cast<uint32_t>(cap);
-  const int rc = launch_pass_tiled(kind, *p, o.streams(rng), N, remote0, d, Scale3{scale[0], scale[1], scale[2]}, *param,
-                                   o.main, inbox, static_cast<uint32_t>(n_in), box);
+  const int rc = launch_pass_tiled(kind, *p, o.streams(rng), N, remote0, d, s3, *param, o.main, inbox,
+                                   static_cast<uint32_t>(n_in), box);
   if (!inbox) o.drew(rng);
   return rc;
 }
@@ -1064,7 +1132,7 @@ int soil_slab_create(soil_slab** out, const soil_slab_config* cfg, const soil_pa
     }
     if (int rc = ops->alloc(ops->ctx, &q, 2 * s->box_cap * soil_slab::kRecBytes); rc != SOIL_OK) return bail(rc);
     s->inbox = q;
-    if (int rc = ops->alloc(ops->ctx, &q, 8); rc != SOIL_OK) return bail(rc);
+    if (int rc = ops->alloc(ops->ctx, &q, 16); rc != SOIL_OK) return bail(rc);
     s->out_count = static_cast<uint32_t*>(q);
   }
   // The neighbours' refresh depths are computed, not exchanged (round 4): that is only right when every

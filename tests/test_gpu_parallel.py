@@ -335,9 +335,10 @@ def _single_domain(oracle, H, W, pp, steps):
     return m, layers0
 
 
-@pytest.mark.parametrize("world,S,W,maxage,wire", [(2, 64, 128, 48, "local"), (3, 96, 128, 96, "local"),
-                                                  (4, 48, 192, 128, "local"), (3, 64, 256, 64, "rccl")])
-def test_walkers_handed_over_at_the_slab_edge_match_single_domain(hip, oracle, world, S, W, maxage, wire):
+@pytest.mark.parametrize("world,S,W,maxage,wire,pair", [(2, 64, 128, 48, "local", False), (3, 96, 128, 96, "local", True),
+                                                       (4, 48, 192, 128, "local", False), (4, 48, 192, 128, "local", True),
+                                                       (3, 64, 256, 64, "rccl", True)])
+def test_walkers_handed_over_at_the_slab_edge_match_single_domain(hip, oracle, world, S, W, maxage, wire, pair):
     """SOIL_SLAB_MIGRATE (soil_slab.h; SURVEY.md 8e option B): a shallow halo of 16 ghost rows, a walker
     that gets to its far end travels as its 64-byte record and is walked on by the neighbour — in slabs so
     low that a walker crosses several of them (48 rows, 128 steps).  Same walks as the single-domain step: the same
@@ -351,7 +352,7 @@ def test_walkers_handed_over_at_the_slab_edge_match_single_domain(hip, oracle, w
     info = [None] * world
     shared = RcclLoopWire.Shared(world) if wire == "rccl" else None
     try:
-        got = _run_world(world, S, W, pp, steps, maxage, info=info, mode="migrate",
+        got = _run_world(world, S, W, pp, steps, maxage, info=info, mode="migrate", pair=pair,
                          wire=RcclLoopWire if wire == "rccl" else LocalWire, shared=shared)
         if shared is not None:
             assert shared.groups > 0 and shared.bytes > 0
@@ -363,9 +364,13 @@ def test_walkers_handed_over_at_the_slab_edge_match_single_domain(hip, oracle, w
     assert sum(i["migration"]["walkers_handed"] for i in info) > 0     # walkers did cross
     assert all(i["migration"]["passes"] >= 2 * steps for i in info)
     m, layers0 = _single_domain(oracle, H, W, pp, steps)
+    # three free-running steps: from the second on, a walker whose first step flips on a last-bit difference
+    # of an accumulated flux (summation order) walks elsewhere — a counted handful of cells, as in
+    # tests/test_gpu_oracle_fullsize.py
+    from test_gpu_parity import _close_but_for_stray_walks
     for k in got:
         want = to_np(getattr(m, k))
-        np.testing.assert_allclose(got[k], want, rtol=1e-4, atol=1e-5 * (np.nanmax(np.abs(want)) + 1e-30), err_msg=k)
+        _close_but_for_stray_walks(got[k], want, 1e-4, 1e-5 * (np.nanmax(np.abs(want)) + 1e-30), 1e-3, "migrate, " + k)
     assert np.abs(to_np(m.layers) - layers0).max() > 0
 
 
@@ -377,7 +382,7 @@ def test_migrate_mode_on_a_strong_split_with_full_lives(hip, oracle):
     op = script_param(oracle.default_param())
     pp = product_param(op)
     info = [None] * world
-    got = _run_world(world, S, W, pp, steps, maxage, info=info, mode="migrate")
+    got = _run_world(world, S, W, pp, steps, maxage, info=info, mode="migrate", pair=True)
     handed = sum(i["migration"]["walkers_handed"] for i in info)
     assert 0 < handed < steps * 2 * (world * S * W // 8)               # a fraction of the walkers, not all
     m, _ = _single_domain(oracle, world * S, W, pp, steps)

@@ -49,6 +49,10 @@ def main():
                     help="strong scaling: ONE grid of this size cut into `world` slabs (BASELINE config 5: "
                          "16384); the figure to compare with is the same grid on one GPU "
                          "(python bench.py --size 16384)")
+    ap.add_argument("--mode", default="deep", choices=("deep", "migrate"),
+                    help="deep halos, or walkers handed over at a shallow halo's end (soil_slab.h).  With this "
+                         "wire nobody hands this rank anything: the time lacks the launches that walk the "
+                         "immigrants on (about as many walkers as `handed` says left)")
     args = ap.parse_args()
     from soillib_amd import soil
     from soillib_amd.parallel import CallbackComm, SlabRunner
@@ -62,7 +66,7 @@ def main():
             S, Wc, cell = args.size, args.size, 20.0 / args.size
         r = SlabRunner(rows_per_rank=S, W=Wc, param=param, particles_div=8, seed=0,
                        comm=CallbackComm(world // 2, world, NullWire()),
-                       scale=[cell, cell, 4.0], noise_rows=Wc)
+                       scale=[cell, cell, 4.0], noise_rows=Wc, mode=args.mode)
         for _ in range(args.warmup):
             r.step()
         r.sync()
@@ -75,10 +79,11 @@ def main():
         steps = soil.particle_steps(reset=True) / args.steps
         base = base or ms
         print("world %d rank %d: rows %d (+%d ghost), N %d: %.2f ms/step, %.2f G particle steps, "
-              "compute-side efficiency %.3f; repeated launches %d, ghost rows walked / bound %.2f" % (
+              "compute-side efficiency %.3f; repeated launches %d, ghost rows walked / bound %.2f; mode %s %s" % (
                   world, r.rank, S, r.rows - S, r.N, ms, steps / 1e9,
                   base / ms / (world if args.strong else 1), r.fallbacks,
-                  r.halo_rows["window"] / max(r.halo_rows["window_full"], 1)), flush=True)
+                  r.halo_rows["window"] / max(r.halo_rows["window_full"], 1), r.mode,
+                  {k: v // (args.steps + args.warmup) for k, v in r.migration.items()}), flush=True)
         r.close()
         del r
         from soillib_amd import silt
