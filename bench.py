@@ -234,6 +234,10 @@ def parse_args():
                          "statistical parity (tests/test_fast_particles.py), the mode of the line's `value`; "
                          "'exact' = IEEE quotients, the oracle's walks step for step.  A single-GPU run in fast "
                          "mode also times the exact mode and reports it as `exact_arithmetic`")
+    ap.add_argument("--halo-mode", choices=("deep", "migrate"), default=os.environ.get("SOIL_BENCH_HALO_MODE", "deep"),
+                    help="multi-GPU runs: how a walk that crosses a slab's edge is served (include/soil_slab.h): "
+                         "'deep' halos of ceil(sqrt(2) maxage) + 2 rows trimmed to the measured reach, or 'migrate': a "
+                         "16-row halo, walkers handed over at its far end as 64-byte records")
     ap.add_argument("--particle-mode", type=int, default=0,
                     help="0 auto, 1 direct (reference launch shape), 2 staged — ablation")
     return ap.parse_args()
@@ -318,7 +322,7 @@ def timed_steps(runner, ev, steps, warmup, world):
     return elapsed, phase, soil.particle_steps(reset=True)
 
 
-def slab_runner(S, Wcols, strong, param, particles_div, comm, pair):
+def slab_runner(S, Wcols, strong, param, particles_div, comm, pair, mode="deep"):
     """One rank of the library's slab runner (soil_slab_create: csrc/slab_runner.hip)."""
     from soillib_amd import parallel
     # weak scaling: every slab is a piece of the same kind of landscape — cell size
@@ -327,12 +331,12 @@ def slab_runner(S, Wcols, strong, param, particles_div, comm, pair):
     return parallel.SlabRunner(rows_per_rank=S, W=Wcols, param=param,
                                particles_div=particles_div, seed=0,
                                scale=[20.0 / Wcols, 20.0 / Wcols, 4.0],
-                               noise_rows=Wcols if strong else S, comm=comm, pair=pair)
+                               noise_rows=Wcols if strong else S, comm=comm, pair=pair, mode=mode)
 
 
 def halo_report(runner):
     hr = runner.halo_rows
-    return {"ghost_rows_bound": runner.G,
+    return {"mode": runner.mode, "migration": runner.migration, "ghost_rows_bound": runner.G,
             "rows_shipped_vs_bound": (hr["flux"] + hr["field"]) / max(hr["full"], 1),
             "ghost_rows_walked_vs_bound": hr["window"] / max(hr["window_full"], 1),
             "reach_rows_last_steps": runner.reach_hist, "repeated_launches": runner.fallbacks,
@@ -377,7 +381,7 @@ def main():
     if slabbed:
         from soillib_amd import parallel
         comm = parallel.default_comm(device=True)      # RCCL inside the library; gloo by SOIL_DIST_BACKEND
-        runner = slab_runner(S, Wcols, strong, param, args.particles_div, comm, not serial)
+        runner = slab_runner(S, Wcols, strong, param, args.particles_div, comm, not serial, args.halo_mode)
         H_global, W = runner.H, Wcols
     else:
         H_global, W = S, Wcols
@@ -544,7 +548,7 @@ def strong_scaling_block(args, weak_runner, ev, rank, world, param, G, comm, pai
     if weak_runner.G > S:
         return {"skipped": "ghost depth %d exceeds the %d rows of a slab" % (weak_runner.G, S)}
     weak_runner.close()          # the weak run's planes go back to the device first
-    runner = slab_runner(S, G, True, param, args.particles_div, comm, pair)
+    runner = slab_runner(S, G, True, param, args.particles_div, comm, pair, args.halo_mode)
     K = args.steps
     elapsed, phase, psteps = timed_steps(runner, ev, K, args.warmup, world)
     block = {
@@ -559,6 +563,18 @@ def strong_scaling_block(args, weak_runner, ev, rank, world, param, G, comm, pai
         "gparticle_steps_per_s": psteps * world / elapsed / 1e9,
     }
     runner.close()
+    # ... and the same split with the other way of serving walks that cross a slab's edge (soil_slab.h), so
+    # that one multi-GPU run settles which of the two the wire favours
+    other = "migrate" if args.halo_mode == "deep" else "deep"
+    if os.environ.get("SOIL_BENCH_ONE_HALO_MODE") != "1" and not (other == "deep" and weak_runner.G > S):
+        r2 = slab_runner(S, G, True, param, args.particles_div, comm, pair, other)
+        e2, ph2, _ = timed_steps(r2, ev, K, args.warmup, world)
+        block["other_halo_mode"] = {
+            "mode": other, "ms_per_step": e2 / K * 1e3, "value": G * G / (e2 / K) / 1e6,
+            "phases_ms": {"particles": (ph2[0] + ph2[1]) / K, "cells_fused": (ph2[2] - ph2[3] - ph2[4]) / K,
+                          "exchange_flux_exposed": ph2[3] / K, "exchange_field_exposed": ph2[4] / K},
+            "halo": halo_report(r2)}
+        r2.close()
     # the same grid on one GPU (rank 0; the others wait at the barrier)
     if rank == 0 and os.environ.get("SOIL_BENCH_NO_1GPU_REF") != "1":
         k1 = max(2, min(K, 4))
@@ -567,6 +583,8 @@ def strong_scaling_block(args, weak_runner, ev, rank, world, param, G, comm, pai
         block["one_gpu"] = {"ms_per_step": e1 / k1 * 1e3, "value": G * G / (e1 / k1) / 1e6,
                             "steps": k1, "warmup": 1}
         block["speedup_vs_1gpu"] = (e1 / k1) / (elapsed / K)
+        if "other_halo_mode" in block:
+            block["other_halo_mode"]["speedup_vs_1gpu"] = (e1 / k1) / (block["other_halo_mode"]["ms_per_step"] * 1e-3)
         del single
     comm.barrier()
     return block

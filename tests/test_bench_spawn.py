@@ -53,7 +53,11 @@ def test_bare_multi_gpu_bench_prints_one_line_with_the_strong_scaling_block(hip)
     sb = out["strong16384"]
     assert sb["grid"] == [2048, 2048] and sb["rows_per_gpu"] == 1024 and sb["scaling"] == "strong"
     assert sb["value"] > 0 and sb["speedup_vs_1gpu"] > 0 and sb["one_gpu"]["ms_per_step"] > 0
-    assert sb["halo"]["repeated_launches"] >= 0
+    assert sb["halo"]["repeated_launches"] >= 0 and sb["halo"]["mode"] == "deep"
+    # the same split with walkers handed over at a shallow halo's end, timed beside it
+    om = sb["other_halo_mode"]
+    assert om["mode"] == "migrate" and om["halo"]["mode"] == "migrate" and om["halo"]["ghost_rows_bound"] == 16
+    assert om["value"] > 0 and om["speedup_vs_1gpu"] > 0 and om["halo"]["migration"]["walkers_handed"] > 0
     for k in ("exchange_flux_exposed", "exchange_field_exposed"):
         assert k in sb["phases_ms"]
 

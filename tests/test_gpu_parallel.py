@@ -496,7 +496,8 @@ def test_trimmed_halos_and_repeats_on_one_gpu(hip, oracle, pair):
                                    atol=1e-5 * (np.nanmax(np.abs(want)) + 1e-30), err_msg=k)
 
 
-def test_two_processes_share_one_gpu_over_gloo(hip, oracle, tmp_path):
+@pytest.mark.parametrize("mode", ["deep", "migrate"])
+def test_two_processes_share_one_gpu_over_gloo(hip, oracle, tmp_path, mode):
     """The sharded step with real process separation: two ranks launched by
     torch.distributed.run, both on GPU 0, exchanging their halos through the gloo backend.
     Everything but the wire (RCCL on a real node) is what bench.py --gpus 2 runs."""
@@ -507,12 +508,12 @@ def test_two_processes_share_one_gpu_over_gloo(hip, oracle, tmp_path):
     from soillib_amd.erosion import ErosionModel
     world, S, W, maxage, steps = 2, 96, 128, 24, 3
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, SOIL_DEVICE="0", SOIL_DIST_BACKEND="gloo")
+    env = dict(os.environ, SOIL_DEVICE="0", SOIL_DIST_BACKEND="gloo", SOIL_SLAB_MODE=mode)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
     res = subprocess.run(
         [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
-         "--master-addr", "127.0.0.1", "--master-port", "29631",
+         "--master-addr", "127.0.0.1", "--master-port", "29631" if mode == "deep" else "29633",
          os.path.join(root, "tests", "parallel_gpu_worker.py"), str(tmp_path), str(S), str(W),
          str(maxage), str(steps)],
         cwd=root, env=env, capture_output=True, text=True, timeout=900)
