@@ -171,3 +171,20 @@ def test_rccl_bootstrap_failure_falls_back_on_every_rank(tmp_path):
          "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(script)],
         capture_output=True, text=True, timeout=300, env=env, cwd=str(tmp_path))
     assert out.returncode == 0 and out.stdout.count("FALLBACK_OK") == 2, out.stdout + out.stderr
+
+
+def test_migrate_mode_is_refused_by_a_back_end_that_cannot_hand_walkers_over():
+    """SOIL_SLAB_MIGRATE needs soil_slab_ops.particles_pass (the HIP back-end has it; the oracle back-end
+    of these CPU jobs does not): soil_slab_create says so instead of running the deep-halo step."""
+    from soillib_amd import soil
+    from soillib_amd.parallel import CallbackOps, SelfComm, SlabRunner
+
+    class NoPass:                      # every entry NULL: create must stop before it calls any of them
+        pass
+
+    p = soil.param_t()
+    p.maxage = 8
+    with pytest.raises(ValueError, match="particles_pass"):
+        SlabRunner(rows_per_rank=32, W=32, param=p, comm=SelfComm(), ops=CallbackOps(NoPass()), mode="migrate")
+    with pytest.raises(KeyError):
+        SlabRunner(rows_per_rank=32, W=32, param=p, comm=SelfComm(), ops=CallbackOps(NoPass()), mode="sideways")
