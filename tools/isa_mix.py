@@ -78,8 +78,12 @@ def main():
                               stderr=subprocess.DEVNULL)
         asm = open(out).read()
     res = {}
-    for kind, label, pat in ((0, "fluvial_rounds", r"^_ZN4soil13k_tiled_roundILi0ELi1ELi78ELi64ELi768ELb0E.*:"),
-                             (1, "debris_rounds", r"^_ZN4soil13k_tiled_roundILi1ELi1ELi104ELi64ELi768ELb0E.*:")):
+    # the variant the bench line runs: fast arithmetic (SOIL_ISA_ARITH=exact: the IEEE step)
+    fast = os.environ.get("SOIL_ISA_ARITH", "fast") != "exact"
+    tail = "ELb0ELb0ELb%dEE" % (1 if fast else 0)     # ALB, SPARSE, FAST
+    res_arith = "fast" if fast else "exact"
+    for kind, label, pat in ((0, "fluvial_rounds", r"^_ZN4soil13k_tiled_roundILi0ELi1ELi78ELi64ELi768%s.*:" % tail),
+                             (1, "debris_rounds", r"^_ZN4soil13k_tiled_roundILi1ELi1ELi104ELi64ELi768%s.*:" % tail)):
         loop = stepping_loop(asm, pat)
         valu = [i.split()[0] for i in loop if i.startswith("v_") and not i.startswith("v_readlane") or "dpp" in i]
         valu += [i.split()[0] for i in loop if i.startswith("v_readlane") or i.startswith("v_writelane")]
@@ -91,6 +95,7 @@ def main():
         other_ops = {op: n for op, n in hist.items() if not is_typed(op)}
         n_other = sum(other_ops.values())
         res[label] = {
+            "arithmetic": res_arith,
             "loop_instructions": len(loop), "valu": len(valu),
             "salu_and_waitcnt": sum(1 for i in loop if i.startswith("s_") and not i.startswith("s_cbranch") and not i.startswith("s_branch")),
             "branches": sum(1 for i in loop if i.startswith("s_cbranch") or i.startswith("s_branch")),

@@ -2,10 +2,13 @@
 # Collects everything profiles/<name>/ holds, on the GPU box:
 #   gpurun --timeout 2400 -- 'tools/profile_final.sh r04_final'
 # then, back in the container:  python tools/profile_post.py r04_final
-name=${1:-r04_final}
+name=${1:-r05_final}
 out=/root/repo/gpurun_out/$name; rm -rf $out; mkdir -p $out
 cd /tmp; export TMPDIR=/tmp
+# the line as the driver runs it: fast particle arithmetic, the exact mode timed beside it (`exact_arithmetic`)
 python /root/repo/bench.py --steps 10 --warmup 2 2>/dev/null | tail -1 > $out/bench_line.json
+python /root/repo/bench.py --steps 10 --warmup 2 --no-cpu-baseline --particle-arith exact 2>/dev/null | tail -1 > $out/bench_line_exact.json
+export SOIL_BENCH_NO_EXACT=1   # the profiled passes below: one arithmetic (fast) per process
 # the same step with the two particle launches one after the other: per-launch phase timings, and
 # kernel durations / counters that are not mixed with the other launch's kernels
 python /root/repo/bench.py --steps 10 --warmup 2 --no-cpu-baseline --sequential-particles 2>/dev/null | tail -1 > $out/bench_line_sequential.json

@@ -9,10 +9,25 @@ import shutil
 import sys
 
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
-name = sys.argv[1] if len(sys.argv) > 1 else "r04_final"
+name = sys.argv[1] if len(sys.argv) > 1 else "r05_final"
 src = os.path.join(ROOT, "gpurun_out", name)
 dst = os.path.join(ROOT, "profiles", name)
 os.makedirs(dst, exist_ok=True)
+
+
+def targs(kernel):   # template arguments of k_tiled_round<KIND, DEP, TR, TC, NT, ALB, SPARSE, FAST>
+    m = re.search(r"k_tiled_round<([^>]*)>", kernel)
+    return [a.strip() for a in m.group(1).split(",")] if m else []
+
+
+def is_sparse(kernel):
+    a = targs(kernel)
+    return len(a) > 6 and a[6] in ("true", "1")
+
+
+def is_fast(kernel):
+    a = targs(kernel)
+    return len(a) > 7 and a[7] in ("true", "1")
 
 
 def short(kernel):
@@ -47,7 +62,7 @@ if os.path.isdir(os.path.join(src, "stats_default")):      # the default step: l
     for f in os.listdir(os.path.join(src, "stats_default")):
         if f.endswith("kernel_stats.csv"):
             shutil.copy(os.path.join(src, "stats_default", f), os.path.join(dst, "kernel_stats_default_step.csv"))
-for f in ("bench_line.json", "bench_line_sequential.json", "bench_c2_1024x10000.json"):
+for f in ("bench_line.json", "bench_line_exact.json", "bench_line_sequential.json", "bench_c2_1024x10000.json"):
     if os.path.exists(os.path.join(src, f)) and os.path.getsize(os.path.join(src, f)) > 2:
         shutil.copy(os.path.join(src, f), os.path.join(dst, f))
 
@@ -124,7 +139,8 @@ for kind, label in ((0, "fluvial_rounds"), (1, "debris_rounds")):
     for i, (a, b) in enumerate(zip(ra, rb)):
         cyc = a["GRBM_GUI_ACTIVE"] / 8
         rows.append({
-            "round": i, "kernel": "sparse tiles (one wave, hashed accumulators)" if a["name"].rstrip(">").endswith("true") else "dense tiles",
+            "round": i, "kernel": "sparse tiles (one wave, hashed accumulators)" if is_sparse(a["name"]) else "dense tiles",
+            "arithmetic": "fast" if is_fast(a["name"]) else "exact",
             "duration_us": round(a["dur_us"], 1), "shader_clock_ghz": round(cyc / a["dur_us"] / 1e3, 2),
             "SQ_INSTS_VALU": a["SQ_INSTS_VALU"], "SQ_INSTS_VALU_TRANS_F32": a["SQ_INSTS_VALU_TRANS_F32"],
             "active_inst_valu_x4_per_cycle": round(4 * a["SQ_ACTIVE_INST_VALU"] / (1024 * cyc), 3),
