@@ -126,11 +126,11 @@ typedef struct soil_slab soil_slab; /* opaque */
  * SOIL_SLAB_DEEP_HALO  every rank carries ceil(sqrt(2) maxage) + 2 ghost rows a side and walks its own
  *                      walkers to their end; rows of flux and fields travel, trimmed to the measured
  *                      reach (the default; SURVEY.md 8e's option A made exact by the halo's depth).
- * SOIL_SLAB_MIGRATE    a shallow halo (16 ghost rows a side, SOIL_MIGRATE_HALO); a walker that reaches its far
+ * SOIL_SLAB_MIGRATE    a shallow halo (64 ghost rows a side, SOIL_MIGRATE_HALO); a walker that reaches its far
  *                      end is handed over as the 64-byte record the tiled transport parks it as anyway, the
  *                      neighbour walks it on in a further launch of the same step (SURVEY.md 8e's option
- *                      B).  What travels: the walkers that cross (a few per cent, 64 B each) and 16 rows of
- *                      flux and fields; slabs down to 16 rows, 1.6 % ghost rows at 2048-row slabs.  What it
+ *                      B).  What travels: the walkers that cross (a few per cent, 64 B each) and 64 rows of
+ *                      flux and fields; 6 % ghost rows at 2048-row slabs.  What it
  *                      costs: a host look at two counters and an all-reduce per pass, one or two short
  *                      launches per kind and step for the immigrants.  Same walks either way. */
 #define SOIL_SLAB_DEEP_HALO 0

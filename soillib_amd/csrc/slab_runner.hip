@@ -20,6 +20,8 @@
 #include <mutex>
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -393,9 +395,21 @@ struct soil_slab {
       if (!any) return SOIL_OK;
       SLAB_TRY(ops->fill_f32(ops->ctx, reinterpret_cast<float*>(out_count), 0.0f, 4, 0));  // (all-zero bits)
       if (n_in > 0) {
+        static const bool verbose = std::getenv("SOIL_SLAB_VERBOSE") != nullptr;
+        std::chrono::steady_clock::time_point t0;
+        if (verbose) {
+          SLAB_TRY(ops->sync(ops->ctx));
+          t0 = std::chrono::steady_clock::now();
+        }
         SLAB_TRY(ops->particles_pass(ops->ctx, kind, &pl, rng, nullptr, N, remote0, &dom, scale, &param, inbox, n_in,
                                      out_box[0], out_box[1], out_count, cap));
         ++passes;
+        if (verbose) {
+          SLAB_TRY(ops->sync(ops->ctx));
+          std::fprintf(stderr, "[slab rank %d] kind %d pass %lld: %lld immigrants walked on in %.3f ms\n", rank, kind,
+                       static_cast<long long>(pass + 1), static_cast<long long>(n_in),
+                       std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+        }
       }
       SLAB_TRY(ops->to_host(ops->ctx, counts, out_count, 8));
       if (counts[0] > cap || counts[1] > cap)
@@ -1065,8 +1079,12 @@ int soil_slab_create(soil_slab** out, const soil_slab_config* cfg, const soil_pa
     // walks on 64-row slabs were still crossing after four passes).  On kMigrateHalo ghost rows it walks
     // on as the deep-halo walkers do — its deposits there go home with the flux halo, that many rows —
     // and is handed over only at their far end, well inside the neighbour's rows: coming back takes
-    // another kMigrateHalo steps.
-    int64_t halo = 16;
+    // another 2 x that many steps.
+    // How deep: immigrants' launches per step on an interior rank of a 4-way split of 16384^2 (fast arithmetic,
+    // SOIL_SLAB_VERBOSE) — 16 rows: 230 k fluvial + 143 k debris walkers, 3.35 + 0.2 + 2.46 + 0.26 ms in two
+    // passes per kind; 64 rows: 140 k + 62 k, 1.44 + 1.31 ms, one pass; 128 rows: 54 k + 8 k, 0.48 + 0.55 ms —
+    // against 15 / 59 / 118 MB of flux and field rows per neighbour on the wire.  64 is where the two meet.
+    int64_t halo = 64;
     if (const char* e = std::getenv("SOIL_MIGRATE_HALO")) halo = std::max(1, std::atoi(e));
     s->G = std::min<int64_t>(std::min<int64_t>(halo, s->S), soil_ghost_rows(param));
   }

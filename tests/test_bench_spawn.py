@@ -56,7 +56,7 @@ def test_bare_multi_gpu_bench_prints_one_line_with_the_strong_scaling_block(hip)
     assert sb["halo"]["repeated_launches"] >= 0 and sb["halo"]["mode"] == "deep"
     # the same split with walkers handed over at a shallow halo's end, timed beside it
     om = sb["other_halo_mode"]
-    assert om["mode"] == "migrate" and om["halo"]["mode"] == "migrate" and om["halo"]["ghost_rows_bound"] == 16
+    assert om["mode"] == "migrate" and om["halo"]["mode"] == "migrate" and om["halo"]["ghost_rows_bound"] == 64
     assert om["value"] > 0 and om["speedup_vs_1gpu"] > 0 and om["halo"]["migration"]["walkers_handed"] > 0
     for k in ("exchange_flux_exposed", "exchange_field_exposed"):
         assert k in sb["phases_ms"]

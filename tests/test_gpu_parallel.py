@@ -338,12 +338,13 @@ def _single_domain(oracle, H, W, pp, steps):
 @pytest.mark.parametrize("world,S,W,maxage,wire,pair", [(2, 64, 128, 48, "local", False), (3, 96, 128, 96, "local", True),
                                                        (4, 48, 192, 128, "local", False), (4, 48, 192, 128, "local", True),
                                                        (3, 64, 256, 64, "rccl", True)])
-def test_walkers_handed_over_at_the_slab_edge_match_single_domain(hip, oracle, world, S, W, maxage, wire, pair):
+def test_walkers_handed_over_at_the_slab_edge_match_single_domain(hip, oracle, monkeypatch, world, S, W, maxage, wire, pair):
     """SOIL_SLAB_MIGRATE (soil_slab.h; SURVEY.md 8e option B): a shallow halo of 16 ghost rows, a walker
     that gets to its far end travels as its 64-byte record and is walked on by the neighbour — in slabs so
     low that a walker crosses several of them (48 rows, 128 steps).  Same walks as the single-domain step: the same
     particle-step count and, up to the fp32 summation order of the deposits, the same planes."""
     from soillib_amd import soil
+    monkeypatch.setenv("SOIL_MIGRATE_HALO", "16")      # (the default, 64 rows, would be these slabs' whole height)
     op = script_param(oracle.default_param())
     op.maxage = maxage
     pp = product_param(op)
