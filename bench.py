@@ -237,7 +237,7 @@ def parse_args():
     ap.add_argument("--halo-mode", choices=("deep", "migrate"), default=os.environ.get("SOIL_BENCH_HALO_MODE", "deep"),
                     help="multi-GPU runs: how a walk that crosses a slab's edge is served (include/soil_slab.h): "
                          "'deep' halos of ceil(sqrt(2) maxage) + 2 rows trimmed to the measured reach, or 'migrate': a "
-                         "16-row halo, walkers handed over at its far end as 64-byte records")
+                         "64-row halo, walkers handed over at its far end as 64-byte records")
     ap.add_argument("--particle-mode", type=int, default=0,
                     help="0 auto, 1 direct (reference launch shape), 2 staged — ablation")
     return ap.parse_args()
