@@ -74,45 +74,41 @@ __device__ __forceinline__ void normalize_albedo_cell(float* __restrict__ albedo
 __device__ __forceinline__ float transfer_cell(float2& delta, float2 layer, float2 grad,
                                                float upliftBase, float massHeight, float2 speed,
                                                float debrisHeight, Scale3 s, const Param& p) {
-  const float dt = p.timeStep;                         // :476
-  const float ku = p.uplift;                           // :477
-  const float kfs = p.suspensionRateFluvial / 64.0f;   // :478
-  const float kfd = p.depositionRateFluvial * 1.33f;   // :479
-  const float fD = p.frictionFactor / 8.0f;            // :480
-  const float alpha = p.fluvialExponent;               // :481
-  const float rho = p.densityWater;                    // :482
-  const float g = p.gravity;                           // :483
-  const float tau_y = p.yieldStress;                   // :484
-  const float kds = p.suspensionRateDebris;            // :485
-  const float kdd = p.depositionRateDebris;            // :486
-  const float kL = p.landslideRateDebris;              // :487
+  // rate constants of the launch, derived as erosion.cu:476-487 derives them
+  const float step = p.timeStep;
+  const float pick_rate = p.suspensionRateFluvial / 64.0f;    // :478
+  const float settle_rate = p.depositionRateFluvial * 1.33f;  // :479
+  const float drag = p.frictionFactor / 8.0f;                 // :480
 
-  const float L = length2(s.x, s.y);                   // :493
-  const float slope = length2(grad.x, grad.y);         // :494
+  const float cell_diag = length2(s.x, s.y);                  // :493
+  const float steepness = length2(grad.x, grad.y);            // :494
 
-  const float v = length2(speed.x, speed.y);           // :498
-  const float shear = 0.125f * fD * rho * v * v;       // :499
-  const float power = powf_(shear * slope, alpha);     // :500
-  const float suspend = kfs * power;                   // :502
-  const float deposit = kfd * massHeight;              // :505
-  const float uplift = ku * upliftBase;                // :506
+  // water: stream power picks sediment up, suspended mass settles (:498-506)
+  const float flow_speed = length2(speed.x, speed.y);
+  const float bed_shear = 0.125f * drag * p.densityWater * flow_speed * flow_speed;
+  const float stream_power = powf_(bed_shear * steepness, p.fluvialExponent);
+  const float picked_up = pick_rate * stream_power;
+  const float settled = settle_rate * massHeight;
+  const float raised = p.uplift * upliftBase;
 
-  const float excessSlope = slope - p.critSlopeBedrock;                             // :510
-  const float shearLandslide = fmaxf(0.0f, kL * excessSlope);                       // :511
-  const float shearYield = g * (debrisHeight * excessSlope - tau_y);                // :512
-  const float suspendDebris = shearLandslide + kds * fmaxf(0.0f, shearYield);       // :513
-  const float depositDebris = fminf(debrisHeight, fmaxf(0.0f, -kdd * shearYield));  // :514
+  // debris: landslides above the critical slope, yield stress either way (:510-514)
+  const float over_critical = steepness - p.critSlopeBedrock;
+  const float slide = fmaxf(0.0f, p.landslideRateDebris * over_critical);
+  const float yield_excess = p.gravity * (debrisHeight * over_critical - p.yieldStress);
+  const float debris_up = slide + p.suspensionRateDebris * fmaxf(0.0f, yield_excess);
+  const float debris_down = fminf(debrisHeight, fmaxf(0.0f, -p.depositionRateDebris * yield_excess));
 
-  float transfer = dt * (deposit - suspend + depositDebris - suspendDebris);  // :526
-  transfer = fmaxf(transfer, -0.25f * L * slope);                             // :527
-  transfer = fminf(transfer, 0.25f * L * 0.3f);                               // :528
+  // what the cell gains (+) or loses (-) this step, limited to a quarter of the slope's drop (:526-528)
+  float transfer = step * (settled - picked_up + debris_down - debris_up);
+  transfer = fmaxf(transfer, -0.25f * cell_diag * steepness);
+  transfer = fminf(transfer, 0.25f * cell_diag * 0.3f);
 
-  delta.x += dt * uplift / s.z;              // :532
-  delta.y += fmaxf(0.0f, transfer / s.z);    // :533
-  if (transfer < 0.0f) {                     // :535-545
-    const float limited = fmaxf(-layer.y * s.z, transfer);
-    delta.y += limited / s.z;
-    transfer -= limited;
+  delta.x += step * raised / s.z;            // :532  bedrock rises
+  delta.y += fmaxf(0.0f, transfer / s.z);    // :533  a gain goes to the sediment
+  if (transfer < 0.0f) {                     // :535-545  a loss takes sediment first, bedrock for the rest
+    const float from_sediment = fmaxf(-layer.y * s.z, transfer);
+    delta.y += from_sediment / s.z;
+    transfer -= from_sediment;
     delta.x += transfer / s.z;
   }
   return transfer;
