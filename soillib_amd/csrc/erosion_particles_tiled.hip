@@ -1607,6 +1607,10 @@ __global__ void __launch_bounds__(NT, SPARSE ? 2 : round_waves_per_simd(KIND, TR
   // Only a queue longer than the work-group is handed out through s_next.
   PRec r;
   r.iter = -1;
+  // (Round 5, tried: queue entry e to wave e % waves, so that walkers parked one after the other — they travel
+  // together down a channel and lose each other's swaps by construction when they share a wave — stand in
+  // different waves: 8192^2 27.7 -> 28.5 ms, the waves no longer retire by residence class; 1024^2 1.245 ->
+  // 1.227 ms.  Not kept.)
   bool have = lane_sub < cnt;
   if (have) r = in[order[first + lane_sub]];
   uint32_t gate_ticket = 0;
