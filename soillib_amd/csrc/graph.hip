@@ -185,6 +185,7 @@ void launch_steepest4(int32_t* out, const float* height, int64_t H, int64_t W, h
     case 3: return launch_steepest4_as<K, STORE_K, RowWalkTall<kWatch>>(out, height, H, W, st);
     case 4: return launch_steepest4_as<K, STORE_K, RowWalkBlock4<kWatch>>(out, height, H, W, st);
     case 5: return launch_steepest4_as<K, STORE_K, RowWalkBlock2<kWatch>>(out, height, H, W, st);
+    case 6: return launch_steepest4_as<K, STORE_K, RowWalkShort<kWatch>>(out, height, H, W, st);
     default: return launch_steepest4_as<K, STORE_K, RowWalkFlat<kWatch>>(out, height, H, W, st);
   }
 }

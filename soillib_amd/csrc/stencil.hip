@@ -128,6 +128,7 @@ static void win_launch_as(KF kernel, int64_t H, int64_t W, hipStream_t st, A... 
       case 3: win_launch_as<RowWalkTall<WATCH>>(K_FAST<RowWalkTall<WATCH>>, H, W, st, __VA_ARGS__); break; \
       case 4: win_launch_as<RowWalkBlock4<WATCH>>(K_FAST<RowWalkBlock4<WATCH>>, H, W, st, __VA_ARGS__); break; \
       case 5: win_launch_as<RowWalkBlock2<WATCH>>(K_FAST<RowWalkBlock2<WATCH>>, H, W, st, __VA_ARGS__); break; \
+      case 6: win_launch_as<RowWalkShort<WATCH>>(K_FAST<RowWalkShort<WATCH>>, H, W, st, __VA_ARGS__); break; \
       default: win_launch_as<RowWalkFlat<WATCH>>(K_FAST<RowWalkFlat<WATCH>>, H, W, st, __VA_ARGS__); break; \
     }                                                                                               \
   } while (0)
@@ -301,6 +302,7 @@ __device__ __forceinline__ Row12 load_row12(const float* __restrict__ in, int64_
   return Row12{{l0, l1, a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, r0, r1}};
 }
 
+template <int BAND>
 __global__ void __launch_bounds__(kWinBlock)
     k_laplacian4x2(float* __restrict__ out, const float* __restrict__ in, int64_t H, int64_t W, Scale2 s) {
   __shared__ float4 s_tile[kWinBlock / 64][128];
@@ -308,9 +310,9 @@ __global__ void __launch_bounds__(kWinBlock)
   const float hx = (1.0f / s.x / s.x);  // :175
   const float hy = (1.0f / s.y / s.y);  // :176
   const int64_t wave_y0 = (static_cast<int64_t>(blockIdx.x) * kWinBlock + (threadIdx.x & ~63u)) * 4;
-  for (int64_t band = blockIdx.y; band * kWinBand < H; band += gridDim.y) {
-    int64_t x = band * kWinBand;
-    const int64_t x_end = (x + kWinBand < H) ? x + kWinBand : H;
+  for (int64_t band = blockIdx.y; band * BAND < H; band += gridDim.y) {
+    int64_t x = band * BAND;
+    const int64_t x_end = (x + BAND < H) ? x + BAND : H;
     bool has_up = x > 0, has_dn = x + 1 < H;
     Row12 up = load_row12(in, x - 1, W, t.y0, has_up), mid = load_row12(in, x, W, t.y0, true);
     Row12 dn = load_row12(in, x + 1, W, t.y0, has_dn);
@@ -802,7 +804,18 @@ int soil_laplacian(float* out, const float* in, int64_t H, int64_t W, int D, con
   else if (D == 1)
     k_laplacian<1><<<grid_rows(H, W, kSBlock), kSBlock, 0, as_stream(stream)>>>(out, in, H, W, s);
   else if (D == 2 && W % 4 == 0 && W >= 4)  // grad.cu:200-202
-    k_laplacian4x2<<<win_grid(H, W), kWinBlock, 0, as_stream(stream)>>>(out, in, H, W, s);
+  {
+    // (round 5, 8192^2: bands of 32 | 16 | 8 | 4 rows 0.256 | 0.220 | 0.241 | 0.235 ms)
+    static const int band = [] { const char* e = std::getenv("SOIL_LAP2_BAND"); return e ? std::atoi(e) : 16; }();
+    auto grid = [&](int b) {
+      const int64_t bands = (H + b - 1) / b;
+      return dim3(static_cast<unsigned>((W / 4 + kWinBlock - 1) / kWinBlock), static_cast<unsigned>(bands < 65535 ? bands : 65535));
+    };
+    if (band == 4) k_laplacian4x2<4><<<grid(4), kWinBlock, 0, as_stream(stream)>>>(out, in, H, W, s);
+    else if (band == 8) k_laplacian4x2<8><<<grid(8), kWinBlock, 0, as_stream(stream)>>>(out, in, H, W, s);
+    else if (band == 16) k_laplacian4x2<16><<<grid(16), kWinBlock, 0, as_stream(stream)>>>(out, in, H, W, s);
+    else k_laplacian4x2<32><<<grid(32), kWinBlock, 0, as_stream(stream)>>>(out, in, H, W, s);
+  }
   else if (D == 2)
     k_laplacian<2><<<grid_rows(H, 2 * W, kSBlock), kSBlock, 0, as_stream(stream)>>>(out, in, H, W, s);
   else

@@ -205,6 +205,8 @@ template <bool WATCH>
 using RowWalkFlat = RowWalkReg<WATCH, WinFlatShape>;
 template <bool WATCH>
 using RowWalkTall = RowWalkReg<WATCH, WinBandRows<kWinBand / 2>>;  // bands of 16 rows
+template <bool WATCH>
+using RowWalkShort = RowWalkReg<WATCH, WinBandRows<8>>;  // bands of 8 rows
 
 // ---- blocks of a few rows, asked for at once (round 5) -------------------------------------------
 //
@@ -452,7 +454,7 @@ constexpr int win_lds_floats() {
 inline int win_shape(int dflt) {
   static const int env = [] {
     const char* e = std::getenv("SOIL_WIN_SHAPE");
-    return (e && e[0] >= '0' && e[0] <= '5') ? e[0] - '0' : -1;
+    return (e && e[0] >= '0' && e[0] <= '6') ? e[0] - '0' : -1;
   }();
   return env >= 0 ? env : dflt;
 }
