@@ -3002,7 +3002,8 @@ int launch_pair_tiled(const soil_erosion_planes& P, Streams rng_fluvial, Streams
         // on small grids (1024^2 is ONE column group: 32 work-groups of 256 threads for the whole chip,
         // 107 us per step of BASELINE config 2's 1.4 ms; round 5)
         const int64_t rows = hi - lo + 1, groups = (d.W / 4 + kWinBlock - 1) / kWinBlock;
-        const int band_rows = static_cast<int>(std::max<int64_t>(2, std::min<int64_t>(kWinBand, rows * groups / 1024)));
+        static const int band_max = env_int("SOIL_PACK_BAND", kWinBand);
+        const int band_rows = static_cast<int>(std::max<int64_t>(2, std::min<int64_t>(band_max, rows * groups / 1024)));
         const int64_t bands = (rows + band_rows - 1) / band_rows;
         k_tiled_pack_pair4<<<dim3(static_cast<unsigned>(groups), static_cast<unsigned>(std::min<int64_t>(bands, 65535))), kWinBlock, 0, st>>>(
             A.p4, B.p4, reinterpret_cast<const float2*>(P.layers), reinterpret_cast<const float2*>(P.velocity),
