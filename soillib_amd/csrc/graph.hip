@@ -489,8 +489,10 @@ __global__ void __launch_bounds__(kGBlock)
     for (int k = 0; k < K; ++k) {
       if (k < c) {
         donor[k * elem + n] = dn[k];
-        const float D = TENSOR_DECAY ? decayIn[dn[k]] : 1.0f;
-        decay[k * elem + n] = (k < 4) ? D : powf_(D, 1.414f);
+        if (TENSOR_DECAY) {  // (without a decay tensor every edge's decay is 1: no decay array at all, k_rake_compress)
+          const float D = decayIn[dn[k]];
+          decay[k * elem + n] = (k < 4) ? D : powf_(D, 1.414f);
+        }
       }
     }
   }
@@ -546,8 +548,10 @@ __global__ void __launch_bounds__(kWinBlock)
         for (int k = 0; k < K; ++k) {
           if (k < ci[c]) {
             donor[k * elem + n0 + c] = dn[c][k];
-            const float D = TENSOR_DECAY ? decayIn[dn[c][k]] : 1.0f;
-            decay[k * elem + n0 + c] = (k < 4) ? D : powf_(D, 1.414f);
+            if (TENSOR_DECAY) {
+              const float D = decayIn[dn[c][k]];
+              decay[k * elem + n0 + c] = (k < 4) ? D : powf_(D, 1.414f);
+            }
           }
         }
       }
@@ -564,7 +568,13 @@ __global__ void __launch_bounds__(kWinBlock)
 // 4096^2 DEM most cells are final after a few of the 26 rounds).  (2) A round whose
 // predecessor left every cell at -1 has nothing to do and returns at once
 // (`flags`: [round % 3] = "work left", set by the previous round).
-template <int K>
+//
+// DECAY = false (round 5): `accumulate` without a decay tensor (BASELINE config 3's call,
+// example/dem_multiflow.py:48).  The reference then runs with a decay of 1 on every edge (:382-420
+// with no tensor: D = 1, and powf(1, 1.414) = 1), 1.0f * v is v bit for bit and so is a product of
+// ones: the decay arrays are neither made (k_donors), read, gathered nor written — a third of the
+// bytes a pending cell moves per round — and the sums are the same floats added in the same order.
+template <int K, bool DECAY>
 __global__ void __launch_bounds__(kGBlock)
     k_rake_compress(Acc out, const Acc in, int64_t elem, int* __restrict__ flags, int round) {
   // the word round + 2 will read is cleared either way: a round that returns at once must not
@@ -585,7 +595,7 @@ __global__ void __launch_bounds__(kGBlock)
       for (int k = 0; k < K; ++k) {  // :448-468
         if (k < count) {
           donors[k] = in.donor[k * elem + n];
-          decays[k] = in.decay[k * elem + n];
+          decays[k] = DECAY ? in.decay[k * elem + n] : 1.0f;
         }
       }
       const bool was_final = count == 0;
@@ -594,7 +604,7 @@ __global__ void __launch_bounds__(kGBlock)
         const float decay = decays[k];
         const int dcount = in.count[donor];  // :476
         if (dcount <= 0) {                   // :479-487
-          value += decay * in.value[donor];
+          value += DECAY ? decay * in.value[donor] : in.value[donor];
           donors[k] = donors[count - 1];
           decays[k] = decays[count - 1];
           donors[count - 1] = -1;
@@ -602,9 +612,9 @@ __global__ void __launch_bounds__(kGBlock)
           count -= 1;
           k -= 1;
         } else if (dcount == 1) {  // :490-494
-          value += decay * in.value[donor];
+          value += DECAY ? decay * in.value[donor] : in.value[donor];
           donors[k] = in.donor[donor];  // slot 0 of the donor
-          decays[k] = decay * in.decay[donor];
+          if (DECAY) decays[k] = decay * in.decay[donor];
         }
       }
       out.value[n] = value;  // :498
@@ -618,7 +628,7 @@ __global__ void __launch_bounds__(kGBlock)
         for (int k = 0; k < K; ++k) {  // :500-520
           if (k < count) {
             out.donor[k * elem + n] = donors[k];
-            out.decay[k * elem + n] = decays[k];
+            if (DECAY) out.decay[k * elem + n] = decays[k];
           }
         }
       }
@@ -680,8 +690,13 @@ static int accumulate_impl(float* out, const int32_t* graph, const float* source
   // took the same 2.28 ms; with the record kept as a mirror beside the arrays (16 bytes more written per
   // pending cell and round) 3.08 ms.  Bytes are what a round costs, at ~2.4 TB/s.)
   for (int64_t i = 0; i <= iter; ++i) {                                             // :560-563
-    k_rake_compress<K><<<nb, kGBlock, 0, st>>>(B, A, elem, flags, static_cast<int>(2 * i));
-    k_rake_compress<K><<<nb, kGBlock, 0, st>>>(A, B, elem, flags, static_cast<int>(2 * i + 1));
+    if (decayIn) {
+      k_rake_compress<K, true><<<nb, kGBlock, 0, st>>>(B, A, elem, flags, static_cast<int>(2 * i));
+      k_rake_compress<K, true><<<nb, kGBlock, 0, st>>>(A, B, elem, flags, static_cast<int>(2 * i + 1));
+    } else {
+      k_rake_compress<K, false><<<nb, kGBlock, 0, st>>>(B, A, elem, flags, static_cast<int>(2 * i));
+      k_rake_compress<K, false><<<nb, kGBlock, 0, st>>>(A, B, elem, flags, static_cast<int>(2 * i + 1));
+    }
   }
   SOIL_LAUNCH_CHECK();
   SOIL_HIP(hipStreamSynchronize(st));  // cudaDeviceSynchronize, graph.cu:564

@@ -70,6 +70,12 @@ int main() {
   run<0, 64>("ds_add_f32 x4 (SoA planes, random cell)");
   run<0, 32>("ds_add_f32 x4 (SoA planes, random cell)");
   run<0, 8>("ds_add_f32 x4 (SoA planes, random cell)");
+  run<0, 2>("ds_add_f32 x4 (SoA planes, random cell)");
+  run<0, 1>("ds_add_f32 x4 (SoA planes, random cell)");
+  run<5, 16>("ds_add_f32 x1");
+  run<5, 4>("ds_add_f32 x1");
+  run<5, 1>("ds_add_f32 x1");
+  run<6, 2>("float add via ds_cmpst CAS loops x4");
   run<4, 64>("ds_add_f32 x4 (AoS float4, random cell)");
   run<5, 64>("ds_add_f32 x1");
   run<6, 64>("float add via ds_cmpst CAS loops x4");

@@ -4,7 +4,7 @@
 #   gpurun -- 'tools/timeline_c2.sh <outdir> [size]'
 out=${1:-gpurun_out/tl}; size=${2:-1024}; mkdir -p $out
 cd /tmp; export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d /root/repo/$out/trace -o t -- python /root/repo/bench.py --size $size --steps 8 --warmup 60 --no-cpu-baseline > /root/repo/$out/bench_traced.json 2>/dev/null
+SOIL_BENCH_NO_EXACT=1 rocprofv3 --kernel-trace --output-format csv -d /root/repo/$out/trace -o t -- python /root/repo/bench.py --size $size --steps 8 --warmup ${WARMUP:-60} --no-cpu-baseline > /root/repo/$out/bench_traced.json 2>/dev/null
 cd /root/repo
 python - <<PY
 import csv,glob
