@@ -502,16 +502,16 @@ __global__ void __launch_bounds__(kGBlock)
 // eight neighbours a cell asks are compile-time positions of the window, no gathers and no 64-bit
 // index arithmetic per neighbour —, count and value as 16-byte stores.  (The window moves the
 // int32 indices as float bit patterns: loads, shuffles and selects do not touch them.)
-template <int K, bool TENSOR_DECAY>
+template <int K, bool TENSOR_DECAY, class Walk>
 __global__ void __launch_bounds__(kWinBlock)
     k_donors4(int32_t* __restrict__ count, int32_t* __restrict__ donor, float* __restrict__ decay,
               float* __restrict__ value, const int32_t* __restrict__ graph,
               const float* __restrict__ source, const float* __restrict__ decayIn, int64_t H,
               int64_t W) {
-  const WinThread t = win_thread(W);
+  const WinThread t = Walk::thread(H, W);
   const int64_t elem = H * W;
   const int32_t iW = static_cast<int32_t>(W);
-  RowWalk w;
+  SOIL_WIN_WALK(Walk, w, W);
   SOIL_WIN_ROWS(x, w, reinterpret_cast<const float*>(graph), H, W, t) {
     const int32_t n0 = static_cast<int32_t>(x * W + t.y0);
     int4 cnt;
@@ -663,10 +663,24 @@ static int accumulate_impl(float* out, const int32_t* graph, const float* source
   const bool wide = W % 4 == 0 && W >= 4 &&
                     ((reinterpret_cast<uintptr_t>(graph) | reinterpret_cast<uintptr_t>(source) |
                       reinterpret_cast<uintptr_t>(A.value) | reinterpret_cast<uintptr_t>(A.count)) & 15) == 0;
-  if (decayIn && wide)  // :552-556
-    k_donors4<K, true><<<win_grid(H, W), kWinBlock, 0, st>>>(A.count, A.donor, A.decay, A.value, graph, source, decayIn, H, W);
-  else if (wide)
-    k_donors4<K, false><<<win_grid(H, W), kWinBlock, 0, st>>>(A.count, A.donor, A.decay, A.value, graph, source, nullptr, H, W);
+  if (wide) {  // :552-556
+    // (round 5: blocks of rows on grids whose band walk is under 2048 work-groups, window.hpp win_shape_for —
+    // 4096^2, BASELINE config 3: band walk | blocks of four | two rows 143 | 118 | 116 us per realisation)
+    const int shape = win_shape_for(0, 5, H, W);
+    auto go = [&](auto kern, dim3 grid) {
+      kern<<<grid, kWinBlock, 0, st>>>(A.count, A.donor, A.decay, A.value, graph, source, decayIn, H, W);
+    };
+    if (shape == 4) {
+      if (decayIn) go(k_donors4<K, true, RowWalkBlock4<false>>, RowWalkBlock4<false>::grid(H, W));
+      else go(k_donors4<K, false, RowWalkBlock4<false>>, RowWalkBlock4<false>::grid(H, W));
+    } else if (shape == 5) {
+      if (decayIn) go(k_donors4<K, true, RowWalkBlock2<false>>, RowWalkBlock2<false>::grid(H, W));
+      else go(k_donors4<K, false, RowWalkBlock2<false>>, RowWalkBlock2<false>::grid(H, W));
+    } else {
+      if (decayIn) go(k_donors4<K, true, RowWalk>, win_grid(H, W));
+      else go(k_donors4<K, false, RowWalk>, win_grid(H, W));
+    }
+  }
   else if (decayIn)
     k_donors<K, true><<<grid_rows(H, W, kGBlock), kGBlock, 0, st>>>(A.count, A.donor, A.decay, A.value, graph, source,
                                               decayIn, H, W);
@@ -688,7 +702,13 @@ static int accumulate_impl(float* out, const int32_t* graph, const float* source
   // value, first slot and first decay in ONE 16-byte record — one gather per donor instead of up to four,
   // five memory instructions per pending cell instead of ten to twelve, the same bytes — the realisation
   // took the same 2.28 ms; with the record kept as a mirror beside the arrays (16 bytes more written per
-  // pending cell and round) 3.08 ms.  Bytes are what a round costs, at ~2.4 TB/s.)
+  // pending cell and round) 3.08 ms.  Bytes are what a round costs, at ~2.4 TB/s.
+  // Round 5: not the bytes either.  Without the decay arrays (DECAY = false) the rounds move 216 instead of
+  // 279 B/cell and take 1.64 instead of 2.03 ms, still at 2.2 TB/s; slots written as whole 32-byte sectors (the
+  // eight lanes of a sector all write slot k as soon as one has a donor there: more bytes, no partly written
+  // sectors): 1.87 | 1.88 ms; the arrays and slot planes a non-power-of-two apart (64 elements ... 1 M between
+  // them instead of 64 MiB exactly): 1.99 | 1.99 ... 1.94 on one box.  tools/pmc_rake.sh: round 0 issues 242
+  // vector, 80 scalar, 15 load and 6 store instructions per wave and 64 cells — 0.36 of the vector issue slots.)
   for (int64_t i = 0; i <= iter; ++i) {                                             // :560-563
     if (decayIn) {
       k_rake_compress<K, true><<<nb, kGBlock, 0, st>>>(B, A, elem, flags, static_cast<int>(2 * i));
