@@ -574,9 +574,28 @@ __global__ void __launch_bounds__(kWinBlock)
 // with no tensor: D = 1, and powf(1, 1.414) = 1), 1.0f * v is v bit for bit and so is a product of
 // ones: the decay arrays are neither made (k_donors), read, gathered nor written — a third of the
 // bytes a pending cell moves per round — and the sums are the same floats added in the same order.
-template <int K, bool DECAY>
+// A word at a 32-bit BYTE offset from a uniform base: the form the compiler turns into a load with a scalar
+// base and one offset register per lane (`global_load_dword v, v, s[..]`) instead of a 64-bit address per lane.
+template <typename T, typename IDX>
+__device__ __forceinline__ T& word_at(T* base, IDX i) {
+  if constexpr (sizeof(IDX) == 4)
+    return *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + static_cast<uint32_t>(i * 4u));
+  else
+    return base[i];
+}
+template <typename T, typename IDX>
+__device__ __forceinline__ const T& word_at(const T* base, IDX i) {
+  if constexpr (sizeof(IDX) == 4)
+    return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + static_cast<uint32_t>(i * 4u));
+  else
+    return base[i];
+}
+// IDX: uint32_t where K * elem words are under 4 GiB (a uniform base and a 32-bit offset per lane instead
+// of a 64-bit address per lane), int64_t otherwise.
+template <int K, bool DECAY, typename IDX>
 __global__ void __launch_bounds__(kGBlock)
-    k_rake_compress(Acc out, const Acc in, int64_t elem, int* __restrict__ flags, int round) {
+    k_rake_compress(Acc out, const Acc in, int64_t elem64, int* __restrict__ flags, int round) {
+  const IDX elem = static_cast<IDX>(elem64);
   // the word round + 2 will read is cleared either way: a round that returns at once must not
   // leave its predecessor's "work left" standing for the round three launches on
   if (blockIdx.x == 0 && threadIdx.x == 0) flags[(round + 2) % 3] = 0;
@@ -584,27 +603,27 @@ __global__ void __launch_bounds__(kGBlock)
   bool pending = false;
   // a grid of a few work-groups per CU strides over the cells: a round that returns at once (11 of
   // the 26 at 4096^2) costs a few us instead of the 15 us it takes to hand out 65 536 work-groups
-  for (int64_t n = static_cast<int64_t>(blockIdx.x) * kGBlock + threadIdx.x; n < elem;
-       n += static_cast<int64_t>(gridDim.x) * kGBlock) {
-    int count = in.count[n];  // :441
+  for (IDX n = static_cast<IDX>(blockIdx.x) * kGBlock + threadIdx.x; n < elem;
+       n += static_cast<IDX>(gridDim.x) * kGBlock) {
+    int count = word_at(in.count, n);  // :441
     if (count >= 0) {
-      float value = in.value[n];  // :440
+      float value = word_at(in.value, n);  // :440
       int32_t donors[K];
       float decays[K];
 #pragma unroll
       for (int k = 0; k < K; ++k) {  // :448-468
         if (k < count) {
-          donors[k] = in.donor[k * elem + n];
-          decays[k] = DECAY ? in.decay[k * elem + n] : 1.0f;
+          donors[k] = word_at(in.donor, k * elem + n);
+          decays[k] = DECAY ? word_at(in.decay, k * elem + n) : 1.0f;
         }
       }
       const bool was_final = count == 0;
       for (int k = 0; k < count; ++k) {  // :471
-        const int32_t donor = donors[k];
+        const IDX donor = static_cast<IDX>(donors[k]);
         const float decay = decays[k];
-        const int dcount = in.count[donor];  // :476
+        const int dcount = word_at(in.count, donor);  // :476
         if (dcount <= 0) {                   // :479-487
-          value += DECAY ? decay * in.value[donor] : in.value[donor];
+          value += DECAY ? decay * word_at(in.value, donor) : word_at(in.value, donor);
           donors[k] = donors[count - 1];
           decays[k] = decays[count - 1];
           donors[count - 1] = -1;
@@ -612,23 +631,23 @@ __global__ void __launch_bounds__(kGBlock)
           count -= 1;
           k -= 1;
         } else if (dcount == 1) {  // :490-494
-          value += DECAY ? decay * in.value[donor] : in.value[donor];
-          donors[k] = in.donor[donor];  // slot 0 of the donor
-          if (DECAY) decays[k] = decay * in.decay[donor];
+          value += DECAY ? decay * word_at(in.value, donor) : word_at(in.value, donor);
+          donors[k] = word_at(in.donor, donor);  // slot 0 of the donor
+          if (DECAY) decays[k] = decay * word_at(in.decay, donor);
         }
       }
-      out.value[n] = value;  // :498
+      word_at(out.value, n) = value;  // :498
       if (was_final) {       // both buffers hold the final value from here on
-        out.count[n] = -1;
-        in.count[n] = -1;
+        word_at(out.count, n) = -1;
+        word_at(in.count, n) = -1;
       } else {
-        out.count[n] = count;  // :499
+        word_at(out.count, n) = count;  // :499
         pending = true;        // still has donors, or became final only in `out`
 #pragma unroll
         for (int k = 0; k < K; ++k) {  // :500-520
           if (k < count) {
-            out.donor[k * elem + n] = donors[k];
-            if (DECAY) out.decay[k * elem + n] = decays[k];
+            word_at(out.donor, k * elem + n) = donors[k];
+            if (DECAY) word_at(out.decay, k * elem + n) = decays[k];
           }
         }
       }
@@ -709,13 +728,24 @@ static int accumulate_impl(float* out, const int32_t* graph, const float* source
   // sectors): 1.87 | 1.88 ms; the arrays and slot planes a non-power-of-two apart (64 elements ... 1 M between
   // them instead of 64 MiB exactly): 1.99 | 1.99 ... 1.94 on one box.  tools/pmc_rake.sh: round 0 issues 242
   // vector, 80 scalar, 15 load and 6 store instructions per wave and 64 cells — 0.36 of the vector issue slots.)
+  // (Round 5: the gathers of a cell asked for together — count -> value and slots -> every donor's count and
+  // value -> the first slots of the donors that hold one -> stores: four round trips whatever the number of
+  // donors, the list walked in registers as the two pointers the reference's loop amounts to, no branch
+  // between the loads (with one per slot the compiler waits for each load in turn: vmcnt(0) everywhere) —
+  // bit-identical and SLOWER: 1.97-2.02 against 1.79-1.80 ms per realisation.  The rounds are not bound by
+  // the length of a wave's chain of loads but by the number of its memory requests.)
+  const bool idx32 = static_cast<uint64_t>(elem) * K * sizeof(float) < (1ull << 32);
   for (int64_t i = 0; i <= iter; ++i) {                                             // :560-563
-    if (decayIn) {
-      k_rake_compress<K, true><<<nb, kGBlock, 0, st>>>(B, A, elem, flags, static_cast<int>(2 * i));
-      k_rake_compress<K, true><<<nb, kGBlock, 0, st>>>(A, B, elem, flags, static_cast<int>(2 * i + 1));
-    } else {
-      k_rake_compress<K, false><<<nb, kGBlock, 0, st>>>(B, A, elem, flags, static_cast<int>(2 * i));
-      k_rake_compress<K, false><<<nb, kGBlock, 0, st>>>(A, B, elem, flags, static_cast<int>(2 * i + 1));
+    for (int r = static_cast<int>(2 * i); r < static_cast<int>(2 * i) + 2; ++r) {
+      const Acc& o = (r & 1) ? A : B;
+      const Acc& in = (r & 1) ? B : A;
+      if (idx32) {
+        if (decayIn) k_rake_compress<K, true, uint32_t><<<nb, kGBlock, 0, st>>>(o, in, elem, flags, r);
+        else k_rake_compress<K, false, uint32_t><<<nb, kGBlock, 0, st>>>(o, in, elem, flags, r);
+      } else {
+        if (decayIn) k_rake_compress<K, true, int64_t><<<nb, kGBlock, 0, st>>>(o, in, elem, flags, r);
+        else k_rake_compress<K, false, int64_t><<<nb, kGBlock, 0, st>>>(o, in, elem, flags, r);
+      }
     }
   }
   SOIL_LAUNCH_CHECK();
