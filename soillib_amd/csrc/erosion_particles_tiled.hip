@@ -1342,8 +1342,11 @@ struct CasDeposit {
     }
     if (lost) {
       // The failed swap answered with what the word holds now: swap again against that — twice at
-      // most — before falling back to the native add.  A ds_add_f32 keeps the LDS pipe ~170
-      // cycles per instruction however few lanes take part, a ds_cmpst ~6: once walkers share
+      // most — before falling back to the native add.  (Rounds 2-4 read the microbenchmark as "a
+      // ds_add_f32 keeps the LDS pipe ~170 cycles per instruction however few lanes take part"; measured
+      // by active lanes in round 5 — 64: 169, 32: 86, 8: 22, 2: 6.5, 1: 4.3 cycles — it is 2.65 cycles per
+      // ACTIVE lane, so a few losers' native adds are cheap on the pipe; what the repeated swaps buy is the
+      // retry without the float pipe's serialisation when many lanes lost.)  A ds_cmpst ~6: once walkers share
       // channels (every round after the first) a quarter of all wave-iterations have a loser,
       // and with four native adds each the pipe was 0.7 busy against 0.46 in the first round.
 #pragma unroll
@@ -2508,7 +2511,10 @@ struct TiledRun {
     // 1.29 | 1.29 | 1.30 late (steps 6000-7500, three runs each); 2048^2 2.76 | 2.81 | 2.82: keeps 44)
     const bool all_resident = tiles_of(shape_early, 0) <= resident_groups_hint();
     steps_per_round = env_kind("SOIL_TILED_STEPS", KIND, KIND == FLUVIAL ? (shape_early == kShapeFull ? 64 : (all_resident ? 36 : 44))
-                                                                         : (shape_early == kShapeFull ? 40 : 32));
+                                                                         : (shape_early == kShapeFull ? 40 : (all_resident ? 48 : 32)));
+    // (round 5, debris where every tile's work-group is resident at once: its chain of 14 rounds had become the
+    // longer of the two at 1024^2 — 24 | 32 | 40 | 48 | 56 | 64 steps: 1.32 | 1.25 | 1.17 | 1.15 | 1.14 | 1.15 ms per
+    // step late in a run (steps 3000-4500, three runs each, fast arithmetic), 1.585 | 1.575 early)
     // Worth its launch in front of every round only where a round is many generations of work-groups:
     // measured on one box, ms per step with | without: 1024^2 1.48 | 1.45, 2048^2 4.44 | 4.17, 4096^2
     // 9.11 | 8.99, 8192^2 31.97 | 32.23 — on from 16 tiles per resident work-group slot (SOIL_TILED_SPARSE=1
