@@ -2207,9 +2207,16 @@ __global__ void __launch_bounds__(256)
   const int64_t base = static_cast<int64_t>(k.x0) * k.W;
   // (Round 4: this launch is as long as the longest walk left — 0.74 / 0.80 ms at the end of every
   // 8192^2 step, ~3 us per step of a straggler with 250 steps to go.  Asking for the neighbouring rows'
-  // records an iteration ahead, with streaming or with plain loads, changed nothing: a step does not
-  // wait for its gather but for the iteration before's returnless atomics, which count in the same
-  // vmcnt the gather is waited on and are acknowledged from the memory side.)
+  // records an iteration ahead, with streaming or with plain loads, changed nothing.  Round 5: nor is it
+  // the returnless atomics, as round 4 supposed.  The listing has a vmcnt(0) at the loop's head (the record's
+  // loads are first looked at there) and one in front of the cell record's use (the deposits stand under a
+  // branch), so every step did wait for its atomics — but with the record waited for before the loop and
+  // the deposits issued on every step behind the gather (adding -0.0f where the walker has not left its
+  // cell: `vmcnt(4)` in front of the record's use) the two launches took 835 / 764 us against 834 / 715, and
+  // with everything waited for BEFORE the step's arithmetic 899 / 881: the atomics are acknowledged within
+  // the arithmetic's time either way.  A step is its gather's latency — a sector of a 1 GiB plane nobody
+  // else has touched, ~2.5 us with the translation — plus ~0.6 us of arithmetic; exact or fast arithmetic
+  // changes the launch by 5 %.  Removed again.)
   for (;;) {
     if (r.px < 0 || r.py < 0 || r.px >= k.Hf || r.py >= k.Wf) break;
     const int cx = cell32(r.px), cy = cell32(r.py);
