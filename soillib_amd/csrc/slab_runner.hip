@@ -968,6 +968,9 @@ int rccl_all_reduce(void* c, float* buf, int64_t n, void* stream) {
 }
 int rccl_barrier(void* c) {
   RcclCtx& r = *static_cast<RcclCtx*>(c);
+  // every rank's own device work first (the runner's streams are non-blocking: the null stream does not
+  // wait for them), then the collective: past the barrier all ranks' earlier work is done
+  SOIL_HIP(hipDeviceSynchronize());
   SOIL_RCCL(g_rccl.AllReduce(r.scratch, r.scratch, 1, 7, 0, r.comm, nullptr));
   SOIL_HIP(hipStreamSynchronize(nullptr));
   return SOIL_OK;
