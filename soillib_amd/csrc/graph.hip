@@ -186,6 +186,8 @@ void launch_steepest4(int32_t* out, const float* height, int64_t H, int64_t W, h
     case 4: return launch_steepest4_as<K, STORE_K, RowWalkBlock4<kWatch>>(out, height, H, W, st);
     case 5: return launch_steepest4_as<K, STORE_K, RowWalkBlock2<kWatch>>(out, height, H, W, st);
     case 6: return launch_steepest4_as<K, STORE_K, RowWalkShort<kWatch>>(out, height, H, W, st);
+    case 7: return launch_steepest4_as<K, STORE_K, RowWalkStack2<kWatch>>(out, height, H, W, st);
+    case 8: return launch_steepest4_as<K, STORE_K, RowWalkStack4<kWatch>>(out, height, H, W, st);
     default: return launch_steepest4_as<K, STORE_K, RowWalkFlat<kWatch>>(out, height, H, W, st);
   }
 }
@@ -342,6 +344,8 @@ static void launch_random_weighted(const RwBatch& b, const float* height, int64_
     const int shape = win_shape_for(4, 4, H, W);
     if (shape == 4) k_random_weighted4<K, RowWalkBlock4<false>><<<RowWalkBlock4<false>::grid(H, W), kWinBlock, 0, st>>>(b, height, H, W, seed, rw_const(T));
     else if (shape == 5) k_random_weighted4<K, RowWalkBlock2<false>><<<RowWalkBlock2<false>::grid(H, W), kWinBlock, 0, st>>>(b, height, H, W, seed, rw_const(T));
+    else if (shape == 7) k_random_weighted4<K, RowWalkStack2<false>><<<RowWalkStack2<false>::grid(H, W), kWinBlock, 0, st>>>(b, height, H, W, seed, rw_const(T));
+    else if (shape == 8) k_random_weighted4<K, RowWalkStack4<false>><<<RowWalkStack4<false>::grid(H, W), kWinBlock, 0, st>>>(b, height, H, W, seed, rw_const(T));
     else k_random_weighted4<K, RowWalk><<<win_grid(H, W), kWinBlock, 0, st>>>(b, height, H, W, seed, rw_const(T));
   }
   else
@@ -839,8 +843,8 @@ int soil_slope(float* slope, const float* tensor, const int32_t* flow, int64_t H
       (reinterpret_cast<uintptr_t>(slope) & 15) == 0 && (reinterpret_cast<uintptr_t>(tensor) & 15) == 0) {
     // (round 5, ms at 8192^2 by shape — band walk | blocks of four rows | of two: see DESIGN.md 3.3)
     const int shape = win_shape_for(5, 5, H, W);
-    auto k = shape == 4 ? k_slope4<RowWalkBlock4<false>> : (shape == 5 ? k_slope4<RowWalkBlock2<false>> : k_slope4<RowWalk>);
-    const dim3 grid = shape == 4 ? RowWalkBlock4<false>::grid(H, W) : (shape == 5 ? RowWalkBlock2<false>::grid(H, W) : win_grid(H, W));
+    auto k = shape == 4 ? k_slope4<RowWalkBlock4<false>> : (shape == 5 ? k_slope4<RowWalkBlock2<false>> : (shape == 7 ? k_slope4<RowWalkStack2<false>> : (shape == 8 ? k_slope4<RowWalkStack4<false>> : k_slope4<RowWalk>)));
+    const dim3 grid = shape == 4 ? RowWalkBlock4<false>::grid(H, W) : (shape == 5 ? RowWalkBlock2<false>::grid(H, W) : (shape == 7 ? RowWalkStack2<false>::grid(H, W) : (shape == 8 ? RowWalkStack4<false>::grid(H, W) : win_grid(H, W))));
     k<<<grid, kWinBlock, 0, as_stream(stream)>>>(slope, tensor, flow, H, W, Scale2{scale[0], scale[1]});
   } else
     k_slope<<<grid_rows(H, W, kGBlock), kGBlock, 0, as_stream(stream)>>>(

@@ -129,6 +129,8 @@ static void win_launch_as(KF kernel, int64_t H, int64_t W, hipStream_t st, A... 
       case 4: win_launch_as<RowWalkBlock4<WATCH>>(K_FAST<RowWalkBlock4<WATCH>>, H, W, st, __VA_ARGS__); break; \
       case 5: win_launch_as<RowWalkBlock2<WATCH>>(K_FAST<RowWalkBlock2<WATCH>>, H, W, st, __VA_ARGS__); break; \
       case 6: win_launch_as<RowWalkShort<WATCH>>(K_FAST<RowWalkShort<WATCH>>, H, W, st, __VA_ARGS__); break; \
+      case 7: win_launch_as<RowWalkStack2<WATCH>>(K_FAST<RowWalkStack2<WATCH>>, H, W, st, __VA_ARGS__); break; \
+      case 8: win_launch_as<RowWalkStack4<WATCH>>(K_FAST<RowWalkStack4<WATCH>>, H, W, st, __VA_ARGS__); break; \
       default: win_launch_as<RowWalkFlat<WATCH>>(K_FAST<RowWalkFlat<WATCH>>, H, W, st, __VA_ARGS__); break; \
     }                                                                                               \
   } while (0)
@@ -190,10 +192,7 @@ __global__ void __launch_bounds__(kWinBlock)
     }
     if (redo) gradient_group(of, w, t, W, s, rx, ry, DivWritten{});
     // the wave's 256 cells start at column y0 - 4 * lane (lanes past the row's end sit on the last group)
-    const int lane = static_cast<int>(threadIdx.x & 63u);
-    const int64_t wave_y0 = (t.group * kWinBlock + (threadIdx.x & ~63u)) * 4;
-    (void)lane;
-    store_pair_contiguous(reinterpret_cast<float4*>(out + x * W + wave_y0), o[0], o[1],
+    store_pair_contiguous(reinterpret_cast<float4*>(out + x * W + t.wave_y0), o[0], o[1],
                           s_tile[threadIdx.x >> 6], t.live);
   }
 }
@@ -783,7 +782,7 @@ int soil_negslope(float* out, const float* in, int64_t H, int64_t W, const float
   SOIL_REQUIRE(H > 0 && W > 0, "negslope: empty grid");
   const bool fast = plain_scale(scale[0]) && plain_scale(scale[1]);
   if (W % 4 == 0 && W >= 4)
-    SOIL_WIN_LAUNCH(4, 4, fast, kNegslopeFast, kNegslopeWritten, true, H, W, as_stream(stream), out, in, H, W,
+    SOIL_WIN_LAUNCH(8, 4, fast, kNegslopeFast, kNegslopeWritten, true, H, W, as_stream(stream), out, in, H, W,
                     Scale2{scale[0], scale[1]});
   else
     k_negslope<<<grid_rows(H, W, kSBlock), kSBlock, 0, as_stream(stream)>>>(

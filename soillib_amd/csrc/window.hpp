@@ -35,6 +35,7 @@ struct WinThread {
   bool live;
   int64_t group;  // the work-group's 1024 columns: group * 1024 ..
   int64_t row;    // the flat shape's row (-1: none); unused by the band shape
+  int64_t wave_y0 = (group * kWinBlock + (threadIdx.x & ~63u)) * 4;  // first column of the wave's 256 (lanes past the row's end included)
 };
 __device__ __forceinline__ WinThread win_thread(int64_t W) {
   const int64_t y = (static_cast<int64_t>(blockIdx.x) * kWinBlock + threadIdx.x) * 4;
@@ -264,8 +265,32 @@ struct WinBlockRows {  // a work-group owns R rows of 1024 columns; work-groups 
   static __device__ __forceinline__ bool band_ok(int64_t band, int64_t H) { return band >= 0 && band * R < H; }
   static __device__ __forceinline__ int64_t band_next(int64_t) { return -1; }
 };
-template <bool WATCH, int R>
-struct RowBlockReg : WinBlockRows<R> {
+// Round 5, second half: the same blocks with the work-group's four waves STACKED — wave w owns rows
+// (4 b + w) R .. + R of one 256-column strip instead of a quarter of a 1024-column row piece.  The two extra
+// rows a wave asks for are then its neighbour waves' own rows, on their way into the same CU's vector
+// cache, instead of rows of work-groups on other CUs (out of L2).  SOIL_WIN_SHAPE 7 / 8: R = 2 / 4.
+template <int R>
+struct WinStackRows {
+  static constexpr int kBand = R;
+  static constexpr int kWaves = kWinBlock / 64;
+  static int64_t strips(int64_t W) { return (W / 4 + 63) / 64; }
+  static dim3 grid(int64_t H, int64_t W) {
+    return dim3(static_cast<unsigned>(strips(W) * ((H + R * kWaves - 1) / (R * kWaves))));
+  }
+  static __device__ __forceinline__ WinThread thread(int64_t, int64_t W) {
+    const uint32_t G = static_cast<uint32_t>((W / 4 + 63) / 64);
+    const uint32_t b = blockIdx.x / G, g = blockIdx.x - b * G;
+    const int64_t y = (static_cast<int64_t>(g) * 64 + (threadIdx.x & 63u)) * 4;
+    WinThread t{y < W ? y : W - 4, y < W, static_cast<int64_t>(g), static_cast<int64_t>(b) * kWaves + (threadIdx.x >> 6)};
+    t.wave_y0 = static_cast<int64_t>(g) * 256;
+    return t;
+  }
+  static __device__ __forceinline__ int64_t band_first(const WinThread& t) { return t.row; }
+  static __device__ __forceinline__ bool band_ok(int64_t band, int64_t H) { return band >= 0 && band * R < H; }
+  static __device__ __forceinline__ int64_t band_next(int64_t) { return -1; }
+};
+template <bool WATCH, int R, class SHAPE = WinBlockRows<R>>
+struct RowBlockReg : SHAPE {
   static constexpr int kLdsFloats = 4;
   Row6 up, mid, dn;
   Row6 ahead[R > 1 ? R - 1 : 1];  // rows x + 2 .. x + R of the block's first row x, taken by next()
@@ -312,6 +337,10 @@ template <bool WATCH>
 using RowWalkBlock4 = RowBlockReg<WATCH, 4>;
 template <bool WATCH>
 using RowWalkBlock2 = RowBlockReg<WATCH, 2>;
+template <bool WATCH>
+using RowWalkStack2 = RowBlockReg<WATCH, 2, WinStackRows<2>>;
+template <bool WATCH>
+using RowWalkStack4 = RowBlockReg<WATCH, 4, WinStackRows<4>>;
 
 // ---- the same walk with the rows landing in LDS (round 4) ---------------------------------------
 //
@@ -436,8 +465,8 @@ using RowWalkDma = RowWalkLds<false>;
 // `SOIL_WIN_WALK(Walk, w, W);` declares walk `w` of either kind with the LDS it needs
 template <bool WATCH, class SHAPE>
 __device__ __forceinline__ void win_bind(RowWalkReg<WATCH, SHAPE>&, float*, int64_t) {}
-template <bool WATCH, int R>
-__device__ __forceinline__ void win_bind(RowBlockReg<WATCH, R>&, float*, int64_t) {}
+template <bool WATCH, int R, class SHAPE>
+__device__ __forceinline__ void win_bind(RowBlockReg<WATCH, R, SHAPE>&, float*, int64_t) {}
 template <bool WATCH>
 __device__ __forceinline__ void win_bind(RowWalkLds<WATCH>& w, float* lds, int64_t W) { w.bind(lds, W); }
 template <class Walk>
@@ -454,7 +483,7 @@ constexpr int win_lds_floats() {
 inline int win_shape(int dflt) {
   static const int env = [] {
     const char* e = std::getenv("SOIL_WIN_SHAPE");
-    return (e && e[0] >= '0' && e[0] <= '6') ? e[0] - '0' : -1;
+    return (e && e[0] >= '0' && e[0] <= '8') ? e[0] - '0' : -1;
   }();
   return env >= 0 ? env : dflt;
 }
