@@ -141,6 +141,26 @@ def test_accumulation_drains_every_cell_at_4096(hip):
         assert (acc.reshape(-1)[recv] > acc[f >= 0]).all()
 
 
+def test_accumulate_without_decay_arrays_equals_decay_of_ones_at_4096(hip):
+    """BASELINE config 3's call (no decay tensor: no decay arrays, 32-bit offsets) against the general
+    kernel fed a decay tensor of ones, on non-integer sources: bit for bit (graph.cu:577-583)."""
+    from soillib_amd import silt, soil
+    S = 4096
+    p = soil.noise_t()
+    p.seed = 11.0
+    p.ext = [S, S]
+    h = soil.noise(silt.shape(S, S), p, host=silt.gpu)
+    silt.multiply(h, 100.0)
+    src = soil.noise(silt.shape(S, S), p, host=silt.gpu)   # values in (-1, 1): sums that round
+    ones = silt.tensor(silt.float32, silt.shape(S, S), silt.gpu)
+    silt.set(ones, 1.0)
+    for edge in (soil.d4, soil.d8):
+        flow = soil.random_weighted(h, edge, 0, 3, 10.0)
+        a = soil.accumulate(flow, src, edge).cpu().numpy()
+        b = soil.accumulate_decay(flow, src, ones, edge).cpu().numpy()
+        assert (a.view(np.uint32) == b.view(np.uint32)).all()
+
+
 def test_random_weighted_receivers_at_2048(hip, oracle):
     """BASELINE config 3's graph maker at size against the oracle's exact statement: the DEM of
     dem_multiflow.py (heights of ~100 m, T = 10, D8), 4.2 M cells, two draws.  The receivers are equal

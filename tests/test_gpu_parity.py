@@ -597,6 +597,13 @@ def test_accumulate_bit_exact(hip, oracle, H, W, edge):
     g = oracle.steepest(h, edge)
     acc = to_np(soil.accumulate(to_gpu(g), to_gpu(ones), edge))
     assert acc[g < 0].sum() == H * W            # every cell reaches exactly one outlet
+    # `accumulate` is `accumulate_decay` with a decay of exactly 1 on every edge (graph.cu:577-583): the call
+    # without a tensor runs without decay arrays (k_rake_compress<K, DECAY = false>), the one with an all-ones
+    # tensor with them — the same floats in the same order either way
+    for graph in (g, oracle.random_weighted(h, edge, 0, 2, 10.0)):
+        a = to_np(soil.accumulate(to_gpu(graph), to_gpu(src), edge))
+        b = to_np(soil.accumulate_decay(to_gpu(graph), to_gpu(src), to_gpu(ones), edge))
+        assert_bit_equal(a, b, "accumulate against accumulate_decay with ones")
 
 
 # ----------------------------------------------------------- stencils
