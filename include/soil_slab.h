@@ -110,7 +110,10 @@ typedef struct soil_slab_ops {
    * top of that iteration, state untouched; out_count[0..1] (back-end memory, zeroed by the caller)
    * count them.  kind 2: both kinds' spawn launches overlapped (soil_particles_pair_slab; the debris
    * launch draws from `rng_debris`); fluvial records go to the first cap / 2 slots of the boxes, debris
-   * records to the second half, out_count[0..3] = fluvial up, down, debris up, down.
+   * records to the second half, out_count[0..3] = fluvial up, down, debris up, down.  kind 2 with an
+   * `inbox`: both kinds' handed-over walkers walked on side by side — the inbox holds the fluvial records
+   * first, then the debris ones, `n_in` = fluvial count | debris count << 32 (both > 0); boxes and counts
+   * as for kind 2.
    * NULL: the back-end has no such launch and the mode is refused. */
   int (*particles_pass)(void* ctx, int32_t kind, const soil_erosion_planes* planes, soil_rng* rng,
                         soil_rng* rng_debris, int64_t N, float* remote0, const soil_domain* dom, const float scale[3],

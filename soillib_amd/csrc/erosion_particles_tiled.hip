@@ -2938,7 +2938,8 @@ static int run_tiled(float* flux0, float* flux1, float* fluxV, float* fluxA,
 // back into it; the host alternates between the two runs' decisions.
 int launch_pair_tiled(const soil_erosion_planes& P, Streams rng_fluvial, Streams rng_debris, int64_t N,
                       float* remote0, const Dom& d, Scale3 s, const Param& p, hipStream_t st, bool overwrite,
-                      MigrateBox box_fluvial, MigrateBox box_debris) {
+                      MigrateBox box_fluvial, MigrateBox box_debris, const void* inbox_fluvial, uint32_t n_fluvial,
+                      const void* inbox_debris, uint32_t n_debris) {
   // forked streams and their events, one set per (thread, device)
   struct Fork {
     hipStream_t sA = nullptr, sB = nullptr;
@@ -2983,6 +2984,8 @@ int launch_pair_tiled(const soil_erosion_planes& P, Streams rng_fluvial, Streams
   // work-groups before the round's last one has started: 35.66 / 36.25 / 38.21 against 35.66.)
   const int pair_mode = env_int("SOIL_PAIR_MODE", 0);
   const bool turns = pair_mode == 2 || (pair_mode == 0 && N >= 500000);
+  // (immigrants' launches side by side, slab runner's migrate mode: taking turns as the streams' count says — 2.33 ms
+  // for 140 k fluvial + 62 k debris walkers of a 4-way split of 16384^2; mixed freely 2.5-2.7; one after the other 2.75)
   const bool serial_pair = pair_mode == 3;
   if (turns) {
     void* g = nullptr;
@@ -2999,11 +3002,17 @@ int launch_pair_tiled(const soil_erosion_planes& P, Streams rng_fluvial, Streams
   // still be in flight on the workspace the next call reuses.
   A.overwrite = B.overwrite = overwrite;
   A.box = box_fluvial, B.box = box_debris;
+  const bool immigrants = inbox_fluvial != nullptr || inbox_debris != nullptr;
+  if (immigrants) {  // both kinds' handed-over walkers, walked on side by side: the step's pack pass stands
+    A.inbox = static_cast<const PRec*>(inbox_fluvial), A.n_in = n_fluvial;
+    B.inbox = static_cast<const PRec*>(inbox_debris), B.n_in = n_debris;
+    A.skip_pack = B.skip_pack = true;
+  }
   auto run = [&]() -> int {
     if (int rc = A.setup(); rc != SOIL_OK) return rc;
     if (int rc = B.setup(); rc != SOIL_OK) return rc;
     static const bool fused_pack = env_int("SOIL_PACK_PAIR", 1) == 1;   // 2: off (A/B)
-    if (fused_pack) {
+    if (fused_pack && !immigrants) {
       const int64_t lo = stencil_lo(d), hi = stencil_hi(d);
       static const bool pack4 = env_int("SOIL_PACK_WINDOW", 1) == 1;  // 2: the one-cell-per-thread pass (A/B)
       const bool wide = pack4 && d.W % 4 == 0 && d.W >= 4 &&

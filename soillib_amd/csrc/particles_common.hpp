@@ -111,7 +111,11 @@ int launch_debris_tiled(float* massFlux, float* velocityFlux, float* albedoFlux,
 int launch_pair_tiled(const soil_erosion_planes& P, Streams rng_fluvial, Streams rng_debris,
                       int64_t N, float* remote0, const Dom& d, Scale3 s, const Param& p,
                       hipStream_t st, bool overwrite, MigrateBox box_fluvial = MigrateBox{},
-                      MigrateBox box_debris = MigrateBox{});
+                      MigrateBox box_debris = MigrateBox{}, const void* inbox_fluvial = nullptr,
+                      uint32_t n_fluvial = 0, const void* inbox_debris = nullptr, uint32_t n_debris = 0);
+// (inboxes: both launches start from handed-over records instead of the streams' spawns — the immigrants of
+// both kinds walked on side by side, slab runner's migrate mode; the pack pass of the step's spawn launches
+// stands)
 // the slab entry points of soil_hip.h on explicit streams (the slab runner's HIP back-end)
 int particles_fluvial_streams(const soil_erosion_planes& P, Streams rng, int64_t N, float* remote0,
                               const Dom& d, Scale3 s, const Param& p, hipStream_t st);

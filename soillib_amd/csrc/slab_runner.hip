@@ -418,6 +418,76 @@ struct soil_slab {
     }
     return fail(SOIL_ERR_HIP, "slab step (migrate): walkers still crossing after maxage + 2 passes");
   }
+  // Both kinds' immigrants in one pass each round of hand-overs (the paired step): one all-reduce of the four
+  // counts, one exchange of up to four transfers per neighbour pair (fluvial before debris on every link),
+  // and — where a rank received walkers of both kinds — their two launches side by side like the step's
+  // spawn launches (chains of a dozen thin rounds each: latency, not work).  The boxes stay halves: fluvial
+  // leavers in the first half of out_up / out_down, debris in the second; the inbox holds the fluvial
+  // arrivals (from above, from below), then the debris ones.  SOIL_MIGRATE_PAIR=0: kind by kind (migrate_on).
+  int migrate_on_both(const soil_erosion_planes& pl, const soil_domain& dom, const uint32_t first[4], int64_t half) {
+    const int64_t max_pass = static_cast<int64_t>(std::min<uint64_t>(param.maxage, 1u << 20)) + 2;
+    uint32_t counts[4] = {first[0], first[1], first[2], first[3]};
+    char* const up_d = static_cast<char*>(out_box[0]) + half * kRecBytes;
+    char* const down_d = static_cast<char*>(out_box[1]) + half * kRecBytes;
+    for (int64_t pass = 0; pass <= max_pass; ++pass) {
+      for (int j = 0; j < 4; ++j)
+        if (counts[j] > half)
+          return fail(SOIL_ERR_OUT_OF_MEMORY, "slab step (migrate): more walkers left the slab in one pass than half a box holds");
+      const int mine[4] = {up >= 0 ? static_cast<int>(counts[0]) : 0, down >= 0 ? static_cast<int>(counts[1]) : 0,
+                           up >= 0 ? static_cast<int>(counts[2]) : 0, down >= 0 ? static_cast<int>(counts[3]) : 0};
+      std::vector<int> all;
+      SLAB_TRY(all_ints(mine, 4, all));
+      int64_t total = 0;
+      for (int v : all) total += v;
+      if (total == 0) return SOIL_OK;
+      walkers_handed += mine[0] + mine[1] + mine[2] + mine[3];
+      // what the neighbour above handed DOWN is mine, and what the one below handed UP
+      const int64_t in_f_up = up >= 0 ? all[static_cast<size_t>(4 * up + 1)] : 0, in_f_down = down >= 0 ? all[static_cast<size_t>(4 * down)] : 0;
+      const int64_t in_d_up = up >= 0 ? all[static_cast<size_t>(4 * up + 3)] : 0, in_d_down = down >= 0 ? all[static_cast<size_t>(4 * down + 2)] : 0;
+      const int64_t n_f = in_f_up + in_f_down, n_d = in_d_up + in_d_down;
+      if (n_f + n_d > 2 * box_cap)
+        return fail(SOIL_ERR_OUT_OF_MEMORY, "slab step (migrate): more walkers arrive than the inbox holds");
+      char* const in = static_cast<char*>(inbox);
+      std::vector<soil_xfer> sends, recvs;
+      if (mine[0]) sends.push_back({out_box[0], mine[0] * kRecBytes, up});
+      if (mine[1]) sends.push_back({out_box[1], mine[1] * kRecBytes, down});
+      if (mine[2]) sends.push_back({up_d, mine[2] * kRecBytes, up});
+      if (mine[3]) sends.push_back({down_d, mine[3] * kRecBytes, down});
+      if (in_f_up) recvs.push_back({in, in_f_up * kRecBytes, up});
+      if (in_f_down) recvs.push_back({in + in_f_up * kRecBytes, in_f_down * kRecBytes, down});
+      if (in_d_up) recvs.push_back({in + n_f * kRecBytes, in_d_up * kRecBytes, up});
+      if (in_d_down) recvs.push_back({in + (n_f + in_d_up) * kRecBytes, in_d_down * kRecBytes, down});
+      SLAB_TRY(exchange(sends, recvs, 0));
+      SLAB_TRY(ops->fill_f32(ops->ctx, reinterpret_cast<float*>(out_count), 0.0f, 4, 0));  // (all-zero bits)
+      static const bool verbose = std::getenv("SOIL_SLAB_VERBOSE") != nullptr;
+      std::chrono::steady_clock::time_point t0;
+      if (verbose && n_f + n_d > 0) {
+        SLAB_TRY(ops->sync(ops->ctx));
+        t0 = std::chrono::steady_clock::now();
+      }
+      if (n_f > 0 && n_d > 0) {
+        SLAB_TRY(ops->particles_pass(ops->ctx, 2, &pl, rng, rng_debris, N, remote0, &dom, scale, &param, inbox, n_f | (n_d << 32),
+                                     out_box[0], out_box[1], out_count, 2 * half));
+        passes += 2;
+      } else if (n_f > 0) {
+        SLAB_TRY(ops->particles_pass(ops->ctx, 0, &pl, rng, nullptr, N, remote0, &dom, scale, &param, inbox, n_f, out_box[0],
+                                     out_box[1], out_count, half));
+        ++passes;
+      } else if (n_d > 0) {
+        SLAB_TRY(ops->particles_pass(ops->ctx, 1, &pl, rng, nullptr, N, remote0, &dom, scale, &param, inbox, n_d, up_d, down_d,
+                                     out_count + 2, half));
+        ++passes;
+      }
+      if (verbose && n_f + n_d > 0) {
+        SLAB_TRY(ops->sync(ops->ctx));
+        std::fprintf(stderr, "[slab rank %d] pass %lld: %lld fluvial + %lld debris immigrants walked on in %.3f ms\n", rank,
+                     static_cast<long long>(pass + 1), static_cast<long long>(n_f), static_cast<long long>(n_d),
+                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+      }
+      SLAB_TRY(ops->to_host(ops->ctx, counts, out_count, 16));
+    }
+    return fail(SOIL_ERR_HIP, "slab step (migrate): walkers still crossing after maxage + 2 passes");
+  }
   // Per step: the spawn launches of both kinds (overlapped like soil_erode_step's when the runner pairs
   // its launches, else one after the other), then per kind the immigrants' launches.
   int migrate_particles(const soil_erosion_planes& pl, const soil_domain& dom, uint64_t off, bool paired,
@@ -439,6 +509,8 @@ struct soil_slab {
       // records stay where they are until their turn.
       const void* src_f[2] = {out_box[0], out_box[1]};
       const void* src_d[2] = {static_cast<char*>(out_box[0]) + half * kRecBytes, static_cast<char*>(out_box[1]) + half * kRecBytes};
+      static const bool side_by_side = !(std::getenv("SOIL_MIGRATE_PAIR") && std::atoi(std::getenv("SOIL_MIGRATE_PAIR")) == 0);
+      if (side_by_side) return migrate_on_both(pl, dom, c, half);
       SLAB_TRY(migrate_on(0, pl, dom, c, src_f, half));
       SLAB_TRY(migrate_on(1, pl, dom, c + 2, src_d, half));
       return SOIL_OK;
@@ -763,7 +835,8 @@ int hip_pair(void* c, const soil_erosion_planes* p, soil_rng* rf, soil_rng* rd, 
   o.drew(rd);
   return rc;
 }
-// kind 0 / 1: one launch of that kind (soil_slab.h).  kind 2: both kinds' SPAWN launches overlapped, as
+// kind 0 / 1: one launch of that kind (soil_slab.h).  kind 2 with an inbox: both kinds' immigrants walked on
+// side by side (n_in = fluvial | debris << 32, the fluvial records first).  kind 2: both kinds' SPAWN launches overlapped, as
 // hip_pair runs them (`rng`: the fluvial streams; the debris launch draws from `rng_debris`, two draws on):
 // the boxes are halves — fluvial records in the first `cap / 2` slots of out_up / out_down, debris in the
 // second, out_count[0..3] = fluvial up, down, debris up, down.
@@ -776,15 +849,22 @@ int hip_pass(void* c, int32_t kind, const soil_erosion_planes* p, soil_rng* rng,
   SOIL_REQUIRE(kind >= 0 && kind <= 2, "particles_pass: kind 0 (fluvial), 1 (debris) or 2 (both spawn launches)");
   SOIL_REQUIRE(N > 0 && N <= 0x7fffffffll && d.H * d.W <= 0x7fffffffll && d.H < (1 << 24) && d.W < (1 << 24),
                "particles_pass: the tiled launch shape needs 1 .. 2^31 - 1 particles and cells, rows and columns below 2^24");
-  SOIL_REQUIRE(n_in >= 0 && n_in <= 0xffffffffll && cap >= 0 && cap <= 0xffffffffll, "particles_pass: bad record counts");
+  SOIL_REQUIRE(n_in >= 0 && (kind == 2 || n_in <= 0xffffffffll) && cap >= 0 && cap <= 0xffffffffll, "particles_pass: bad record counts");
   const Scale3 s3{scale[0], scale[1], scale[2]};
   if (kind == 2) {
-    SOIL_REQUIRE(!inbox && rng_debris, "particles_pass: the overlapped launches start from the streams (two tensors)");
+    SOIL_REQUIRE(rng_debris, "particles_pass: the overlapped launches need both kinds' streams");
     const uint32_t half = static_cast<uint32_t>(cap / 2);
     MigrateBox bf, bd;
     bf.up = out_up, bf.down = out_down, bf.count = out_count, bf.cap = half;
     bd.up = static_cast<char*>(out_up) + static_cast<size_t>(half) * 64, bd.down = static_cast<char*>(out_down) + static_cast<size_t>(half) * 64;
     bd.count = out_count + 2, bd.cap = half;
+    if (inbox) {  // both kinds' immigrants: n_in = fluvial count | debris count << 32, fluvial records first
+      const uint32_t n_f = static_cast<uint32_t>(n_in & 0xffffffffll), n_d = static_cast<uint32_t>(n_in >> 32);
+      SOIL_REQUIRE(n_f > 0 && n_d > 0, "particles_pass: the overlapped immigrants' launches want walkers of both kinds");
+      if (int rc = o.clear_stale(); rc != SOIL_OK) return rc;
+      return launch_pair_tiled(*p, o.streams(rng), o.streams(rng_debris), N, remote0, d, s3, *param, o.main, false, bf, bd,
+                               inbox, n_f, static_cast<const char*>(inbox) + static_cast<size_t>(n_f) * 64, n_d);
+    }
     const int rc = launch_pair_tiled(*p, o.streams(rng), o.streams(rng_debris), N, remote0, d, s3, *param, o.main,
                                      o.flux_stale, bf, bd);
     o.flux_stale = false;
