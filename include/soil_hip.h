@@ -50,7 +50,8 @@ typedef enum soil_status {
   SOIL_ERR_NO_DEVICE = -2,        /* no HIP device / runtime failure at init            */
   SOIL_ERR_HIP = -3,              /* a HIP runtime call failed (message has the detail) */
   SOIL_ERR_OUT_OF_MEMORY = -4,
-  SOIL_ERR_IO = -5 /* silt::error::missing_file / an unreadable or unsupported file (tiff.hpp:73) */
+  SOIL_ERR_IO = -5, /* silt::error::missing_file / an unreadable or unsupported file (tiff.hpp:73) */
+  SOIL_ERR_COMM = -6 /* the wire between ranks failed or timed out (soil_slab.h); no reference counterpart */
 } soil_status;
 
 /* graph.hpp:11-14  enum edge_t { D4 = 0, D8 = 1 } */

@@ -48,6 +48,10 @@ typedef struct soil_comm {
   /* in-place sum over all ranks of `n` floats in back-end memory */
   int (*all_reduce_sum_f32)(void* ctx, float* buf, int64_t n, void* stream);
   int (*barrier)(void* ctx);
+  /* May be NULL.  SOIL_OK, or the failure of a wire that has given up meanwhile (a stream-ordered
+   * transfer that did not complete within its timeout and was aborted): the runner asks after every
+   * wait on its streams, so that a step never returns planes a dead wire left half-filled. */
+  int (*status)(void* ctx);
 } soil_comm;
 
 /* RCCL communicator owned by the library.  The 128-byte id is made by one rank
@@ -64,6 +68,19 @@ int soil_comm_rccl_create(soil_comm** out, const uint8_t id[128], int32_t rank, 
 int soil_comm_rccl_destroy(soil_comm* comm);
 /* what RCCL reports for the communicator: ncclCommCount, ncclCommUserRank, ncclCommCuDevice */
 int soil_comm_rccl_info(const soil_comm* comm, int32_t* count, int32_t* rank, int32_t* device);
+/* which librccl the library bound (the file the symbols came from, NUL-terminated into path[capacity])
+ * and its ncclGetVersion code (major * 10000 + minor * 100 + patch); no device touched */
+int soil_comm_rccl_library(char* path, int32_t capacity, int32_t* version);
+/* Bounded waits.  Every RCCL communicator has a watchdog thread: a library call that does not return,
+ * or a transfer on a stream that does not complete, within SOIL_RCCL_TIMEOUT_S seconds (default 30;
+ * ncclCommInitRank: SOIL_RCCL_INIT_TIMEOUT_S, default 120) makes it call ncclCommAbort — the blocked
+ * call and the stream come back — and every later call on the communicator, soil_slab_step and
+ * soil_slab_sync return SOIL_ERR_COMM; soil_last_error() names the operation, the first peer, the
+ * byte count, the rank and the librccl file.  A hung wire fails; it does not hang the host. */
+/* a wire whose every operation blocks like a transfer whose peer never shows up, under the same
+ * watchdog (timeout_s): what the tests use to prove that the runner surfaces the failure */
+int soil_comm_wedged_create(soil_comm** out, int32_t rank, int32_t world, double timeout_s);
+int soil_comm_wedged_destroy(soil_comm* comm);
 /* a one-rank world that needs no library at all (exchange with oneself: device copies) */
 int soil_comm_self_create(soil_comm** out);
 int soil_comm_self_destroy(soil_comm* comm);
@@ -105,8 +122,10 @@ typedef struct soil_slab_ops {
   void* (*stream)(void* ctx, int32_t lane);
   /* SOIL_SLAB_MIGRATE (below): one launch of `kind` (0 fluvial, 1 debris) that ADDS to the kind's flux
    * planes — from the streams' spawns (`inbox` NULL) or from `n_in` walkers handed over by the neighbours
-   * (64-byte records, taken as they are).  A walker that steps off the owned rows [dom->r0, dom->r1), in
-   * the grid and with life left, is written to `out_up` / `out_down` (room for `cap` records each) at the
+   * (64-byte records, taken as they are; at most N of a kind per launch).  A walker that steps off the
+   * rows the launch was given — the owned rows plus the shallow halo either side, i.e. off local rows
+   * [0, dom->rows) of a slab with neighbours there —, in the grid and with life left, is written to
+   * `out_up` / `out_down` (room for `cap` records each; a record beyond `cap` is counted, not written) at the
    * top of that iteration, state untouched; out_count[0..1] (back-end memory, zeroed by the caller)
    * count them.  kind 2: both kinds' spawn launches overlapped (soil_particles_pair_slab; the debris
    * launch draws from `rng_debris`); fluvial records go to the first cap / 2 slots of the boxes, debris

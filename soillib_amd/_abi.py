@@ -16,6 +16,8 @@ SOIL_ERR_INVALID_ARGUMENT = -1
 SOIL_ERR_NO_DEVICE = -2
 SOIL_ERR_HIP = -3
 SOIL_ERR_OUT_OF_MEMORY = -4
+SOIL_ERR_IO = -5
+SOIL_ERR_COMM = -6
 
 D4, D8 = 0, 1
 SOIL_CELLS_KEEP_FLUX = 1
@@ -173,7 +175,8 @@ SOIL_COMM_HOST_ORDERED = 1
 class Comm(C.Structure):
     """soil_comm: the wire between the ranks of a slab world."""
     _fields_ = [("ctx", C.c_void_p), ("rank", C.c_int32), ("world", C.c_int32), ("flags", C.c_int32),
-                ("exchange", EXCHANGE_FN), ("all_reduce_sum_f32", ALLREDUCE_FN), ("barrier", BARRIER_FN)]
+                ("exchange", EXCHANGE_FN), ("all_reduce_sum_f32", ALLREDUCE_FN), ("barrier", BARRIER_FN),
+                ("status", BARRIER_FN)]   # may be NULL: has the wire given up meanwhile?
 
 
 _PP = C.POINTER(ErosionPlanes)
@@ -237,6 +240,9 @@ SLAB_SIGNATURES = {
     "soil_comm_rccl_probe": (cint, [C.POINTER(C.c_int32)]),
     "soil_comm_rccl_info": (cint, [C.POINTER(Comm), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                    C.POINTER(C.c_int32)]),
+    "soil_comm_rccl_library": (cint, [C.c_char_p, C.c_int32, C.POINTER(C.c_int32)]),
+    "soil_comm_wedged_create": (cint, [C.POINTER(C.POINTER(Comm)), C.c_int32, C.c_int32, C.c_double]),
+    "soil_comm_wedged_destroy": (cint, [C.POINTER(Comm)]),
     "soil_comm_self_create": (cint, [C.POINTER(C.POINTER(Comm))]),
     "soil_comm_self_destroy": (cint, [C.POINTER(Comm)]),
     "soil_slab_create": (cint, [C.POINTER(vp), C.POINTER(SlabConfig), C.POINTER(Param), C.POINTER(Comm),
@@ -298,6 +304,10 @@ class SoilError(RuntimeError):
     pass
 
 
+class CommError(SoilError):
+    """SOIL_ERR_COMM: the wire between ranks failed or timed out (include/soil_slab.h)."""
+
+
 def check(rc):
     if rc == SOIL_OK:
         return
@@ -306,6 +316,8 @@ def check(rc):
         raise ValueError(msg)  # std::invalid_argument in the reference
     if rc == SOIL_ERR_OUT_OF_MEMORY:
         raise MemoryError(msg)
+    if rc == SOIL_ERR_COMM:
+        raise CommError("libsoil_hip error %d: %s" % (rc, msg))
     raise SoilError("libsoil_hip error %d: %s" % (rc, msg))
 
 

@@ -17,10 +17,14 @@
 // slab edge).
 #include <dlfcn.h>
 
-#include <mutex>
-
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -69,7 +73,7 @@ const Plane kFluxDebris[2] = {kDebrisFlux, kDebrisVelocityFlux};              //
 using soil::fail;
 
 // what soillib_amd/_abi.py mirrors with ctypes
-static_assert(sizeof(soil_xfer) == 24 && sizeof(soil_comm) == 48 && sizeof(soil_slab_ops) == 20 * 8 &&
+static_assert(sizeof(soil_xfer) == 24 && sizeof(soil_comm) == 56 && sizeof(soil_slab_ops) == 20 * 8 &&
                   sizeof(soil_slab_config) == 80 && sizeof(soil_slab_info) == 192,
               "soil_slab.h struct layout changed: update soillib_amd/_abi.py");
 
@@ -108,8 +112,8 @@ struct soil_slab {
   bool window = true;  // SOIL_HALO_WINDOW=0: every launch on all the ghost rows (A/B)
   int64_t w0 = 0, w1 = 0;
   int64_t rows_window = 0, rows_window_full = 0;  // ghost rows the launches were given so far / the bound
-  // SOIL_SLAB_MIGRATE: walkers handed over at the slab's edge (soil_slab.h).  One ghost row a side; the
-  // boxes hold 64-byte walker records: out[0] / out[1] what this rank hands up / down, `inbox` what the
+  // SOIL_SLAB_MIGRATE: walkers handed over at the far end of a shallow halo (G = SOIL_MIGRATE_HALO = 64
+  // ghost rows a side, soil_slab_create below).  The boxes hold 64-byte walker records: out[0] / out[1] what this rank hands up / down, `inbox` what the
   // neighbours handed it ([from above | from below]); two counters on the device.
   int mode = SOIL_SLAB_DEEP_HALO;
   static constexpr int64_t kRecBytes = 64;
@@ -154,6 +158,7 @@ struct soil_slab {
     rows_window_full += gu + gd;
   }
   void* stream(int lane) const { return ops->stream ? ops->stream(ops->ctx, lane) : nullptr; }
+  int wire_status() const { return comm->status ? comm->status(comm->ctx) : SOIL_OK; }
 
 #define SLAB_TRY(expr)                     \
   do {                                     \
@@ -187,8 +192,9 @@ struct soil_slab {
     if (host_ordered) SLAB_TRY(ops->sync(ops->ctx));
     SLAB_TRY(comm->all_reduce_sum_f32(comm->ctx, ints, total, stream(0)));
     SLAB_TRY(ops->to_host(ops->ctx, h.data(), ints, n * 4));
+    SLAB_TRY(wire_status());  // the copy waited for the stream: a wire that gave up meanwhile left garbage
     out.resize(static_cast<size_t>(n));
-    for (int64_t i = 0; i < n; ++i) out[static_cast<size_t>(i)] = static_cast<int>(h[static_cast<size_t>(i)] + 0.5f);
+    for (int64_t i = 0; i < n; ++i) out[static_cast<size_t>(i)] = static_cast<int>(std::lround(h[static_cast<size_t>(i)]));
     return SOIL_OK;
   }
 
@@ -354,13 +360,36 @@ struct soil_slab {
   // cell it stands on is made of the same fields.
   // counts[0..1] walkers this rank has just handed up / down (already in out_box); exchanges them, returns
   // the walkers that arrived (in `inbox`) and whether anybody anywhere handed anything over
-  int hand_over(const uint32_t counts[2], const void* const src[2], int64_t& n_in, bool& any) {
-    if (counts[0] > box_cap || counts[1] > box_cap)
-      return fail(SOIL_ERR_OUT_OF_MEMORY, "slab step (migrate): more walkers left the slab in one pass than its boxes hold");
+  // Failures of the hand-over are decided on numbers every rank holds: a rank whose box overflowed sends
+  // kOverflow in place of its count, and the arrivals of EVERY rank are checked from the gathered counts —
+  // so all ranks leave the step together with the same error instead of one returning while its peers wait
+  // in the next collective for ever.  An inbox holds 2 * box_cap records, but the launch that walks them on
+  // has room for N (the record, destination and rank arrays of the tiled transport): more than N arrivals
+  // of one kind are refused (unpaired launches let up to 2 N through).
+  static constexpr int kOverflow = -1;
+  int gathered_failure(const std::vector<int>& all, int k) const {
+    for (int v : all)
+      if (v == kOverflow)
+        return fail(SOIL_ERR_OUT_OF_MEMORY, "slab step (migrate): more walkers left a slab in one pass than its boxes hold");
+    for (int q = 0; q < world; ++q)
+      for (int kind = 0; kind < k / 2; ++kind) {
+        const int64_t from_up = q > 0 ? all[static_cast<size_t>(k * (q - 1) + 2 * kind + 1)] : 0;
+        const int64_t from_down = q + 1 < world ? all[static_cast<size_t>(k * (q + 1) + 2 * kind)] : 0;
+        if (from_up + from_down > std::min<int64_t>(N, 2 * box_cap))
+          return fail(SOIL_ERR_OUT_OF_MEMORY, "slab step (migrate): more walkers arrive at rank " + std::to_string(q) +
+                                                  " in one pass than its launch has room for (N = " + std::to_string(N) +
+                                                  "): slabs this small against walks this long want the deep-halo mode");
+      }
+    return SOIL_OK;
+  }
+  int hand_over(const uint32_t counts[2], const void* const src[2], int64_t cap, int64_t& n_in, bool& any) {
     // (no neighbour on a side: the grid ends there, such walkers are out of bounds and never get here)
-    const int mine[2] = {up >= 0 ? static_cast<int>(counts[0]) : 0, down >= 0 ? static_cast<int>(counts[1]) : 0};
+    const bool over = counts[0] > cap || counts[1] > cap;
+    const int mine[2] = {over ? kOverflow : (up >= 0 ? static_cast<int>(counts[0]) : 0),
+                         over ? kOverflow : (down >= 0 ? static_cast<int>(counts[1]) : 0)};
     std::vector<int> all;
     SLAB_TRY(all_ints(mine, 2, all));
+    SLAB_TRY(gathered_failure(all, 2));
     int64_t total = 0;
     for (int v : all) total += v;
     any = total > 0;
@@ -369,8 +398,6 @@ struct soil_slab {
     walkers_handed += mine[0] + mine[1];
     const int64_t from_up = up >= 0 ? all[static_cast<size_t>(2 * up + 1)] : 0;
     const int64_t from_down = down >= 0 ? all[static_cast<size_t>(2 * down)] : 0;
-    if (from_up + from_down > 2 * box_cap)
-      return fail(SOIL_ERR_OUT_OF_MEMORY, "slab step (migrate): more walkers arrive than the inbox holds");
     std::vector<soil_xfer> sends, recvs;
     if (mine[0]) sends.push_back({const_cast<void*>(src[0]), mine[0] * kRecBytes, up});
     if (mine[1]) sends.push_back({const_cast<void*>(src[1]), mine[1] * kRecBytes, down});
@@ -391,7 +418,7 @@ struct soil_slab {
     for (int64_t pass = 0; pass <= max_pass; ++pass) {
       int64_t n_in = 0;
       bool any = false;
-      SLAB_TRY(hand_over(counts, src, n_in, any));
+      SLAB_TRY(hand_over(counts, src, cap, n_in, any));
       if (!any) return SOIL_OK;
       SLAB_TRY(ops->fill_f32(ops->ctx, reinterpret_cast<float*>(out_count), 0.0f, 4, 0));  // (all-zero bits)
       if (n_in > 0) {
@@ -411,12 +438,10 @@ struct soil_slab {
                        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
         }
       }
-      SLAB_TRY(ops->to_host(ops->ctx, counts, out_count, 8));
-      if (counts[0] > cap || counts[1] > cap)
-        return fail(SOIL_ERR_OUT_OF_MEMORY, "slab step (migrate): more walkers left the slab in one pass than its boxes hold");
+      SLAB_TRY(ops->to_host(ops->ctx, counts, out_count, 8));  // (an overflow travels with the next hand-over)
       src[0] = out_box[0], src[1] = out_box[1];
     }
-    return fail(SOIL_ERR_HIP, "slab step (migrate): walkers still crossing after maxage + 2 passes");
+    return fail(SOIL_ERR_HIP, "slab step (migrate): walkers still crossing after maxage + 2 passes");  // (the same pass on every rank)
   }
   // Both kinds' immigrants in one pass each round of hand-overs (the paired step): one all-reduce of the four
   // counts, one exchange of up to four transfers per neighbour pair (fluvial before debris on every link),
@@ -430,13 +455,14 @@ struct soil_slab {
     char* const up_d = static_cast<char*>(out_box[0]) + half * kRecBytes;
     char* const down_d = static_cast<char*>(out_box[1]) + half * kRecBytes;
     for (int64_t pass = 0; pass <= max_pass; ++pass) {
-      for (int j = 0; j < 4; ++j)
-        if (counts[j] > half)
-          return fail(SOIL_ERR_OUT_OF_MEMORY, "slab step (migrate): more walkers left the slab in one pass than half a box holds");
-      const int mine[4] = {up >= 0 ? static_cast<int>(counts[0]) : 0, down >= 0 ? static_cast<int>(counts[1]) : 0,
-                           up >= 0 ? static_cast<int>(counts[2]) : 0, down >= 0 ? static_cast<int>(counts[3]) : 0};
+      bool over = false;
+      for (int j = 0; j < 4; ++j) over = over || counts[j] > half;
+      int mine[4] = {up >= 0 ? static_cast<int>(counts[0]) : 0, down >= 0 ? static_cast<int>(counts[1]) : 0,
+                     up >= 0 ? static_cast<int>(counts[2]) : 0, down >= 0 ? static_cast<int>(counts[3]) : 0};
+      if (over) mine[0] = mine[1] = mine[2] = mine[3] = kOverflow;  // every rank fails together (gathered_failure)
       std::vector<int> all;
       SLAB_TRY(all_ints(mine, 4, all));
+      SLAB_TRY(gathered_failure(all, 4));
       int64_t total = 0;
       for (int v : all) total += v;
       if (total == 0) return SOIL_OK;
@@ -445,7 +471,7 @@ struct soil_slab {
       const int64_t in_f_up = up >= 0 ? all[static_cast<size_t>(4 * up + 1)] : 0, in_f_down = down >= 0 ? all[static_cast<size_t>(4 * down)] : 0;
       const int64_t in_d_up = up >= 0 ? all[static_cast<size_t>(4 * up + 3)] : 0, in_d_down = down >= 0 ? all[static_cast<size_t>(4 * down + 2)] : 0;
       const int64_t n_f = in_f_up + in_f_down, n_d = in_d_up + in_d_down;
-      if (n_f + n_d > 2 * box_cap)
+      if (n_f + n_d > 2 * box_cap)  // (cannot happen: each kind's arrivals fit a half box a side)
         return fail(SOIL_ERR_OUT_OF_MEMORY, "slab step (migrate): more walkers arrive than the inbox holds");
       char* const in = static_cast<char*>(inbox);
       std::vector<soil_xfer> sends, recvs;
@@ -501,9 +527,7 @@ struct soil_slab {
       passes += 2;
       SLAB_TRY(ops->to_host(ops->ctx, c, out_count, 16));
       if (mark) mark(mctx, 1);
-      const int64_t half = box_cap / 2;
-      if (c[0] > half || c[1] > half || c[2] > half || c[3] > half)
-        return fail(SOIL_ERR_OUT_OF_MEMORY, "slab step (migrate): more walkers left the slab than half a box holds");
+      const int64_t half = box_cap / 2;  // (an overflow of a half box is reported by all ranks together: migrate_on*)
       // The fluvial leavers lie in the boxes' first halves, the debris ones in the second.  The launches
       // that walk immigrants on write THEIR leavers into the first halves only (cap = half): the debris
       // records stay where they are until their turn.
@@ -957,14 +981,162 @@ void* hip_stream(void* c, int32_t lane) {
 
 namespace {
 
+// ---- a bounded wait for a wire ---------------------------------------------------------------------
+// A transfer that never completes must become an error, not a process that sits until somebody kills
+// it (the driver's one execution of the RCCL point-to-point path hung for 300 s and
+// took the whole GPU test session with it).  WireWatch is a small watchdog thread per communicator:
+// the wire tells it when the calling thread enters / leaves a library call and hands it a completion
+// token (a HIP event recorded behind the operation) for everything it has put on a stream; when a call
+// or a token is older than the timeout the watchdog calls the wire's abort hook (ncclCommAbort: the
+// blocked call returns, the device kernel sees the abort flag and exits, the host's stream waits come
+// back) and every later call on the communicator returns SOIL_ERR_COMM with the description.
+struct WireOp {
+  const char* op = "";
+  int32_t n_sends = 0, n_recvs = 0, peer = -1;
+  int64_t bytes = 0;
+  std::string describe() const {
+    char b[160];
+    std::snprintf(b, sizeof b, "%s (%d sends, %d receives, first peer %d, %lld bytes)", op, n_sends, n_recvs, peer,
+                  static_cast<long long>(bytes));
+    return b;
+  }
+};
+
+class WireWatch {
+ public:
+  using Clock = std::chrono::steady_clock;
+  struct Hooks {
+    std::function<void()> thread_start;        // e.g. hipSetDevice on the watchdog thread
+    std::function<int(void*)> token_state;     // 1 complete, 0 pending, < 0 broken
+    std::function<void(void*)> token_release;  // back to the pool
+    std::function<std::string()> async_error;  // "" while the library is content
+    std::function<void()> abort;               // must make blocked calls and stream work return
+    std::string where;                         // "librccl /path (2.26.6), rank 3 of 8"
+  };
+  WireWatch(double timeout_s, Hooks h) : timeout_(timeout_s), hooks_(std::move(h)) {
+    thread_ = std::thread([this] { run(); });
+  }
+  ~WireWatch() {
+    {
+      std::lock_guard<std::mutex> l(m_);
+      stop_ = true;
+    }
+    cv_.notify_all();
+    if (thread_.joinable()) thread_.join();
+    for (auto& it : pending_) hooks_.token_release(it.token);
+  }
+  // brackets a library call on the calling thread
+  void enter(const WireOp& op) {
+    std::lock_guard<std::mutex> l(m_);
+    in_call_ = true, call_ = op, call_t0_ = Clock::now();
+  }
+  void leave() {
+    std::lock_guard<std::mutex> l(m_);
+    in_call_ = false;
+  }
+  void track(void* token, const WireOp& op) {
+    std::lock_guard<std::mutex> l(m_);
+    pending_.push_back(Item{token, op, Clock::now()});
+  }
+  bool dead() {
+    std::lock_guard<std::mutex> l(m_);
+    return dead_;
+  }
+  std::string error() {
+    std::lock_guard<std::mutex> l(m_);
+    return error_;
+  }
+  // blocks until everything tracked has completed or the watchdog has given up
+  void drain() {
+    std::unique_lock<std::mutex> l(m_);
+    idle_.wait(l, [this] { return dead_ || pending_.empty(); });
+  }
+  double timeout() const { return timeout_; }
+
+ private:
+  struct Item {
+    void* token;
+    WireOp op;
+    Clock::time_point t0;
+  };
+  void give_up(std::unique_lock<std::mutex>& l, const std::string& why) {
+    dead_ = true;
+    error_ = why + " on " + hooks_.where + "; the communicator was aborted";
+    l.unlock();
+    hooks_.abort();  // not under the lock: the blocked caller takes it in leave()
+    l.lock();
+    idle_.notify_all();
+  }
+  void run() {
+    if (hooks_.thread_start) hooks_.thread_start();
+    std::unique_lock<std::mutex> l(m_);
+    while (!stop_) {
+      cv_.wait_for(l, std::chrono::milliseconds(pending_.empty() && !in_call_ ? 100 : 10));
+      if (stop_ || dead_) continue;
+      const auto now = Clock::now();
+      auto age = [&](Clock::time_point t) { return std::chrono::duration<double>(now - t).count(); };
+      while (!pending_.empty()) {
+        const int st = hooks_.token_state(pending_.front().token);
+        if (st == 0) break;
+        if (st < 0) {
+          give_up(l, "the device reported a failure behind " + pending_.front().op.describe());
+          break;
+        }
+        hooks_.token_release(pending_.front().token);
+        pending_.pop_front();
+      }
+      if (dead_) continue;
+      if (pending_.empty()) idle_.notify_all();
+      if (hooks_.async_error) {
+        const std::string e = hooks_.async_error();
+        if (!e.empty()) {
+          give_up(l, "asynchronous error " + e);
+          continue;
+        }
+      }
+      char sec[32];
+      std::snprintf(sec, sizeof sec, "%.1f s", timeout_);
+      if (in_call_ && age(call_t0_) > timeout_)
+        give_up(l, std::string("no return from ") + call_.describe() + " within " + sec + " (SOIL_RCCL_TIMEOUT_S)");
+      else if (!pending_.empty() && age(pending_.front().t0) > timeout_)
+        give_up(l, std::string("no completion of ") + pending_.front().op.describe() + " within " + sec +
+                       " (SOIL_RCCL_TIMEOUT_S)");
+    }
+  }
+  const double timeout_;
+  Hooks hooks_;
+  std::mutex m_;
+  std::condition_variable cv_, idle_;
+  std::deque<Item> pending_;
+  bool in_call_ = false, stop_ = false, dead_ = false;
+  WireOp call_;
+  Clock::time_point call_t0_;
+  std::string error_;
+  std::thread thread_;
+};
+
+double env_seconds(const char* name, double dflt) {
+  if (const char* e = std::getenv(name)) {
+    char* end = nullptr;
+    const double v = std::strtod(e, &end);
+    if (end != e && v > 0) return v;
+  }
+  return dflt;
+}
+
 // The few entry points of rccl.h this file needs, bound at run time.  (ncclUniqueId is 128 bytes,
-// ncclComm_t an opaque pointer; ncclInt8 = 0, ncclFloat32 = 7, ncclSum = 0 — nccl.h's enums.)
+// ncclComm_t an opaque pointer; ncclInt8 = 0, ncclFloat32 = 7, ncclSum = 0, ncclInProgress = 7 —
+// nccl.h's enums.)
 struct Id128 { char bytes[128]; };
 struct Rccl {
   void* lib = nullptr;
+  std::string path;  // the file the symbols came from (dladdr)
+  int version = 0;
   int (*GetUniqueId)(void*) = nullptr;
   int (*CommInitRank)(void**, int, /* ncclUniqueId by value */ Id128, int) = nullptr;
   int (*CommDestroy)(void*) = nullptr;
+  int (*CommAbort)(void*) = nullptr;
+  int (*CommGetAsyncError)(void*, int*) = nullptr;
   int (*GroupStart)() = nullptr;
   int (*GroupEnd)() = nullptr;
   int (*Send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
@@ -980,13 +1152,18 @@ struct Rccl {
 Rccl g_rccl;
 std::mutex g_rccl_mutex;
 
+// Which librccl: SOIL_RCCL_LIB if set; else a copy the process has loaded already (a Python host
+// that imported torch has the wheel's: two RCCLs in one process would each bring their idea of the
+// HIP runtime); else the ROCm installation's librccl.so.1 through the usual search path, which is
+// what a torch-less C++ host gets.  soil_comm_rccl_library() reports the outcome.
 int rccl_load() {
   std::lock_guard<std::mutex> lock(g_rccl_mutex);  // several host threads may make their communicators at once
   if (g_rccl.lib) return SOIL_OK;
   void* h = nullptr;
-  if (const char* e = std::getenv("SOIL_RCCL_LIB")) h = dlopen(e, RTLD_NOW | RTLD_GLOBAL);
-  // a copy the process has loaded already (PyTorch's) before one of our own choosing: two RCCLs
-  // in one process would each bring their idea of the HIP runtime
+  if (const char* e = std::getenv("SOIL_RCCL_LIB")) {
+    h = dlopen(e, RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return fail(SOIL_ERR_INVALID_ARGUMENT, std::string("SOIL_RCCL_LIB: ") + dlerror());
+  }
   for (const char* name : {"librccl.so", "librccl.so.1"})
     if (!h) h = dlopen(name, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
   for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
@@ -999,6 +1176,8 @@ int rccl_load() {
   RCCL_BIND(GetUniqueId, "ncclGetUniqueId");
   RCCL_BIND(CommInitRank, "ncclCommInitRank");
   RCCL_BIND(CommDestroy, "ncclCommDestroy");
+  RCCL_BIND(CommAbort, "ncclCommAbort");
+  RCCL_BIND(CommGetAsyncError, "ncclCommGetAsyncError");
   RCCL_BIND(GroupStart, "ncclGroupStart");
   RCCL_BIND(GroupEnd, "ncclGroupEnd");
   RCCL_BIND(Send, "ncclSend");
@@ -1010,50 +1189,187 @@ int rccl_load() {
   RCCL_BIND(GetErrorString, "ncclGetErrorString");
   RCCL_BIND(GetVersion, "ncclGetVersion");
 #undef RCCL_BIND
+  Dl_info info{};
+  if (dladdr(reinterpret_cast<void*>(g_rccl.GetVersion), &info) && info.dli_fname) g_rccl.path = info.dli_fname;
+  (void)g_rccl.GetVersion(&g_rccl.version);
   g_rccl.lib = h;
   return SOIL_OK;
 }
 
-int rccl_fail(int e, const char* what) {
-  return fail(SOIL_ERR_HIP, std::string("RCCL error ") + std::to_string(e) + " (" +
-                                (g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "?") + ") from " + what);
+std::string rccl_where() {
+  char v[48];
+  std::snprintf(v, sizeof v, " (RCCL/NCCL %d.%d.%d)", g_rccl.version / 10000, g_rccl.version / 100 % 100,
+                g_rccl.version % 100);
+  return "librccl " + (g_rccl.path.empty() ? std::string("?") : g_rccl.path) + v;
 }
+
+int rccl_fail(int e, const char* what) {
+  return fail(SOIL_ERR_COMM, std::string("RCCL error ") + std::to_string(e) + " (" +
+                                 (g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "?") + ") from " + what + " on " +
+                                 rccl_where());
+}
+
+struct RcclCtx {
+  void* comm = nullptr;
+  float* scratch = nullptr;  // barrier
+  int device = 0, rank = 0, world = 1;
+  std::mutex events_mutex;
+  std::vector<hipEvent_t> events;  // pool of completion tokens
+  std::unique_ptr<WireWatch> watch;
+
+  hipEvent_t take_event() {
+    {
+      std::lock_guard<std::mutex> l(events_mutex);
+      if (!events.empty()) {
+        hipEvent_t e = events.back();
+        events.pop_back();
+        return e;
+      }
+    }
+    hipEvent_t e = nullptr;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+      (void)hipGetLastError();
+      return nullptr;
+    }
+    return e;
+  }
+  void give_event(hipEvent_t e) {
+    std::lock_guard<std::mutex> l(events_mutex);
+    events.push_back(e);
+  }
+  int dead_rc() { return fail(SOIL_ERR_COMM, watch->error()); }
+  // the operation just issued on `st`: a token behind it for the watchdog
+  int issued(hipStream_t st, const WireOp& op) {
+    if (hipEvent_t e = take_event()) {
+      if (hipEventRecord(e, st) == hipSuccess) {
+        watch->track(e, op);
+      } else {
+        (void)hipGetLastError();
+        give_event(e);
+      }
+    }
+    return SOIL_OK;
+  }
+};
+
+// every RCCL call of a live communicator: bracketed for the watchdog; a failure after the watchdog has
+// aborted is reported as the timeout it was
+#define SOIL_RCCL_CALL(r, expr)                                        \
+  do {                                                                 \
+    const int rccl_e_ = (expr);                                        \
+    if (rccl_e_ != 0) {                                                \
+      (r).watch->leave();                                              \
+      return (r).watch->dead() ? (r).dead_rc() : rccl_fail(rccl_e_, #expr); \
+    }                                                                  \
+  } while (0)
 #define SOIL_RCCL(expr)                                  \
   do {                                                   \
     const int rccl_e_ = (expr);                          \
     if (rccl_e_ != 0) return rccl_fail(rccl_e_, #expr);  \
   } while (0)
 
-struct RcclCtx {
-  void* comm = nullptr;
-  float* scratch = nullptr;  // barrier
-};
-
 int rccl_exchange(void* c, const soil_xfer* sends, int32_t ns, const soil_xfer* recvs, int32_t nr, void* stream) {
   RcclCtx& r = *static_cast<RcclCtx*>(c);
+  if (r.watch->dead()) return r.dead_rc();
   hipStream_t st = static_cast<hipStream_t>(stream);
-  SOIL_RCCL(g_rccl.GroupStart());
+  WireOp op;
+  op.op = "exchange [ncclGroupStart .. ncclRecv/ncclSend .. ncclGroupEnd]";
+  op.n_sends = ns, op.n_recvs = nr, op.peer = ns ? sends[0].peer : (nr ? recvs[0].peer : -1);
+  for (int i = 0; i < ns; ++i) op.bytes += sends[i].bytes;
+  for (int i = 0; i < nr; ++i) op.bytes += recvs[i].bytes;
+  r.watch->enter(op);
+  SOIL_RCCL_CALL(r, g_rccl.GroupStart());
   for (int i = 0; i < nr; ++i)
-    SOIL_RCCL(g_rccl.Recv(recvs[i].ptr, static_cast<size_t>(recvs[i].bytes), 0 /* ncclInt8 */, recvs[i].peer, r.comm, st));
+    SOIL_RCCL_CALL(r, g_rccl.Recv(recvs[i].ptr, static_cast<size_t>(recvs[i].bytes), 0 /* ncclInt8 */, recvs[i].peer,
+                                  r.comm, st));
   for (int i = 0; i < ns; ++i)
-    SOIL_RCCL(g_rccl.Send(sends[i].ptr, static_cast<size_t>(sends[i].bytes), 0, sends[i].peer, r.comm, st));
-  SOIL_RCCL(g_rccl.GroupEnd());
-  return SOIL_OK;
+    SOIL_RCCL_CALL(r, g_rccl.Send(sends[i].ptr, static_cast<size_t>(sends[i].bytes), 0, sends[i].peer, r.comm, st));
+  SOIL_RCCL_CALL(r, g_rccl.GroupEnd());
+  r.watch->leave();
+  if (r.watch->dead()) return r.dead_rc();
+  return r.issued(st, op);
 }
 int rccl_all_reduce(void* c, float* buf, int64_t n, void* stream) {
   RcclCtx& r = *static_cast<RcclCtx*>(c);
-  SOIL_RCCL(g_rccl.AllReduce(buf, buf, static_cast<size_t>(n), 7 /* ncclFloat32 */, 0 /* ncclSum */, r.comm,
-                             static_cast<hipStream_t>(stream)));
-  return SOIL_OK;
+  if (r.watch->dead()) return r.dead_rc();
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  WireOp op;
+  op.op = "all_reduce_sum_f32 [ncclAllReduce]", op.bytes = n * 4;
+  r.watch->enter(op);
+  SOIL_RCCL_CALL(r, g_rccl.AllReduce(buf, buf, static_cast<size_t>(n), 7 /* ncclFloat32 */, 0 /* ncclSum */, r.comm, st));
+  r.watch->leave();
+  if (r.watch->dead()) return r.dead_rc();
+  return r.issued(st, op);
 }
 int rccl_barrier(void* c) {
   RcclCtx& r = *static_cast<RcclCtx*>(c);
+  if (r.watch->dead()) return r.dead_rc();
   // every rank's own device work first (the runner's streams are non-blocking: the null stream does not
   // wait for them), then the collective: past the barrier all ranks' earlier work is done
   SOIL_HIP(hipDeviceSynchronize());
-  SOIL_RCCL(g_rccl.AllReduce(r.scratch, r.scratch, 1, 7, 0, r.comm, nullptr));
-  SOIL_HIP(hipStreamSynchronize(nullptr));
+  WireOp op;
+  op.op = "barrier [ncclAllReduce of one word]", op.bytes = 4;
+  r.watch->enter(op);
+  SOIL_RCCL_CALL(r, g_rccl.AllReduce(r.scratch, r.scratch, 1, 7, 0, r.comm, nullptr));
+  r.watch->leave();
+  r.issued(nullptr, op);
+  // a bounded wait: the watchdog aborts a transfer that does not complete, which ends the kernel
+  for (;;) {
+    const hipError_t q = hipStreamQuery(nullptr);
+    if (q == hipSuccess) break;
+    if (q != hipErrorNotReady) return hip_fail(q, "hipStreamQuery (barrier)", __FILE__, __LINE__);
+    if (r.watch->dead()) return r.dead_rc();
+    std::this_thread::sleep_for(std::chrono::microseconds(20));
+  }
+  if (r.watch->dead()) return r.dead_rc();
   return SOIL_OK;
+}
+// what the runner asks after it has waited for its streams: did the wire give up meanwhile?
+int rccl_status(void* c) {
+  RcclCtx& r = *static_cast<RcclCtx*>(c);
+  return r.watch->dead() ? r.dead_rc() : SOIL_OK;
+}
+
+// ---- a wire that never delivers (tests) ------------------------------------------------------------
+// soil_comm_wedged_create: exchange / all-reduce / barrier block like a transfer whose peer never
+// shows up, under the same watchdog as the RCCL wire; its abort hook releases the blocked caller.
+struct WedgedCtx {
+  std::mutex m;
+  std::condition_variable cv;
+  bool aborted = false;
+  std::unique_ptr<WireWatch> watch;
+  int block(const WireOp& op) {
+    if (watch->dead()) return fail(SOIL_ERR_COMM, watch->error());
+    watch->enter(op);
+    {
+      std::unique_lock<std::mutex> l(m);
+      cv.wait(l, [this] { return aborted; });
+    }
+    watch->leave();
+    return fail(SOIL_ERR_COMM, watch->error());
+  }
+};
+int wedged_exchange(void* c, const soil_xfer* sends, int32_t ns, const soil_xfer* recvs, int32_t nr, void*) {
+  WireOp op;
+  op.op = "exchange [wedged test wire]", op.n_sends = ns, op.n_recvs = nr;
+  op.peer = ns ? sends[0].peer : (nr ? recvs[0].peer : -1);
+  for (int i = 0; i < ns; ++i) op.bytes += sends[i].bytes;
+  for (int i = 0; i < nr; ++i) op.bytes += recvs[i].bytes;
+  return static_cast<WedgedCtx*>(c)->block(op);
+}
+int wedged_all_reduce(void* c, float*, int64_t n, void*) {
+  WireOp op;
+  op.op = "all_reduce_sum_f32 [wedged test wire]", op.bytes = n * 4;
+  return static_cast<WedgedCtx*>(c)->block(op);
+}
+int wedged_barrier(void* c) {
+  WireOp op;
+  op.op = "barrier [wedged test wire]";
+  return static_cast<WedgedCtx*>(c)->block(op);
+}
+int wedged_status(void* c) {
+  WedgedCtx& w = *static_cast<WedgedCtx*>(c);
+  return w.watch->dead() ? fail(SOIL_ERR_COMM, w.watch->error()) : SOIL_OK;
 }
 
 // a world of one: exchanges with oneself are device copies
@@ -1273,7 +1589,8 @@ int soil_slab_create(soil_slab** out, const soil_slab_config* cfg, const soil_pa
 
 int soil_slab_step(soil_slab* slab, soil_slab_mark_fn mark, void* mark_ctx) {
   SOIL_REQUIRE(slab, "slab_step: null runner");
-  return slab->step(mark, mark_ctx);
+  if (int rc = slab->step(mark, mark_ctx); rc != SOIL_OK) return rc;
+  return slab->wire_status();
 }
 
 int soil_slab_plane(soil_slab* slab, const char* name, float** data, int64_t* rows, int64_t* channels) {
@@ -1307,7 +1624,8 @@ int soil_slab_get_info(const soil_slab* s, soil_slab_info* info) {
 
 int soil_slab_sync(soil_slab* slab) {
   SOIL_REQUIRE(slab, "slab_sync: null runner");
-  return slab->ops->sync(slab->ops->ctx);
+  if (int rc = slab->ops->sync(slab->ops->ctx); rc != SOIL_OK) return rc;
+  return slab->wire_status();
 }
 
 int soil_slab_stream(soil_slab* slab, int32_t lane, void** stream) {
@@ -1357,33 +1675,96 @@ int soil_comm_rccl_probe(int32_t* version) {
   return SOIL_OK;
 }
 
+int soil_comm_rccl_library(char* path, int32_t capacity, int32_t* version) {
+  if (int rc = rccl_load(); rc != SOIL_OK) return rc;
+  if (path && capacity > 0) {
+    std::strncpy(path, g_rccl.path.c_str(), static_cast<size_t>(capacity) - 1);
+    path[capacity - 1] = 0;
+  }
+  if (version) *version = g_rccl.version;
+  return SOIL_OK;
+}
+
 int soil_comm_rccl_create(soil_comm** out, const uint8_t id[128], int32_t rank, int32_t world) {
   SOIL_DEVICE();
   SOIL_REQUIRE(out && id && world >= 1 && rank >= 0 && rank < world, "comm_rccl_create: bad argument");
   if (int rc = rccl_load(); rc != SOIL_OK) return rc;
+  int device = 0;
+  SOIL_HIP(hipGetDevice(&device));
+  char who[64];
+  std::snprintf(who, sizeof who, ", rank %d of %d, device %d", rank, world, device);
+  // ncclCommInitRank blocks until every rank of the world has called it; a rank that never shows up
+  // must not hold this one for ever.  There is no communicator to abort yet, so the call runs on a
+  // helper thread that is left behind if it does not return in time (SOIL_RCCL_INIT_TIMEOUT_S, 120 s).
+  struct Init {
+    std::mutex m;
+    std::condition_variable cv;
+    bool done = false;
+    int e = 0;
+    void* comm = nullptr;
+  };
+  auto init = std::make_shared<Init>();
   Id128 uid;
   std::memcpy(uid.bytes, id, 128);
-  RcclCtx* r = new RcclCtx;
-  if (const int e = g_rccl.CommInitRank(&r->comm, world, uid, rank); e != 0) {
-    delete r;
-    return rccl_fail(e, "ncclCommInitRank");
+  std::thread([init, uid, rank, world, device] {
+    void* comm = nullptr;
+    int e = hipSetDevice(device) == hipSuccess ? g_rccl.CommInitRank(&comm, world, uid, rank) : 1 /* ncclUnhandledCudaError */;
+    std::lock_guard<std::mutex> l(init->m);
+    init->done = true, init->e = e, init->comm = comm;
+    init->cv.notify_all();
+  }).detach();
+  const double init_timeout = env_seconds("SOIL_RCCL_INIT_TIMEOUT_S", 120.0);
+  {
+    std::unique_lock<std::mutex> l(init->m);
+    if (!init->cv.wait_for(l, std::chrono::duration<double>(init_timeout), [&] { return init->done; })) {
+      char sec[32];
+      std::snprintf(sec, sizeof sec, "%.1f s", init_timeout);
+      return fail(SOIL_ERR_COMM, std::string("no return from ncclCommInitRank within ") + sec +
+                                     " (SOIL_RCCL_INIT_TIMEOUT_S; is every rank of the world up?) on " + rccl_where() + who);
+    }
   }
+  if (init->e != 0) return rccl_fail(init->e, "ncclCommInitRank");
+  RcclCtx* r = new RcclCtx;
+  r->comm = init->comm, r->device = device, r->rank = rank, r->world = world;
   if (hipMalloc(reinterpret_cast<void**>(&r->scratch), 4) != hipSuccess || hipMemset(r->scratch, 0, 4) != hipSuccess) {
     (void)hipGetLastError();
     (void)g_rccl.CommDestroy(r->comm);
     delete r;
     return fail(SOIL_ERR_OUT_OF_MEMORY, "comm_rccl_create: no device memory for the barrier word");
   }
+  WireWatch::Hooks h;
+  h.where = rccl_where() + who;
+  h.thread_start = [device] { (void)hipSetDevice(device); };
+  h.token_state = [](void* t) {
+    const hipError_t q = hipEventQuery(static_cast<hipEvent_t>(t));
+    if (q == hipSuccess) return 1;
+    (void)hipGetLastError();
+    return q == hipErrorNotReady ? 0 : -1;
+  };
+  h.token_release = [r](void* t) { r->give_event(static_cast<hipEvent_t>(t)); };
+  h.async_error = [r]() -> std::string {
+    int e = 0;
+    if (!r->comm || g_rccl.CommGetAsyncError(r->comm, &e) != 0 || e == 0 || e == 7 /* ncclInProgress */) return "";
+    return std::string(g_rccl.GetErrorString(e)) + " (ncclCommGetAsyncError)";
+  };
+  h.abort = [r] {
+    void* comm = r->comm;
+    r->comm = nullptr;
+    if (comm) (void)g_rccl.CommAbort(comm);
+  };
+  r->watch.reset(new WireWatch(env_seconds("SOIL_RCCL_TIMEOUT_S", 30.0), std::move(h)));
   soil_comm* c = new soil_comm{};
   c->ctx = r, c->rank = rank, c->world = world, c->flags = 0;
   c->exchange = rccl_exchange, c->all_reduce_sum_f32 = rccl_all_reduce, c->barrier = rccl_barrier;
+  c->status = rccl_status;
   *out = c;
   return SOIL_OK;
 }
 
 int soil_comm_rccl_info(const soil_comm* comm, int32_t* count, int32_t* rank, int32_t* device) {
   SOIL_REQUIRE(comm && comm->ctx && g_rccl.lib, "comm_rccl_info: not an RCCL communicator");
-  const RcclCtx& r = *static_cast<const RcclCtx*>(comm->ctx);
+  RcclCtx& r = *static_cast<RcclCtx*>(comm->ctx);
+  if (r.watch->dead()) return r.dead_rc();
   int v = 0;
   if (count) {
     SOIL_RCCL(g_rccl.CommCount(r.comm, &v));
@@ -1404,10 +1785,45 @@ int soil_comm_rccl_destroy(soil_comm* comm) {
   if (!comm) return SOIL_OK;
   RcclCtx* r = static_cast<RcclCtx*>(comm->ctx);
   if (r) {
-    (void)hipDeviceSynchronize();
-    if (r->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(r->comm);
+    r->watch->drain();  // bounded by the watchdog: what is still in flight completes or is aborted
+    const bool dead = r->watch->dead();
+    r->watch.reset();
+    if (!dead) (void)hipDeviceSynchronize();
+    if (!dead && r->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(r->comm);
     (void)hipFree(r->scratch);
+    for (hipEvent_t e : r->events) (void)hipEventDestroy(e);
     delete r;
+  }
+  delete comm;
+  return SOIL_OK;
+}
+
+int soil_comm_wedged_create(soil_comm** out, int32_t rank, int32_t world, double timeout_s) {
+  SOIL_REQUIRE(out && world >= 1 && rank >= 0 && rank < world && timeout_s > 0, "comm_wedged_create: bad argument");
+  WedgedCtx* w = new WedgedCtx;
+  WireWatch::Hooks h;
+  h.where = "the wedged test wire (soil_comm_wedged_create)";
+  h.token_state = [](void*) { return 0; };
+  h.token_release = [](void*) {};
+  h.abort = [w] {
+    std::lock_guard<std::mutex> l(w->m);
+    w->aborted = true;
+    w->cv.notify_all();
+  };
+  w->watch.reset(new WireWatch(timeout_s, std::move(h)));
+  soil_comm* c = new soil_comm{};
+  c->ctx = w, c->rank = rank, c->world = world, c->flags = SOIL_COMM_HOST_ORDERED;
+  c->exchange = wedged_exchange, c->all_reduce_sum_f32 = wedged_all_reduce, c->barrier = wedged_barrier;
+  c->status = wedged_status;
+  *out = c;
+  return SOIL_OK;
+}
+
+int soil_comm_wedged_destroy(soil_comm* comm) {
+  if (!comm) return SOIL_OK;
+  if (WedgedCtx* w = static_cast<WedgedCtx*>(comm->ctx)) {
+    w->watch.reset();
+    delete w;
   }
   delete comm;
   return SOIL_OK;

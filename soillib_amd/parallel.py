@@ -70,6 +70,28 @@ class SelfComm:
             self._c = None
 
 
+class WedgedComm:
+    """A wire whose every operation blocks like a transfer whose peer never shows up, under the
+    library's watchdog (soil_comm_wedged_create): the tests' proof that a dead wire surfaces as
+    CommError within its timeout instead of hanging the host."""
+
+    def __init__(self, rank=0, world=2, timeout_s=1.0):
+        self.rank, self.world = rank, world
+        self._c = C.POINTER(_abi.Comm)()
+        _abi.check(_abi.lib().soil_comm_wedged_create(C.byref(self._c), rank, world, float(timeout_s)))
+
+    def c_comm(self):
+        return self._c
+
+    def describe(self):
+        return {"backend": "wedged (test)", "world_size": self.world}
+
+    def close(self):
+        if self._c:
+            _abi.lib().soil_comm_wedged_destroy(self._c)
+            self._c = None
+
+
 def _dist_env():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 
@@ -84,6 +106,14 @@ def _init_gloo():
             os.environ.setdefault(k, v)
         dist.init_process_group(backend="gloo")
     return dist
+
+
+def rccl_library():
+    """Which librccl the library bound and its version (soil_comm_rccl_library)."""
+    path, v = C.create_string_buffer(1024), C.c_int32()
+    _abi.check(_abi.lib().soil_comm_rccl_library(path, 1024, C.byref(v)))
+    return {"librccl": path.value.decode(), "rccl_version": "%d.%d.%d" % (v.value // 10000, v.value // 100 % 100,
+                                                                          v.value % 100)}
 
 
 class RcclComm:
@@ -138,8 +168,8 @@ class RcclComm:
     def describe(self):
         n, r, d = C.c_int32(), C.c_int32(), C.c_int32()
         _abi.check(_abi.lib().soil_comm_rccl_info(self._c, C.byref(n), C.byref(r), C.byref(d)))
-        return {"backend": "rccl (libsoil_hip: ncclSend/ncclRecv groups)", "world_size": int(n.value),
-                "rank": int(r.value), "device": int(d.value)}
+        return dict(rccl_library(), backend="rccl (libsoil_hip: ncclSend/ncclRecv groups)",
+                    world_size=int(n.value), rank=int(r.value), device=int(d.value))
 
     def close(self, keep_group=False):
         if self._c:

@@ -47,7 +47,7 @@ def test_struct_layouts_match_the_header():
     assert ctypes.sizeof(_abi.Domain) == 48
     assert ctypes.sizeof(_abi.ErosionPlanes) == 15 * 8
     assert ctypes.sizeof(_abi.NoiseParam) == 28
-    assert ctypes.sizeof(_abi.Xfer) == 24 and ctypes.sizeof(_abi.Comm) == 48
+    assert ctypes.sizeof(_abi.Xfer) == 24 and ctypes.sizeof(_abi.Comm) == 56
     assert ctypes.sizeof(_abi.SlabOps) == 8 * 20 and ctypes.sizeof(_abi.SlabConfig) == 80   # (static_assert in slab_runner.hip)
     assert ctypes.sizeof(_abi.SlabInfo) == 9 * 8 + 8 + 16 + 4 * 8 + 16 + 8 + 2 * 8 + 2 * 8 + 8 == 192
     from oracle import pyoracle

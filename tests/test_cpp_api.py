@@ -13,34 +13,77 @@ def _build(tmp, name="test_cpp_api"):
     assert os.path.exists(_abi.LIB_PATH), "build libsoil_hip.so first"
     exe = os.path.join(str(tmp), name)
     libdir = os.path.dirname(_abi.LIB_PATH)
-    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"),
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-pthread", "-I", os.path.join(ROOT, "include"),
                            os.path.join(ROOT, "tests", "cpp", name + ".cpp"), "-o", exe,
                            "-L", libdir, "-lsoil_hip", "-Wl,-rpath," + libdir,
                            "-Wl,-rpath,/opt/rocm/lib"])
     return exe
 
 
+def _run(cmd, timeout, env=None):
+    """Runs a test binary; on expiry the child is killed and what it printed so far (line-buffered
+    MARK lines, tests/cpp/watchdog.hpp) is IN the failure message — a hang names its place."""
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env)
+    try:
+        out, _ = proc.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        proc.kill()
+        out, _ = proc.communicate()
+        pytest.fail("%s did not finish in %d s; output so far:\n%s" % (os.path.basename(cmd[0]), timeout, out[-6000:]))
+    return proc.returncode, out
+
+
 def test_cpp_mirror_compiles_and_refuses_without_device(tmp_path):
-    exe = _build(tmp_path)
-    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
-    assert out.returncode == 0, out.stdout + out.stderr
-    assert "NO_DEVICE_OK" in out.stdout or "CPP_API_OK" in out.stdout
+    from soillib_amd import _abi
+    if _abi.lib().soil_device_count() > 0:
+        pytest.skip("a HIP device is visible: test_cpp_mirror_on_gpu runs the same binary")
+    rc, out = _run([_build(tmp_path)], 120)
+    assert rc == 0 and "NO_DEVICE_OK" in out, out
 
 
 @pytest.mark.gpu
 def test_cpp_mirror_on_gpu(tmp_path):
-    exe = _build(tmp_path)
-    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
-    assert out.returncode == 0 and "CPP_API_OK" in out.stdout, out.stdout + out.stderr
-    # the grouped ncclSend / ncclRecv path on the real RCCL (a one-rank communicator exchanging with itself)
-    rccl = [l for l in out.stdout.splitlines() if l.startswith("RCCL_SELF")]
-    assert rccl and rccl[0].split()[2] == "1", out.stdout
+    rc, out = _run([_build(tmp_path)], 90)   # the binary's own watchdog ends it after 60 s
+    assert rc == 0 and "CPP_API_OK" in out, out
+    _check_against_python_binding(out, ("SLAB0",))
+
+
+@pytest.mark.gpu
+def test_cpp_rccl_wire_on_gpu(tmp_path):
+    """The RCCL wire from a bare, torch-less C++ process: slab runner over a
+    one-rank communicator, 65.5 MB self-exchange, grouped transfers, all-reduce.  Its own test and
+    its own short budget: the round-5 hang of this block took the whole session with it."""
+    # the library's own bounded waits first (WireWatch: a transfer that does not complete is aborted and
+    # reported), then the binary's watchdog (75 s), then this wrapper (100 s): whichever fires names the place
+    env = dict(os.environ, SOIL_RCCL_TIMEOUT_S="15", SOIL_RCCL_INIT_TIMEOUT_S="30", NCCL_DEBUG="WARN")
+    rc, out = _run([_build(tmp_path, "test_cpp_rccl")], 100, env=env)
+    if rc != 0 and "no return from ncclCommInitRank" in out:
+        pytest.skip("RCCL cannot bootstrap a one-rank communicator on this box (the wire itself was not reached):\n"
+                    + out[-3000:])
+    assert rc == 0 and "CPP_RCCL_OK" in out, out
+    if "EXIT_HUNG" in out:
+        print("WARNING: every check passed, but the process did not get through the ROCm libraries' exit handlers")
+    lib = [l for l in out.splitlines() if l.startswith("RCCL_LIB")]
+    assert lib and "librccl" in lib[0], out
+    rccl = [l for l in out.splitlines() if l.startswith("RCCL_SELF")]
+    assert rccl and rccl[0].split()[2] == "1", out
+    assert "RCCL_GROUP ok" in out and "RCCL_REDUCE ok" in out
+    print(lib[0])
     print(rccl[0])
+    # the runner over RCCL walked the walks of the one-rank wire's runner in test_cpp_api
+    rc0, out0 = _run([_build(tmp_path)], 90)
+    assert rc0 == 0, out0
+    s0 = [l for l in out0.splitlines() if l.startswith("SLAB0")][0].split()
+    s1 = [l for l in out.splitlines() if l.startswith("SLAB1")][0].split()
+    assert int(s0[1]) == int(s1[1]) and abs(float(s0[2]) - float(s1[2])) <= 1e-6 * abs(float(s0[2]))
+
+
+def _check_against_python_binding(stdout, slab_tags):
     # the same three steps through the Python binding of the same step driver (legacy soil.erode)
     import numpy as np
     import soillib as soil
     from soillib_amd import silt
-    line = [l for l in out.stdout.splitlines() if l.startswith("ERODE3")][0].split()
+    line = [l for l in stdout.splitlines() if l.startswith("ERODE3")][0].split()
     S = 96
     q = soil.noise_t()
     q.seed = 3.0
@@ -71,15 +114,13 @@ def test_cpp_mirror_on_gpu(tmp_path):
     assert abs(d - float(line[3])) <= 1e-4 * abs(d)
     # the slab runner (soil::slab_runner over soil_slab_*): the same grid, parameters and seed as
     # the three soil::erode steps above, hence the same walks and the same terrain
-    for tag in ("SLAB0", "SLAB1"):
-        sl = [l for l in out.stdout.splitlines() if l.startswith(tag)][0].split()
+    for tag in slab_tags:
+        sl = [l for l in stdout.splitlines() if l.startswith(tag)][0].split()
         assert int(sl[1]) == int(line[1])
         assert abs(float(sl[2]) - float(line[2])) <= 1e-6 * abs(h) + 1e-6
 
 
 def test_cpp_io_roundtrip(tmp_path):
     """soil::io::tiff / geotiff of soil.hpp: host-only, runs without a GPU."""
-    exe = _build(tmp_path, "test_cpp_io")
-    out = subprocess.run([exe, str(tmp_path / "cpp.tiff")], capture_output=True, text=True,
-                         timeout=120)
-    assert out.returncode == 0 and "CPP_IO_OK" in out.stdout, out.stdout + out.stderr
+    rc, out = _run([_build(tmp_path, "test_cpp_io"), str(tmp_path / "cpp.tiff")], 120)
+    assert rc == 0 and "CPP_IO_OK" in out, out

@@ -188,3 +188,33 @@ def test_migrate_mode_is_refused_by_a_back_end_that_cannot_hand_walkers_over():
         SlabRunner(rows_per_rank=32, W=32, param=p, comm=SelfComm(), ops=CallbackOps(NoPass()), mode="migrate")
     with pytest.raises(KeyError):
         SlabRunner(rows_per_rank=32, W=32, param=p, comm=SelfComm(), ops=CallbackOps(NoPass()), mode="sideways")
+
+
+def test_a_wire_that_never_delivers_fails_the_runner_within_its_timeout(oracle):
+    """A dead wire must fail, not hang.  soil_comm_wedged_create blocks in
+    every operation like a transfer whose peer never shows up, under the same watchdog as the RCCL
+    communicator (WireWatch, csrc/slab_runner.hip 3): the library's runner — oracle plugged in as
+    back-end — must come back with SOIL_ERR_COMM naming the operation, and stay failed."""
+    import time
+    import parallel_worker as pw
+    from soillib_amd import _abi, parallel
+    param = pw.copy_param(script_param(oracle.default_param()), _abi.Param())
+    param.maxage = 8
+    comm = parallel.WedgedComm(rank=0, world=2, timeout_s=0.5)
+    t0 = time.time()
+    with pytest.raises(_abi.CommError) as e:
+        runner = parallel.SlabRunner(rows_per_rank=24, W=32, param=param, particles_div=8, seed=0,
+                                     ops=parallel.CallbackOps(pw.OracleOps()), comm=comm)
+        for _ in range(2):
+            runner.step()
+    took = time.time() - t0
+    msg = str(e.value)
+    assert "within 0.5 s" in msg and "wedged test wire" in msg and "aborted" in msg, msg
+    assert "bytes" in msg and ("all_reduce_sum_f32" in msg or "exchange" in msg or "barrier" in msg), msg
+    assert took < 10.0, took
+    # the communicator stays dead: the next call fails at once with the same report
+    c = comm.c_comm().contents
+    t1 = time.time()
+    assert c.barrier(c.ctx) == _abi.SOIL_ERR_COMM and c.status(c.ctx) == _abi.SOIL_ERR_COMM
+    assert time.time() - t1 < 0.2 and "within 0.5 s" in _abi.last_error()
+    comm.close()
