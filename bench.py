@@ -206,6 +206,15 @@ def _respawn(n):
     return subprocess.call(cmd, env=env)
 
 
+ARITH_NOTE = {
+    "exact": "IEEE quotients and square root in the particle step (soil_set_particle_arith(0)): the reference "
+             "build's arithmetic, trajectories equal to the oracle's step for step (the mode of the -m gpu parity tests)",
+    "fast": "quotients of the particle step as numerator x v_rcp_f32(denominator), v_sqrt_f32 "
+            "(soil_set_particle_arith(1)): LESS accurate than the reference's own arithmetic; statistical parity "
+            "with the oracle only — plane sums 2e-3, visited cells 0.5 %, step counts 0.5 % (tests/test_fast_particles.py)",
+}
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -229,11 +238,13 @@ def parse_args():
     ap.add_argument("--sequential-particles", action="store_true",
                     help="the two particle launches back to back, each timed by itself")
     ap.add_argument("--particle-arith", choices=("fast", "exact"),
-                    default=os.environ.get("SOIL_BENCH_ARITH", "fast"),
-                    help="arithmetic of the particle step (soil_set_particle_arith): 'fast' = v_rcp_f32 quotients, "
-                         "statistical parity (tests/test_fast_particles.py), the mode of the line's `value`; "
-                         "'exact' = IEEE quotients, the oracle's walks step for step.  A single-GPU run in fast "
-                         "mode also times the exact mode and reports it as `exact_arithmetic`")
+                    default=os.environ.get("SOIL_BENCH_ARITH", "exact"),
+                    help="arithmetic of the particle step (soil_set_particle_arith): 'exact' (default, the mode of "
+                         "the line's `value`) = IEEE quotients and square root as the reference's CUDA build has "
+                         "them (no -use_fast_math, CMakeLists.txt:19), the oracle's walks step for step — the mode "
+                         "of the parity tests; 'fast' = v_rcp_f32 quotients, statistical parity only "
+                         "(tests/test_fast_particles.py).  A single-GPU run also times the OTHER mode for a few "
+                         "steps and reports it as the side block `fast_arithmetic` / `exact_arithmetic`")
     ap.add_argument("--halo-mode", choices=("deep", "migrate"), default=os.environ.get("SOIL_BENCH_HALO_MODE", "deep"),
                     help="multi-GPU runs: how a walk that crosses a slab's edge is served (include/soil_slab.h): "
                          "'deep' halos of ceil(sqrt(2) maxage) + 2 rows trimmed to the measured reach, or 'migrate': a "
@@ -344,6 +355,25 @@ def halo_report(runner):
 
 
 def main():
+    """A wire that fails or times out (SOIL_ERR_COMM: the library aborts a transfer that does not complete
+    within SOIL_RCCL_TIMEOUT_S, include/soil_slab.h) ends the run with ONE JSON line that says so and a
+    non-zero exit code — not a process that sits until the driver kills it."""
+    from soillib_amd import _abi
+    try:
+        _main()
+    except _abi.CommError as e:
+        rank = int(os.environ.get("RANK", "0"))
+        print("[bench rank %d] the wire failed: %s" % (rank, e), file=sys.stderr, flush=True)
+        if rank == 0:
+            args = parse_args()
+            print(json.dumps({"metric": "Mcells/s on %d^2 hydraulic-erosion step" % (args.grid or args.size), "value": None,
+                              "unit": "Mcells/s", "n_gpus": int(os.environ.get("WORLD_SIZE", "1")), "steps": args.steps,
+                              "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True,
+                              "nccl_ranks": {"backend": "TIMEOUT", "error": str(e)}}), flush=True)
+        os._exit(3)   # (an aborted communicator: no orderly teardown of the libraries)
+
+
+def _main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # started by hand or by a driver as plain `python bench.py --gpus N`
@@ -389,17 +419,16 @@ def main():
 
     ev = Events(_abi, 6)
     elapsed, phase, psteps_rank = timed_steps(runner, ev, args.steps, args.warmup, world)
-    exact_block = None
-    if world == 1 and not slabbed and args.particle_arith == "fast" and os.environ.get("SOIL_BENCH_NO_EXACT") != "1":
-        # the same model a few steps on in the exact mode (the parity tests' arithmetic), same harness
-        soil.particle_arith("exact")
+    other_block, other = None, ("fast" if args.particle_arith == "exact" else "exact")
+    if world == 1 and not slabbed and os.environ.get("SOIL_BENCH_NO_OTHER_ARITH", os.environ.get("SOIL_BENCH_NO_EXACT")) != "1":
+        # the same model a few steps on in the other arithmetic, same harness — a side block, never `value`
+        soil.particle_arith(other)
         ke = max(2, min(args.steps, 6))
         e_el, e_ph, e_ps = timed_steps(runner, ev, ke, 1, world)
-        soil.particle_arith("fast")
-        exact_block = {"ms_per_step": e_el / ke * 1e3, "value": H_global * W / (e_el / ke) / 1e6, "unit": "Mcells/s",
+        soil.particle_arith(args.particle_arith)
+        other_block = {"ms_per_step": e_el / ke * 1e3, "value": H_global * W / (e_el / ke) / 1e6, "unit": "Mcells/s",
                        "steps": ke, "warmup": 1, "gparticle_steps_per_s": e_ps / e_el / 1e9,
-                       "note": "IEEE quotients and square root in the particle step: trajectories equal to the "
-                               "oracle's step for step (the mode of the -m gpu parity tests)"}
+                       "note": ARITH_NOTE[other]}
     final = None
     if not slabbed:
         # sanity of the evolved terrain (outside the timed region): no NaN/inf may appear
@@ -488,12 +517,10 @@ def main():
                             "slabs, same harness" % (G, world) if strong_block else ""),
             "grid": [H_global, W], "particles": cells // args.particles_div, "maxage": 256,
             "parallelism": "row-slabs x%d" % world if world > 1 else "single GPU",
-            "particle_arithmetic": (
-                "fast: quotients of the particle step as numerator x v_rcp_f32(denominator), v_sqrt_f32 "
-                "(soil_set_particle_arith(1)); statistical parity with the oracle — plane sums 2e-3, visited "
-                "cells 0.5 %, step counts 0.5 % — tests/test_fast_particles.py; the exact mode is timed beside it "
-                "(`exact_arithmetic`)" if args.particle_arith == "fast" else
-                "exact: IEEE quotients and square root (soil_set_particle_arith(0)), the oracle's walks step for step"),
+            "particle_arithmetic": args.particle_arith + ": " + ARITH_NOTE[args.particle_arith],
+            "arith_vs_reference": ("same as the reference's CUDA build: IEEE division and square root, __expf/__powf "
+                                   "as the fast intrinsics the source names" if args.particle_arith == "exact" else
+                                   "approximate reciprocal; reference is IEEE"),
         },
         "final_state": final,
         "halo": halo,
@@ -525,8 +552,8 @@ def main():
                      "avg_launch_ms": t_cells * 1e3},
     }
     out["roofline_particles"] = proof
-    if exact_block:
-        out["exact_arithmetic"] = exact_block
+    if other_block:
+        out[other + "_arithmetic"] = other_block
     if strong_block:
         out["strong16384"] = strong_block
     if world == 1 and not args.no_cpu_baseline:

@@ -7,13 +7,20 @@
 //             halo (250 rows x 16384 cells x 16 B = 65.5 MB), bytes checked
 //   group     four transfers of unequal sizes in one group, gaps between the destinations untouched
 //   reduce    ncclAllReduce of a world of one
-// Stages named on the command line run alone (diagnosis); none = all.  Every stage prints a marker
+//   absent    (only when named) a world of two whose second rank never shows up: soil_comm_rccl_create
+//             must come back with SOIL_ERR_COMM after SOIL_RCCL_INIT_TIMEOUT_S instead of waiting for ever
+//   stall     (only when named) a transfer that cannot complete — the stream is held by a
+//             hipStreamWaitValue32 in front of it — must be aborted by the library's watchdog after
+//             SOIL_RCCL_TIMEOUT_S: status / the next call return SOIL_ERR_COMM naming the operation
+// Stages named on the command line run alone (diagnosis); none = all but the last two.  Every stage prints a marker
 // first; the watchdog of watchdog.hpp ends a hung binary with the marker it hung in.
 #include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <soil.hpp>
 #include <string>
+
+#include <hip/hip_runtime_api.h>  // the stall stage holds a stream with hipStreamWaitValue32
 
 #include "watchdog.hpp"
 
@@ -37,6 +44,66 @@ int main(int argc, char** argv) {
     int32_t v = 0;
     check(soil_comm_rccl_library(path, sizeof path, &v));
     std::printf("RCCL_LIB %s version %d.%d.%d\n", path, v / 10000, v / 100 % 100, v % 100);
+  }
+  auto named = [&](const char* stage) { return argc >= 2 && want(stage); };
+  if (named("absent")) {
+    mark("absent: ncclCommInitRank of a world of two, alone");
+    const auto id = soil::comm::rccl_unique_id();
+    soil_comm* c = nullptr;
+    const double t0 = since_start();
+    const int rc = soil_comm_rccl_create(&c, id.data(), 0, 2);
+    std::printf("RCCL_ABSENT rc %d after %.1f s: %s\n", rc, since_start() - t0, soil_last_error());
+    EXPECT(rc == SOIL_ERR_COMM && c == nullptr);
+    EXPECT(std::strstr(soil_last_error(), "ncclCommInitRank") && std::strstr(soil_last_error(), "librccl"));
+    std::printf("CPP_RCCL_OK\n");
+    std::fflush(stdout);
+    _exit(0);  // (a helper thread is still inside ncclCommInitRank: no orderly exit from here)
+  }
+  if (named("stall")) {
+    mark("stall: communicator");
+    soil::comm wire = soil::comm::rccl(soil::comm::rccl_unique_id(), 0, 1);
+    const soil_comm* c = wire.get();
+    const size_t bytes = 1 << 20;
+    float *src = nullptr, *dst = nullptr;
+    uint32_t* flag = nullptr;
+    check(soil_malloc(reinterpret_cast<void**>(&src), bytes));
+    check(soil_malloc(reinterpret_cast<void**>(&dst), bytes));
+    check(soil_malloc(reinterpret_cast<void**>(&flag), 64));
+    check(soil_set_f32(reinterpret_cast<float*>(flag), 0.0f, 16, nullptr));
+    check(soil_device_synchronize());
+    hipStream_t held = nullptr, side = nullptr;
+    EXPECT(hipStreamCreateWithFlags(&held, hipStreamNonBlocking) == hipSuccess);
+    EXPECT(hipStreamCreateWithFlags(&side, hipStreamNonBlocking) == hipSuccess);
+    mark("stall: hipStreamWaitValue32 holds the stream");
+    if (hipStreamWaitValue32(held, flag, 1, hipStreamWaitValueGte, 0xffffffffu) != hipSuccess) {
+      std::printf("RCCL_STALL skipped: hipStreamWaitValue32 is not available here\nCPP_RCCL_OK\n");
+      std::fflush(stdout);
+      _exit(0);
+    }
+    mark("stall: exchange behind the held stream");
+    const soil_xfer s{src, int64_t(bytes), 0}, r{dst, int64_t(bytes), 0};
+    EXPECT(c->exchange(c->ctx, &s, 1, &r, 1, held) == SOIL_OK);  // stream-ordered: returns at once
+    const double t0 = since_start();
+    mark("stall: waiting for the watchdog");
+    int st = SOIL_OK;
+    while ((st = c->status(c->ctx)) == SOIL_OK && since_start() - t0 < 20.0)
+      std::this_thread::sleep_for(std::chrono::milliseconds(20));
+    const double took = since_start() - t0;
+    std::printf("RCCL_STALL status %d after %.2f s: %s\n", st, took, soil_last_error());
+    EXPECT(st == SOIL_ERR_COMM);
+    EXPECT(std::strstr(soil_last_error(), "no completion of exchange") && std::strstr(soil_last_error(), "1 sends") &&
+           std::strstr(soil_last_error(), "librccl") && std::strstr(soil_last_error(), "aborted"));
+    mark("stall: the communicator stays failed");
+    EXPECT(c->exchange(c->ctx, &s, 1, &r, 1, held) == SOIL_ERR_COMM);
+    EXPECT(c->all_reduce_sum_f32(c->ctx, dst, 4, held) == SOIL_ERR_COMM);
+    mark("stall: release the stream");
+    const uint32_t one = 1;
+    EXPECT(hipMemcpyAsync(flag, &one, 4, hipMemcpyHostToDevice, side) == hipSuccess);
+    EXPECT(hipStreamSynchronize(side) == hipSuccess);
+    EXPECT(hipStreamSynchronize(held) == hipSuccess);
+    std::printf("CPP_RCCL_OK\n");
+    std::fflush(stdout);
+    _exit(0);  // (the communicator was aborted: leave without the libraries' exit handlers)
   }
   if (want("slab")) {
     mark("slab: unique id");

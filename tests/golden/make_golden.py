@@ -1,6 +1,9 @@
 #!/usr/bin/env python
 """Generates the committed golden fixtures of tests/golden/.  Run in the authoring
-container (where /root/reference exists):  python tests/golden/make_golden.py
+container (where /root/reference exists):  python tests/golden/make_golden.py [--accept key1,key2]
+
+Existing fixtures are NOT overwritten unless every key that would change is named in --accept;
+the script prints max |delta| per moved key (put that table in the commit message).
 
   noise_*.npy        soil.noise heightmaps produced by the REFERENCE's own generator:
                      source/soillib/external/FastNoiseLite.h compiled in place into
@@ -102,21 +105,75 @@ def oracle_small():
     out["blur2"] = o.gaussian_blur(inp["blur_in"], 3.0)
     out["normal"] = o.normal(h, (0.4, 1.7, 3.0))
     meta = dict(H=H, W=W, N=N, scale=np.array(scale, np.float32), rng_seed=11, rng_offset=5)
-    np.savez_compressed(os.path.join(HERE, "oracle_small.npz"),
-                        **{"in_" + k: v for k, v in inp.items()},
-                        **{"out_" + k: v for k, v in out.items()},
-                        **{"meta_" + k: v for k, v in meta.items()})
+    new = {}
+    new.update({"in_" + k: v for k, v in inp.items()})
+    new.update({"out_" + k: v for k, v in out.items()})
+    new.update({"meta_" + k: np.asarray(v) for k, v in meta.items()})
+    return new
+
+
+def diff_report(old, new):
+    """[(key, what)] for every key whose stored array would change (bitwise, NaN == NaN)."""
+    moved = []
+    for k in sorted(set(old) | set(new)):
+        if k not in old:
+            moved.append((k, "new key"))
+        elif k not in new:
+            moved.append((k, "key dropped"))
+        else:
+            a, b = np.asarray(old[k]), np.asarray(new[k])
+            if a.shape != b.shape or a.dtype != b.dtype:
+                moved.append((k, "shape/dtype %s %s -> %s %s" % (a.shape, a.dtype, b.shape, b.dtype)))
+            elif a.tobytes() != b.tobytes():
+                d = np.abs(a.astype(np.float64) - b.astype(np.float64))
+                d = d[np.isfinite(d)]
+                moved.append((k, "max |delta| %.6g over %d of %d elements" % (
+                    d.max() if d.size else float("nan"), int((a != b).sum()), a.size)))
+    return moved
+
+
+def guarded_write(path, new, accept, writer, loader):
+    """Fixture discipline: a fixture that is re-cut whenever a kernel wants a
+    different oracle freezes nothing.  An existing file is only overwritten when every key that would
+    move is named in --accept; the per-key report printed here belongs in the commit message."""
+    if os.path.exists(path):
+        moved = diff_report(loader(path), new)
+        if not moved:
+            print("%s: unchanged" % os.path.basename(path))
+            return True
+        for k, what in moved:
+            print("%s: %-28s %s%s" % (os.path.basename(path), k, what, "" if k in accept else "   <-- NOT accepted"))
+        refused = [k for k, _ in moved if k not in accept]
+        if refused:
+            print("REFUSED: %s would change in %d key(s) not listed in --accept (%s); nothing written"
+                  % (os.path.basename(path), len(refused), ",".join(refused)))
+            return False
+    writer(path, new)
+    print("%s: written" % os.path.basename(path))
+    return True
 
 
 def main():
+    import argparse
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument("--accept", default="", help="comma-separated keys (oracle_small.npz: in_*/out_*/meta_*; a noise "
+                                                 "file: its name) that are allowed to change; everything else must "
+                                                 "reproduce bit for bit or the file is left alone")
+    args = ap.parse_args()
+    accept = set(k for k in args.accept.split(",") if k)
     ref_so = os.path.join(ROOT, "oracle", "_ref", "libfnl_ref.so")
     if not os.path.exists(ref_so):
         raise SystemExit("oracle/_ref/libfnl_ref.so missing: run `make -C oracle ref` where "
                          "/root/reference is mounted")
+    ok = True
     for name, (H, W, kw) in NOISE_CASES.items():
-        np.save(os.path.join(HERE, name + ".npy"), reference_noise(H, W, **kw))
-    oracle_small()
-    print("golden fixtures written to", HERE)
+        ok &= guarded_write(os.path.join(HERE, name + ".npy"), {name: reference_noise(H, W, **kw)}, accept,
+                            lambda p, d: np.save(p, next(iter(d.values()))), lambda p: {name: np.load(p)})
+    ok &= guarded_write(os.path.join(HERE, "oracle_small.npz"), oracle_small(), accept,
+                        lambda p, d: np.savez_compressed(p, **d), lambda p: dict(np.load(p)))
+    if not ok:
+        raise SystemExit(2)
+    print("golden fixtures in", HERE)
 
 
 if __name__ == "__main__":

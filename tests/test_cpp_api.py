@@ -13,10 +13,11 @@ def _build(tmp, name="test_cpp_api"):
     assert os.path.exists(_abi.LIB_PATH), "build libsoil_hip.so first"
     exe = os.path.join(str(tmp), name)
     libdir = os.path.dirname(_abi.LIB_PATH)
+    hip = ["-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__", "-L/opt/rocm/lib", "-lamdhip64"] if name == "test_cpp_rccl" else []
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-pthread", "-I", os.path.join(ROOT, "include"),
                            os.path.join(ROOT, "tests", "cpp", name + ".cpp"), "-o", exe,
                            "-L", libdir, "-lsoil_hip", "-Wl,-rpath," + libdir,
-                           "-Wl,-rpath,/opt/rocm/lib"])
+                           "-Wl,-rpath,/opt/rocm/lib"] + hip)
     return exe
 
 
@@ -76,6 +77,28 @@ def test_cpp_rccl_wire_on_gpu(tmp_path):
     s0 = [l for l in out0.splitlines() if l.startswith("SLAB0")][0].split()
     s1 = [l for l in out.splitlines() if l.startswith("SLAB1")][0].split()
     assert int(s0[1]) == int(s1[1]) and abs(float(s0[2]) - float(s1[2])) <= 1e-6 * abs(float(s0[2]))
+
+
+@pytest.mark.gpu
+def test_rccl_wire_fails_instead_of_hanging(tmp_path):
+    """The bounded waits of the RCCL wire on the real library: a rank that never
+    shows up ends soil_comm_rccl_create with SOIL_ERR_COMM; a transfer that cannot complete (its stream is
+    held) is aborted by the watchdog — ncclCommAbort — and the communicator stays failed, with the
+    operation, the byte count and the librccl file in soil_last_error()."""
+    exe = _build(tmp_path, "test_cpp_rccl")
+    env = dict(os.environ, SOIL_RCCL_INIT_TIMEOUT_S="4", SOIL_RCCL_TIMEOUT_S="2", SOIL_TEST_WATCHDOG_S="50", NCCL_DEBUG="WARN")
+    rc, out = _run([exe, "absent"], 70, env=env)
+    assert rc == 0 and "CPP_RCCL_OK" in out, out
+    line = [l for l in out.splitlines() if l.startswith("RCCL_ABSENT")][0]
+    assert "within 4.0 s" in line and 3.5 < float(line.split()[4]) < 15.0, line
+    print(line)
+    env["SOIL_RCCL_INIT_TIMEOUT_S"] = "45"
+    rc, out = _run([exe, "stall"], 70, env=env)
+    assert rc == 0 and "CPP_RCCL_OK" in out, out
+    line = [l for l in out.splitlines() if l.startswith("RCCL_STALL")][0]
+    if "skipped" not in line:
+        assert "within 2.0 s" in line and 1.5 < float(line.split()[4]) < 12.0, line
+    print(line)
 
 
 def _check_against_python_binding(stdout, slab_tags):
