@@ -218,9 +218,15 @@ ARITH_NOTE = {
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--size", type=int, default=8192, help="rows per GPU and columns")
+    ap.add_argument("--config", choices=("c1", "c2", "c3", "c4"), default="c4",
+                    help="which of BASELINE.json's configs the line is for: c4 (default) = configs[3], the 8192^2 "
+                         "coupled step the metric is quoted on (and configs[4] with --gpus N / --grid); c2 = configs[1], "
+                         "1024^2 x 10 000 steps (example/erosion_gpu.py:75-106), this same step loop; c1 = configs[0], "
+                         "256^2 GeoTIFF -> host normal map; c3 = configs[2], 4096^2 D8 multi-flow accumulation, "
+                         "K = --steps realisations (512) — bench_configs.py.  One JSON line each")
+    ap.add_argument("--steps", type=int, default=None, help="default: 10 (c4), 10000 (c2), 200 (c1), 512 = K (c3)")
+    ap.add_argument("--warmup", type=int, default=None, help="default: 2 (c4), 10 (c2), 5 (c1), 8 (c3)")
+    ap.add_argument("--size", type=int, default=None, help="rows per GPU and columns (8192; c2: 1024; c3: 4096)")
     ap.add_argument("--grid", type=int, default=int(os.environ.get("SOIL_BENCH_GRID", "0")),
                     help="STRONG scaling on a fixed grid x grid domain as the line's `value` "
                          "(BASELINE.json configs[4]: 16384): every rank takes grid/N rows of all "
@@ -251,7 +257,16 @@ def parse_args():
                          "64-row halo, walkers handed over at its far end as 64-byte records")
     ap.add_argument("--particle-mode", type=int, default=0,
                     help="0 auto, 1 direct (reference launch shape), 2 staged — ablation")
-    return ap.parse_args()
+    args = ap.parse_args()
+    args.steps_given, args.warmup_given, args.size_given = args.steps is not None, args.warmup is not None, args.size is not None
+    dflt = {"c4": (10, 2, 8192), "c2": (10000, 10, 1024), "c1": (200, 5, 256), "c3": (512, 8, 4096)}[args.config]
+    if args.steps is None:
+        args.steps = dflt[0]
+    if args.warmup is None:
+        args.warmup = dflt[1]
+    if args.size is None:
+        args.size = dflt[2]
+    return args
 
 
 class _Single:
@@ -375,6 +390,21 @@ def main():
 
 def _main():
     args = parse_args()
+    if args.config in ("c1", "c3"):
+        if args.gpus > 1:
+            raise SystemExit("--config %s is a single-GPU line (c3's realisations shard over ranks: "
+                             "tools/bench_accumulate.py --gpus N)" % args.config)
+        import bench_configs
+        from soillib_amd import _abi
+        if args.config == "c3" or _abi.lib().soil_device_count() > 0:
+            _abi.check(_abi.lib().soil_set_device(int(os.environ.get("SOIL_DEVICE", "0"))))
+        line = (bench_configs.run_c1 if args.config == "c1" else bench_configs.run_c3)(args)
+        try:
+            C.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(line), flush=True)
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # started by hand or by a driver as plain `python bench.py --gpus N`
         raise SystemExit(_respawn(args.gpus))
@@ -509,6 +539,7 @@ def _main():
         "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {
+            "baseline_config": {"c4": "configs[3]" if world == 1 else "configs[3] weak-scaled", "c2": "configs[1]"}.get(args.config),
             "workload": "%dx%d coupled hydraulic+thermal erosion step (fluvial+debris particle "
                         "transport, N=cells/%d, maxage 256, + fused cell phase), OpenSimplex2-FBm "
                         "heightmap, example/erosion_gpu.py parameters%s" % (
