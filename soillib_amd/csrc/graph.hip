@@ -594,80 +594,170 @@ __device__ __forceinline__ const T& word_at(const T* base, IDX i) {
   else
     return base[i];
 }
+// One cell of one round (graph.cu:438-520), `in` -> `out`.  Returns whether the cell has to be looked at
+// again in the next round (it still has donors, or it became final only in `out`).  The cell's count on
+// entry is passed in: the dense rounds read it for every cell, the listed rounds only for their cells.
+template <int K, bool DECAY, typename IDX>
+__device__ __forceinline__ bool rake_cell(const Acc& out, const Acc& in, IDX elem, IDX n, int count) {
+  float value = word_at(in.value, n);  // :440
+  int32_t donors[K];
+  float decays[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {  // :448-468
+    if (k < count) {
+      donors[k] = word_at(in.donor, k * elem + n);
+      decays[k] = DECAY ? word_at(in.decay, k * elem + n) : 1.0f;
+    }
+  }
+  const bool was_final = count == 0;
+  for (int k = 0; k < count; ++k) {  // :471
+    const IDX donor = static_cast<IDX>(donors[k]);
+    const float decay = decays[k];
+    const int dcount = word_at(in.count, donor);  // :476
+    if (dcount <= 0) {                   // :479-487
+      value += DECAY ? decay * word_at(in.value, donor) : word_at(in.value, donor);
+      donors[k] = donors[count - 1];
+      decays[k] = decays[count - 1];
+      donors[count - 1] = -1;
+      decays[count - 1] = 0.0f;
+      count -= 1;
+      k -= 1;
+    } else if (dcount == 1) {  // :490-494
+      value += DECAY ? decay * word_at(in.value, donor) : word_at(in.value, donor);
+      donors[k] = word_at(in.donor, donor);  // slot 0 of the donor
+      if (DECAY) decays[k] = decay * word_at(in.decay, donor);
+    }
+  }
+  word_at(out.value, n) = value;  // :498
+  if (was_final) {       // both buffers hold the final value from here on
+    word_at(out.count, n) = -1;
+    word_at(in.count, n) = -1;
+    return false;
+  }
+  word_at(out.count, n) = count;  // :499
+#pragma unroll
+  for (int k = 0; k < K; ++k) {  // :500-520
+    if (k < count) {
+      word_at(out.donor, k * elem + n) = donors[k];
+      if (DECAY) word_at(out.decay, k * elem + n) = decays[k];
+    }
+  }
+  return true;  // still has donors, or became final only in `out`
+}
+
+// The lists of the listed rounds (round 6) are kept per work-group: work-group b of a round writes the
+// cells it wants looked at again into segment b of the list (`seg` entries: its share of the cells in the
+// dense round that makes the first list, never more afterwards) and their number into fill[b]; work-group
+// b of the next round reads that segment.  ONE counter for the whole list was tried first: an atomic per
+// wave on one address — 262 144 of them in the round that makes the list at 4096^2 — serialises at the
+// memory side: 7.1 ms per accumulation instead of 1.8 (profiles/r06_accumulate/experiments.txt).  The
+// counter of a segment lives in LDS; the entries of a wave stand side by side in the order of its lanes,
+// so the cells of neighbouring lanes stay neighbours in memory.
+template <typename IDX>
+__device__ __forceinline__ void rake_append(bool again, IDX n, uint32_t* __restrict__ segment, uint32_t* s_fill) {
+  const uint64_t m = __ballot(again);
+  if (m == 0) return;
+  const int lane = static_cast<int>(threadIdx.x & 63u), leader = __ffsll(static_cast<long long>(m)) - 1;
+  uint32_t base = 0;
+  if (lane == leader) base = atomicAdd(s_fill, static_cast<uint32_t>(__popcll(m)));
+  base = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(base), leader));
+  if (again) segment[base + static_cast<uint32_t>(__popcll(m & ((1ull << lane) - 1ull)))] = static_cast<uint32_t>(n);
+}
+
+// Control words of the dense rounds of one accumulation (workspace): flags[0..2] = "work left"
+constexpr int kRakeFlags = 4;
+__global__ void k_rake_init(int* __restrict__ flags) {
+  if (threadIdx.x < kRakeFlags) flags[threadIdx.x] = threadIdx.x == 0 ? 1 : 0;
+}
+
 // IDX: uint32_t where K * elem words are under 4 GiB (a uniform base and a 32-bit offset per lane instead
 // of a 64-bit address per lane), int64_t otherwise.
+// `list_out` (round 6): the dense round in front of the listed rounds writes down the cells the next round
+// has to look at (k_rake_list).
 template <int K, bool DECAY, typename IDX>
 __global__ void __launch_bounds__(kGBlock)
-    k_rake_compress(Acc out, const Acc in, int64_t elem64, int* __restrict__ flags, int round) {
+    k_rake_compress(Acc out, const Acc in, int64_t elem64, int* __restrict__ flags, int round,
+                    uint32_t* __restrict__ list_out, uint32_t* __restrict__ fill_out, uint32_t seg) {
   const IDX elem = static_cast<IDX>(elem64);
+  __shared__ uint32_t s_fill;
   // the word round + 2 will read is cleared either way: a round that returns at once must not
   // leave its predecessor's "work left" standing for the round three launches on
   if (blockIdx.x == 0 && threadIdx.x == 0) flags[(round + 2) % 3] = 0;
-  if (flags[round % 3] == 0) return;
+  if (flags[round % 3] == 0) {
+    if (list_out && threadIdx.x == 0) fill_out[blockIdx.x] = 0;  // nothing pending anywhere: empty lists
+    return;
+  }
+  if (list_out) {
+    if (threadIdx.x == 0) s_fill = 0;
+    __syncthreads();
+  }
+  uint32_t* const segment = list_out ? list_out + static_cast<size_t>(blockIdx.x) * seg : nullptr;
   bool pending = false;
   // a grid of a few work-groups per CU strides over the cells: a round that returns at once (11 of
   // the 26 at 4096^2) costs a few us instead of the 15 us it takes to hand out 65 536 work-groups
   for (IDX n = static_cast<IDX>(blockIdx.x) * kGBlock + threadIdx.x; n < elem;
        n += static_cast<IDX>(gridDim.x) * kGBlock) {
-    int count = word_at(in.count, n);  // :441
-    if (count >= 0) {
-      float value = word_at(in.value, n);  // :440
-      int32_t donors[K];
-      float decays[K];
-#pragma unroll
-      for (int k = 0; k < K; ++k) {  // :448-468
-        if (k < count) {
-          donors[k] = word_at(in.donor, k * elem + n);
-          decays[k] = DECAY ? word_at(in.decay, k * elem + n) : 1.0f;
-        }
-      }
-      const bool was_final = count == 0;
-      for (int k = 0; k < count; ++k) {  // :471
-        const IDX donor = static_cast<IDX>(donors[k]);
-        const float decay = decays[k];
-        const int dcount = word_at(in.count, donor);  // :476
-        if (dcount <= 0) {                   // :479-487
-          value += DECAY ? decay * word_at(in.value, donor) : word_at(in.value, donor);
-          donors[k] = donors[count - 1];
-          decays[k] = decays[count - 1];
-          donors[count - 1] = -1;
-          decays[count - 1] = 0.0f;
-          count -= 1;
-          k -= 1;
-        } else if (dcount == 1) {  // :490-494
-          value += DECAY ? decay * word_at(in.value, donor) : word_at(in.value, donor);
-          donors[k] = word_at(in.donor, donor);  // slot 0 of the donor
-          if (DECAY) decays[k] = decay * word_at(in.decay, donor);
-        }
-      }
-      word_at(out.value, n) = value;  // :498
-      if (was_final) {       // both buffers hold the final value from here on
-        word_at(out.count, n) = -1;
-        word_at(in.count, n) = -1;
-      } else {
-        word_at(out.count, n) = count;  // :499
-        pending = true;        // still has donors, or became final only in `out`
-#pragma unroll
-        for (int k = 0; k < K; ++k) {  // :500-520
-          if (k < count) {
-            word_at(out.donor, k * elem + n) = donors[k];
-            if (DECAY) word_at(out.decay, k * elem + n) = decays[k];
-          }
-        }
-      }
-    }
+    const int count = word_at(in.count, n);  // :441
+    bool again = false;
+    if (count >= 0) again = rake_cell<K, DECAY, IDX>(out, in, elem, n, count);
+    pending = pending || again;
+    if (list_out) rake_append<IDX>(again, n, segment, &s_fill);
   }
   if (__any(pending) && (threadIdx.x & 63) == 0) flags[(round + 1) % 3] = 1;
+  if (list_out) {
+    __syncthreads();
+    if (threadIdx.x == 0) fill_out[blockIdx.x] = s_fill;
+  }
 }
+
+// A round over the LISTS of the cells that still change (round 6).  After a handful of rounds a few per
+// cent of the cells are pending — 9 % going into round 6 of a 4096^2 D8 realisation, 0.8 % into round 10
+// (tools/count_rake_bytes.py) — and a dense round still reads the count of every cell: rounds 6-15 cost
+// 0.45 ms of the 1.61 ms of the 26 rounds for 4 bytes per cell each.  A listed round touches its cells
+// only and makes the lists of the next round; a work-group whose segment is empty returns at once.
+template <int K, bool DECAY, typename IDX>
+__global__ void __launch_bounds__(kGBlock)
+    k_rake_list(Acc out, const Acc in, int64_t elem64, const uint32_t* __restrict__ list_in,
+                const uint32_t* __restrict__ fill_in, uint32_t* __restrict__ list_out, uint32_t* __restrict__ fill_out,
+                uint32_t seg) {
+  const IDX elem = static_cast<IDX>(elem64);
+  const uint32_t n_in = fill_in[blockIdx.x];
+  if (n_in == 0) {
+    if (threadIdx.x == 0) fill_out[blockIdx.x] = 0;
+    return;
+  }
+  __shared__ uint32_t s_fill;
+  if (threadIdx.x == 0) s_fill = 0;
+  __syncthreads();
+  const uint32_t* const mine = list_in + static_cast<size_t>(blockIdx.x) * seg;
+  uint32_t* const segment = list_out + static_cast<size_t>(blockIdx.x) * seg;
+  for (uint32_t i = threadIdx.x; i < n_in; i += kGBlock) {
+    const IDX n = static_cast<IDX>(mine[i]);
+    const int count = word_at(in.count, n);  // (>= 0: it is on the list)
+    const bool again = rake_cell<K, DECAY, IDX>(out, in, elem, n, count);
+    rake_append<IDX>(again, n, segment, &s_fill);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) fill_out[blockIdx.x] = s_fill;
+}
+
+// Workspace slots of an accumulation: soil_multiflow keeps two of them going side by side (kAccLanes)
+constexpr int kAccLanes = 2;
+constexpr int kAccSlot[kAccLanes] = {0, 10};
 
 template <int K>
 static int accumulate_impl(float* out, const int32_t* graph, const float* source,
-                           const float* decayIn, int64_t H, int64_t W, hipStream_t st) {
+                           const float* decayIn, int64_t H, int64_t W, hipStream_t st, bool sync = true, int lane = 0) {
   const int64_t elem = H * W;
   auto align = [](size_t b) { return (b + 255) & ~static_cast<size_t>(255); };
   const size_t b1 = align(sizeof(float) * elem), bK = align(sizeof(float) * elem * K);
   void* base = nullptr;
-  int rc = workspace_get(0, 3 * b1 + 4 * bK + 256, &base);
+  static const unsigned rake_groups = [] { const char* e = std::getenv("SOIL_RAKE_GROUPS"); return e && std::atoi(e) > 0 ? static_cast<unsigned>(std::atoi(e)) : 256u * 32u; }();  // 1024 .. 65536 groups: 3.16 3.02 2.68 2.54 2.61 2.99 ms per realisation
+  const unsigned nb = std::min(blocks_for(elem, kGBlock), rake_groups);
+  // a work-group's segment of the lists of the listed rounds: its share of the cells, in whole waves
+  const size_t seg = ((static_cast<size_t>(elem) + nb - 1) / nb + 255) / 256 * 256;
+  const size_t bL = align(sizeof(uint32_t) * seg * nb), bF = align(sizeof(uint32_t) * nb);
+  int rc = workspace_get(kAccSlot[lane], 3 * b1 + 4 * bK + 2 * bL + 2 * bF + 256, &base);
   if (rc != SOIL_OK) return rc;
   char* p = static_cast<char*>(base);
   Acc A, B;
@@ -679,10 +769,12 @@ static int accumulate_impl(float* out, const int32_t* graph, const float* source
   A.decay = reinterpret_cast<float*>(p);   p += bK;
   B.donor = reinterpret_cast<int32_t*>(p); p += bK;
   B.decay = reinterpret_cast<float*>(p);   p += bK;
+  uint32_t* const list[2] = {reinterpret_cast<uint32_t*>(p), reinterpret_cast<uint32_t*>(p + bL)};
+  p += 2 * bL;
+  uint32_t* const fill[2] = {reinterpret_cast<uint32_t*>(p), reinterpret_cast<uint32_t*>(p + bF)};
+  p += 2 * bF;
   int* flags = reinterpret_cast<int*>(p);
 
-  static const unsigned rake_groups = [] { const char* e = std::getenv("SOIL_RAKE_GROUPS"); return e && std::atoi(e) > 0 ? static_cast<unsigned>(std::atoi(e)) : 256u * 32u; }();  // 1024 .. 65536 groups: 3.16 3.02 2.68 2.54 2.61 2.99 ms per realisation
-  const unsigned nb = std::min(blocks_for(elem, kGBlock), rake_groups);
   const bool wide = W % 4 == 0 && W >= 4 &&
                     ((reinterpret_cast<uintptr_t>(graph) | reinterpret_cast<uintptr_t>(source) |
                       reinterpret_cast<uintptr_t>(A.value) | reinterpret_cast<uintptr_t>(A.count)) & 15) == 0;
@@ -714,8 +806,7 @@ static int accumulate_impl(float* out, const int32_t* graph, const float* source
 
   const int64_t iter =
       static_cast<int64_t>(std::ceil(std::log2(static_cast<float>(elem)) / 2.0f));  // :559
-  const int first_flags[3] = {1, 0, 0};
-  SOIL_HIP(hipMemcpyAsync(flags, first_flags, sizeof(first_flags), hipMemcpyHostToDevice, st));
+  k_rake_init<<<1, 64, 0, st>>>(flags);  // flags = {1, 0, 0} (a kernel, not a copy from the host's stack: stream-ordered)
   // (Round 4: a variant with two / four / eight cells in flight per thread and the donors' words asked
   // for in batches — three round trips per group of cells instead of four to six per cell — ran at
   // 2.23-2.32 / 2.38-2.59 / 3.1 ms per 4096^2 realisation against 2.27-2.36 for this kernel: the
@@ -739,21 +830,42 @@ static int accumulate_impl(float* out, const int32_t* graph, const float* source
   // bit-identical and SLOWER: 1.97-2.02 against 1.79-1.80 ms per realisation.  The rounds are not bound by
   // the length of a wave's chain of loads but by the number of its memory requests.)
   const bool idx32 = static_cast<uint64_t>(elem) * K * sizeof(float) < (1ull << 32);
-  for (int64_t i = 0; i <= iter; ++i) {                                             // :560-563
-    for (int r = static_cast<int>(2 * i); r < static_cast<int>(2 * i) + 2; ++r) {
-      const Acc& o = (r & 1) ? A : B;
-      const Acc& in = (r & 1) ? B : A;
+  // Rounds from `list_from` on run over the lists of the cells that still change (k_rake_list); the dense
+  // round in front of them makes the first lists.  SOIL_RAKE_LIST_FROM: that round (0 or beyond the last
+  // round: dense rounds throughout).  4096^2 D8, ms per accumulation: dense throughout 1.84-1.87; from round
+  // 1 / 2 / 3 / 4 / 5 / 6 / 8: 1.52-1.55 / 1.50-1.54 / 1.50-1.54 / 1.52 / 1.55 / 1.60 / 1.70.
+  // The round count is the reference's: 2 (ceil(log2(HW) / 2) + 1).
+  static const int list_from_env = [] { const char* e = std::getenv("SOIL_RAKE_LIST_FROM"); return e ? std::atoi(e) : 2; }();
+  const int rounds = static_cast<int>(2 * (iter + 1));
+  const int list_from = (list_from_env >= 1 && list_from_env < rounds) ? list_from_env : rounds;
+  const uint32_t seg32 = static_cast<uint32_t>(seg);
+  for (int r = 0; r < rounds; ++r) {                                                // :560-563
+    const Acc& o = (r & 1) ? A : B;
+    const Acc& in = (r & 1) ? B : A;
+    if (r >= list_from) {  // work-group b reads segment b of the lists round r - 1 made, and makes segment b of the next
+      const uint32_t *li = list[r & 1], *fi = fill[r & 1];
+      uint32_t *lo = list[(r + 1) & 1], *fo = fill[(r + 1) & 1];
       if (idx32) {
-        if (decayIn) k_rake_compress<K, true, uint32_t><<<nb, kGBlock, 0, st>>>(o, in, elem, flags, r);
-        else k_rake_compress<K, false, uint32_t><<<nb, kGBlock, 0, st>>>(o, in, elem, flags, r);
+        if (decayIn) k_rake_list<K, true, uint32_t><<<nb, kGBlock, 0, st>>>(o, in, elem, li, fi, lo, fo, seg32);
+        else k_rake_list<K, false, uint32_t><<<nb, kGBlock, 0, st>>>(o, in, elem, li, fi, lo, fo, seg32);
       } else {
-        if (decayIn) k_rake_compress<K, true, int64_t><<<nb, kGBlock, 0, st>>>(o, in, elem, flags, r);
-        else k_rake_compress<K, false, int64_t><<<nb, kGBlock, 0, st>>>(o, in, elem, flags, r);
+        if (decayIn) k_rake_list<K, true, int64_t><<<nb, kGBlock, 0, st>>>(o, in, elem, li, fi, lo, fo, seg32);
+        else k_rake_list<K, false, int64_t><<<nb, kGBlock, 0, st>>>(o, in, elem, li, fi, lo, fo, seg32);
       }
+      continue;
+    }
+    uint32_t* lo = r + 1 == list_from ? list[(r + 1) & 1] : nullptr;
+    uint32_t* fo = fill[(r + 1) & 1];
+    if (idx32) {
+      if (decayIn) k_rake_compress<K, true, uint32_t><<<nb, kGBlock, 0, st>>>(o, in, elem, flags, r, lo, fo, seg32);
+      else k_rake_compress<K, false, uint32_t><<<nb, kGBlock, 0, st>>>(o, in, elem, flags, r, lo, fo, seg32);
+    } else {
+      if (decayIn) k_rake_compress<K, true, int64_t><<<nb, kGBlock, 0, st>>>(o, in, elem, flags, r, lo, fo, seg32);
+      else k_rake_compress<K, false, int64_t><<<nb, kGBlock, 0, st>>>(o, in, elem, flags, r, lo, fo, seg32);
     }
   }
   SOIL_LAUNCH_CHECK();
-  SOIL_HIP(hipStreamSynchronize(st));  // cudaDeviceSynchronize, graph.cu:564
+  if (sync) SOIL_HIP(hipStreamSynchronize(st));  // cudaDeviceSynchronize, graph.cu:564
   return SOIL_OK;
 }
 
