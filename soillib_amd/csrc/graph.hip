@@ -977,6 +977,35 @@ int soil_accumulate(float* out, const int32_t* graph, const float* source, const
   }
 }
 
+// soil_multiflow keeps kAccLanes accumulations in flight (round 6).  The realisations are independent
+// (example/dem_multiflow.py:43-49 loops over them) and the later rounds of an accumulation are short
+// kernels over a few thousand cells that leave the chip idle — 0.3 of the 1.5 ms at 4096^2 — so
+// realisation i runs on lane i % kAccLanes, a stream and a workspace of its own, while the caller's
+// stream makes the graphs (a batch ahead) and adds the results into `sum` IN THE ORDER OF k: the
+// float64 sum is the one the script's loop makes.  SOIL_FLOW_LANES=1: one after the other on the
+// caller's stream (A/B).
+struct FlowLanes {
+  int device = -1;
+  hipStream_t lane[kAccLanes] = {};
+  hipEvent_t start = nullptr, graphs[2] = {}, done[kAccLanes] = {}, used[kAccLanes] = {};
+  int ensure() {
+    int dev = 0;
+    SOIL_HIP(hipGetDevice(&dev));
+    if (device == dev) return SOIL_OK;
+    SOIL_REQUIRE(device < 0, "multiflow: a host thread's lanes belong to the device of its first call");
+    for (int j = 0; j < kAccLanes; ++j) {
+      SOIL_HIP(hipStreamCreateWithFlags(&lane[j], hipStreamNonBlocking));
+      SOIL_HIP(hipEventCreateWithFlags(&done[j], hipEventDisableTiming));
+      SOIL_HIP(hipEventCreateWithFlags(&used[j], hipEventDisableTiming));
+    }
+    SOIL_HIP(hipEventCreateWithFlags(&start, hipEventDisableTiming));
+    for (int j = 0; j < 2; ++j) SOIL_HIP(hipEventCreateWithFlags(&graphs[j], hipEventDisableTiming));
+    device = dev;
+    return SOIL_OK;
+  }
+};
+static thread_local FlowLanes t_flow;
+
 int soil_multiflow(double* sum, const float* height, const float* source, int64_t H, int64_t W,
                    int edge, uint64_t seed, uint64_t k_first, uint64_t k_stride, uint64_t k_end,
                    uint64_t K, float T, void* stream) {
@@ -986,36 +1015,81 @@ int soil_multiflow(double* sum, const float* height, const float* source, int64_
   const int64_t elem = H * W;
   auto align = [](size_t b) { return (b + 255) & ~static_cast<size_t>(255); };
   void* base = nullptr;
-  const size_t b_graph = align(sizeof(int32_t) * elem);
-  if (int rc = workspace_get(3, kRwBatch * b_graph + sizeof(float) * elem, &base); rc != SOIL_OK)
+  const size_t b_graph = align(sizeof(int32_t) * elem), b_acc = align(sizeof(float) * elem);
+  // two batches of graphs (the next one is made while the accumulations of this one run) and a result plane per lane
+  if (int rc = workspace_get(3, 2 * kRwBatch * b_graph + kAccLanes * b_acc, &base); rc != SOIL_OK)
     return rc;
   char* ws = static_cast<char*>(base);
-  float* acc = reinterpret_cast<float*>(ws + kRwBatch * b_graph);
+  float* acc[kAccLanes];
+  for (int j = 0; j < kAccLanes; ++j) acc[j] = reinterpret_cast<float*>(ws + 2 * kRwBatch * b_graph + j * b_acc);
   hipStream_t st = as_stream(stream);
   SOIL_REQUIRE(H > 0 && W > 0 && elem <= INT32_MAX, "multiflow: grid must have 1..2^31-1 cells");
   SOIL_REQUIRE(edge == SOIL_D4 || edge == SOIL_D8, "invalid edge enumerator");
+  static const int lanes_env = [] { const char* e = std::getenv("SOIL_FLOW_LANES"); return e ? std::atoi(e) : kAccLanes; }();
+  const bool side_by_side = lanes_env >= 2;
+  if (side_by_side) {
+    if (int rc = t_flow.ensure(); rc != SOIL_OK) return rc;
+    SOIL_HIP(hipEventRecord(t_flow.start, st));  // the lanes start behind what the caller has queued (`sum` zeroed, the DEM made)
+    for (int j = 0; j < kAccLanes; ++j) SOIL_HIP(hipStreamWaitEvent(t_flow.lane[j], t_flow.start, 0));
+  }
   // kRwBatch realisations' graphs per pass over the heights (the weights of a cell are the same for
   // every draw), then one accumulation each
-  for (uint64_t k = k_first; k < k_end;) {
-    RwBatch b{};
+  struct Batch { RwBatch b; int made; };
+  auto make_batch = [&](uint64_t& k, int set) {
+    Batch q{};
     int m = 0;
     for (; m < kRwBatch && k < k_end; ++m, k += k_stride) {
-      b.graph[m] = reinterpret_cast<int32_t*>(ws + m * b_graph);
-      b.offset[m] = k;
+      q.b.graph[m] = reinterpret_cast<int32_t*>(ws + (static_cast<size_t>(set) * kRwBatch + m) * b_graph);
+      q.b.offset[m] = k;
     }
-    const int made = m;
-    b.n = made;
-    if (edge == SOIL_D4)
-      launch_random_weighted<4>(b, height, H, W, seed, T, st);
-    else
-      launch_random_weighted<8>(b, height, H, W, seed, T, st);
+    q.made = m, q.b.n = m;
+    if (m > 0) {
+      if (edge == SOIL_D4)
+        launch_random_weighted<4>(q.b, height, H, W, seed, T, st);
+      else
+        launch_random_weighted<8>(q.b, height, H, W, seed, T, st);
+    }
+    return q;
+  };
+  uint64_t k = k_first;
+  int set = 0;
+  uint64_t index = 0;  // realisations so far: lane = index % kAccLanes
+  bool lane_used[kAccLanes] = {};
+  Batch cur = make_batch(k, set);
+  SOIL_LAUNCH_CHECK();
+  if (side_by_side && cur.made > 0) SOIL_HIP(hipEventRecord(t_flow.graphs[set], st));
+  while (cur.made > 0) {
+    // the graphs of the next batch, into the other set: its last readers — the accumulations of the batch
+    // before this one — have been waited for by the caller's stream (their results are in `sum`)
+    Batch next = make_batch(k, set ^ 1);
     SOIL_LAUNCH_CHECK();
-    for (int j = 0; j < made; ++j) {
-      if (int rc = soil_accumulate(acc, b.graph[j], source, nullptr, H, W, edge, stream); rc != SOIL_OK) return rc;
-      k_mean_add<<<blocks_for(elem, kGBlock), kGBlock, 0, st>>>(sum, acc, static_cast<float>(K), elem);
+    if (side_by_side && next.made > 0) SOIL_HIP(hipEventRecord(t_flow.graphs[set ^ 1], st));
+    for (int j = 0; j < cur.made; ++j, ++index) {
+      const int lane = side_by_side ? static_cast<int>(index % kAccLanes) : 0;
+      hipStream_t ls = side_by_side ? t_flow.lane[lane] : st;
+      if (side_by_side) {
+        SOIL_HIP(hipStreamWaitEvent(ls, t_flow.graphs[set], 0));
+        if (lane_used[lane]) SOIL_HIP(hipStreamWaitEvent(ls, t_flow.used[lane], 0));  // its result plane has been added
+      }
+      // (stream-ordered: the host does not wait for every realisation as soil_accumulate does for its caller)
+      const int rc = edge == SOIL_D4 ? accumulate_impl<4>(acc[lane], cur.b.graph[j], source, nullptr, H, W, ls, false, lane)
+                                     : accumulate_impl<8>(acc[lane], cur.b.graph[j], source, nullptr, H, W, ls, false, lane);
+      if (rc != SOIL_OK) return rc;
+      if (side_by_side) {
+        SOIL_HIP(hipEventRecord(t_flow.done[lane], ls));
+        SOIL_HIP(hipStreamWaitEvent(st, t_flow.done[lane], 0));
+      }
+      k_mean_add<<<blocks_for(elem, kGBlock), kGBlock, 0, st>>>(sum, acc[lane], static_cast<float>(K), elem);
       SOIL_LAUNCH_CHECK();
+      if (side_by_side) {
+        SOIL_HIP(hipEventRecord(t_flow.used[lane], st));
+        lane_used[lane] = true;
+      }
     }
+    cur = next;
+    set ^= 1;
   }
+  SOIL_HIP(hipStreamSynchronize(st));  // like soil_accumulate (graph.cu:564), once: every lane's work is behind it
   return SOIL_OK;
 }
 

@@ -9,7 +9,8 @@ tools/pmc_rake.sh say what the memory system really moved for it.
 
   k_donors4   reads graph (3 rows of it, each word once) 4 and source 4; writes count 4, value 4 and one
               donor slot per edge 4 * edges / cell                                        (decay-free call)
-  a round     every cell reads its count 4.  A cell with count >= 0 reads its value 4 and its `count` donor
+  a round     every cell reads its count 4 (a LISTED round, from --list-from on: only the cells on its lists, and
+              their list entries 4; a cell that has to be looked at again costs a list entry 4 more).  A cell with count >= 0 reads its value 4 and its `count` donor
               slots; per donor it gathers the donor's count 4, then (donor final or single-donor) the donor's
               value 4 and (single-donor) the donor's slot 0 4; it writes value 4 and, if it was final already,
               count in both buffers 8, else count 4 and its remaining slots.
@@ -32,6 +33,7 @@ from oracle import pyoracle as o  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--size", type=int, default=4096)
 ap.add_argument("--k", type=int, default=0, help="the realisation (random_weighted's offset)")
+ap.add_argument("--list-from", type=int, default=2, help="the first listed round (csrc/graph.hip: SOIL_RAKE_LIST_FROM); 0: dense rounds throughout")
 ap.add_argument("--out", default="")
 args = ap.parse_args()
 S = args.size
@@ -63,9 +65,11 @@ for r in range(rounds):
     if not work_left:
         per_round.append(0.0)
         continue
-    b = 4.0 * elem                                        # every cell reads its count
     act = cnt >= 0
     n_act = int(act.sum())
+    listed = args.list_from >= 1 and r >= args.list_from
+    # a dense round: every cell reads its count; a listed one: its cells' list entries and counts
+    b = 8.0 * n_act if listed else 4.0 * elem
     b += 4.0 * n_act + 4.0 * int(cnt[act].sum())          # value + its slots
     new_cnt = cnt.copy()
     new_slots = slots.copy()
@@ -90,6 +94,8 @@ for r in range(rounds):
     b += 8.0 * int(was_final.sum())                         # count = -1 in both buffers
     pend = act & ~was_final
     b += 4.0 * int(pend.sum()) + 4.0 * int(keep[pend].sum())
+    if args.list_from >= 1 and r + 1 >= args.list_from:
+        b += 4.0 * int(pend.sum())                          # the entry on the next round's list
     new_cnt[was_final] = -1
     new_cnt[pend] = keep[pend]
     slots = np.where(pend[None, :], out_slots, slots)
@@ -104,7 +110,7 @@ if args.out:
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
     json.dump({"grid": [S, S], "realisation": args.k, "edges_per_cell": edges / elem,
                "bytes_per_cell_k_donors4": setup, "bytes_per_cell_rounds": per_round,
-               "bytes_per_cell_accumulate": total,
+               "bytes_per_cell_accumulate": total, "list_from": args.list_from,
                "how": "tools/count_rake_bytes.py: distinct words read or written per kernel launch by k_donors4 and the "
                       "k_rake_compress rounds of one decay-free accumulate on realisation %d of the %dx%d D8 "
                       "random_weighted(T=10) graph, counted from the kernel's state machine with numpy" % (args.k, S, S)},
