@@ -2,13 +2,13 @@
 # Collects everything profiles/<name>/ holds, on the GPU box:
 #   gpurun --timeout 2400 -- 'tools/profile_final.sh r04_final'
 # then, back in the container:  python tools/profile_post.py r04_final
-name=${1:-r05_final}
+name=${1:-r06_final}
 out=/root/repo/gpurun_out/$name; rm -rf $out; mkdir -p $out
 cd /tmp; export TMPDIR=/tmp
-# the line as the driver runs it: fast particle arithmetic, the exact mode timed beside it (`exact_arithmetic`)
+# the line as the driver runs it: exact (reference) particle arithmetic, the fast mode timed beside it (`fast_arithmetic`)
 python /root/repo/bench.py --steps 10 --warmup 2 2>/dev/null | tail -1 > $out/bench_line.json
-python /root/repo/bench.py --steps 10 --warmup 2 --no-cpu-baseline --particle-arith exact 2>/dev/null | tail -1 > $out/bench_line_exact.json
-export SOIL_BENCH_NO_EXACT=1   # the profiled passes below: one arithmetic (fast) per process
+python /root/repo/bench.py --steps 10 --warmup 2 --no-cpu-baseline --particle-arith fast 2>/dev/null | tail -1 > $out/bench_line_fast.json
+export SOIL_BENCH_NO_OTHER_ARITH=1   # the profiled passes below: one arithmetic (exact, the default) per process
 # the same step with the two particle launches one after the other: per-launch phase timings, and
 # kernel durations / counters that are not mixed with the other launch's kernels
 python /root/repo/bench.py --steps 10 --warmup 2 --no-cpu-baseline --sequential-particles 2>/dev/null | tail -1 > $out/bench_line_sequential.json
@@ -36,6 +36,10 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $out/stencils -o s -- py
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/accumulate -o s -- python /root/repo/tools/bench_accumulate.py > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/stencils_fetch -o p -- python /root/repo/tools/bench_stencils.py > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/stencils_write -o p -- python /root/repo/tools/bench_stencils.py > /dev/null 2>&1
-python /root/repo/bench.py --size 1024 --steps 10000 --warmup 10 --no-cpu-baseline 2>/dev/null | tail -1 > $out/bench_c2_1024x10000.json
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/accumulate_fetch -o p -- python /root/repo/tools/bench_accumulate.py --k 8 > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/accumulate_write -o p -- python /root/repo/tools/bench_accumulate.py --k 8 > /dev/null 2>&1
+unset SOIL_BENCH_NO_OTHER_ARITH
+# the other BASELINE configs in the driver's line format (bench.py --config)
+for c in c1 c2 c3; do python /root/repo/bench.py --config $c 2>/dev/null | tail -1 > $out/bench_$c.json; done
 # drop the raw per-dispatch tables of the big passes once summarised? (kept: they fit the 64 MiB budget)
 find $out -name "*.csv" | head -40; du -sh $out
