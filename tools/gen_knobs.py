@@ -131,7 +131,7 @@ def scan():
                 if name in ("SOIL_OK",) or name.startswith("SOIL_ERR"):
                     continue
                 sites.setdefault(name, [])
-                where = "%s:%d" % (rel, no)
+                where = rel   # (the file, not the line: the table must not move with every edit)
                 if where not in sites[name]:
                     sites[name].append(where)
     return sites
