@@ -160,7 +160,7 @@ __device__ __forceinline__ int cell32(float f) { return (f != f) ? 0 : static_ca
 
 // Diagnostics build (-DSOIL_ABLATE): parts of the round kernel switched off by a bit mask (timing
 // experiments only — the results are wrong by construction).  SOIL_ABLATE=<mask> in the environment:
-// 1 no queue sections, 2 no deposits, 4 deposits as plain LDS stores, 8 no gather of the cell record
+// 1 no queue sections, 2 no deposits, 4 deposits as plain LDS stores, 8 no gather of the cell record, 16 lost swaps dropped
 #ifdef SOIL_ABLATE
 __device__ int soil_ablate = 0;
 #define ABLATED(bit) ((soil_ablate & (bit)) != 0)
@@ -1418,6 +1418,28 @@ extern "C" int soil_prof_read_prepare(unsigned long long* out, int reset) {  // 
 #define PROF_FLUSH(kind)
 #endif
 
+// Diagnostics build (-DSOIL_STATS, tools/stats_round.py): what the deposits of the dense round kernel meet,
+// counted per wave in scalar registers and added up at the end of the work-group.  Not part of the product build.
+//  [0] wave-iterations  [1] lanes stepping  [2] lanes depositing  [3] -
+//  [4] wave-iterations with a lost swap  [5] lanes that lost  [6] losers that share their cell with another depositing
+//  lane of the wave  [7] depositing lanes that do  [8] distinct cells among the losers, summed  [9] wave-iterations
+//  whose losers all stand on ONE cell  [10] lanes still open after the repeats (native add)
+#ifdef SOIL_STATS
+__device__ unsigned long long soil_stats[2][24];
+#define STATS_DECL unsigned long long st_acc[24] = {0}
+#define STATS_ADD(i, n) st_acc[i] += static_cast<unsigned long long>(n)
+#define STATS_FLUSH(kind) { if ((threadIdx.x & 63u) == 0) for (int i = 0; i < 24; ++i) if (st_acc[i]) atomicAdd(&soil_stats[kind][i], st_acc[i]); }
+extern "C" int soil_stats_read(unsigned long long* out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(soil_stats), sizeof(unsigned long long) * 48) != hipSuccess) return 1;
+  if (reset) { unsigned long long z[48] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(soil_stats), z, sizeof(z)) != hipSuccess) return 1; }
+  return 0;
+}
+#else
+#define STATS_DECL
+#define STATS_ADD(i, n)
+#define STATS_FLUSH(kind)
+#endif
+
 // Waves per SIMD the launch is meant to run with (bounds the register allocation): two
 // work-groups of 768 or three of 512 per CU are 6; the colour shape (1024, one per CU) 4.
 // LDS of one work-group of the round kernel: the flux accumulators of its tile (+ a few words)
@@ -1447,6 +1469,7 @@ __device__ __forceinline__ void pin3(float& a, float& b, float& c) { asm volatil
 #ifndef SOIL_RETRY_TOGETHER
 #define SOIL_RETRY_TOGETHER 1
 #endif
+
 __device__ __forceinline__ bool any_lane(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0; }
 // A value the compiler may not look through.  A ballot wants to be the ballot of a comparison of
 // register values (v_cmp writes the mask); given a predicate that was merged over divergent
@@ -1535,6 +1558,7 @@ __global__ void __launch_bounds__(NT, SPARSE ? 2 : round_waves_per_simd(KIND, TR
     if (ticket == gate_target) __hip_atomic_store(my_dense, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
   PROF_DECL;
+  STATS_DECL;
   // this work-group's share of its tile's queue (the scan's block list)
   uint4 job;
   if (packed) {
@@ -1762,6 +1786,9 @@ __global__ void __launch_bounds__(NT, SPARSE ? 2 : round_waves_per_simd(KIND, TR
     // (inverse ballot: free): the ballot of a combined predicate costs a v_cndmask + v_cmp pair.
     uint64_t runm = __builtin_amdgcn_ballot_w64(have);
     uint32_t ended = 0u;
+#ifdef SOIL_STATS
+    int st_owner = static_cast<int>(threadIdx.x & 63u);
+#endif
     for (;;) {
 #ifdef SOIL_PROF
       ++pt_iters;
@@ -1783,6 +1810,9 @@ __global__ void __launch_bounds__(NT, SPARSE ? 2 : round_waves_per_simd(KIND, TR
       const uint32_t lcell = l_org + __umul24(dr, k.Wu) + dc;
       const uint32_t nind = lcell + k.base;  // global cell: cx * W + cy, :103 / :309
       float v_norm = 1.0f;
+#ifdef SOIL_STATS
+      bool st_dep = false;
+#endif
       if (__builtin_amdgcn_inverse_ballot_w64(stepm)) {
         ++r.iter;
         ++nsteps;
@@ -1798,6 +1828,9 @@ __global__ void __launch_bounds__(NT, SPARSE ? 2 : round_waves_per_simd(KIND, TR
         bool deposit = false;
         if (nind != r.ind && !ABLATED(2)) {    // :104-113 / :310-318
           r.ind = nind;
+#ifdef SOIL_STATS
+          st_dep = true;
+#endif
           // DEP 0: native ds_add_f32, fire and forget; DEP 1: CasDeposit
           float v[kFluxPlanes + 3];
           float* pp[kFluxPlanes + 3];
@@ -1833,7 +1866,8 @@ __global__ void __launch_bounds__(NT, SPARSE ? 2 : round_waves_per_simd(KIND, TR
           geom = step_geom<KIND>(r, k);
         }
         // (round 3: swapping right behind the load, as the debris launch does, times the same — 24.07-24.14 ms
-        // either way at 8192^2)
+        // either way at 8192^2; round 6: nor does issuing the swaps in the middle of the geometry, once the
+        // direction is known — 30.40-30.64 against 30.58-30.91 ms per step, A/B on one box)
         if (KIND == FLUVIAL && deposit) dep.swap_all();          // the swaps' round trip hides under step_apply
         v_norm = geom.v_norm;
         // :121-122 / :326-327: a walk that is over shows in `ended` (a value, not a lane mask merged
@@ -1848,7 +1882,69 @@ __global__ void __launch_bounds__(NT, SPARSE ? 2 : round_waves_per_simd(KIND, TR
         PROF_AT(4);  // the step's arithmetic
       }
       runm &= ~__builtin_amdgcn_ballot_w64(opaque(v_norm) < k.eps);  // ... the same exit, for the wave
-      if (DEP == 1 && !SPARSE) dep.template finish<FAST && SOIL_RETRY_TOGETHER>(opaque(lost_bits), c, agg_min, agg_groups, retries);
+#ifdef SOIL_STATS
+      if (DEP == 1 && !SPARSE) {
+        const bool dep_lane = st_dep;
+        const int skey = dep_lane ? c : ~static_cast<int>(threadIdx.x & 63u);
+        int same = 0;
+        for (int l = 0; l < 64; ++l) same += __builtin_amdgcn_readlane(skey, l) == skey ? 1 : 0;
+        const bool shares = dep_lane && same > 1, lostl = lost_bits != 0u;
+        const uint64_t lm = __builtin_amdgcn_ballot_w64(lostl);
+        STATS_ADD(0, 1);
+        STATS_ADD(1, __popcll(stepm));
+        STATS_ADD(2, __popcll(__builtin_amdgcn_ballot_w64(dep_lane)));
+        STATS_ADD(4, lm != 0 ? 1 : 0);
+        STATS_ADD(5, __popcll(lm));
+        STATS_ADD(6, __popcll(__builtin_amdgcn_ballot_w64(lostl && shares)));
+        STATS_ADD(7, __popcll(__builtin_amdgcn_ballot_w64(shares)));
+        int distinct = 0;
+        for (uint64_t t = lm; t != 0;) {
+          const int c0 = __builtin_amdgcn_readlane(skey, __ffsll(static_cast<long long>(t)) - 1);
+          t &= ~__builtin_amdgcn_ballot_w64(skey == c0);
+          ++distinct;
+        }
+        STATS_ADD(8, distinct);
+        STATS_ADD(9, distinct == 1 ? 1 : 0);
+        // distance to the nearest lower lane that deposits on the same cell: 1 | 2 | 3 | 4-7 | 8-15 | 16+ -> [16..21]
+        int near = 0;
+        const int me = static_cast<int>(threadIdx.x & 63u);
+        for (int l = 0; l < 64; ++l) {
+          const int kl = __builtin_amdgcn_readlane(skey, l);
+          if (l < me && kl == skey) near = me - l;  // the last (highest) such lane below wins
+        }
+        const bool has = dep_lane && near > 0;
+        STATS_ADD(12, __popcll(__builtin_amdgcn_ballot_w64(has && near == 1)));
+        STATS_ADD(13, __popcll(__builtin_amdgcn_ballot_w64(has && near == 2)));
+        STATS_ADD(14, __popcll(__builtin_amdgcn_ballot_w64(has && near == 3)));
+        STATS_ADD(15, __popcll(__builtin_amdgcn_ballot_w64(has && near >= 4 && near < 8)));
+        STATS_ADD(16, __popcll(__builtin_amdgcn_ballot_w64(has && near >= 8 && near < 16)));
+        STATS_ADD(17, __popcll(__builtin_amdgcn_ballot_w64(has && near >= 16)));
+        {  // the star of the iteration before (st_owner: the highest lane that deposited on my cell then) as a
+           // prediction: a lane whose owner deposits on its cell again follows; who of the others still collides?
+          const int ok = __builtin_amdgcn_ds_bpermute(st_owner << 2, skey);
+          const bool st_follow = dep_lane && st_owner != me && ok == skey;
+          const int rkey = (dep_lane && !st_follow) ? c : ~me;  // keys of the lanes that would still swap
+          int rsame = 0, high = me;
+          for (int l = 0; l < 64; ++l) {
+            rsame += __builtin_amdgcn_readlane(rkey, l) == rkey ? 1 : 0;
+            if (__builtin_amdgcn_readlane(skey, l) == skey) high = l;
+          }
+          st_owner = dep_lane ? high : me;
+          const uint64_t still = __builtin_amdgcn_ballot_w64(rsame > 1);
+          STATS_ADD(20, __popcll(__builtin_amdgcn_ballot_w64(st_follow)));   // predicted followers
+          STATS_ADD(21, __popcll(still));                                      // lanes that still share a cell among the swappers
+          STATS_ADD(22, still != 0 ? 1 : 0);                                   // iterations with such lanes
+        }
+        STATS_ADD(18, __popcll(__builtin_amdgcn_ballot_w64(has && near == 1 && (me & 1))));      // ... in its aligned pair
+        STATS_ADD(19, __popcll(__builtin_amdgcn_ballot_w64(has && near <= (me & 3))));           // ... in its aligned quad
+      }
+#endif
+#ifdef SOIL_ABLATE
+      // (32, with 16: the swaps' answers waited for and counted, the losers dropped — the wait apart from the making up)
+      if (DEP == 1 && !SPARSE && ABLATED(32)) nsteps += __popcll(__builtin_amdgcn_ballot_w64(opaque(lost_bits) == 0x12345u));
+#endif
+      if (DEP == 1 && !SPARSE && !ABLATED(16))  // (16: lost swaps dropped — what the lost path costs)
+        dep.template finish<FAST && SOIL_RETRY_TOGETHER>(opaque(lost_bits), c, agg_min, agg_groups, retries);
       PROF_AT(5);  // deposit finished
     }
     const bool run = __builtin_amdgcn_inverse_ballot_w64(runm);
@@ -2163,6 +2259,7 @@ __global__ void __launch_bounds__(NT, SPARSE ? 2 : round_waves_per_simd(KIND, TR
     }
   }
   PROF_FLUSH(KIND);  // [9]: flush of the tile's flux
+  if (!SPARSE) STATS_FLUSH(KIND);
   } while (false);
 
   // The work-group that finishes last scans the queues of the round that follows: no launch of its
