@@ -410,6 +410,22 @@ int soil_set_particle_mode(int mode);
  * SOIL_PARTICLE_DIV=fast in the environment makes 1 the default of the process. */
 int soil_set_particle_arith(int mode);
 int soil_get_particle_arith(void);
+/* Spent debris walkers (tiled shape; the loop of erosion.cu:306-349).  With the reference's example
+ * parameters (example/erosion_gpu.py:75-100) a debris walker's two attenuations underflow to exact zeros
+ * within two steps (decay_d ~ -1e18, decay_v ~ 1e10) and it walks the rest of its 256 steps adding +-0 to the
+ * flux planes.  A walker for which that is certain — att_v == 0, att_d * source_d == 0, its state finite, and
+ * every cell of the slab checked by the step's pack pass (excessStress finite and negative at debrisHeight =
+ * eps, record finite), launch constants in range: csrc/erosion_particles_tiled.hip, debris_spent — is
+ *   1 = retired (default): its walk ends there.  The flux planes hold the same bits as if it had been
+ *       walked to the end (x + (+-0) = x); soil_particle_steps counts the steps actually walked.
+ *   0 = walked to the end, as the reference does.
+ *   2 = watched: marked, walked on, and every deposit of a marked walker that is not an exact zero (and every
+ *       marked walker that stops qualifying) counted — soil_debris_retire_violations; the tests want 0.
+ * Off in the slab runner's migrate mode (the walker's later cells lie on other ranks) and with colour planes.
+ * SOIL_DEBRIS_RETIRE in the environment sets the default of the process. */
+int soil_set_debris_retire(int mode);
+int soil_get_debris_retire(void);
+int soil_debris_retire_violations(uint64_t* total, int reset, void* stream);
 /* Ghost rows a slab needs on each interior side so that no trajectory can
  * leave it: ceil(sqrt(2) * maxage) + 2 (one __stepsize step moves a particle
  * by at most sqrt(2) cells, erosion_map.cu:61-76). */

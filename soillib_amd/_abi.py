@@ -128,6 +128,9 @@ SIGNATURES = {
                           vp]),
     "soil_set_particle_mode": (cint, [cint]),
     "soil_set_particle_arith": (cint, [cint]),
+    "soil_set_debris_retire": (cint, [cint]),
+    "soil_get_debris_retire": (cint, []),
+    "soil_debris_retire_violations": (cint, [C.POINTER(u64), cint, vp]),
     "soil_get_particle_arith": (cint, []),
     "soil_ghost_rows": (i64, [C.POINTER(Param)]),
     "soil_particle_steps": (cint, [C.POINTER(u64), cint, vp]),

@@ -45,6 +45,15 @@ static int g_particle_arith = [] {
   return (e && (e[0] == 'f' || e[0] == 'F' || e[0] == '1')) ? 1 : 0;
 }();
 bool particle_arith_fast() { return g_particle_arith == 1; }
+// Spent debris walkers (erosion_particles_tiled.hip: debris_spent): 1 (default) they end their walks, 0 every
+// walker is walked to the end as in the reference, 2 they are marked, walked on and watched (tests).
+// SOIL_DEBRIS_RETIRE in the environment sets the default of the process.
+static int g_debris_retire = [] {
+  const char* e = std::getenv("SOIL_DEBRIS_RETIRE");
+  const int v = e ? std::atoi(e) : 1;
+  return (v >= 0 && v <= 2) ? v : 1;
+}();
+int debris_retire_mode() { return g_debris_retire; }
 
 // ---- where a step gets grad(cell) and velocity(cell) from -------------------
 
@@ -607,6 +616,13 @@ int soil_set_particle_arith(int mode) {
   return SOIL_OK;
 }
 int soil_get_particle_arith(void) { return g_particle_arith; }
+
+int soil_set_debris_retire(int mode) {
+  SOIL_REQUIRE(mode >= 0 && mode <= 2, "debris retirement: 0 off, 1 on, 2 watched");
+  g_debris_retire = mode;
+  return SOIL_OK;
+}
+int soil_get_debris_retire(void) { return g_debris_retire; }
 
 int64_t soil_ghost_rows(const soil_param* param) {
   const double travel = 1.41421356237309515 * static_cast<double>(param ? param->maxage : 512);

@@ -127,6 +127,7 @@ struct TiledCtl {
   // them four to a wave (0: one tile per wave throughout)
   uint32_t sparse_tiny[2];
   uint32_t sparse_pair[2];  // ... and in front of those, the ones of 16 .. 31 walkers: two to a wave
+  uint32_t retire;          // debris: spent walkers end their walk (1) / are watched (2), see debris_spent; written by the spawn
 };
 struct ScanRule {  // when the rounds stop (TiledRun::setup)
   uint32_t round, tail, max_round;
@@ -255,6 +256,67 @@ __device__ __forceinline__ StepConst make_const(const Dom& d, Scale3 s, const Pa
   k.base = static_cast<uint32_t>(d.x0 * d.W);
   k.maxage = p.maxage > 0x7fffffffull ? 0x7fffffffu : static_cast<uint32_t>(p.maxage);
   return k;
+}
+
+// ---- spent debris walkers (round 6) ------------------------------------------------------------
+//
+// A debris walker deposits att_v * source_v and att_d * source_d (:310-318).  With the reference's own
+// example parameters (example/erosion_gpu.py: yieldStress 2e6, a debris height of Q * kl * excess ~ 1e-7)
+// the first step's decay_d is ~ -1e18: att_d underflows to zero on the spot, debrisHeight is eps from
+// then on, decay_v = nu + tau / eps ~ 1e10 takes att_v to zero on the next step — and the walker goes
+// on for the rest of its 256 steps adding exact zeros (8192^2: 0.85 G of the launch's steps; the debris
+// launch was a third of the particle phase).  Such a walker is SPENT: nothing it will ever add can change
+// a bit of a flux plane (x + (+-0) = x; the planes start from +0), and it ends its walk here.
+//
+// When is that certain?  A walker at the top of an iteration with
+//     att_v == 0,   att_d * source_d == 0   (so debrisHeight = eps + (+-0) = eps exactly, :331),
+//     position, speed and sources finite
+// keeps all of it on every later step provided that, for every cell it may stand on,
+//     the cell's record is finite and  excessStress = g * (excessSlope - tau_y / eps)  is finite and < 0  (:340)
+// and nu, tau, kdd >= 0 with nu + tau / eps finite:  then shearRate = kdd (:341), decay_d = ds * kdd *
+// excessStress / v_norm <= 0 or -0 (ds >= 0 or -0, v_norm >= eps > 0: no 0 x inf, no NaN), att_d *= exp(decay_d)
+// in [0, 1] stays finite and att_d * source_d stays +-0; decay_v = nu + tau / eps >= 0, att_v *= exp(-dL *
+// decay_v) = 0 x [0, 1] = 0 (:346); w = 1 / (1 + dL * decay) in (0, 1], the speed and the position stay finite
+// (:335, :347).  The per-cell condition is checked by the pack pass on every cell of the slab with the
+// step's own expression (`debris_cell_bad`; one word, set when a cell fails: then nobody retires in this
+// launch), the launch constants on the host (TiledRun::setup), the walker's own state by `debris_spent`.
+// A NaN walker (reference quirks) never qualifies.  soil_set_debris_retire(0) walks every walker
+// to the end as the reference does (same planes, bit for bit up to the order of the additions);
+// mode 2 marks spent walkers (PRec::a2), walks them on and counts every deposit that is not an exact zero
+// and every marked walker that stops qualifying (soil_debris_retire_violations: the tests want 0).
+__device__ unsigned long long soil_retire_violations_dev = 0;
+#ifdef SOIL_RETIRE_DEBUG
+__device__ float soil_retire_dbg[16];
+__device__ int soil_retire_dbg_taken = 0;
+__device__ __forceinline__ void retire_dbg(const PRec& r, float kind) {
+  if (atomicAdd(&soil_retire_dbg_taken, 1) == 0) {
+    float* o = soil_retire_dbg;
+    o[0] = kind, o[1] = r.px, o[2] = r.py, o[3] = r.spx, o[4] = r.spy, o[5] = r.a0, o[6] = r.a1, o[7] = r.a2, o[8] = r.s0;
+    o[9] = r.svx, o[10] = r.svy, o[11] = static_cast<float>(r.iter);
+  }
+}
+extern "C" int soil_retire_dbg_read(float* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(soil_retire_dbg), sizeof(float) * 16) == hipSuccess ? 0 : 1;
+}
+#define RETIRE_DBG(r, k) retire_dbg(r, k)
+#else
+#define RETIRE_DBG(r, k)
+#endif
+__device__ __forceinline__ bool debris_cell_bad(const float4 qd, const Param& param) {
+  const float es = param.gravity * (qd.z - param.yieldStress / 1E-12f);  // :340 with debrisHeight = eps
+  const float t = (qd.x - qd.x) + (qd.y - qd.y) + (es - es);             // 0 iff all three are finite
+  return !(es < 0.0f) || !(t == 0.0f);
+}
+__device__ __forceinline__ bool debris_spent(const PRec& r) {
+  if (!(r.a1 == 0.0f && r.a0 * r.s0 == 0.0f)) return false;
+  const float t = ((r.px - r.px) + (r.py - r.py)) + ((r.spx - r.spx) + (r.spy - r.spy)) +
+                  ((r.svx - r.svx) + (r.svy - r.svy)) + ((r.s0 - r.s0) + (r.a0 - r.a0));
+  return t == 0.0f && r.a0 >= 0.0f;
+}
+static bool debris_params_allow_retire(const Param& p) {
+  auto ok = [](float v, float hi) { return v >= 0.0f && v <= hi; };
+  return ok(p.viscosityDebris, 1.0e30f) && ok(p.bedShearDebris, 1.0e25f) && ok(p.depositionRateDebris, 1.0e30f) &&
+         (p.gravity - p.gravity) == 0.0f && (p.yieldStress - p.yieldStress) == 0.0f;
 }
 
 // The body of one loop iteration AFTER the bookkeeping at its top (oob, ++iter,
@@ -500,10 +562,11 @@ template <int KIND>
 __global__ void __launch_bounds__(256)
     k_tiled_pack(float4* __restrict__ q4, const float2* __restrict__ layers,
                  const float2* __restrict__ velocity, const float* __restrict__ waterHeight,
-                 Dom d, Scale3 s, Param param, int64_t row_lo, int64_t row_end) {
+                 Dom d, Scale3 s, Param param, int64_t row_lo, int64_t row_end, uint32_t* __restrict__ debris_bad) {
   // threads along the row, a work-group walks a band of rows (common.hpp: grid_rows)
   const int64_t y = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
   if (y >= d.W) return;
+  bool bad = false;
   SOIL_ROW_LOOP(band, row_end - row_lo) {
   const int64_t lx = row_lo + band;
   const int64_t l = lx * d.W + y;
@@ -521,10 +584,13 @@ __global__ void __launch_bounds__(256)
                         0.125f * fD / (eps + waterHeight[l]), power);
   } else {
     const float nu = param.viscosityDebris;
-    q4[l] = make_float4(-(g * grad.x) + nu * vel.x, -(g * grad.y) + nu * vel.y,
-                        length2(grad.x, grad.y) - param.critSlopeBedrock, 0.0f);
+    const float4 qd = make_float4(-(g * grad.x) + nu * vel.x, -(g * grad.y) + nu * vel.y,
+                                  length2(grad.x, grad.y) - param.critSlopeBedrock, 0.0f);
+    q4[l] = qd;
+    bad = bad || debris_cell_bad(qd, param);
   }
   }
+  if (KIND == DEBRIS && debris_bad && bad) atomicOr(debris_bad, 1u);
 }
 
 // Both launches of a step walk the same layers: one pass evaluates __glocal once per cell and
@@ -533,9 +599,10 @@ __global__ void __launch_bounds__(256)
     k_tiled_pack_pair(float4* __restrict__ q_fluvial, float4* __restrict__ q_debris,
                       const float2* __restrict__ layers, const float2* __restrict__ velocity,
                       const float* __restrict__ waterHeight, const float2* __restrict__ debrisVelocity,
-                      Dom d, Scale3 s, Param param, int64_t row_lo, int64_t row_end) {
+                      Dom d, Scale3 s, Param param, int64_t row_lo, int64_t row_end, uint32_t* __restrict__ debris_bad) {
   const int64_t y = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
   if (y >= d.W) return;
+  bool bad = false;
   SOIL_ROW_LOOP(band, row_end - row_lo) {
   const int64_t lx = row_lo + band;
   const int64_t l = lx * d.W + y;
@@ -555,10 +622,13 @@ __global__ void __launch_bounds__(256)
   }
   {  // the debris record, as k_tiled_pack<DEBRIS>
     const float nu = param.viscosityDebris;
-    q_debris[l] = make_float4(-(g * grad.x) + nu * dvel.x, -(g * grad.y) + nu * dvel.y,
-                              glen - param.critSlopeBedrock, 0.0f);
+    const float4 qd = make_float4(-(g * grad.x) + nu * dvel.x, -(g * grad.y) + nu * dvel.y,
+                                  glen - param.critSlopeBedrock, 0.0f);
+    q_debris[l] = qd;
+    bad = bad || debris_cell_bad(qd, param);
   }
   }
+  if (debris_bad && bad) atomicOr(debris_bad, 1u);
 }
 
 // The pair pass with four cells per thread (round 4; widths that are a multiple of four, 16-byte
@@ -600,8 +670,10 @@ __global__ void __launch_bounds__(kWinBlock)
     k_tiled_pack_pair4(float4* __restrict__ q_fluvial, float4* __restrict__ q_debris,
                        const float2* __restrict__ layers, const float2* __restrict__ velocity,
                        const float* __restrict__ waterHeight, const float2* __restrict__ debrisVelocity,
-                       Dom d, Scale3 s, Param param, int64_t row_lo, int64_t row_end, int band_rows) {
+                       Dom d, Scale3 s, Param param, int64_t row_lo, int64_t row_end, int band_rows,
+                       uint32_t* __restrict__ debris_bad) {
   __shared__ float4 s_tile[kWinBlock / 64][256];
+  bool bad = false;
   const WinThread t = win_thread(d.W);
   const int lane = static_cast<int>(threadIdx.x & 63u);
   float4* const tile = s_tile[threadIdx.x >> 6];
@@ -639,6 +711,7 @@ __global__ void __launch_bounds__(kWinBlock)
         {  // the debris record, as k_tiled_pack<DEBRIS>
           const float nu = param.viscosityDebris;
           qd[c] = make_float4(-(g * grad.x) + nu * dvx[c], -(g * grad.y) + nu * dvy[c], glen - param.critSlopeBedrock, 0.0f);
+          bad = bad || debris_cell_bad(qd[c], param);  // (a lane past the row's end looks at real cells, its clamped group's)
         }
       }
       // 64 bytes per lane and plane -> 1 KiB-contiguous stores through the wave's tile
@@ -665,6 +738,7 @@ __global__ void __launch_bounds__(kWinBlock)
       mid = dn;
     }
   }
+  if (debris_bad && bad) atomicOr(debris_bad, 1u);
 }
 
 // ---- spawn: draws, ownership, trajectory initialisation (erosion.cu:49-96 / :262-302)
@@ -675,9 +749,13 @@ __global__ void __launch_bounds__(256)
                   uint32_t* __restrict__ count, Streams rng, int64_t N, const float4* __restrict__ p4,
                   const float* __restrict__ waterSource, const float* __restrict__ albedoSource,
                   Dom d, Scale3 s, Param param,
-                  int tiles_w, TileShape ts, int steps_per_round, TiledCtl* __restrict__ ctl) {
+                  int tiles_w, TileShape ts, int steps_per_round, TiledCtl* __restrict__ ctl,
+                  const uint32_t* __restrict__ retire_bad, uint32_t retire_mode) {
   const int64_t n = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
-  if (n == 0) ctl->live = static_cast<uint32_t>(N);  // the spawn fills slots 0 .. N-1 (scan 0 turns it into `slots`)
+  if (n == 0) {
+    ctl->live = static_cast<uint32_t>(N);  // the spawn fills slots 0 .. N-1 (scan 0 turns it into `slots`)
+    ctl->retire = (retire_mode != 0u && retire_bad && *retire_bad == 0u) ? retire_mode : 0u;  // (the pack pass is over)
+  }
   if (n >= N) return;
   const bool in_range = true;
   PRec r;
@@ -760,9 +838,13 @@ template <int KIND>
 __global__ void __launch_bounds__(256)
     k_tiled_inject(PRec* __restrict__ recs, uint32_t* __restrict__ dest, uint32_t* __restrict__ rank,
                    uint32_t* __restrict__ count, const PRec* __restrict__ inbox, uint32_t n_in, Dom d, Param param,
-                   int tiles_w, TileShape ts, int steps_per_round, TiledCtl* __restrict__ ctl) {
+                   int tiles_w, TileShape ts, int steps_per_round, TiledCtl* __restrict__ ctl,
+                   const uint32_t* __restrict__ retire_bad, uint32_t retire_mode) {
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-  if (i == 0) ctl->live = n_in;
+  if (i == 0) {
+    ctl->live = n_in;
+    ctl->retire = (retire_mode != 0u && retire_bad && *retire_bad == 0u) ? retire_mode : 0u;
+  }
   if (i >= n_in) return;
   const PRec r = inbox[i];
   const uint32_t maxage = param.maxage > 0x7fffffffull ? 0x7fffffffu : static_cast<uint32_t>(param.maxage);
@@ -1519,6 +1601,7 @@ __global__ void __launch_bounds__(NT, SPARSE ? 2 : round_waves_per_simd(KIND, TR
   }
   static_assert(!SPARSE || (NT == kSparseLanes && !ALB && DEP == 1), "a sparse tile: one wave, no colour planes");
   const uint32_t n_dense = ctl->blocks_of[round & 1u];
+  const uint32_t retire = (KIND == DEBRIS) ? ctl->retire : 0u;  // debris_spent: 1 spent walkers end here, 2 they are watched
   // SPARSE: the last `n_tiny` of the round's sparse tiles hold fewer than 16 walkers and go four to a
   // wave, a quarter of the wave each (`sub`): a wave of 6-14 walkers issues every instruction for 64
   // lanes, and thirty such waves per CU share the vector pipes — the late rounds' sparse kernels were
@@ -1835,6 +1918,10 @@ __global__ void __launch_bounds__(NT, SPARSE ? 2 : round_waves_per_simd(KIND, TR
           float v[kFluxPlanes + 3];
           float* pp[kFluxPlanes + 3];
           deposit_terms(c, v, pp);
+          if (KIND == DEBRIS && retire == 2u && r.a2 != 0.0f && !(v[0] == 0.0f && v[1] == 0.0f && v[2] == 0.0f)) {
+            atomicAdd(&soil_retire_violations_dev, 1ull);  // a marked walker added something: must not happen
+            RETIRE_DBG(r, 3.0f);
+          }
           if constexpr (SPARSE) sparse_deposit(c, lcell, v);
 #pragma unroll
           for (int j = 0; j < kFluxPlanes + (ALB ? 3 : 0); ++j) {
@@ -1879,6 +1966,29 @@ __global__ void __launch_bounds__(NT, SPARSE ? 2 : round_waves_per_simd(KIND, TR
           ended |= step_apply<KIND>(r, q, k, geom) ? 0u : 1u;
         }
         if (deposit) lost_bits = dep.lost_bits();                // the swaps' answers, only now
+        if (KIND == DEBRIS && retire != 0u) {
+          // a spent walker (debris_spent) has nothing left to add: its walk ends at the top of the next
+          // iteration — like the `v_norm < eps` exit, it just is not taken up again
+          // (a walk that has just ended — v_norm < eps — computed on regardless, step_apply: its record may
+          // hold anything and is dropped)
+          const bool walks_on = !(v_norm < k.eps);
+          const bool maybe = walks_on && r.a1 == 0.0f && r.a0 * r.s0 == 0.0f;
+          if (any_lane(maybe)) {
+            const bool spent = maybe && debris_spent(r);
+            if (retire == 1u) {
+              if (spent) {
+                ended |= 1u;
+                v_norm = 0.0f;  // (leaves `runm` with the lanes whose speed ran out, below)
+              }
+            } else {  // watched
+              if (walks_on && r.a2 != 0.0f && !spent) { atomicAdd(&soil_retire_violations_dev, 1ull); RETIRE_DBG(r, 1.0f); }
+              if (spent) r.a2 = 1.0f;
+            }
+          } else if (retire == 2u && walks_on && r.a2 != 0.0f) {
+            atomicAdd(&soil_retire_violations_dev, 1ull);
+            RETIRE_DBG(r, 2.0f);
+          }
+        }
         PROF_AT(4);  // the step's arithmetic
       }
       runm &= ~__builtin_amdgcn_ballot_w64(opaque(v_norm) < k.eps);  // ... the same exit, for the wave
@@ -2302,6 +2412,7 @@ __global__ void __launch_bounds__(256)
   uint32_t nsteps = 0;
   const StepConst k = make_const<KIND>(d, s, param);
   const int64_t base = static_cast<int64_t>(k.x0) * k.W;
+  const uint32_t retire = (KIND == DEBRIS) ? ctl->retire : 0u;
   // (Round 4: this launch is as long as the longest walk left — 0.74 / 0.80 ms at the end of every
   // 8192^2 step, ~3 us per step of a straggler with 250 steps to go.  Asking for the neighbouring rows'
   // records an iteration ahead, with streaming or with plain loads, changed nothing.  Round 5: nor is it
@@ -2341,6 +2452,8 @@ __global__ void __launch_bounds__(256)
         atomicAdd(&fluxV[2 * l], r.a2 * r.svx);
         atomicAdd(&fluxV[2 * l + 1], r.a2 * r.svy);
       } else {
+        if (retire == 2u && r.a2 != 0.0f && !(r.a0 * r.s0 == 0.0f && r.a1 * r.svx == 0.0f && r.a1 * r.svy == 0.0f))
+          atomicAdd(&soil_retire_violations_dev, 1ull);
         atomicAdd(&flux0[l], r.a0 * r.s0);
         atomicAdd(&fluxV[2 * l], r.a1 * r.svx);
         atomicAdd(&fluxV[2 * l + 1], r.a1 * r.svy);
@@ -2353,6 +2466,15 @@ __global__ void __launch_bounds__(256)
       }
     }
     if (!advance<KIND, FAST>(r, q, k)) break;
+    if (KIND == DEBRIS && retire != 0u) {  // (the round kernel's rule)
+      const bool spent = debris_spent(r);
+      if (retire == 1u) {
+        if (spent) break;
+      } else {
+        if (r.a2 != 0.0f && !spent) { atomicAdd(&soil_retire_violations_dev, 1ull); RETIRE_DBG(r, 4.0f); }
+        if (spent) r.a2 = 1.0f;
+      }
+    }
   }
   atomicAdd(steps, static_cast<unsigned long long>(nsteps));  // one atomic per wave
 }
@@ -2532,6 +2654,8 @@ struct TiledRun {
   uint32_t pair_free_below = 0;          // SOIL_PAIR_FREE (per cent of N): rounds of fewer walkers pass the gate (k_pair_gate)
   int host_lag_us = 0;                   // SOIL_TILED_HOST_LAG_US (tests): the host sleeps that long before every look at a word
   int agg_min = 48, agg_groups = 4, retries = 2;
+  uint32_t* retire_bad = nullptr;  // debris: set by the pack pass when a cell rules retirement out (debris_cell_bad)
+  uint32_t retire_mode = 0;        // debris: soil_set_debris_retire, if the launch constants allow it
   bool fast = false;  // the step in fast arithmetic (soil_set_particle_arith; not with colour planes or native adds)
   MigrateBox box{};                 // where walkers that leave the launch's rows go (null count: dropped, as ever)
   const PRec* inbox = nullptr;      // the launch starts from these records instead of the streams' spawns
@@ -2710,6 +2834,12 @@ struct TiledRun {
     block_list = reinterpret_cast<uint4*>(w);     w += b_blk;
     steps_run = reinterpret_cast<unsigned long long*>(w);
     ctl = reinterpret_cast<TiledCtl*>(w + 64);
+    static_assert(64 + sizeof(TiledCtl) <= 224, "the pack pass's word stands behind the block begin() clears");
+    retire_bad = reinterpret_cast<uint32_t*>(w + 224);
+    // spent debris walkers end their walks (debris_spent).  Not in migrate mode: the walker's later cells lie on
+    // other ranks, whose pack passes this rank's word knows nothing about.  Not with colour planes (never measured).
+    retire_mode = (KIND == DEBRIS && !box.count && !fluxA && debris_params_allow_retire(p))
+                      ? static_cast<uint32_t>(debris_retire_mode()) : 0u;
     rc = step_counter(&steps_global);
     if (rc != SOIL_OK) return rc;
     // pinned word + events, one set per (thread, device, kind): a host thread that moves on to
@@ -2809,21 +2939,24 @@ struct TiledRun {
     if (!ready)
       if (int rc = setup(); rc != SOIL_OK) return rc;
     const int64_t lo = stencil_lo(d), hi = stencil_hi(d);
-    if (hi >= lo && !skip_pack)
+    if (hi >= lo && !skip_pack) {
+      if (KIND == DEBRIS) SOIL_HIP(hipMemsetAsync(retire_bad, 0, sizeof(uint32_t), st));
       k_tiled_pack<KIND><<<grid_rows(hi - lo + 1, d.W, 256), 256, 0, st>>>(
           p4, reinterpret_cast<const float2*>(layers), reinterpret_cast<const float2*>(velocity),
-          waterHeight, d, s, p, lo, hi + 1);
+          waterHeight, d, s, p, lo, hi + 1, KIND == DEBRIS ? retire_bad : nullptr);
+    }
     SOIL_HIP(hipMemsetAsync(count, 0, b_cnt, st));
     // the step counter of the run and, behind it, the device's control block: mode 0, the N spawn
     // slots as what "the round before" left
     SOIL_HIP(hipMemsetAsync(steps_run, 0, 64 + sizeof(TiledCtl), st));
     if (inbox) {
       k_tiled_inject<KIND><<<blocks_for(std::max<int64_t>(n_in, 1), 256), 256, 0, st>>>(
-          cur, dest, rank, count, inbox, n_in, d, p, tiles_w_of(shape_of(0), 0), ts_of(shape_of(0), 0), steps_per_round, ctl);
+          cur, dest, rank, count, inbox, n_in, d, p, tiles_w_of(shape_of(0), 0), ts_of(shape_of(0), 0), steps_per_round, ctl,
+          retire_bad, retire_mode);
     } else {
       k_tiled_spawn<KIND><<<blocks_for(N, 256), 256, 0, st>>>(
           cur, dest, rank, count, rng, N, p4, waterSource, albedoSource, d, s, p, tiles_w_of(shape_of(0), 0),
-          ts_of(shape_of(0), 0), steps_per_round, ctl);
+          ts_of(shape_of(0), 0), steps_per_round, ctl, retire_bad, retire_mode);
     }
     SOIL_LAUNCH_CHECK();
     live_known = inbox ? static_cast<int64_t>(n_in) : N;  // slots of the record array to look at (spawn output, then survivor slots)
@@ -3116,6 +3249,7 @@ int launch_pair_tiled(const soil_erosion_planes& P, Streams rng_fluvial, Streams
                         ((reinterpret_cast<uintptr_t>(P.layers) | reinterpret_cast<uintptr_t>(P.velocity) |
                           reinterpret_cast<uintptr_t>(P.waterHeight) | reinterpret_cast<uintptr_t>(P.debrisVelocity) |
                           reinterpret_cast<uintptr_t>(A.p4) | reinterpret_cast<uintptr_t>(B.p4)) & 15u) == 0;
+      if (hi >= lo) SOIL_HIP(hipMemsetAsync(B.retire_bad, 0, sizeof(uint32_t), st));
       if (hi >= lo && wide) {
         // rows per work-group: the window shape's 32 where that still makes four work-groups per CU, fewer
         // on small grids (1024^2 is ONE column group: 32 work-groups of 256 threads for the whole chip,
@@ -3126,12 +3260,12 @@ int launch_pair_tiled(const soil_erosion_planes& P, Streams rng_fluvial, Streams
         const int64_t bands = (rows + band_rows - 1) / band_rows;
         k_tiled_pack_pair4<<<dim3(static_cast<unsigned>(groups), static_cast<unsigned>(std::min<int64_t>(bands, 65535))), kWinBlock, 0, st>>>(
             A.p4, B.p4, reinterpret_cast<const float2*>(P.layers), reinterpret_cast<const float2*>(P.velocity),
-            P.waterHeight, reinterpret_cast<const float2*>(P.debrisVelocity), d, s, p, lo, hi + 1, band_rows);
+            P.waterHeight, reinterpret_cast<const float2*>(P.debrisVelocity), d, s, p, lo, hi + 1, band_rows, B.retire_bad);
       }
       else if (hi >= lo)
         k_tiled_pack_pair<<<grid_rows(hi - lo + 1, d.W, 256), 256, 0, st>>>(
             A.p4, B.p4, reinterpret_cast<const float2*>(P.layers), reinterpret_cast<const float2*>(P.velocity),
-            P.waterHeight, reinterpret_cast<const float2*>(P.debrisVelocity), d, s, p, lo, hi + 1);
+            P.waterHeight, reinterpret_cast<const float2*>(P.debrisVelocity), d, s, p, lo, hi + 1, B.retire_bad);
       SOIL_LAUNCH_CHECK();
       A.skip_pack = B.skip_pack = true;
     }
@@ -3209,3 +3343,18 @@ int launch_pass_tiled(int kind, const soil_erosion_planes& P, Streams rng, int64
 }
 
 }  // namespace soil
+
+// soil_hip.h: what the watched mode of the debris retirement (soil_set_debris_retire(2)) has counted
+extern "C" int soil_debris_retire_violations(uint64_t* total, int reset, void* stream) {
+  using namespace soil;
+  SOIL_REQUIRE(total, "soil_debris_retire_violations: null pointer");
+  SOIL_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+  unsigned long long v = 0;
+  SOIL_HIP(hipMemcpyFromSymbol(&v, HIP_SYMBOL(soil_retire_violations_dev), sizeof(v)));
+  if (reset) {
+    const unsigned long long z = 0;
+    SOIL_HIP(hipMemcpyToSymbol(HIP_SYMBOL(soil_retire_violations_dev), &z, sizeof(z)));
+  }
+  *total = v;
+  return SOIL_OK;
+}

@@ -89,6 +89,7 @@ int launch_pass_tiled(int kind, const soil_erosion_planes& P, Streams rng, int64
 
 // the launch shape a launch of N particles on domain d gets (erosion_particles.hip)
 bool use_tiled_launch(int64_t N, const Dom& d);
+int debris_retire_mode();    // soil_set_debris_retire / SOIL_DEBRIS_RETIRE (erosion_particles.hip): 0 off, 1 on, 2 watched
 bool particle_arith_fast();  // soil_set_particle_arith(1) / SOIL_PARTICLE_DIV=fast (erosion_particles.hip)
 
 // exclusive scan of per-tile counts, start[tiles] = total (one 1024-thread group;

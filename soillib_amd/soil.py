@@ -308,6 +308,27 @@ def particle_arith(mode=None):
     return "fast" if _abi.lib().soil_get_particle_arith() == 1 else "exact"
 
 
+def debris_retire(mode=None):
+    """What becomes of spent debris walkers in the tiled launch shape (soil_hip.h: soil_set_debris_retire; not
+    in the reference): 1 / "on" (default) — a walker whose every further deposit is certain to be an exact
+    zero ends its walk; 0 / "off" — every walker is walked to the end as the reference does (same flux planes);
+    2 / "watch" — marked and walked on, deposits counted (debris_retire_violations).  Returns the mode in
+    force (0, 1, 2); with an argument, sets it first."""
+    names = {"off": 0, 0: 0, "on": 1, 1: 1, "watch": 2, 2: 2}
+    if mode is not None:
+        if mode not in names:
+            raise ValueError("debris_retire: 'off', 'on' or 'watch'")
+        _call("soil_set_debris_retire", names[mode])
+    return _abi.lib().soil_get_debris_retire()
+
+
+def debris_retire_violations(reset=True):
+    """Deposits other than exact zeros made by walkers the watched mode had marked as spent (must be 0)."""
+    n = C.c_uint64(0)
+    _call("soil_debris_retire_violations", C.byref(n), 1 if reset else 0, _abi.stream())
+    return n.value
+
+
 def layer_merge(height, layers):
     """model.cpp:343-351 -> soil::layer_merge (erosion.cu:747-757)."""
     _call("soil_layer_merge", _f(height, "height"), _f(layers, "layers"), height.elem(),

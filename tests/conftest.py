@@ -14,6 +14,24 @@ os.environ.setdefault("SOIL_RCCL_TIMEOUT_S", "20")
 os.environ.setdefault("SOIL_RCCL_INIT_TIMEOUT_S", "45")
 
 
+# Spent debris walkers (include/soil_hip.h: soil_set_debris_retire) are WATCHED throughout the suite — marked,
+# walked to the end as the reference walks them (so the step counts equal the oracle's) and every deposit of a
+# marked walker that is not an exact zero counted; the fixture below wants that count to be zero after every
+# GPU test.  The product's default (they end their walks) is what tests/test_debris_retire.py runs.  In the
+# environment, so that the compiled C++ hosts and spawned workers of the tests inherit it.
+os.environ.setdefault("SOIL_DEBRIS_RETIRE", "2")
+
+
+@pytest.fixture(autouse=True)
+def _no_spent_walker_ever_adds_anything(request):
+    yield
+    if request.node.get_closest_marker("gpu") is None:
+        return
+    from soillib_amd import _abi, soil
+    if _abi.lib().soil_device_count() > 0:
+        assert soil.debris_retire_violations(reset=True) == 0, "a debris walker marked as spent went on to add something"
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
@@ -38,7 +56,7 @@ def hip():
 # failure hides: the oracle-parity files of the hot path run before the infrastructure tests (compiled
 # C++ hosts, spawned bench processes) and the RCCL / multi-process tests run last (one
 # hung RCCL test in front of the suite left 381 parity tests unreached).
-_ORDER = ["test_gpu_parity", "test_golden", "test_oracle_kat", "test_gpu_oracle_fullsize", "test_fast_particles",
+_ORDER = ["test_gpu_parity", "test_debris_retire", "test_golden", "test_oracle_kat", "test_gpu_oracle_fullsize", "test_fast_particles",
           "test_fma_tolerance", "test_gpu_window_shapes", "test_gpu_fullsize", "test_gpu_api_surface",
           "test_abi_symbols", "test_io_tiff", "test_knobs", "test_parallel_gloo", "test_cpp_api", "test_bench_configs",
           "test_bench_spawn", "test_gpu_parallel"]

@@ -47,6 +47,7 @@ KNOBS = {
     # ---- the step
     "SOIL_STEP_PAIR": ("step", "0: fluvial and debris launches one after the other instead of overlapped on two streams (read per step)"),
     "SOIL_PARTICLE_DIV": ("step", "fast: the process starts with the fast particle arithmetic (soil_set_particle_arith(1)) [exact]"),
+    "SOIL_DEBRIS_RETIRE": ("step", "spent debris walkers — every further deposit certain to be an exact zero (soil_set_debris_retire): 1 end their walks, 0 are walked to the end as the reference walks them, 2 are marked, walked on and watched (the test suite's setting, tests/conftest.py) [1]"),
     # ---- tiled particle transport (erosion_particles_tiled.hip, TiledRun::setup); NAME_F / NAME_D per kind
     "SOIL_TILED_SHAPE": ("particles", "round kernel shape 0..3 = 64x64x512 | 64x64x768 | colour | LDS-filling 78/104 rows x 768 [by grid size]"),
     "SOIL_TILED_SHAPE_F": ("particles", "... of the fluvial launch"),
