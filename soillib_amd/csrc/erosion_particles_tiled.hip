@@ -750,14 +750,21 @@ __global__ void __launch_bounds__(256)
                   const float* __restrict__ waterSource, const float* __restrict__ albedoSource,
                   Dom d, Scale3 s, Param param,
                   int tiles_w, TileShape ts, int steps_per_round, TiledCtl* __restrict__ ctl,
-                  const uint32_t* __restrict__ retire_bad, uint32_t retire_mode) {
+                  const uint32_t* __restrict__ retire_bad, uint32_t retire_mode, bool fast,
+                  unsigned long long* __restrict__ steps) {
   const int64_t n = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  const uint32_t retire = (retire_mode != 0u && retire_bad && *retire_bad == 0u) ? retire_mode : 0u;  // (the pack pass is over)
   if (n == 0) {
     ctl->live = static_cast<uint32_t>(N);  // the spawn fills slots 0 .. N-1 (scan 0 turns it into `slots`)
-    ctl->retire = (retire_mode != 0u && retire_bad && *retire_bad == 0u) ? retire_mode : 0u;  // (the pack pass is over)
+    ctl->retire = retire;
   }
-  if (n >= N) return;
-  const bool in_range = true;
+  __shared__ uint32_t s_head_steps;
+  if (KIND == DEBRIS && retire == 1u) {  // (uniform)
+    if (threadIdx.x == 0) s_head_steps = 0;
+    __syncthreads();
+  }
+  uint32_t head_steps = 0;
+  const bool in_range = n < N;
   PRec r;
   uint32_t tile = kNoTile;
   const float2 pos = in_range ? spawn_position(rng, n, d) : make_float2(-1.0f, -1.0f);
@@ -815,11 +822,32 @@ __global__ void __launch_bounds__(256)
       r.sa0 = albedoSource ? source_mass * albedoSource[3 * l] : 0.0f;  // :91 / :299
       r.sa1 = albedoSource ? source_mass * albedoSource[3 * l + 1] : 0.0f;
       r.sa2 = albedoSource ? source_mass * albedoSource[3 * l + 2] : 0.0f;
-      tile = queue_key(static_cast<int>(d.x0), pos.x, pos.y, spx, spy,
-                       param.maxage > 0x7fffffffull ? 0x7fffffffu : static_cast<uint32_t>(param.maxage),
-                       tiles_w, ts, steps_per_round);
+      const uint32_t maxage = param.maxage > 0x7fffffffull ? 0x7fffffffu : static_cast<uint32_t>(param.maxage);
+      bool walks_on = true;
+      if (KIND == DEBRIS && retire == 1u && maxage > 1u) {
+        // The walker's FIRST step, here (debris_spent): with the example's parameters it is the last one that can
+        // matter — att_d and att_v underflow to exact zeros in it — and a walker that is spent after it is never
+        // made: no record, no place in a queue, no slot in round 0.  The iteration is the round kernel's: the
+        // walker stands on its spawn cell (no deposit: nind == ind, :309), `++iter < maxage` passes, the record of
+        // the cell is the one the spawn has just read.  Whoever is not spent starts round 0 with iter = 1.
+        const StepConst k = make_const<DEBRIS>(d, s, param);
+        r.iter = 1;
+        head_steps = 1;
+        walks_on = fast ? advance<DEBRIS, true>(r, q, k) : advance<DEBRIS, false>(r, q, k);  // false: v_norm < eps, :326-327
+        walks_on = walks_on && !debris_spent(r);
+      }
+      if (walks_on)
+        tile = queue_key(static_cast<int>(d.x0), r.px, r.py, r.spx, r.spy, maxage - static_cast<uint32_t>(r.iter),
+                         tiles_w, ts, steps_per_round);
     }
   }
+  if (KIND == DEBRIS && retire == 1u) {  // the steps taken here, one atomic per work-group
+    const uint32_t in_wave = static_cast<uint32_t>(__popcll(__builtin_amdgcn_ballot_w64(head_steps != 0u)));
+    if ((threadIdx.x & 63u) == 0 && in_wave) atomicAdd(&s_head_steps, in_wave);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_head_steps) atomicAdd(steps, static_cast<unsigned long long>(s_head_steps));
+  }
+  if (!in_range) return;
   // (Handing record slots only to the walkers that are made — so that a slab owning an eighth of the
   // streams sorts an eighth of the slots — was tried with uniform streams: one counter for the whole
   // launch, drawn from once per wave, is a million same-address atomics at 67 M streams: 61 instead
@@ -2956,7 +2984,7 @@ struct TiledRun {
     } else {
       k_tiled_spawn<KIND><<<blocks_for(N, 256), 256, 0, st>>>(
           cur, dest, rank, count, rng, N, p4, waterSource, albedoSource, d, s, p, tiles_w_of(shape_of(0), 0),
-          ts_of(shape_of(0), 0), steps_per_round, ctl, retire_bad, retire_mode);
+          ts_of(shape_of(0), 0), steps_per_round, ctl, retire_bad, retire_mode, fast, steps_run);
     }
     SOIL_LAUNCH_CHECK();
     live_known = inbox ? static_cast<int64_t>(n_in) : N;  // slots of the record array to look at (spawn output, then survivor slots)
