@@ -214,6 +214,16 @@ ARITH_NOTE = {
             "with the oracle only — plane sums 2e-3, visited cells 0.5 %, step counts 0.5 % (tests/test_fast_particles.py)",
 }
 
+DEBRIS_NOTE = {
+    1: "spent debris walkers end their walks (soil_set_debris_retire(1), the default): with these parameters a debris "
+       "walker's attenuations underflow to exact zeros in its first step and the reference walks it through the "
+       "other ~100 adding +-0; the product ends a walk once that is certain (include/soil_hip.h) — same flux planes "
+       "(x + 0 = x), tests/test_debris_retire.py; the whole GPU suite runs with the walkers marked and watched and "
+       "counts no deposit from a marked one.  `debris_walked_to_the_end` times the same steps without it",
+    0: "every debris walker walked to the end (soil_set_debris_retire(0)), as the reference's kernel does",
+    2: "spent debris walkers marked, walked on and watched (soil_set_debris_retire(2): the test suite's mode)",
+}
+
 
 def parse_args():
     ap = argparse.ArgumentParser()
@@ -459,6 +469,22 @@ def _main():
         other_block = {"ms_per_step": e_el / ke * 1e3, "value": H_global * W / (e_el / ke) / 1e6, "unit": "Mcells/s",
                        "steps": ke, "warmup": 1, "gparticle_steps_per_s": e_ps / e_el / 1e9,
                        "note": ARITH_NOTE[other]}
+    walked_block = None
+    retire_mode = soil.debris_retire()
+    if (world == 1 and not slabbed and retire_mode == 1 and
+            os.environ.get("SOIL_BENCH_NO_OTHER_ARITH", os.environ.get("SOIL_BENCH_NO_EXACT")) != "1"):
+        # the same model a few steps on with every debris walker walked to the end, as the reference walks them
+        # (soil_set_debris_retire(0)): the same flux planes, the work the default leaves out — a side block
+        soil.debris_retire(0)
+        kw = max(2, min(args.steps, 6))
+        w_el, w_ph, w_ps = timed_steps(runner, ev, kw, 1, world)
+        soil.debris_retire(1)
+        walked_block = {"ms_per_step": w_el / kw * 1e3, "value": H_global * W / (w_el / kw) / 1e6, "unit": "Mcells/s",
+                        "steps": kw, "warmup": 1, "particle_steps_per_step": w_ps // kw,
+                        "gparticle_steps_per_s": w_ps / w_el / 1e9,
+                        "note": "soil_set_debris_retire(0): every debris walker walked through all of its steps, as the "
+                                "reference's kernel does (erosion.cu:306-349) — the same flux planes as the line's own "
+                                "mode (tests/test_debris_retire.py), 0.85 G more particle steps of exact zeros per step"}
     final = None
     if not slabbed:
         # sanity of the evolved terrain (outside the timed region): no NaN/inf may appear
@@ -552,6 +578,7 @@ def _main():
             "arith_vs_reference": ("same as the reference's CUDA build: IEEE division and square root, __expf/__powf "
                                    "as the fast intrinsics the source names" if args.particle_arith == "exact" else
                                    "approximate reciprocal; reference is IEEE"),
+            "debris_walkers": DEBRIS_NOTE[retire_mode],
         },
         "final_state": final,
         "halo": halo,
@@ -585,6 +612,8 @@ def _main():
     out["roofline_particles"] = proof
     if other_block:
         out[other + "_arithmetic"] = other_block
+    if walked_block:
+        out["debris_walked_to_the_end"] = walked_block
     if strong_block:
         out["strong16384"] = strong_block
     if world == 1 and not args.no_cpu_baseline:

@@ -1923,6 +1923,7 @@ __global__ void __launch_bounds__(NT, SPARSE ? 2 : round_waves_per_simd(KIND, TR
       float v_norm = 1.0f;
 #ifdef SOIL_STATS
       bool st_dep = false;
+      int st_zero = 0;
 #endif
       if (__builtin_amdgcn_inverse_ballot_w64(stepm)) {
         ++r.iter;
@@ -1941,6 +1942,9 @@ __global__ void __launch_bounds__(NT, SPARSE ? 2 : round_waves_per_simd(KIND, TR
           r.ind = nind;
 #ifdef SOIL_STATS
           st_dep = true;
+          st_zero = KIND == FLUVIAL ? ((r.a2 * r.svx == 0.0f && r.a2 * r.svy == 0.0f ? 1 : 0) | (r.a1 * r.s1 == 0.0f ? 2 : 0) |
+                                       (r.a0 * r.s0 == 0.0f ? 4 : 0))
+                                    : 0;
 #endif
           // DEP 0: native ds_add_f32, fire and forget; DEP 1: CasDeposit
           float v[kFluxPlanes + 3];
@@ -2040,6 +2044,12 @@ __global__ void __launch_bounds__(NT, SPARSE ? 2 : round_waves_per_simd(KIND, TR
           const int c0 = __builtin_amdgcn_readlane(skey, __ffsll(static_cast<long long>(t)) - 1);
           t &= ~__builtin_amdgcn_ballot_w64(skey == c0);
           ++distinct;
+        }
+        {  // deposits whose velocity pair | mass | water term is an exact zero; iterations where every deposit's pair is
+          const uint64_t dm = __builtin_amdgcn_ballot_w64(dep_lane), zv = __builtin_amdgcn_ballot_w64(dep_lane && (st_zero & 1));
+          STATS_ADD(10, __popcll(zv));
+          STATS_ADD(11, __popcll(__builtin_amdgcn_ballot_w64(dep_lane && (st_zero & 2))));
+          STATS_ADD(23, dm != 0 && zv == dm ? 1 : 0);
         }
         STATS_ADD(8, distinct);
         STATS_ADD(9, distinct == 1 ? 1 : 0);
