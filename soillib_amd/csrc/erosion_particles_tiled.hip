@@ -824,7 +824,7 @@ __global__ void __launch_bounds__(256)
       r.sa2 = albedoSource ? source_mass * albedoSource[3 * l + 2] : 0.0f;
       const uint32_t maxage = param.maxage > 0x7fffffffull ? 0x7fffffffu : static_cast<uint32_t>(param.maxage);
       bool walks_on = true;
-      if (KIND == DEBRIS && retire == 1u && maxage > 1u) {
+      if (KIND == DEBRIS && retire == 1u && maxage > 1u && (spx - spx) + (spy - spy) == 0.0f) {  // (a NaN speed walks on as ever)
         // The walker's FIRST step, here (debris_spent): with the example's parameters it is the last one that can
         // matter — att_d and att_v underflow to exact zeros in it — and a walker that is spent after it is never
         // made: no record, no place in a queue, no slot in round 0.  The iteration is the round kernel's: the
@@ -835,6 +835,12 @@ __global__ void __launch_bounds__(256)
         head_steps = 1;
         walks_on = fast ? advance<DEBRIS, true>(r, q, k) : advance<DEBRIS, false>(r, q, k);  // false: v_norm < eps, :326-327
         walks_on = walks_on && !debris_spent(r);
+        // ... and where the step took it: off the grid the walk is over (:306), off the slab's rows it is another
+        // rank's (a finite walker leaves nothing behind: park_remote), as the round kernel sorts a stop out
+        const int ix = floor_cell(r.px), iy = floor_cell(r.py);
+        const bool oob = static_cast<uint32_t>(ix) >= static_cast<uint32_t>(d.H) || static_cast<uint32_t>(iy) >= k.Wu;
+        const int lx = ix - k.x0;
+        walks_on = walks_on && !oob && !(lx < k.lo || lx > k.hi) && r.px == r.px && r.py == r.py;
       }
       if (walks_on)
         tile = queue_key(static_cast<int>(d.x0), r.px, r.py, r.spx, r.spy, maxage - static_cast<uint32_t>(r.iter),

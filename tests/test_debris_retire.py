@@ -211,3 +211,64 @@ def test_bench_workload_8192(hip, oracle, retire):
     assert out["on"][0] * 5 < out["off"][0]
     _same_planes(out["on"][1], out["off"][1], "8192^2 debris mass flux")
     _same_planes(out["on"][2], out["off"][2], "8192^2 debris velocity flux")
+
+
+@pytest.mark.parametrize("pair", [False, True])
+def test_row_slabs_in_the_default_mode(hip, oracle, retire, pair):
+    """The library's slab runner (deep halos, include/soil_slab.h) with spent walkers retired on every slab —
+    a walker's first step, taken in the spawn, may carry it off its slab's rows or off the grid — against the
+    single domain that walks everybody to the end: a 1024 x 512 grid in three slabs, two steps."""
+    from soillib_amd import silt, soil
+    from soillib_amd.erosion import ErosionModel
+    from test_gpu_parallel import _run_world
+    from test_gpu_parity import _close_but_for_stray_walks
+    world, W, maxage, steps = 3, 512, 48, 2
+    S = 1026 // world
+    op = script_param(oracle.default_param())
+    op.maxage = maxage
+    pp = product_param(op)
+    H = world * S
+    retire("on")
+    got = _run_world(world, S, W, pp, steps, maxage, pair=pair)
+    retire("off")
+    m = ErosionModel(H, W, (20.0 / H, 20.0 / W, 4.0), pp, H * W // 8, seed=0)
+    npar = soil.noise_t()
+    npar.seed = 3.0
+    npar.ext = [H, W]
+    layers0 = np.zeros((H, W, 2), np.float32)
+    layers0[..., 0] = to_np(soil.noise(silt.shape(H, W), npar, host=silt.gpu))
+    m.set_layers(to_gpu(layers0))
+    silt.set(m.rainfall, 1.0)
+    for _ in range(steps):
+        m.step()
+    for k in got:
+        want = to_np(getattr(m, k))
+        _close_but_for_stray_walks(got[k], want, 1e-4, 1e-5 * (np.nanmax(np.abs(want)) + 1e-30), 1e-3, "slabs, " + k)
+
+
+def test_first_steps_that_leave_the_grid(hip, oracle, retire):
+    """A ramp that sends every walker of the rim off the grid with its first step: the spawn's own step ends those
+    walks (erosion.cu:306), whatever the mode — same steps as the oracle with the retirement off, same planes on."""
+    from soillib_amd import soil
+    H, W = 96, 160
+    N = H * W
+    op = script_param(oracle.default_param())
+    op.maxage = 32
+    pp = product_param(op)
+    scale = (20.0 / H, 20.0 / W, 400.0)
+    x = np.arange(H, dtype=np.float32)[:, None] + np.zeros((1, W), np.float32)
+    layers = np.zeros((H, W, 2), np.float32)
+    layers[..., 0] = -0.01 * x - 0.003 * np.arange(W, dtype=np.float32)[None, :]      # downhill towards the far corner
+    vel0 = np.zeros((H, W, 2), np.float32)
+    mf, vf = np.zeros((H, W), np.float32), np.zeros((H, W, 2), np.float32)
+    want = oracle.particles_debris(mf, vf, None, oracle.rng_seed(N, 6, 0), layers, vel0, None, scale, op)
+    assert hip.soil_set_particle_mode(3) == 0
+    retire("off")
+    steps_off, mf_off, vf_off = _debris_launch(soil, layers, vel0, N, scale, pp)
+    assert steps_off == want
+    retire("on")
+    steps_on, mf_on, vf_on = _debris_launch(soil, layers, vel0, N, scale, pp)
+    assert steps_on <= want
+    for got, ref, what in ((mf_on, mf, "mass flux"), (vf_on, vf, "velocity flux"), (mf_off, mf, "mass flux, off"),
+                           (vf_off, vf, "velocity flux, off")):
+        _same_planes(got, ref, what, rtol=1e-4)
