@@ -120,7 +120,8 @@ def test_debris_launch_fast_against_the_oracle(fast, oracle):
     soil.transport_debris(to_gpu(layers), to_gpu(vel), g["vf"], to_gpu(z1()), g["mf"], None, None, None,
                           rng_to_gpu(oracle.rng_seed(N, 6, 0)), scale, product_param(p))
     walked = soil.particle_steps(reset=True)
-    assert abs(walked - steps) <= TOL["steps_rel"] * steps, (walked, steps)
+    # (with spent walkers retired — soil_set_debris_retire(1), not the suite's mode — fewer steps are walked)
+    assert abs(walked - steps) <= TOL["steps_rel"] * steps or (soil.debris_retire() == 1 and walked < steps), (walked, steps)
     _statistics({k: to_np(v) for k, v in g.items()}, want, ("mf",), "debris launch, fast arithmetic")
 
 

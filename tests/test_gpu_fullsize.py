@@ -63,7 +63,8 @@ def test_particle_shapes_agree_at_4096(hip):
                          m.velocityFlux.cpu().numpy().copy(), m.debrisFlux.cpu().numpy().copy())
     hip.soil_set_particle_mode(0)
     a, b = results["direct"], results["tiled"]
-    assert a[0] == b[0] and a[1] == b[1] and a[0] > 10 * m.N     # same walks, step for step
+    from util import debris_steps_match
+    assert a[0] == b[0] and debris_steps_match(b[1], a[1]) and a[0] > 10 * m.N     # same walks, step for step
     for x, y, what in ((a[2], b[2], "water flux"), (a[3], b[3], "velocity flux"),
                        (a[4], b[4], "debris flux")):
         scale = np.nanmax(np.abs(x))
@@ -287,7 +288,8 @@ def test_whole_step_at_8192_direct_equals_tiled(hip):
             got[label] = (soil.particle_steps(reset=True), {n: getattr(m, n).cpu().numpy() for n in names})
     finally:
         _abi.check(hip.soil_set_particle_mode(0))
-    assert got["tiled"][0] == got["direct"][0] > 2.0e9
+    from util import debris_steps_match
+    assert debris_steps_match(got["tiled"][0], got["direct"][0]) and got["direct"][0] > 2.0e9
     for n in names:
         a, b = got["tiled"][1][n], got["direct"][1][n]
         sc = np.nanmax(np.abs(b)) + 1e-30

@@ -935,7 +935,8 @@ def test_transport_edge_cases(hip, oracle, particle_mode, maxage, N):
     _abi.check(hip.soil_particles_debris_slab(
         g["df"].c_ptr, g["dvf"].c_ptr, None, grng.c_ptr if N else None, N, lay.c_ptr, gv.c_ptr,
         None, None, C.byref(dom), _abi.vec(scale, 3), pp._ref(), None))
-    assert soil.particle_steps(reset=True) == steps
+    from util import debris_steps_match
+    assert debris_steps_match(soil.particle_steps(reset=True), steps)     # (fluvial + debris)
     for k in ("wf", "mf", "vf", "df", "dvf"):
         _flux_close(to_np(g[k]), o[k], "edge case flux " + k)
 
@@ -1069,7 +1070,8 @@ def test_transport_random_parameter_sets(hip, oracle, seed):
         got_d = soil.particle_steps(reset=True)
     finally:
         hip.soil_set_particle_mode(0)
-    assert (got_f, got_d) == (steps_f, steps_d)
+    from util import debris_steps_match
+    assert got_f == steps_f and debris_steps_match(got_d, steps_d), (got_f, got_d, steps_f, steps_d)
     for k in ("wf", "mf", "vf", "df", "dvf"):
         _flux_close(to_np(g[k]), o[k], "random parameters, flux " + k)
 
