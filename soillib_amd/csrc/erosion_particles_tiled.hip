@@ -1928,7 +1928,7 @@ __global__ void __launch_bounds__(NT, SPARSE ? 2 : round_waves_per_simd(KIND, TR
       const uint32_t nind = lcell + k.base;  // global cell: cx * W + cy, :103 / :309
       float v_norm = 1.0f;
 #ifdef SOIL_STATS
-      bool st_dep = false;
+      bool st_dep = false, st_stuck = false;
       int st_zero = 0;
 #endif
       if (__builtin_amdgcn_inverse_ballot_w64(stepm)) {
@@ -1995,6 +1995,9 @@ __global__ void __launch_bounds__(NT, SPARSE ? 2 : round_waves_per_simd(KIND, TR
         // direction is known — 30.40-30.64 against 30.58-30.91 ms per step, A/B on one box)
         if (KIND == FLUVIAL && deposit) dep.swap_all();          // the swaps' round trip hides under step_apply
         v_norm = geom.v_norm;
+#ifdef SOIL_STATS
+        st_stuck = geom.dL == 0.0f && !(geom.v_norm < k.eps);  // a step of length zero: the walker stays where it is (step_geom: "stuck on a cell corner")
+#endif
         // :121-122 / :326-327: a walk that is over shows in `ended` (a value, not a lane mask merged
         // through the branches of the iteration: `have` stays what it was when the loop began)
         if constexpr (FAST) {
@@ -2053,9 +2056,12 @@ __global__ void __launch_bounds__(NT, SPARSE ? 2 : round_waves_per_simd(KIND, TR
         }
         {  // deposits whose velocity pair | mass | water term is an exact zero; iterations where every deposit's pair is
           const uint64_t dm = __builtin_amdgcn_ballot_w64(dep_lane), zv = __builtin_amdgcn_ballot_w64(dep_lane && (st_zero & 1));
-          STATS_ADD(10, __popcll(zv));
-          STATS_ADD(11, __popcll(__builtin_amdgcn_ballot_w64(dep_lane && (st_zero & 2))));
-          STATS_ADD(23, dm != 0 && zv == dm ? 1 : 0);
+          (void)dm; (void)zv;  // (round 6: 0.0 % in either launch; the slots count walkers that do not move instead)
+          const uint64_t sm = __builtin_amdgcn_ballot_w64(st_stuck);
+          STATS_ADD(10, __popcll(sm));                                  // lanes whose step has length zero
+          STATS_ADD(11, sm != 0 && sm == stepm ? 1 : 0);                 // wave-iterations in which nobody else steps
+          STATS_ADD(23, sm != 0 && __popcll(stepm & ~sm) <= 8 ? 1 : 0);  // ... in which at most 8 others do
+          STATS_ADD(3, __popcll(stepm) <= 8 ? 1 : 0);                    // wave-iterations of at most 8 lanes
         }
         STATS_ADD(8, distinct);
         STATS_ADD(9, distinct == 1 ? 1 : 0);

@@ -55,8 +55,9 @@ for step in range(WARM + 2):
         print("   lanes with a lower lane of the wave on their cell: %.2f per iteration; nearest such lane at distance "
               "1: %.1f %%, 2: %.1f %%, 3: %.1f %%, 4-7: %.1f %%, 8-15: %.1f %%, 16+: %.1f %%; in the aligned pair %.1f %%, quad %.1f %%"
               % (sum(h) / it, *[100.0 * x / tot for x in h], 100.0 * v[18] / tot, 100.0 * v[19] / tot))
-        print("   deposits whose velocity pair is an exact zero: %.1f %%, whose mass term is: %.1f %%; wave-iterations in which "
-              "every deposit's velocity pair is zero: %.1f %%" % (100.0 * v[10] / max(dep, 1), 100.0 * v[11] / max(dep, 1), 100.0 * v[23] / it))
+        print("   steps of length zero (a walker that stays where it is): %.2f %% of the steps; wave-iterations in which nobody else steps: "
+              "%.2f %%, in which at most 8 others do: %.2f %%; wave-iterations of at most 8 stepping lanes: %.2f %%"
+              % (100.0 * v[10] / max(lanes, 1), 100.0 * v[11] / it, 100.0 * v[23] / it, 100.0 * v[3] / it))
         print("   star of the iteration before as the prediction: %.2f followers per iteration; lanes that still share a cell "
               "among the swappers %.2f per iteration, iterations with any %.1f %%"
               % (v[20] / it, v[21] / it, 100.0 * v[22] / it))
