@@ -53,6 +53,35 @@ def test_flow_graph_draws_share_a_block_between_four_cells(oracle):
     assert oracle.rng_uniform(rng, [44 >> 2])[0] == u[44 - 40]
 
 
+def test_flow_graph_draws_are_uniform_and_independent(oracle):
+    """The four cells that share a Philox block take its four words: their draws have to be as good as four
+    blocks' word 0 were (rounds 1-4) — uniform on (0, 1], no correlation between neighbouring cells of a row
+    (same block and across blocks), between the rows of a grid, or between two realisations (offsets k, k + 1:
+    example/dem_multiflow.py:43-49).  Bounds: 5 sigma of the estimators for N = 65 536 draws."""
+    W = 256
+    n = np.arange(W * W)
+    u0 = oracle.rng_uniform_cell(0, 3, n).astype(np.float64)
+    u1 = oracle.rng_uniform_cell(0, 4, n).astype(np.float64)
+    N = float(u0.size)
+    assert abs(u0.mean() - 0.5) < 5.0 / np.sqrt(12.0 * N)
+    assert abs(u0.var() - 1.0 / 12.0) < 5.0 * np.sqrt(1.0 / 180.0 / N)
+    hist = np.histogram(u0, bins=64, range=(0.0, 1.0))[0]
+    chi2 = ((hist - N / 64.0) ** 2 / (N / 64.0)).sum()
+    assert chi2 < 63.0 + 5.0 * np.sqrt(2.0 * 63.0)      # chi-square with 63 degrees of freedom
+    corr = lambda a, b: float(np.corrcoef(a, b)[0, 1])
+    g = u0.reshape(W, W)
+    for lag in (1, 2, 3, 4):                              # within a block (lags 1-3) and across blocks
+        assert abs(corr(g[:, :-lag].ravel(), g[:, lag:].ravel())) < 5.0 / np.sqrt(N)
+    assert abs(corr(g[:-1].ravel(), g[1:].ravel())) < 5.0 / np.sqrt(N)       # the cell below
+    assert abs(corr(g[:-1, :-1].ravel(), g[1:, 1:].ravel())) < 5.0 / np.sqrt(N)
+    assert abs(corr(u0, u1)) < 5.0 / np.sqrt(N)           # two realisations of one cell
+    # the words of one block, pairwise
+    b = u0.reshape(-1, 4)
+    for i in range(4):
+        for j in range(i + 1, 4):
+            assert abs(corr(b[:, i], b[:, j])) < 5.0 / np.sqrt(N / 4.0)
+
+
 def test_expf_within_one_ulp_of_libm(oracle):
     xs = np.concatenate([np.linspace(-87, 88, 20001), np.linspace(-1, 1, 2001)]).astype(np.float32)
     mine = oracle.expf(xs).astype(np.float64)
